@@ -1,0 +1,435 @@
+"""CPU oracle for the Deep Fluids velocity-field train step  --  TEST INFRASTRUCTURE ONLY.
+
+This module is the checker, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+The shipped path (``deep_fluids_amd``) must never route through it.
+
+It is a NumPy restatement (index form, written from SURVEY.md Appendix A, not copied)
+of the reference algorithm on the north-star path.  Each function cites the reference
+file:line it follows (paths relative to the upstream repo root).
+
+Parity status
+-------------
+* Stencils (curl / jacobian / jacobian3 / divergence / divergence3 and the *_np twins):
+  PINNED -- checked bit-exactly against golden vectors captured by executing the
+  reference's own ``ops.py`` source under a NumPy-backed ``tensorflow`` stub
+  (``tests/golden/make_golden.py`` -> ``tests/golden/stencils_*.npz``).
+* Generator graph structure (layer order, residual adds, up-sampling placement, variable
+  names): PINNED -- the reference's own ``model.py`` is executed under the same stub with
+  the slim layer arithmetic supplied by this module (``tests/golden/generator_*.npz``).
+* conv / fully-connected / nearest-resize / Adam arithmetic: lives in TensorFlow 1.15,
+  which is absent here and not installable -> "parity unpinned" for that arithmetic.
+  It follows the published TF-1.15 semantics listed in SURVEY.md A.3-A.5 and is
+  cross-checked against PyTorch-CPU (``oracle/df_oracle_torch.py``) as an independent
+  second implementation.
+"""
+from __future__ import annotations
+
+import math
+import numpy as np
+
+# ----------------------------------------------------------------------------------------
+# Forward-difference stencils (ops.py:205-290)
+# ----------------------------------------------------------------------------------------
+
+def fdiff(f, axis):
+    """D_a f: forward difference along ``axis``; the LAST DIFFERENCE (not the last value)
+    is replicated so the output keeps the input extent.  ops.py:214-217, 243-253, 269-270."""
+    f = np.asarray(f)
+    n = f.shape[axis]
+    if n < 2:
+        raise ValueError("forward difference needs extent >= 2 along axis %d" % axis)
+    d = np.diff(f, axis=axis)
+    last = np.take(d, [n - 2], axis=axis)
+    return np.concatenate([d, last], axis=axis)
+
+
+def fdiff_adj(g, axis):
+    """Adjoint of :func:`fdiff`: fold the replicated row into the
+    difference it copies, then apply the transpose of the plain difference."""
+    g = np.moveaxis(np.asarray(g), axis, 0)
+    n = g.shape[0]
+    gp = g[: n - 1].copy()
+    gp[n - 2] += g[n - 1]
+    out = np.empty_like(g)
+    out[0] = -gp[0]
+    out[1 : n - 1] = gp[: n - 2] - gp[1 : n - 1]
+    out[n - 1] = gp[n - 2]
+    return np.moveaxis(out, 0, axis)
+
+
+def curl(x):
+    """2-D curl of a scalar stream function, NHWC.  ops.py:264-274.
+    x [B,Y,X,1] -> [B,Y,X,2] with u = D_y psi, v = -D_x psi."""
+    x = np.asarray(x)
+    psi = x[..., 0]
+    u = fdiff(psi, 1)
+    v = -fdiff(psi, 2)
+    return np.stack([u, v], axis=-1)
+
+
+def curl_bwd(g):
+    """Adjoint of :func:`curl`: g [B,Y,X,2] -> dpsi [B,Y,X,1]."""
+    g = np.asarray(g)
+    d = fdiff_adj(g[..., 0], 1) - fdiff_adj(g[..., 1], 2)
+    return d[..., None]
+
+
+def jacobian(x):
+    """2-D Jacobian + vorticity, NHWC.  ops.py:205-225.
+    x [B,Y,X,2] -> j [B,Y,X,4] = (dudx,dudy,dvdx,dvdy), w [B,Y,X,1] = dvdx-dudy."""
+    x = np.asarray(x)
+    u, v = x[..., 0], x[..., 1]
+    dudx, dudy = fdiff(u, 2), fdiff(u, 1)
+    dvdx, dvdy = fdiff(v, 2), fdiff(v, 1)
+    j = np.stack([dudx, dudy, dvdx, dvdy], axis=-1)
+    w = (dvdx - dudy)[..., None]
+    return j, w
+
+
+def jacobian_bwd(gj, gw=None):
+    """Adjoint of :func:`jacobian`: (gj [..,4], gw [..,1] or None) -> dx [..,2]."""
+    gj = np.asarray(gj)
+    g = [gj[..., i] for i in range(4)]
+    if gw is not None:
+        gw = np.asarray(gw)[..., 0]
+        g[2] = g[2] + gw
+        g[1] = g[1] - gw
+    du = fdiff_adj(g[0], 2) + fdiff_adj(g[1], 1)
+    dv = fdiff_adj(g[2], 2) + fdiff_adj(g[3], 1)
+    return np.stack([du, dv], axis=-1)
+
+
+# axis numbers of a [B,Z,Y,X,C] tensor ("x: bzyxd", ops.py:228)
+_AX3 = {"x": 3, "y": 2, "z": 1}
+
+
+def jacobian3(x):
+    """3-D Jacobian + curl, NDHWC.  ops.py:227-262.
+    x [B,Z,Y,X,3] -> j [..,9] = (dudx,dudy,dudz,dvdx,dvdy,dvdz,dwdx,dwdy,dwdz),
+                     c [..,3] = (dwdy-dvdz, dudz-dwdx, dvdx-dudy)."""
+    x = np.asarray(x)
+    d = {}
+    for ci, cn in enumerate("uvw"):
+        for an in "xyz":
+            d[cn + an] = fdiff(x[..., ci], _AX3[an])
+    j = np.stack([d["ux"], d["uy"], d["uz"], d["vx"], d["vy"], d["vz"],
+                  d["wx"], d["wy"], d["wz"]], axis=-1)
+    c = np.stack([d["wy"] - d["vz"], d["uz"] - d["wx"], d["vx"] - d["uy"]], axis=-1)
+    return j, c
+
+
+def curl3(x):
+    """North-star alias: ``jacobian3(x)[1]`` (trainer3.py:18 consumes only c)."""
+    return jacobian3(x)[1]
+
+
+def jacobian3_bwd(gj=None, gc=None):
+    """Adjoint of :func:`jacobian3`: (gj [..,9] or None, gc [..,3] or None) -> dx [..,3]."""
+    ref = gj if gj is not None else gc
+    shp = np.asarray(ref).shape[:-1]
+    dt = np.asarray(ref).dtype
+    names = ["ux", "uy", "uz", "vx", "vy", "vz", "wx", "wy", "wz"]
+    g = {n: np.zeros(shp, dt) for n in names}
+    if gj is not None:
+        gj = np.asarray(gj)
+        for i, n in enumerate(names):
+            g[n] = g[n] + gj[..., i]
+    if gc is not None:
+        gc = np.asarray(gc)
+        g["wy"] = g["wy"] + gc[..., 0]; g["vz"] = g["vz"] - gc[..., 0]
+        g["uz"] = g["uz"] + gc[..., 1]; g["wx"] = g["wx"] - gc[..., 1]
+        g["vx"] = g["vx"] + gc[..., 2]; g["uy"] = g["uy"] - gc[..., 2]
+    out = []
+    for cn in "uvw":
+        acc = 0
+        for an in "xyz":
+            acc = acc + fdiff_adj(g[cn + an], _AX3[an])
+        out.append(acc)
+    return np.stack(out, axis=-1)
+
+
+def divergence(x):
+    """Interior forward-difference divergence, output shrinks by one per axis. ops.py:276-284."""
+    x = np.asarray(x)
+    dudx = x[:, :-1, 1:, 0] - x[:, :-1, :-1, 0]
+    dvdy = x[:, 1:, :-1, 1] - x[:, :-1, :-1, 1]
+    return (dudx + dvdy)[..., None]
+
+
+def divergence3(x):
+    """ops.py:286-290."""
+    x = np.asarray(x)
+    dudx = x[:, :-1, :-1, 1:, 0] - x[:, :-1, :-1, :-1, 0]
+    dvdy = x[:, :-1, 1:, :-1, 1] - x[:, :-1, :-1, :-1, 1]
+    dwdz = x[:, 1:, :-1, :-1, 2] - x[:, :-1, :-1, :-1, 2]
+    return (dudx + dvdy + dwdz)[..., None]
+
+
+def vort_np(x):
+    """ops.py:305-310."""
+    x = np.asarray(x)
+    return (fdiff(x[..., 1], 2) - fdiff(x[..., 0], 1))[..., None]
+
+
+def grad_np(x):
+    """ops.py:319-324 (pressure gradient)."""
+    x = np.asarray(x)
+    return np.stack([fdiff(x[..., 0], 2), fdiff(x[..., 0], 1)], axis=-1)
+
+
+# ----------------------------------------------------------------------------------------
+# Losses (trainer.py:170-172, trainer3.py:49-51)
+# ----------------------------------------------------------------------------------------
+
+def l1_mean(a, b):
+    """mean(|a-b|) over all elements.  trainer.py:170-171."""
+    a = np.asarray(a); b = np.asarray(b)
+    return np.abs(a - b).mean(dtype=np.float64 if a.dtype == np.float64 else a.dtype)
+
+
+def l1_mean_bwd(a, b, gscale=1.0):
+    """d/da mean|a-b| = sign(a-b)/N  (TF Abs grad uses sign; 0 at 0)."""
+    a = np.asarray(a); b = np.asarray(b)
+    return (np.sign(a - b) * (gscale / a.size)).astype(a.dtype)
+
+
+# ----------------------------------------------------------------------------------------
+# Layers (ops.py:9-24, 66-91; TF-1.15 slim semantics SURVEY.md A.3)
+# ----------------------------------------------------------------------------------------
+
+def lrelu(x, leak=0.2):
+    """ops.py:9-10."""
+    return np.maximum(x, leak * x)
+
+
+def _same_pads(n, k, s):
+    o = -(-n // s)
+    pt = max((o - 1) * s + k - n, 0)
+    return o, pt // 2, pt - pt // 2
+
+
+def conv_same(x, w, b=None, stride=1):
+    """slim.conv2d / conv3d, channels-last, padding='SAME' (ops.py:12-16).
+    x [B,*S,Cin], w [*k,Cin,Cout] (HWIO / DHWIO), b [Cout] or None."""
+    x = np.asarray(x); w = np.asarray(w)
+    nd = x.ndim - 2
+    k = w.shape[:nd]
+    geo = [_same_pads(x.shape[1 + a], k[a], stride) for a in range(nd)]
+    outs = [g[0] for g in geo]
+    xp = np.pad(x, [(0, 0)] + [(g[1], g[2]) for g in geo] + [(0, 0)])
+    out = np.zeros([x.shape[0]] + outs + [w.shape[-1]], dtype=np.result_type(x, w))
+    for tap in np.ndindex(*k):
+        sl = tuple(slice(t, t + (o - 1) * stride + 1, stride) for t, o in zip(tap, outs))
+        out += xp[(slice(None),) + sl] @ w[tap]
+    if b is not None:
+        out += b
+    return out
+
+
+def conv_same_bwd(x, w, dout, stride=1, need_dx=True):
+    """Backward of :func:`conv_same`: returns (dx, dw, db)."""
+    x = np.asarray(x); w = np.asarray(w); dout = np.asarray(dout)
+    nd = x.ndim - 2
+    k = w.shape[:nd]
+    geo = [_same_pads(x.shape[1 + a], k[a], stride) for a in range(nd)]
+    outs = [g[0] for g in geo]
+    pads = [(0, 0)] + [(g[1], g[2]) for g in geo] + [(0, 0)]
+    xp = np.pad(x, pads)
+    dxp = np.zeros_like(xp)
+    dw = np.zeros_like(w)
+    d2 = dout.reshape(-1, w.shape[-1])
+    for tap in np.ndindex(*k):
+        sl = (slice(None),) + tuple(slice(t, t + (o - 1) * stride + 1, stride) for t, o in zip(tap, outs))
+        dw[tap] = xp[sl].reshape(-1, w.shape[-2]).T @ d2
+        if need_dx:
+            dxp[sl] += dout @ w[tap].T
+    unpad = (slice(None),) + tuple(slice(g[1], g[1] + x.shape[1 + a]) for a, g in enumerate(geo))
+    db = d2.sum(axis=0)
+    return (dxp[unpad] if need_dx else None), dw, db
+
+
+def linear(x, w, b=None):
+    """slim.fully_connected, W [in,out] (ops.py:23-24)."""
+    out = np.asarray(x) @ np.asarray(w)
+    return out + b if b is not None else out
+
+
+def upscale_nn(x, scale=2):
+    """Nearest-neighbour up-sampling of every spatial axis of a channels-last tensor;
+    src = dst // scale  (tf.image.resize_nearest_neighbor, align_corners=False).
+    2-D: ops.py:75-77; 3-D: ops.py:79-91 (two 2-D resizes == one 3-D nearest resize)."""
+    x = np.asarray(x)
+    for a in range(1, x.ndim - 1):
+        x = np.repeat(x, scale, axis=a)
+    return x
+
+
+def upscale_nn_bwd(g, scale=2):
+    g = np.asarray(g)
+    nd = g.ndim - 2
+    shp = [g.shape[0]]
+    for a in range(nd):
+        shp += [g.shape[1 + a] // scale, scale]
+    shp += [g.shape[-1]]
+    return g.reshape(shp).sum(axis=tuple(2 + 2 * a for a in range(nd)))
+
+
+# ----------------------------------------------------------------------------------------
+# Generator (model.py:5-87)
+# ----------------------------------------------------------------------------------------
+
+def generator_plan(output_shape, filters, num_conv=4, repeat=0):
+    """Layer bookkeeping of GeneratorBE / GeneratorBE3 (model.py:8-19, 51-61)."""
+    spatial = list(output_shape[:-1])
+    repeat_num = int(np.log2(np.max(spatial))) - 2 if repeat == 0 else repeat
+    f = 2 ** (repeat_num - 1)
+    assert repeat_num > 0 and all(s % f == 0 for s in spatial), "model.py:12 / :55"
+    x0_shape = [s // f for s in spatial] + [filters]
+    n_layers = 1 + repeat_num * num_conv + 1
+    return repeat_num, x0_shape, n_layers
+
+
+def xavier_uniform(rng, shape):
+    """slim xavier_initializer() (uniform): limit = sqrt(6/(fan_in+fan_out)), SURVEY A.4."""
+    rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+    fan_in, fan_out = rf * shape[-2], rf * shape[-1]
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def generator_init(rng, c_num, output_shape, filters, name="G", num_conv=4, conv_k=3, last_k=3, repeat=0):
+    """Variables in TF/slim naming order: '<name>/<n>_fc|_conv/{weights,biases}'."""
+    nd = len(output_shape) - 1
+    repeat_num, x0_shape, _ = generator_plan(output_shape, filters, num_conv, repeat)
+    p = {}
+    p["%s/0_fc/weights" % name] = xavier_uniform(rng, (c_num, int(np.prod(x0_shape))))
+    p["%s/0_fc/biases" % name] = np.zeros(int(np.prod(x0_shape)), np.float32)
+    ln = 1
+    for _ in range(repeat_num * num_conv):
+        p["%s/%d_conv/weights" % (name, ln)] = xavier_uniform(rng, (conv_k,) * nd + (filters, filters))
+        p["%s/%d_conv/biases" % (name, ln)] = np.zeros(filters, np.float32)
+        ln += 1
+    p["%s/%d_conv/weights" % (name, ln)] = xavier_uniform(rng, (last_k,) * nd + (filters, output_shape[-1]))
+    p["%s/%d_conv/biases" % (name, ln)] = np.zeros(output_shape[-1], np.float32)
+    return p
+
+
+def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, leak=0.2, keep=False):
+    """GeneratorBE (model.py:5-46) / GeneratorBE3 (model.py:48-87), skip_concat=False.
+    Returns out (and, if keep, the cache needed by :func:`generator_bwd`)."""
+    repeat_num, x0_shape, _ = generator_plan(output_shape, filters, num_conv, repeat)
+    W = lambda n, kind: p["%s/%d_%s/weights" % (name, n, kind)]
+    Bv = lambda n, kind: p["%s/%d_%s/biases" % (name, n, kind)]
+    cache = {"z": z, "acts": [], "blocks": []}
+    x = linear(z, W(0, "fc"), Bv(0, "fc")).reshape([-1] + x0_shape)
+    ln = 1
+    x0 = x
+    for idx in range(repeat_num):
+        blk = {"x0": x0, "ins": [], "outs": [], "ln": []}
+        for _ in range(num_conv):
+            blk["ins"].append(x); blk["ln"].append(ln)
+            x = lrelu(conv_same(x, W(ln, "conv"), Bv(ln, "conv")), leak)
+            blk["outs"].append(x)
+            ln += 1
+        x = x + x0                                   # model.py:35 / :40
+        blk["up"] = idx < repeat_num - 1
+        if blk["up"]:
+            x = upscale_nn(x, 2)                     # model.py:36 / :78
+            x0 = x
+        cache["blocks"].append(blk)
+    cache["last_in"] = x; cache["last_ln"] = ln
+    out = conv_same(x, W(ln, "conv"), Bv(ln, "conv"))
+    return (out, cache) if keep else out
+
+
+def generator_bwd(dout, cache, p, name="G", leak=0.2):
+    """Manual reverse pass of :func:`generator_fwd`; returns grads keyed like ``p``."""
+    g = {}
+    ln = cache["last_ln"]
+    dx, dw, db = conv_same_bwd(cache["last_in"], p["%s/%d_conv/weights" % (name, ln)], dout)
+    g["%s/%d_conv/weights" % (name, ln)] = dw; g["%s/%d_conv/biases" % (name, ln)] = db
+    for blk in reversed(cache["blocks"]):
+        if blk["up"]:
+            dx = upscale_nn_bwd(dx, 2)
+        dy = dx
+        for xin, xout, l in zip(reversed(blk["ins"]), reversed(blk["outs"]), reversed(blk["ln"])):
+            dpre = dx * np.where(xout > 0, 1.0, leak).astype(dx.dtype)
+            dx, dw, db = conv_same_bwd(xin, p["%s/%d_conv/weights" % (name, l)], dpre)
+            g["%s/%d_conv/weights" % (name, l)] = dw; g["%s/%d_conv/biases" % (name, l)] = db
+        dx = dx + dy
+    d2 = dx.reshape(dx.shape[0], -1)
+    g["%s/0_fc/weights" % name] = np.asarray(cache["z"]).T @ d2
+    g["%s/0_fc/biases" % name] = d2.sum(axis=0)
+    return g
+
+
+# ----------------------------------------------------------------------------------------
+# Train step (trainer.py:136-184, trainer3.py:14-63) + TF1 Adam + LR schedule
+# ----------------------------------------------------------------------------------------
+
+def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, need_grad=True):
+    """G_ = curl(psi) | jacobian3(psi)[1];  loss = w1*mean|G_-x| + w2*mean|J(G_)-J(x)|.
+    Returns dict(loss, l1, j_l1, u, dpsi)."""
+    if is_3d:
+        u = curl3(psi); ju, _ = jacobian3(u); jx, _ = jacobian3(x)
+    else:
+        u = curl(psi); ju, _ = jacobian(u); jx, _ = jacobian(x)
+    l1 = l1_mean(u, x); jl1 = l1_mean(ju, jx)
+    res = {"loss": w1 * l1 + w2 * jl1, "l1": l1, "j_l1": jl1, "u": u, "ju": ju, "jx": jx}
+    if need_grad:
+        du = l1_mean_bwd(u, x, w1)
+        dj = l1_mean_bwd(ju, jx, w2)
+        if is_3d:
+            du = du + jacobian3_bwd(gj=dj)
+            res["dpsi"] = jacobian3_bwd(gc=du)
+        else:
+            du = du + jacobian_bwd(dj)
+            res["dpsi"] = curl_bwd(du)
+    return res
+
+
+def adam_tf1(p, g, m, v, t, lr, beta1=0.5, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer update: lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+    theta -= lr_t * m / (sqrt(v) + eps)  ("epsilon-hat" form).  ``t`` is the 1-based step."""
+    lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    p = p - lr_t * m / (np.sqrt(v) + eps)
+    return p, m, v
+
+
+def lr_cosine(step, max_step, lr_max=1e-4, lr_min=2.5e-6):
+    """trainer.py:74-75: assigned AFTER each step with the already-incremented step."""
+    return lr_min + 0.5 * (lr_max - lr_min) * (math.cos(step * math.pi / max_step) + 1.0)
+
+
+def train_step(z, x, p, opt, output_shape, filters, is_3d, num_conv=4, repeat=0, w1=1.0, w2=1.0,
+               name="G"):
+    """One full step: G fwd -> curl -> Jacobian -> L1 losses -> bwd -> TF1 Adam (in place on
+    copies).  ``opt`` = dict(m, v, t, lr).  Returns (new_p, new_opt, info)."""
+    psi, cache = generator_fwd(z, p, output_shape, filters, name, num_conv, repeat, keep=True)
+    res = velocity_loss(psi, x, is_3d, w1, w2)
+    grads = generator_bwd(res["dpsi"], cache, p, name)
+    t = opt["t"] + 1
+    new_p, new_m, new_v = {}, {}, {}
+    for k in p:
+        new_p[k], new_m[k], new_v[k] = adam_tf1(p[k], grads[k], opt["m"][k], opt["v"][k], t, opt["lr"])
+    info = {k: res[k] for k in ("loss", "l1", "j_l1", "u")}
+    info["psi"] = psi; info["grads"] = grads
+    return new_p, {"m": new_m, "v": new_v, "t": t, "lr": opt["lr"]}, info
+
+
+# ----------------------------------------------------------------------------------------
+# Synthetic inputs
+# ----------------------------------------------------------------------------------------
+
+def synthetic_batch(rng, batch, spatial, c_num=3):
+    """y ~ U(-1,1) [B,c_num];  x = curl(psi_gt) rescaled to max|x| = 1 (divergence-free,
+    in [-1,1] like the reference's normalised data, data.py:87-88,329)."""
+    is_3d = len(spatial) == 3
+    y = rng.uniform(-1, 1, size=(batch, c_num)).astype(np.float32)
+    psi = rng.uniform(-1, 1, size=[batch] + list(spatial) + [3 if is_3d else 1]).astype(np.float32)
+    x = curl3(psi) if is_3d else curl(psi)
+    x = (x / np.abs(x).max()).astype(np.float32)
+    return x, y
