@@ -1,0 +1,91 @@
+"""ctypes binding of libdeepfluids_hip.so (the C-ABI declared in include/deepfluids_hip.h).
+
+There is NO fallback: if the HIP library is missing this module raises at import of the first
+symbol, and every compute entry point of the package goes through it.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdeepfluids_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "deepfluids_hip.h")
+
+P, I64, I32, F32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+# name -> (restype, argtypes)
+SIGNATURES = {
+    "df_version": (I32, []),
+    "df_last_error": (ctypes.c_char_p, []),
+    "df_curl2d_fwd": (I32, [P, P, I64, I64, I64, P]),
+    "df_curl2d_bwd": (I32, [P, P, I64, I64, I64, P]),
+    "df_jacobian2d_fwd": (I32, [P, P, P, I64, I64, I64, P]),
+    "df_jacobian2d_bwd": (I32, [P, P, P, I64, I64, I64, P]),
+    "df_jacobian3d_fwd": (I32, [P, P, P, I64, I64, I64, I64, P]),
+    "df_jacobian3d_bwd": (I32, [P, P, P, I64, I64, I64, I64, P]),
+    "df_divergence2d": (I32, [P, P, I64, I64, I64, P]),
+    "df_divergence3d": (I32, [P, P, I64, I64, I64, I64, P]),
+    "df_l1_mean_workspace_bytes": (I64, [I64]),
+    "df_l1_mean_fwd": (I32, [P, P, I64, P, P, I64, P]),
+    "df_l1_mean_bwd": (I32, [P, P, P, F32, P, I64, P]),
+    "df_lrelu_fwd": (I32, [P, P, F32, I64, P]),
+    "df_lrelu_bwd": (I32, [P, P, P, F32, I64, P]),
+    "df_add": (I32, [P, P, P, I64, P]),
+    "df_upsample2x_fwd": (I32, [P, P, I64, I64, I64, I64, I64, I32, P]),
+    "df_upsample2x_bwd": (I32, [P, P, I64, I64, I64, I64, I64, I32, P]),
+    "df_linear_fwd": (I32, [P, P, P, P, I64, I64, I64, P]),
+    "df_linear_bwd": (I32, [P, P, P, P, P, P, I64, I64, I64, P]),
+    "df_colsum_workspace_bytes": (I64, [I64, I64]),
+    "df_colsum": (I32, [P, P, I64, I64, P, I64, P]),
+    "df_adam_tf1_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, P]),
+    "df_conv_packed_elems": (I64, [I64, I64, I64, I32]),
+    "df_conv_pack_weights": (I32, [P, P, I64, I64, I64, I32, P]),
+    "df_conv_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),
+    "df_conv_wgrad_workspace_bytes": (I64, [I64, I64, I64, I64, I64, I64, I32]),
+    "df_conv_wgrad": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
+}
+
+DF_CONV_LRELU, DF_CONV_RESIDUAL, DF_CONV_MASK, DF_CONV_BIAS = 1, 2, 4, 8
+
+_lib = None
+
+
+class DeepFluidsHipError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every function the public header declares (used by the export test)."""
+    src = open(HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(df_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DeepFluidsHipError(
+                "libdeepfluids_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C deep_fluids_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning df_* entry point; raise with df_last_error() on failure."""
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if rc != 0:
+        msg = h.df_last_error()
+        raise DeepFluidsHipError("%s failed (%d): %s" % (name, rc, msg.decode() if msg else ""))
+
+
+def query(name, *args):
+    """Call a value-returning helper (workspace sizes, version)."""
+    return getattr(lib(), name)(*args)

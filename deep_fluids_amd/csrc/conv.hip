@@ -1,0 +1,314 @@
+// 3x3 / 3x3x3 SAME convolution, channels-last fp32, on the gfx950 matrix cores
+// (reference: slim.conv2d / slim.conv3d behind ops.py:12-16, called from model.py:26,42,68,84).
+//
+// Implicit GEMM   D[voxel][cout] = sum_{tap,cin} X[voxel + off(tap)][cin] * W[tap][cin][cout]
+// with v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 cycles per instruction per SIMD,
+// 157 TFLOP/s chip peak -- the reference computes in fp32, so does this path.
+//
+// Workgroup = 256 threads (4 waves) = one spatial tile of 128 output voxels (TZ x TY x TX) times an
+// N-tile of 32/64/128 output channels.  The K loop runs over chunks of 16 input channels:
+//   * A operand: the tile's HALO'd input block [TZ+kz-1][TY+2][TX+2][16ch] is staged once per chunk in
+//     LDS (zero-filled outside the image = SAME padding); all 9/27 taps then read it at constant
+//     offsets.  Row stride 20 floats: a wave's ds_read_b128 (lane = voxel, 4 consecutive channels)
+//     is bank-conflict-free (20/4 odd -> the 16 lanes of a b128 group hit 16 distinct 16-byte slots).
+//     Lanes 0-31 read channels c..c+3 and lanes 32-63 channels c+4..c+7 of their voxel, so ONE
+//     ds_read_b128 feeds FOUR MFMAs (k = lane>>5 selects the channel quad).
+//   * B operand: weights are re-packed once per update (df_conv_pack_weights) to
+//     Wp[tap][cin/8][half][cout][4] so that the same lane->k assignment is ONE coalesced 16-byte
+//     global load per four MFMAs, served from L2 (the whole filter bank is 1.7 MB);  no LDS, no
+//     barrier on the weight stream.
+//   => per wave and step: MB ds_read_b128 + NB global_load_dwordx4 for 4*MB*NB MFMAs (16 at 2x2),
+//      one barrier pair per 16-channel chunk (every 27*32 = 864 MFMAs per wave in 3-D).
+// Epilogue (fused): bias, lrelu, residual add, lrelu-backward mask (dgrad).
+// The dgrad is the same kernel on mirrored/transposed packed weights (mode 1).
+#include "df_common.hpp"
+
+namespace {
+
+using df::ceil_div;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int CK = 16;          // input channels per LDS chunk
+constexpr int LDS_STRIDE = 20;  // floats per staged voxel (16 + 4 pad)
+
+struct ConvArgs {
+  const float* x;
+  const f32x4* wp;
+  const float* bias;
+  const float* residual;
+  const float* mask_src;
+  float* y;
+  int B, D, H, W, Cin, Cout;
+  int Kpad, Npad;       // padded K (multiple of 16) and N (multiple of the N tile) of the packed weights
+  int nz, ny, nx;       // tiles per axis
+  int ntiles;
+  int flags;
+  float leak;
+};
+
+// ---- weight packing ---------------------------------------------------------------------------------
+// mode 0: Wp[tap][k8][half][n][s] = w[tap][k8*8+half*4+s][n]            (K = cin,  N = cout)
+// mode 1: Wp[tap][k8][half][n][s] = w[T-1-tap][n][k8*8+half*4+s]        (K = cout, N = cin; taps mirrored)
+__global__ __launch_bounds__(kThreads) void pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps,
+                                                        int cin, int cout, int Kpad, int Npad, int mode) {
+  const int64_t total = static_cast<int64_t>(taps) * Kpad * Npad;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int s = static_cast<int>(i & 3);
+    int64_t r = i >> 2;
+    const int n = static_cast<int>(r % Npad); r /= Npad;
+    const int half = static_cast<int>(r & 1); r >>= 1;
+    const int k8 = static_cast<int>(r % (Kpad / 8));
+    const int tap = static_cast<int>(r / (Kpad / 8));
+    const int k = k8 * 8 + half * 4 + s;
+    const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+    float v = 0.f;
+    if (k < K && n < N) {
+      v = mode == 0 ? w[(static_cast<int64_t>(tap) * cin + k) * cout + n]
+                    : w[(static_cast<int64_t>(taps - 1 - tap) * cin + n) * cout + k];
+    }
+    wp[i] = v;
+  }
+}
+
+inline int ntile_for(int64_t N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
+inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// ---- main kernel --------------------------------------------------------------------------------------
+template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, bool VEC>
+__global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
+  static_assert(TZ * TY * TX == 128 && WM * MB * 32 == 128 && WM * WN == 4, "tile shape");
+  constexpr int PZ = KZ / 2;
+  constexpr int HZ = TZ + KZ - 1, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  constexpr int NPIECE = HV * (CK / 4);
+  constexpr int NLOAD = (NPIECE + kThreads - 1) / kThreads;
+  constexpr int NTAP = KZ * 9;
+  constexpr int NTILE = WN * NB * 32;
+  __shared__ __attribute__((aligned(16))) float sA[HV * LDS_STRIDE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, r = lane & 31;
+
+  // XCD-aware, bijective tile mapping: workgroup b runs on XCD b % 8 (observed); give each XCD a contiguous
+  // run of tiles so that neighbouring tiles (which share halos) share an L2.  Speed only, never correctness.
+  int tile;
+  {
+    const int bid = blockIdx.x, q = a.ntiles >> 3, rem = a.ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int ix = tile % a.nx;
+  int t2 = tile / a.nx;
+  const int iy = t2 % a.ny; t2 /= a.ny;
+  const int iz = t2 % a.nz;
+  const int b = t2 / a.nz;
+  const int tz0 = iz * TZ, ty0 = iy * TY, tx0 = ix * TX;
+  const int n0 = blockIdx.y * NTILE;
+
+  // per-lane LDS index (16-byte units: 5 per staged voxel) of this lane's voxel row in each M block,
+  // at tap (0,0,0), channel quad `half`
+  const f32x4* sA4 = reinterpret_cast<const f32x4*>(sA);
+  constexpr int S4 = LDS_STRIDE / 4;
+  int aidx[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = (wm * MB + mb) * 32 + r;
+    const int lx = m % TX, ly = (m / TX) % TY, lz = m / (TX * TY);
+    aidx[mb] = ((lz * HY + ly) * HX + lx) * S4 + half;
+  }
+  // per-lane packed-weight pointers (float4 units): ((tapk8 * 2 + half) * Npad + col)
+  const int64_t bstep = 2LL * a.Npad;            // float4s per (tap,k8) record
+  const int K8 = a.Kpad >> 3;
+  const f32x4* bptr[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bptr[nb] = a.wp + static_cast<int64_t>(half) * a.Npad + n0 + (wn * NB + nb) * 32 + r;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.f;
+
+  const int nchunk = a.Kpad / CK;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    // ---- stage the halo'd input block of this 16-channel chunk ------------------------------------
+    float4 stg[NLOAD];
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int p = it * kThreads + tid;
+      const int hv = p >> 2, q = p & 3;
+      const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+      const int gz = tz0 + hz - PZ, gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+      const int ch = chunk * CK + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool inb = p < NPIECE && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      if (inb) {
+        const int64_t vox = ((static_cast<int64_t>(b) * a.D + gz) * a.H + gy) * a.W + gx;
+        const float* src = a.x + vox * a.Cin + ch;
+        if (VEC) {
+          if (ch < a.Cin) v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (ch + 0 < a.Cin) v.x = src[0];
+          if (ch + 1 < a.Cin) v.y = src[1];
+          if (ch + 2 < a.Cin) v.z = src[2];
+          if (ch + 3 < a.Cin) v.w = src[3];
+        }
+      }
+      stg[it] = v;
+    }
+    __syncthreads();   // every wave has finished reading the previous chunk
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int p = it * kThreads + tid;
+      if (p < NPIECE) *reinterpret_cast<float4*>(&sA[(p >> 2) * LDS_STRIDE + (p & 3) * 4]) = stg[it];
+    }
+    __syncthreads();
+
+    // ---- 9 / 27 taps x 2 channel-octets, software-pipelined by one step ---------------------------
+    const f32x4* bchunk[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bchunk[nb] = bptr[nb] + static_cast<int64_t>(chunk * 2) * bstep;
+    const int64_t tapstride = static_cast<int64_t>(K8) * bstep;
+
+    // A fragments: one step ahead (LDS);  B fragments: two steps ahead (L2), ring of three
+    f32x4 af[2][MB], bf[3][NB];
+    auto lds_a = [&](int step, f32x4 (&dst)[MB]) {
+      const int tap = step >> 1, c8 = step & 1;
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      const int toff = ((dz * HY + dy) * HX + dx) * S4 + c8 * 2;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) dst[mb] = sA4[aidx[mb] + toff];
+    };
+    auto glb_b = [&](int step, f32x4 (&dst)[NB]) {
+      const int tap = step >> 1, c8 = step & 1;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) dst[nb] = bchunk[nb][tap * tapstride + c8 * bstep];
+    };
+    glb_b(0, bf[0]);
+    glb_b(1, bf[1]);
+    lds_a(0, af[0]);
+
+#pragma unroll
+    for (int step = 0; step < NTAP * 2; ++step) {
+      const int ca = step & 1, cb = step % 3;
+      if (step + 2 < NTAP * 2) glb_b(step + 2, bf[(step + 2) % 3]);
+      if (step + 1 < NTAP * 2) lds_a(step + 1, af[ca ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetches at the head of the step
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ca][mb][s], bf[cb][nb][s], acc[mb][nb], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: D layout col = lane&31 (cout), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (voxel) ----------
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int col = n0 + (wn * NB + nb) * 32 + r;
+    const bool colok = col < a.Cout;
+    const float bv = (a.flags & DF_CONV_BIAS) && colok ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = (wm * MB + mb) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int lx = m % TX, ly = (m / TX) % TY, lz = m / (TX * TY);
+        const int gz = tz0 + lz, gy = ty0 + ly, gx = tx0 + lx;
+        if (colok && gz < a.D && gy < a.H && gx < a.W) {
+          const int64_t o = (((static_cast<int64_t>(b) * a.D + gz) * a.H + gy) * a.W + gx) * a.Cout + col;
+          float v = acc[mb][nb][e] + bv;
+          if (a.flags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
+          if (a.flags & DF_CONV_RESIDUAL) v += a.residual[o];
+          if (a.flags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
+          a.y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB>
+int launch(const ConvArgs& a_in, hipStream_t s) {
+  ConvArgs a = a_in;
+  a.nz = (int)ceil_div(a.D, TZ); a.ny = (int)ceil_div(a.H, TY); a.nx = (int)ceil_div(a.W, TX);
+  const int64_t nt = static_cast<int64_t>(a.B) * a.nz * a.ny * a.nx;
+  DF_REQUIRE(nt < (1LL << 31), DF_ESHAPE, "df_conv_fwd: too many tiles");
+  a.ntiles = (int)nt;
+  dim3 grid((unsigned)nt, (unsigned)(a.Npad / (WN * NB * 32)));
+  const bool vec = (a.Cin % 4 == 0) && df::aligned16(a.x);
+  if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, true>), grid, dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, false>), grid, dim3(kThreads), 0, s, a);
+  return df::launched("df_conv_fwd");
+}
+
+template <int KZ, int TZ, int TY, int TX>
+int launch_n(const ConvArgs& a, hipStream_t s) {
+  const int nt = ntile_for(a.Cout);
+  if (nt == 128) return launch<KZ, TZ, TY, TX, 2, 2, 2, 2>(a, s);
+  if (nt == 64) return launch<KZ, TZ, TY, TX, 2, 2, 2, 1>(a, s);
+  return launch<KZ, TZ, TY, TX, 4, 1, 1, 1>(a, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t df_conv_packed_elems(int64_t taps, int64_t cin, int64_t cout, int mode) {
+  const int64_t K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  return taps * round_up(K, CK) * round_up(N, ntile_for(N));
+}
+
+int df_conv_pack_weights(const float* w, float* wp, int64_t taps, int64_t cin, int64_t cout, int mode,
+                         df_stream_t stream) {
+  DF_REQUIRE(w && wp, DF_EINVAL, "df_conv_pack_weights: null pointer");
+  DF_REQUIRE((taps == 9 || taps == 27) && cin > 0 && cout > 0 && (mode == 0 || mode == 1), DF_EINVAL,
+             "df_conv_pack_weights: taps must be 9 or 27, mode 0|1");
+  const int64_t K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  const int Kpad = (int)round_up(K, CK), Npad = (int)round_up(N, ntile_for(N));
+  const int64_t total = taps * Kpad * Npad;
+  int64_t g = ceil_div(total, kThreads);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)g), dim3(kThreads), 0, df::as_stream(stream), w, wp, (int)taps, (int)cin,
+                     (int)cout, Kpad, Npad, mode);
+  return df::launched("df_conv_pack_weights");
+}
+
+int df_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
+                float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int flags,
+                float leak, df_stream_t stream) {
+  DF_REQUIRE(x && wp && y, DF_EINVAL, "df_conv_fwd: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_conv_fwd: non-positive extent");
+  DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_conv_fwd: kz must be 1 (2-D) or 3 (3-D)");
+  DF_REQUIRE(kz == 3 || D == 1, DF_ESHAPE, "df_conv_fwd: D must be 1 when kz == 1");
+  DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "df_conv_fwd: DF_CONV_BIAS without bias");
+  DF_REQUIRE(!(flags & DF_CONV_RESIDUAL) || residual, DF_EINVAL, "df_conv_fwd: DF_CONV_RESIDUAL without residual");
+  DF_REQUIRE(!(flags & DF_CONV_MASK) || mask_src, DF_EINVAL, "df_conv_fwd: DF_CONV_MASK without mask_src");
+  DF_REQUIRE(df::aligned16(wp), DF_EALIGN, "df_conv_fwd: packed weights must be 16-byte aligned");
+  DF_REQUIRE(B * D * H * W * (Cin > Cout ? Cin : Cout) < (1LL << 40), DF_ESHAPE, "df_conv_fwd: tensor too large");
+  ConvArgs a;
+  a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.bias = bias; a.residual = residual; a.mask_src = mask_src;
+  a.y = y;
+  a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.Kpad = (int)round_up(Cin, CK); a.Npad = (int)round_up(Cout, ntile_for(Cout));
+  a.flags = flags; a.leak = leak;
+  a.nz = a.ny = a.nx = a.ntiles = 0;
+  hipStream_t s = df::as_stream(stream);
+  if (kz == 3) {
+    if (W >= 12) return launch_n<3, 2, 4, 16>(a, s);
+    return launch_n<3, 4, 4, 8>(a, s);
+  }
+  if (W >= 12) return launch_n<1, 1, 8, 16>(a, s);
+  return launch_n<1, 1, 16, 8>(a, s);
+}
+
+}  // extern "C"

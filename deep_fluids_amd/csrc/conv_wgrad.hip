@@ -1,0 +1,316 @@
+// Weight gradient of the 3x3 / 3x3x3 SAME convolution on the gfx950 matrix cores (fp32-exact MFMA).
+// (reference: TF autodiff of slim.conv2d/conv3d, trainer.py:184 `minimize(g_loss, var_list=G_var)`.)
+//
+//   gW[tap][ci][co] = sum_voxels X[voxel + off(tap)][ci] * G[voxel][co]        (X zero outside the image)
+//
+// GEMM view: M = ci, N = co, K = voxels (millions) -> v_mfma_f32_32x32x2_f32 with k = 2 voxels per
+// instruction.  Both operands are "K-major rows" in channels-last memory (32 lanes x 8 bytes = one
+// contiguous 256-byte row segment per half-wave), so they go STRAIGHT from L1/L2 to the MFMA operand
+// registers: no LDS, no barriers, waves run free.
+//   * a wave owns a 64(ci) x 64(co) quadrant for the three dx taps of one (dz,dy): 12 accumulator
+//     tiles = 192 AGPRs; lane (half, r) holds ci = ci0+2r+{0,1} and co = co0+2r+{0,1} (float2 loads);
+//   * the two half-waves walk two different image rows along x; X positions x-1, x, x+1 come from an
+//     8-deep register ring (one new 8-byte load per step), G from a second ring; loads run 5-6 steps
+//     (~4000 cycles) ahead of their use, and the stream is continuous across row pairs;
+//   * per step and wave: 2 global_load_dwordx2 for 12 MFMAs (768 cycles);
+//   * workgroup = the four quadrants of 128x128; grid = (voxel ranges x (dz,dy)) x ci-blocks x co-blocks;
+//     each workgroup writes its partial [3][128][128] to the workspace, a second kernel reduces the
+//     ranges in a fixed order (deterministic), and also finishes the bias gradient sum_voxels G.
+#include "df_common.hpp"
+
+namespace {
+
+using df::ceil_div;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads = 256;
+constexpr int kMaxRanges = 128;
+
+struct WgradArgs {
+  const float* x;
+  const float* g;
+  float* partial;      // [nranges][taps][Cinp][Coutp]
+  float* bpartial;     // [nranges][Coutp]
+  const float* zeros;  // 64 zero bytes (in the workspace, cleared by a memset node ahead of the launch)
+  int B, D, H, W, Cin, Cout;
+  int Cinp, Coutp;     // padded to 128
+  int Wp;              // W rounded up to 8
+  int nrows, npairs, nranges, pairs_per_range;
+  int ndzdy;           // 9 (3-D) or 3 (2-D)
+  int want_bias;
+};
+
+template <bool XVEC, bool GVEC>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = wave >> 1, qj = wave & 1;
+  const int half = lane >> 5, r = lane & 31;
+
+  // workgroup -> (range, dzdy): XCD x gets a contiguous run of ranges, and the 9 (dz,dy) workgroups of one
+  // range are dispatched back-to-back on the same XCD so they share its L2 (speed only).
+  const int nwg = a.nranges * a.ndzdy;
+  int wg;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, rem = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int range = wg / a.ndzdy, dzdy = wg % a.ndzdy;
+  const int dz = a.ndzdy == 9 ? dzdy / 3 - 1 : 0;
+  const int dy = (a.ndzdy == 9 ? dzdy % 3 : dzdy) - 1;
+  const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
+  if (ci0 >= a.Cin || co0 >= a.Cout) return;   // wave-uniform: quadrant entirely in the padding
+
+  const int p0 = range * a.pairs_per_range;
+  int p1 = p0 + a.pairs_per_range;
+  if (p1 > a.npairs) p1 = a.npairs;
+
+  const int cia = ci0 + 2 * r, coa = co0 + 2 * r;   // this lane's first ci / co
+  const bool ci_ok0 = cia < a.Cin, ci_ok1 = cia + 1 < a.Cin;
+  const bool co_ok0 = coa < a.Cout, co_ok1 = coa + 1 < a.Cout;
+
+  // ---- row cursors.  EVERY load in the main loop is unconditional and its result is used as-is: lanes /
+  // positions / rows that must contribute zero (SAME padding, channel padding, range tail) read a zeroed
+  // 16-byte slot of the workspace instead (address select BEFORE the load).  A load inside a branch, or a
+  // select on the loaded value at load time, would make hipcc wait vmcnt(0) right there and serialise the ring.
+  const float* zb = a.zeros;
+  struct Row { const float* xb; const float* gb; bool xv; bool gv; };
+  auto row_setup = [&](int pair) -> Row {
+    Row rw;
+    const int row = 2 * pair + half;
+    const bool ok = pair < p1 && row < a.nrows;
+    const int y = row % a.H;
+    const int t = row / a.H;
+    const int z = t % a.D;
+    const int b = t / a.D;
+    const int zs = z + dz, ys = y + dy;
+    rw.gv = ok;
+    rw.xv = ok && zs >= 0 && zs < a.D && ys >= 0 && ys < a.H;
+    const int64_t gvox = ((static_cast<int64_t>(b) * a.D + z) * a.H + y) * a.W;
+    const int64_t xvox = ((static_cast<int64_t>(b) * a.D + zs) * a.H + ys) * a.W;
+    rw.gb = a.g + gvox * a.Cout + coa;
+    rw.xb = a.x + xvox * a.Cin + cia;
+    return rw;
+  };
+  // the empty asm makes the selected address opaque, so the compiler cannot turn `*(c ? p : z)` back into
+  // `c ? *p : *z` (two loads behind a divergent branch)
+  // (the select is done on an opaque OFFSET from the kernel-argument pointer so the access stays a global_load)
+  auto pick = [&](bool c, const float* p) -> const float* {
+    int64_t off = c ? p - a.x : zb - a.x;
+    asm("" : "+v"(off));
+    return a.x + off;
+  };
+  auto load_x = [&](const Row& rw, int pos) -> f32x2 {
+    const bool k = rw.xv && pos < a.W;
+    const float* p = rw.xb + static_cast<int64_t>(pos) * a.Cin;
+    f32x2 v;
+    if (XVEC) v = *reinterpret_cast<const f32x2*>(pick(k && ci_ok0, p));
+    else { v[0] = *pick(k && ci_ok0, p); v[1] = *pick(k && ci_ok1, p + 1); }
+    return v;
+  };
+  auto load_g = [&](const Row& rw, int pos) -> f32x2 {
+    const bool k = rw.gv && pos < a.W;
+    const float* p = rw.gb + static_cast<int64_t>(pos) * a.Cout;
+    f32x2 v;
+    if (GVEC) v = *reinterpret_cast<const f32x2*>(pick(k && co_ok0, p));
+    else { v[0] = *pick(k && co_ok0, p); v[1] = *pick(k && co_ok1, p + 1); }
+    return v;
+  };
+
+  f32x16 acc[3][2][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][s][t][e] = 0.f;
+  f32x2 bsum = {0.f, 0.f};
+  const bool do_bias = a.want_bias && dzdy == a.ndzdy / 2 && blockIdx.y == 0 && qi == 0;
+
+  // rings indexed by (position in row) % 8 (Wp % 8 == 0, so the index is continuous across rows);
+  // X holds positions x-1 .. x+6, G holds x .. x+5 relative to the compute cursor x
+  f32x2 xr[8], gr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { xr[i] = f32x2{0.f, 0.f}; gr[i] = f32x2{0.f, 0.f}; }
+  Row cur = row_setup(p0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) xr[i] = load_x(cur, i);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) gr[i] = load_g(cur, i);
+
+  auto step = [&](int u, int x) {
+    __builtin_amdgcn_sched_barrier(0);           // keep this step's two prefetch loads ahead of its MFMAs
+    f32x2 am = xr[(u + 7) & 7], a0 = xr[u], ap = xr[(u + 1) & 7];
+    const f32x2 b = gr[u];
+    if (x == 0) am = f32x2{0.f, 0.f};            // left zero padding (the ring slot holds the previous row's tail)
+    if (x == a.W - 1) ap = f32x2{0.f, 0.f};      // right zero padding (the ring slot may hold the next row's head)
+    bsum[0] += b[0]; bsum[1] += b[1];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[0][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(am[s], b[t], acc[0][s][t], 0, 0, 0);
+        acc[1][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b[t], acc[1][s][t], 0, 0, 0);
+        acc[2][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s], b[t], acc[2][s][t], 0, 0, 0);
+      }
+  };
+
+  for (int pair = p0; pair < p1; ++pair) {
+    const Row nxt = row_setup(pair + 1);
+    for (int x0 = 0; x0 < a.Wp - 8; x0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        xr[(u + 6) & 7] = load_x(cur, x0 + u + 6);
+        gr[(u + 5) & 7] = load_g(cur, x0 + u + 5);
+        step(u, x0 + u);
+      }
+    }
+    {   // last 8 positions of the row: the prefetch cursor crosses into the next row pair
+      const int x0 = a.Wp - 8;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        xr[(u + 6) & 7] = u < 2 ? load_x(cur, x0 + u + 6) : load_x(nxt, u - 2);
+        gr[(u + 5) & 7] = u < 3 ? load_g(cur, x0 + u + 5) : load_g(nxt, u - 3);
+        step(u, x0 + u);
+      }
+    }
+    cur = nxt;
+  }
+
+  // ---- write the partial: D layout col = r (co = co0+2r+t), row i = (e&3)+8(e>>2)+4*half (ci = ci0+2i+s) ------
+  const int taps = a.ndzdy * 3;
+  float* P = a.partial + static_cast<int64_t>(range) * taps * a.Cinp * a.Coutp;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int tap = dzdy * 3 + d;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int ci = ci0 + 2 * i + s, co = co0 + 2 * r + t;
+          P[(static_cast<int64_t>(tap) * a.Cinp + ci) * a.Coutp + co] = acc[d][s][t][e];
+        }
+  }
+  if (do_bias) {
+    bsum[0] += __shfl_xor(bsum[0], 32, 64);
+    bsum[1] += __shfl_xor(bsum[1], 32, 64);
+    if (half == 0) {
+      float* pb = a.bpartial + static_cast<int64_t>(range) * a.Coutp + co0 + 2 * r;
+      pb[0] = bsum[0]; pb[1] = bsum[1];
+    }
+  }
+}
+
+// gw[tap][ci][co] = sum_range partial[range][tap][ci][co]  (fixed order);  gb likewise
+__global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                                const float* __restrict__ bpartial,
+                                                                float* __restrict__ gw, float* __restrict__ gb,
+                                                                int nranges, int taps, int Cin, int Cout, int Cinp,
+                                                                int Coutp) {
+  const int64_t total = static_cast<int64_t>(taps) * Cin * Cout;
+  const int64_t pstride = static_cast<int64_t>(taps) * Cinp * Coutp;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int co = static_cast<int>(i % Cout);
+    const int64_t t2 = i / Cout;
+    const int ci = static_cast<int>(t2 % Cin);
+    const int tap = static_cast<int>(t2 / Cin);
+    const float* p = partial + (static_cast<int64_t>(tap) * Cinp + ci) * Coutp + co;
+    float acc = 0.f;
+    for (int rg = 0; rg < nranges; ++rg) acc += p[rg * pstride];
+    gw[i] = acc;
+  }
+  if (gb && blockIdx.x == 0) {
+    for (int co = threadIdx.x; co < Cout; co += kThreads) {
+      float acc = 0.f;
+      for (int rg = 0; rg < nranges; ++rg) acc += bpartial[static_cast<int64_t>(rg) * Coutp + co];
+      gb[co] = acc;
+    }
+  }
+}
+
+struct Plan {
+  int nrows, npairs, nranges, ppr, Cinp, Coutp, taps, ndzdy;
+  int64_t partial_elems, bpartial_elems;
+};
+
+Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
+  Plan p;
+  p.nrows = (int)(B * D * H);
+  p.npairs = (p.nrows + 1) / 2;
+  p.ndzdy = kz == 3 ? 9 : 3;
+  p.taps = p.ndzdy * 3;
+  // enough workgroups to fill 256 CUs x 2 twice over, but ranges long enough to amortise the 192-register epilogue
+  int want = (2 * 512 + p.ndzdy - 1) / p.ndzdy;
+  const int min_pairs = (int)ceil_div(2048, W);       // >= ~2k steps (~24k MFMAs) per workgroup
+  int maxr = p.npairs / (min_pairs > 0 ? min_pairs : 1);
+  if (maxr < 1) maxr = 1;
+  int nr = want < maxr ? want : maxr;
+  if (nr > kMaxRanges) nr = kMaxRanges;
+  p.ppr = (p.npairs + nr - 1) / nr;
+  p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
+  p.Cinp = (int)(ceil_div(Cin, 128) * 128);
+  p.Coutp = (int)(ceil_div(Cout, 128) * 128);
+  p.partial_elems = static_cast<int64_t>(p.nranges) * p.taps * p.Cinp * p.Coutp;
+  p.bpartial_elems = static_cast<int64_t>(p.nranges) * p.Coutp;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const Plan p = make_plan(B, D, H, W, Cin, Cout, kz);
+  return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + 64;
+}
+
+int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
+                  int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {
+  DF_REQUIRE(x && gy && gw && workspace, DF_EINVAL, "df_conv_wgrad: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_conv_wgrad: non-positive extent");
+  DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_conv_wgrad: kz must be 1 (2-D) or 3 (3-D)");
+  DF_REQUIRE(kz == 3 || D == 1, DF_ESHAPE, "df_conv_wgrad: D must be 1 when kz == 1");
+  DF_REQUIRE(B * D * H < (1LL << 30) && W < (1 << 24), DF_ESHAPE, "df_conv_wgrad: tensor too large");
+  DF_REQUIRE(df::aligned16(workspace), DF_EALIGN, "df_conv_wgrad: workspace must be 16-byte aligned");
+  DF_REQUIRE(workspace_bytes >= df_conv_wgrad_workspace_bytes(B, D, H, W, Cin, Cout, kz), DF_EWORKSPACE,
+             "df_conv_wgrad: workspace too small");
+  const Plan p = make_plan(B, D, H, W, Cin, Cout, kz);
+  WgradArgs a;
+  a.x = x; a.g = gy;
+  a.partial = static_cast<float*>(workspace);
+  a.bpartial = a.partial + p.partial_elems;
+  float* zeros = a.bpartial + p.bpartial_elems;
+  a.zeros = zeros;
+  a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.Cinp = p.Cinp; a.Coutp = p.Coutp;
+  a.Wp = (int)(ceil_div(W, 8) * 8);
+  a.nrows = p.nrows; a.npairs = p.npairs; a.nranges = p.nranges; a.pairs_per_range = p.ppr;
+  a.ndzdy = p.ndzdy; a.want_bias = gb != nullptr;
+  hipStream_t s = df::as_stream(stream);
+  if (hipError_t e = hipMemsetAsync(zeros, 0, 64, s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
+  dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)(p.Cinp / 128), (unsigned)(p.Coutp / 128));
+  const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
+  const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
+  if (xvec && gvec) hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(kThreads), 0, s, a);
+  else if (xvec) hipLaunchKernelGGL((wgrad_kernel<true, false>), grid, dim3(kThreads), 0, s, a);
+  else if (gvec) hipLaunchKernelGGL((wgrad_kernel<false, true>), grid, dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((wgrad_kernel<false, false>), grid, dim3(kThreads), 0, s, a);
+  const int64_t total = static_cast<int64_t>(p.taps) * Cin * Cout;
+  int64_t rg = ceil_div(total, kThreads);
+  if (rg > 2048) rg = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
+                     p.nranges, p.taps, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
+  return df::launched("df_conv_wgrad");
+}
+
+}  // extern "C"

@@ -1,0 +1,410 @@
+// HBM-bound small kernels of the train step: L1 losses (trainer.py:170-171), lrelu (ops.py:9-10),
+// residual add (model.py:35), nearest 2x up-sampling (ops.py:66-91), fully connected (ops.py:23-24),
+// bias-gradient column sums, TF1 Adam (trainer.py:160-162).  All fp32, float4-vectorised where the
+// layout allows, grid-stride over at most 2048 workgroups (8 per CU).
+#include "df_common.hpp"
+
+namespace {
+
+using df::ceil_div;
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 2048;
+
+inline unsigned grid_for(int64_t work_items) {
+  int64_t g = ceil_div(work_items, kThreads);
+  return static_cast<unsigned>(g < 1 ? 1 : (g > kMaxBlocks ? kMaxBlocks : g));
+}
+
+// ---- block reduction: wave shuffle -> LDS -> first wave ------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double part[kThreads / 64];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) part[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (wid == 0) {
+    r = lane < kThreads / 64 ? part[lane] : 0.0;
+    r = wave_sum(r);
+  }
+  __syncthreads();
+  return r;   // valid in thread 0
+}
+
+// ---- L1 mean --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              int64_t n, double* __restrict__ partial) {
+  const int64_t n4 = n >> 2;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  float acc = 0.f;   // per-thread fp32 partial over <= a few thousand terms, promoted to fp64 below
+  double dacc = 0.0;
+  int cnt = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const float4 p = a4[i], q = b4[i];
+    acc += (fabsf(p.x - q.x) + fabsf(p.y - q.y)) + (fabsf(p.z - q.z) + fabsf(p.w - q.w));
+    if (++cnt == 64) { dacc += acc; acc = 0.f; cnt = 0; }
+  }
+  dacc += acc;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dacc += fabsf(a[(n4 << 2) + threadIdx.x] - b[(n4 << 2) + threadIdx.x]);
+  const double s = block_sum(dacc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kThreads) void l1_final_kernel(const double* __restrict__ partial, int nparts, double inv_n,
+                                                            float* __restrict__ out) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kThreads) v += partial[i];
+  const double s = block_sum(v);
+  if (threadIdx.x == 0) out[0] = static_cast<float>(s * inv_n);
+}
+
+__device__ __forceinline__ float sgn(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(kThreads) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ gout, float scale,
+                                                          float* __restrict__ ga, int64_t n) {
+  const float s = scale * (gout ? gout[0] : 1.f);
+  const int64_t n4 = n >> 2;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  float4* g4 = reinterpret_cast<float4*>(ga);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const float4 p = a4[i], q = b4[i];
+    float4 r;
+    r.x = sgn(p.x - q.x) * s; r.y = sgn(p.y - q.y) * s; r.z = sgn(p.z - q.z) * s; r.w = sgn(p.w - q.w) * s;
+    g4[i] = r;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    ga[i] = sgn(a[i] - b[i]) * s;
+  }
+}
+
+// ---- lrelu / add ----------------------------------------------------------------------------------
+template <int OP>   // 0: lrelu fwd (a=x)  1: lrelu bwd (a=gy, b=y)  2: add
+__global__ __launch_bounds__(kThreads) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ y, float leak, int64_t n) {
+  auto f = [&](float p, float q) -> float {
+    if (OP == 0) return fmaxf(p, leak * p);
+    if (OP == 1) return q > 0.f ? p : leak * p;
+    return p + q;
+  };
+  const int64_t n4 = n >> 2;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const float4 p = a4[i];
+    float4 q = p;
+    if (OP != 0) q = b4[i];
+    float4 r;
+    r.x = f(p.x, q.x); r.y = f(p.y, q.y); r.z = f(p.z, q.z); r.w = f(p.w, q.w);
+    y4[i] = r;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    y[i] = f(a[i], OP != 0 ? b[i] : 0.f);
+  }
+}
+
+// ---- nearest 2x up-sampling -----------------------------------------------------------------------
+// one thread per float4 of the SOURCE; it writes the 4 (2-D) or 8 (3-D) destination copies.
+template <bool IS3D>
+__global__ __launch_bounds__(kThreads) void upsample_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y,
+                                                                int64_t nsrc4, int D, int H, int W, int C4) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < nsrc4;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % C4);
+    int64_t r = i / C4;
+    const int w = static_cast<int>(r % W); r /= W;
+    const int h = static_cast<int>(r % H); r /= H;
+    const int d = static_cast<int>(r % D);
+    const int64_t b = r / D;
+    const float4 val = x[i];
+    const int64_t W2 = 2 * W, H2 = 2 * H;
+    const int64_t D2 = IS3D ? 2 * D : 1;
+    const int nd = IS3D ? 2 : 1;
+    for (int dz = 0; dz < nd; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int64_t zz = IS3D ? 2 * d + dz : 0;
+          const int64_t o = (((b * D2 + zz) * H2 + (2 * h + dy)) * W2 + (2 * w + dx)) * C4 + c;
+          y[o] = val;
+        }
+  }
+}
+
+template <bool IS3D>
+__global__ __launch_bounds__(kThreads) void upsample_bwd_kernel(const float4* __restrict__ gy, float4* __restrict__ gx,
+                                                                int64_t nsrc4, int D, int H, int W, int C4) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < nsrc4;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % C4);
+    int64_t r = i / C4;
+    const int w = static_cast<int>(r % W); r /= W;
+    const int h = static_cast<int>(r % H); r /= H;
+    const int d = static_cast<int>(r % D);
+    const int64_t b = r / D;
+    const int64_t W2 = 2 * W, H2 = 2 * H;
+    const int64_t D2 = IS3D ? 2 * D : 1;
+    const int nd = IS3D ? 2 : 1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // summation order (dz, dy, dx) ascending == the oracle's reshape(...).sum(axes) pairwise-free order
+    for (int dz = 0; dz < nd; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int64_t zz = IS3D ? 2 * d + dz : 0;
+          const float4 g = gy[(((b * D2 + zz) * H2 + (2 * h + dy)) * W2 + (2 * w + dx)) * C4 + c];
+          acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        }
+    gx[i] = acc;
+  }
+}
+
+// ---- fully connected with tiny K (K = c_num = 3 in the generator; 16 in the AE decoder) -----------
+__global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int B, int K, int64_t N) {
+  // grid.y = batch row; thread -> output column (coalesced over N)
+  const int b = blockIdx.y;
+  for (int64_t n = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; n < N;
+       n += static_cast<int64_t>(gridDim.x) * kThreads) {
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(x[b * K + k], w[k * N + n], acc);
+    y[b * N + n] = bias ? acc + bias[n] : acc;
+  }
+}
+
+// gw[k][n] = sum_b x[b][k] gy[b][n];  gb[n] = sum_b gy[b][n]   (thread per column n, loop over b: coalesced)
+__global__ __launch_bounds__(kThreads) void linear_bwd_w_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ gy, float* __restrict__ gw,
+                                                                float* __restrict__ gb, int B, int K, int64_t N) {
+  const int k = blockIdx.y;   // k == K -> bias row
+  for (int64_t n = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; n < N;
+       n += static_cast<int64_t>(gridDim.x) * kThreads) {
+    float acc = 0.f;
+    if (k < K) {
+      for (int b = 0; b < B; ++b) acc = fmaf(x[b * K + k], gy[b * N + n], acc);
+      if (gw) gw[k * N + n] = acc;
+    } else {
+      for (int b = 0; b < B; ++b) acc += gy[b * N + n];
+      if (gb) gb[n] = acc;
+    }
+  }
+}
+
+// gx[b][k] = sum_n gy[b][n] w[k][n]   (one workgroup per (b,k); only used when the FC input needs a gradient)
+__global__ __launch_bounds__(kThreads) void linear_bwd_x_kernel(const float* __restrict__ gy,
+                                                                const float* __restrict__ w, float* __restrict__ gx,
+                                                                int K, int64_t N) {
+  const int b = blockIdx.y, k = blockIdx.x;
+  double acc = 0.0;
+  for (int64_t n = threadIdx.x; n < N; n += kThreads) acc += static_cast<double>(gy[b * N + n]) * w[k * N + n];
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) gx[b * K + k] = static_cast<float>(s);
+}
+
+// ---- column sums (bias gradient of a channels-last conv) -------------------------------------------
+// stage 1: workgroup `g` sums rows [g*R, (g+1)*R) of g[rows, C] into partial[g][C] (thread per column, coalesced);
+// stage 2: sums the partials in fp64.  Deterministic.
+constexpr int kColsumRows = 512;
+__global__ __launch_bounds__(kThreads) void colsum_partial_kernel(const float* __restrict__ g, float* __restrict__ partial,
+                                                                  int64_t rows, int C) {
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kColsumRows;
+  const int64_t r1 = r0 + kColsumRows < rows ? r0 + kColsumRows : rows;
+  for (int c = threadIdx.x; c < C; c += kThreads) {
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) acc += g[r * C + c];
+    partial[static_cast<int64_t>(blockIdx.x) * C + c] = acc;
+  }
+}
+__global__ __launch_bounds__(kThreads) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ gb,
+                                                                int64_t nparts, int C) {
+  // one workgroup per column; threads stride over the partials
+  const int c = blockIdx.x;
+  double acc = 0.0;
+  for (int64_t p = threadIdx.x; p < nparts; p += kThreads) acc += partial[p * C + c];
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) gb[c] = static_cast<float>(s);
+}
+
+// ---- TF1 Adam ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                        float lr_t, float b1, float b2, float eps, float gscale) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+int check_n(const void* a, int64_t n, const char* fn) {
+  DF_REQUIRE(a != nullptr, DF_EINVAL, "%s: null pointer", fn);
+  DF_REQUIRE(n > 0, DF_EINVAL, "%s: n must be positive", fn);
+  return DF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t df_l1_mean_workspace_bytes(int64_t n) { (void)n; return static_cast<int64_t>(kMaxBlocks) * sizeof(double); }
+
+int df_l1_mean_fwd(const float* a, const float* b, int64_t n, float* out, void* workspace, int64_t workspace_bytes,
+                   df_stream_t stream) {
+  if (int e = check_n(a, n, "df_l1_mean_fwd")) return e;
+  DF_REQUIRE(b && out && workspace, DF_EINVAL, "df_l1_mean_fwd: null pointer");
+  DF_REQUIRE(df::aligned16(a) && df::aligned16(b), DF_EALIGN, "df_l1_mean_fwd: inputs must be 16-byte aligned");
+  DF_REQUIRE(workspace_bytes >= df_l1_mean_workspace_bytes(n), DF_EWORKSPACE, "df_l1_mean_fwd: workspace too small");
+  const unsigned grid = grid_for(ceil_div(n, 4 * 8));
+  hipStream_t s = df::as_stream(stream);
+  double* part = static_cast<double*>(workspace);
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(grid), dim3(kThreads), 0, s, a, b, n, part);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(kThreads), 0, s, part, (int)grid, 1.0 / static_cast<double>(n), out);
+  return df::launched("df_l1_mean_fwd");
+}
+
+int df_l1_mean_bwd(const float* a, const float* b, const float* gout, float scale, float* ga, int64_t n,
+                   df_stream_t stream) {
+  if (int e = check_n(a, n, "df_l1_mean_bwd")) return e;
+  DF_REQUIRE(b && ga, DF_EINVAL, "df_l1_mean_bwd: null pointer");
+  DF_REQUIRE(df::aligned16(a) && df::aligned16(b) && df::aligned16(ga), DF_EALIGN, "df_l1_mean_bwd: 16-byte alignment");
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(ceil_div(n, 4))), dim3(kThreads), 0, df::as_stream(stream), a, b, gout,
+                     scale / static_cast<float>(n), ga, n);
+  return df::launched("df_l1_mean_bwd");
+}
+
+int df_lrelu_fwd(const float* x, float* y, float leak, int64_t n, df_stream_t stream) {
+  if (int e = check_n(x, n, "df_lrelu_fwd")) return e;
+  DF_REQUIRE(y, DF_EINVAL, "df_lrelu_fwd: null output");
+  DF_REQUIRE(df::aligned16(x) && df::aligned16(y), DF_EALIGN, "df_lrelu_fwd: 16-byte alignment");
+  hipLaunchKernelGGL((ew_kernel<0>), dim3(grid_for(ceil_div(n, 4))), dim3(kThreads), 0, df::as_stream(stream), x, x, y,
+                     leak, n);
+  return df::launched("df_lrelu_fwd");
+}
+
+int df_lrelu_bwd(const float* gy, const float* y, float* gx, float leak, int64_t n, df_stream_t stream) {
+  if (int e = check_n(gy, n, "df_lrelu_bwd")) return e;
+  DF_REQUIRE(y && gx, DF_EINVAL, "df_lrelu_bwd: null pointer");
+  DF_REQUIRE(df::aligned16(gy) && df::aligned16(y) && df::aligned16(gx), DF_EALIGN, "df_lrelu_bwd: 16-byte alignment");
+  hipLaunchKernelGGL((ew_kernel<1>), dim3(grid_for(ceil_div(n, 4))), dim3(kThreads), 0, df::as_stream(stream), gy, y,
+                     gx, leak, n);
+  return df::launched("df_lrelu_bwd");
+}
+
+int df_add(const float* a, const float* b, float* y, int64_t n, df_stream_t stream) {
+  if (int e = check_n(a, n, "df_add")) return e;
+  DF_REQUIRE(b && y, DF_EINVAL, "df_add: null pointer");
+  DF_REQUIRE(df::aligned16(a) && df::aligned16(b) && df::aligned16(y), DF_EALIGN, "df_add: 16-byte alignment");
+  hipLaunchKernelGGL((ew_kernel<2>), dim3(grid_for(ceil_div(n, 4))), dim3(kThreads), 0, df::as_stream(stream), a, b, y,
+                     0.f, n);
+  return df::launched("df_add");
+}
+
+int df_upsample2x_fwd(const float* x, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
+                      df_stream_t stream) {
+  DF_REQUIRE(x && y, DF_EINVAL, "df_upsample2x_fwd: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, DF_EINVAL, "df_upsample2x_fwd: non-positive extent");
+  DF_REQUIRE(C % 4 == 0, DF_ESHAPE, "df_upsample2x_fwd: C must be a multiple of 4 (got %lld)", (long long)C);
+  DF_REQUIRE(is_3d || D == 1, DF_ESHAPE, "df_upsample2x_fwd: D must be 1 for 2-D");
+  DF_REQUIRE(df::aligned16(x) && df::aligned16(y), DF_EALIGN, "df_upsample2x_fwd: 16-byte alignment");
+  const int64_t n4 = B * D * H * W * (C / 4);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  if (is_3d)
+    hipLaunchKernelGGL((upsample_fwd_kernel<true>), dim3(grid_for(n4)), dim3(kThreads), 0, df::as_stream(stream), x4, y4,
+                       n4, (int)D, (int)H, (int)W, (int)(C / 4));
+  else
+    hipLaunchKernelGGL((upsample_fwd_kernel<false>), dim3(grid_for(n4)), dim3(kThreads), 0, df::as_stream(stream), x4, y4,
+                       n4, (int)D, (int)H, (int)W, (int)(C / 4));
+  return df::launched("df_upsample2x_fwd");
+}
+
+int df_upsample2x_bwd(const float* gy, float* gx, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
+                      df_stream_t stream) {
+  DF_REQUIRE(gy && gx, DF_EINVAL, "df_upsample2x_bwd: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, DF_EINVAL, "df_upsample2x_bwd: non-positive extent");
+  DF_REQUIRE(C % 4 == 0, DF_ESHAPE, "df_upsample2x_bwd: C must be a multiple of 4 (got %lld)", (long long)C);
+  DF_REQUIRE(is_3d || D == 1, DF_ESHAPE, "df_upsample2x_bwd: D must be 1 for 2-D");
+  DF_REQUIRE(df::aligned16(gy) && df::aligned16(gx), DF_EALIGN, "df_upsample2x_bwd: 16-byte alignment");
+  const int64_t n4 = B * D * H * W * (C / 4);
+  const float4* g4 = reinterpret_cast<const float4*>(gy);
+  float4* x4 = reinterpret_cast<float4*>(gx);
+  if (is_3d)
+    hipLaunchKernelGGL((upsample_bwd_kernel<true>), dim3(grid_for(n4)), dim3(kThreads), 0, df::as_stream(stream), g4, x4,
+                       n4, (int)D, (int)H, (int)W, (int)(C / 4));
+  else
+    hipLaunchKernelGGL((upsample_bwd_kernel<false>), dim3(grid_for(n4)), dim3(kThreads), 0, df::as_stream(stream), g4, x4,
+                       n4, (int)D, (int)H, (int)W, (int)(C / 4));
+  return df::launched("df_upsample2x_bwd");
+}
+
+int df_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t K, int64_t N,
+                  df_stream_t stream) {
+  DF_REQUIRE(x && w && y, DF_EINVAL, "df_linear_fwd: null pointer");
+  DF_REQUIRE(B > 0 && K > 0 && N > 0 && B < 65536, DF_EINVAL, "df_linear_fwd: bad extent");
+  dim3 grid(grid_for(N), (unsigned)B);
+  hipLaunchKernelGGL(linear_fwd_kernel, grid, dim3(kThreads), 0, df::as_stream(stream), x, w, bias, y, (int)B, (int)K, N);
+  return df::launched("df_linear_fwd");
+}
+
+int df_linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int64_t B,
+                  int64_t K, int64_t N, df_stream_t stream) {
+  DF_REQUIRE(x && w && gy, DF_EINVAL, "df_linear_bwd: null pointer");
+  DF_REQUIRE(B > 0 && K > 0 && N > 0 && B < 65536 && K < 65535, DF_EINVAL, "df_linear_bwd: bad extent");
+  hipStream_t s = df::as_stream(stream);
+  if (gw || gb) {
+    dim3 grid(grid_for(N), (unsigned)(K + 1));
+    hipLaunchKernelGGL(linear_bwd_w_kernel, grid, dim3(kThreads), 0, s, x, gy, gw, gb, (int)B, (int)K, N);
+  }
+  if (gx) {
+    dim3 grid((unsigned)K, (unsigned)B);
+    hipLaunchKernelGGL(linear_bwd_x_kernel, grid, dim3(kThreads), 0, s, gy, w, gx, (int)K, N);
+  }
+  return df::launched("df_linear_bwd");
+}
+
+int64_t df_colsum_workspace_bytes(int64_t rows, int64_t C) {
+  return ceil_div(rows, kColsumRows) * C * static_cast<int64_t>(sizeof(float));
+}
+
+int df_colsum(const float* g, float* gb, int64_t rows, int64_t C, void* workspace, int64_t workspace_bytes,
+              df_stream_t stream) {
+  DF_REQUIRE(g && gb && workspace, DF_EINVAL, "df_colsum: null pointer");
+  DF_REQUIRE(rows > 0 && C > 0 && C < (1 << 20), DF_EINVAL, "df_colsum: bad extent");
+  DF_REQUIRE(workspace_bytes >= df_colsum_workspace_bytes(rows, C), DF_EWORKSPACE, "df_colsum: workspace too small");
+  const int64_t nparts = ceil_div(rows, kColsumRows);
+  hipStream_t s = df::as_stream(stream);
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nparts), dim3(kThreads), 0, s, g, part, rows, (int)C);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)C), dim3(kThreads), 0, s, part, gb, nparts, (int)C);
+  return df::launched("df_colsum");
+}
+
+int df_adam_tf1_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                     float eps, float grad_scale, df_stream_t stream) {
+  if (int e = check_n(p, n, "df_adam_tf1_step")) return e;
+  DF_REQUIRE(g && m && v, DF_EINVAL, "df_adam_tf1_step: null pointer");
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(kThreads), 0, df::as_stream(stream), p, g, m, v, n, lr_t, beta1,
+                     beta2, eps, grad_scale);
+  return df::launched("df_adam_tf1_step");
+}
+
+}  // extern "C"

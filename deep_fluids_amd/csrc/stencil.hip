@@ -1,0 +1,395 @@
+// Forward-difference stencils of the Deep Fluids velocity field (reference ops.py:205-290),
+// written for gfx950: HBM-bound kernels, 64-wide wavefronts, fully coalesced 16-byte stores.
+//
+//   D_a f[i] = f[i+1] - f[i]  (i <= n-2),   D_a f[n-1] = D_a f[n-2]      (the DIFFERENCE is replicated)
+//
+// Data layout: channels-last fp32, x fastest: neighbour strides in voxels are 1 (x), X (y), X*Y (z).
+//
+// jacobian3d_fwd (the >= 70 %-of-HBM-roofline target, 60 B/voxel algorithmic: 12 in + 36 j + 12 c):
+//   one workgroup = 1024 consecutive voxels (4 per thread, lane-consecutive so the three-float
+//   voxel records of a wave form one contiguous 768-byte span per load);  the own record and the
+//   three forward (or, on a boundary, backward) neighbour records come straight from L1/L2 -- the
+//   y/z neighbours were or will be some other workgroup's "own" records, so HBM sees each input byte
+//   once;  the 9+3 results per voxel are transposed through LDS (stride-9 / stride-3 dword writes are
+//   bank-conflict-free, the read-back is ds_read_b128) so that every global store instruction of a
+//   wave writes 1 KiB of contiguous output.
+#include "df_common.hpp"
+
+namespace {
+
+using df::ceil_div;
+
+constexpr int kThreads = 256;
+constexpr int kVoxPerThread = 4;
+constexpr int kVoxPerBlock = kThreads * kVoxPerThread;   // 1024
+
+struct Dims3 {
+  int64_t nvox;   // B*Z*Y*X
+  int Z, Y, X;
+};
+
+// forward difference of one 3-float record along one axis with the replicate-the-difference rule
+__device__ __forceinline__ void diff3(const float* __restrict__ x, int64_t v, int64_t stride, bool last,
+                                      const float (&own)[3], float (&d)[3]) {
+  const int64_t nb = last ? v - stride : v + stride;
+  const float* p = x + nb * 3;
+  const float n0 = p[0], n1 = p[1], n2 = p[2];
+  d[0] = last ? own[0] - n0 : n0 - own[0];
+  d[1] = last ? own[1] - n1 : n1 - own[1];
+  d[2] = last ? own[2] - n2 : n2 - own[2];
+}
+
+// copy `nfloats` floats from LDS (16-byte aligned) to global `dst` (16-byte aligned base) with
+// 16-byte stores; the ragged tail (only in the last workgroup) falls back to dword stores.
+template <bool NT>
+__device__ __forceinline__ void flush_lds(const float* __restrict__ s, float* __restrict__ dst, int64_t nfloats,
+                                          int tid) {
+  const int64_t nq = nfloats >> 2;
+  const float4* s4 = reinterpret_cast<const float4*>(s);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  for (int64_t q = tid; q < nq; q += kThreads) {
+    float4 val = s4[q];
+    if (NT) {
+      __builtin_nontemporal_store(val.x, &dst[q * 4 + 0]);
+      __builtin_nontemporal_store(val.y, &dst[q * 4 + 1]);
+      __builtin_nontemporal_store(val.z, &dst[q * 4 + 2]);
+      __builtin_nontemporal_store(val.w, &dst[q * 4 + 3]);
+    } else {
+      d4[q] = val;
+    }
+  }
+  const int64_t done = nq << 2;
+  if (tid < nfloats - done) dst[done + tid] = s[done + tid];
+}
+
+template <bool WJ, bool WC>
+__global__ __launch_bounds__(kThreads) void jacobian3d_fwd_kernel(const float* __restrict__ x, float* __restrict__ j,
+                                                                  float* __restrict__ c, Dims3 dm) {
+  __shared__ __attribute__((aligned(16))) float smem[(WJ ? kVoxPerBlock * 9 : 0) + (WC ? kVoxPerBlock * 3 : 0)];
+  float* sj = smem;
+  float* sc = smem + (WJ ? kVoxPerBlock * 9 : 0);
+  const int tid = threadIdx.x;
+  const int64_t v0 = static_cast<int64_t>(blockIdx.x) * kVoxPerBlock;
+  const int64_t sy = dm.X, sz = static_cast<int64_t>(dm.X) * dm.Y;
+
+#pragma unroll
+  for (int i = 0; i < kVoxPerThread; ++i) {
+    const int lv = i * kThreads + tid;
+    const int64_t v = v0 + lv;
+    if (v < dm.nvox) {
+      const int64_t row = v / dm.X;
+      const int xx = static_cast<int>(v - row * dm.X);
+      const int64_t slab = row / dm.Y;
+      const int yy = static_cast<int>(row - slab * dm.Y);
+      const int zz = static_cast<int>(slab % dm.Z);
+      const float* p = x + v * 3;
+      const float own[3] = {p[0], p[1], p[2]};
+      float dx[3], dy[3], dz[3];
+      diff3(x, v, 1, xx == dm.X - 1, own, dx);
+      diff3(x, v, sy, yy == dm.Y - 1, own, dy);
+      diff3(x, v, sz, zz == dm.Z - 1, own, dz);
+      if (WJ) {
+        float* o = sj + lv * 9;      // (dudx,dudy,dudz, dvdx,dvdy,dvdz, dwdx,dwdy,dwdz)
+        o[0] = dx[0]; o[1] = dy[0]; o[2] = dz[0];
+        o[3] = dx[1]; o[4] = dy[1]; o[5] = dz[1];
+        o[6] = dx[2]; o[7] = dy[2]; o[8] = dz[2];
+      }
+      if (WC) {
+        float* o = sc + lv * 3;      // (dwdy-dvdz, dudz-dwdx, dvdx-dudy)
+        o[0] = dy[2] - dz[1];
+        o[1] = dz[0] - dx[2];
+        o[2] = dx[1] - dy[0];
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t left = dm.nvox - v0;
+  const int64_t nv = left < kVoxPerBlock ? left : kVoxPerBlock;
+  if (WJ) flush_lds<false>(sj, j + v0 * 9, nv * 9, tid);
+  if (WC) flush_lds<false>(sc, c + v0 * 3, nv * 3, tid);
+}
+
+// ---- adjoint helpers ---------------------------------------------------------------------------
+// out[k] of the adjoint of D along an axis of extent n, given a loader g(i) of the incoming gradient:
+//   gp[i] = g[i] (i < n-2), gp[n-2] = g[n-2] + g[n-1];  out[0] = -gp[0]; out[k] = gp[k-1]-gp[k]; out[n-1] = gp[n-2]
+template <typename G>
+__device__ __forceinline__ float adj_at(const G& g, int k, int n) {
+  auto gp = [&](int i) { return i == n - 2 ? g(i) + g(i + 1) : g(i); };
+  if (k == 0) return -gp(0);
+  if (k == n - 1) return gp(n - 2);
+  return gp(k - 1) - gp(k);
+}
+
+template <bool HJ, bool HC>
+__global__ __launch_bounds__(kThreads) void jacobian3d_bwd_kernel(const float* __restrict__ gj,
+                                                                  const float* __restrict__ gc,
+                                                                  float* __restrict__ gx, Dims3 dm) {
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (v >= dm.nvox) return;
+  const int64_t row = v / dm.X;
+  const int xx = static_cast<int>(v - row * dm.X);
+  const int64_t slab = row / dm.Y;
+  const int yy = static_cast<int>(row - slab * dm.Y);
+  const int zz = static_cast<int>(slab % dm.Z);
+  const int64_t sy = dm.X, sz = static_cast<int64_t>(dm.X) * dm.Y;
+  // G[comp][axis] at voxel w: the gradient w.r.t. D_axis(comp) after folding the curl terms
+  //   ux=j0  uy=j1-c2  uz=j2+c1 | vx=j3+c2  vy=j4  vz=j5-c0 | wx=j6-c1  wy=j7+c0  wz=j8
+  auto G = [&](int64_t w, int comp, int axis) -> float {
+    float r = 0.f;
+    if (HJ) r = gj[w * 9 + comp * 3 + axis];
+    if (HC) {
+      const float* q = gc + w * 3;
+      const int e = comp * 3 + axis;
+      if (e == 1) r -= q[2];
+      if (e == 2) r += q[1];
+      if (e == 3) r += q[2];
+      if (e == 5) r -= q[0];
+      if (e == 6) r -= q[1];
+      if (e == 7) r += q[0];
+    }
+    return r;
+  };
+  float out[3];
+#pragma unroll
+  for (int comp = 0; comp < 3; ++comp) {
+    const int64_t bx = v - xx, by = v - static_cast<int64_t>(yy) * sy, bz = v - static_cast<int64_t>(zz) * sz;
+    float acc = adj_at([&](int i) { return G(bx + i, comp, 0); }, xx, dm.X);
+    acc += adj_at([&](int i) { return G(by + static_cast<int64_t>(i) * sy, comp, 1); }, yy, dm.Y);
+    acc += adj_at([&](int i) { return G(bz + static_cast<int64_t>(i) * sz, comp, 2); }, zz, dm.Z);
+    out[comp] = acc;
+  }
+  float* o = gx + v * 3;
+  o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+}
+
+__global__ __launch_bounds__(kThreads) void divergence3d_kernel(const float* __restrict__ x, float* __restrict__ d,
+                                                                int64_t nout, int Z, int Y, int X) {
+  const int64_t o = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (o >= nout) return;
+  const int X1 = X - 1, Y1 = Y - 1, Z1 = Z - 1;
+  const int xx = static_cast<int>(o % X1);
+  const int64_t r = o / X1;
+  const int yy = static_cast<int>(r % Y1);
+  const int64_t s = r / Y1;
+  const int zz = static_cast<int>(s % Z1);
+  const int64_t b = s / Z1;
+  const int64_t v = ((b * Z + zz) * Y + yy) * X + xx;
+  const int64_t sy = X, sz = static_cast<int64_t>(X) * Y;
+  const float dudx = x[(v + 1) * 3 + 0] - x[v * 3 + 0];
+  const float dvdy = x[(v + sy) * 3 + 1] - x[v * 3 + 1];
+  const float dwdz = x[(v + sz) * 3 + 2] - x[v * 3 + 2];
+  d[o] = dudx + dvdy + dwdz;
+}
+
+// ---- 2-D ---------------------------------------------------------------------------------------
+struct Dims2 {
+  int64_t npix;
+  int Y, X;
+};
+
+__global__ __launch_bounds__(kThreads) void curl2d_fwd_kernel(const float* __restrict__ psi, float2* __restrict__ u,
+                                                              Dims2 dm) {
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (v >= dm.npix) return;
+  const int64_t row = v / dm.X;
+  const int xx = static_cast<int>(v - row * dm.X);
+  const int yy = static_cast<int>(row % dm.Y);
+  const float own = psi[v];
+  const bool ly = yy == dm.Y - 1, lx = xx == dm.X - 1;
+  const float ny = psi[ly ? v - dm.X : v + dm.X];
+  const float nx = psi[lx ? v - 1 : v + 1];
+  float2 r;
+  r.x = ly ? own - ny : ny - own;          //  D_y psi
+  r.y = lx ? nx - own : own - nx;          // -D_x psi   (ops.py:268: x[:,:,:-1] - x[:,:,1:])
+  u[v] = r;
+}
+
+__global__ __launch_bounds__(kThreads) void curl2d_bwd_kernel(const float* __restrict__ gu, float* __restrict__ gpsi,
+                                                              Dims2 dm) {
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (v >= dm.npix) return;
+  const int64_t row = v / dm.X;
+  const int xx = static_cast<int>(v - row * dm.X);
+  const int yy = static_cast<int>(row % dm.Y);
+  const int64_t bx = v - xx, by = v - static_cast<int64_t>(yy) * dm.X;
+  const float a = adj_at([&](int i) { return gu[(by + static_cast<int64_t>(i) * dm.X) * 2 + 0]; }, yy, dm.Y);
+  const float b = adj_at([&](int i) { return gu[(bx + i) * 2 + 1]; }, xx, dm.X);
+  gpsi[v] = a - b;
+}
+
+template <bool WJ, bool WW>
+__global__ __launch_bounds__(kThreads) void jacobian2d_fwd_kernel(const float2* __restrict__ x, float4* __restrict__ j,
+                                                                  float* __restrict__ w, Dims2 dm) {
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (v >= dm.npix) return;
+  const int64_t row = v / dm.X;
+  const int xx = static_cast<int>(v - row * dm.X);
+  const int yy = static_cast<int>(row % dm.Y);
+  const float2 own = x[v];
+  const bool ly = yy == dm.Y - 1, lx = xx == dm.X - 1;
+  const float2 ny = x[ly ? v - dm.X : v + dm.X];
+  const float2 nx = x[lx ? v - 1 : v + 1];
+  float4 r;
+  r.x = lx ? own.x - nx.x : nx.x - own.x;   // dudx
+  r.y = ly ? own.x - ny.x : ny.x - own.x;   // dudy
+  r.z = lx ? own.y - nx.y : nx.y - own.y;   // dvdx
+  r.w = ly ? own.y - ny.y : ny.y - own.y;   // dvdy
+  if (WJ) j[v] = r;
+  if (WW) w[v] = r.z - r.y;
+}
+
+template <bool HJ, bool HW>
+__global__ __launch_bounds__(kThreads) void jacobian2d_bwd_kernel(const float* __restrict__ gj,
+                                                                  const float* __restrict__ gw,
+                                                                  float2* __restrict__ gx, Dims2 dm) {
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (v >= dm.npix) return;
+  const int64_t row = v / dm.X;
+  const int xx = static_cast<int>(v - row * dm.X);
+  const int yy = static_cast<int>(row % dm.Y);
+  const int64_t bx = v - xx, by = v - static_cast<int64_t>(yy) * dm.X;
+  // G: ux=j0  uy=j1-w | vx=j2+w  vy=j3
+  auto G = [&](int64_t p, int e) -> float {
+    float r = 0.f;
+    if (HJ) r = gj[p * 4 + e];
+    if (HW) {
+      if (e == 1) r -= gw[p];
+      if (e == 2) r += gw[p];
+    }
+    return r;
+  };
+  float2 o;
+  o.x = adj_at([&](int i) { return G(bx + i, 0); }, xx, dm.X) +
+        adj_at([&](int i) { return G(by + static_cast<int64_t>(i) * dm.X, 1); }, yy, dm.Y);
+  o.y = adj_at([&](int i) { return G(bx + i, 2); }, xx, dm.X) +
+        adj_at([&](int i) { return G(by + static_cast<int64_t>(i) * dm.X, 3); }, yy, dm.Y);
+  gx[v] = o;
+}
+
+__global__ __launch_bounds__(kThreads) void divergence2d_kernel(const float* __restrict__ x, float* __restrict__ d,
+                                                                int64_t nout, int Y, int X) {
+  const int64_t o = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (o >= nout) return;
+  const int X1 = X - 1, Y1 = Y - 1;
+  const int xx = static_cast<int>(o % X1);
+  const int64_t r = o / X1;
+  const int yy = static_cast<int>(r % Y1);
+  const int64_t b = r / Y1;
+  const int64_t v = (b * Y + yy) * X + xx;
+  d[o] = (x[(v + 1) * 2 + 0] - x[v * 2 + 0]) + (x[(v + X) * 2 + 1] - x[v * 2 + 1]);
+}
+
+int check3(const void* in, int64_t B, int64_t Z, int64_t Y, int64_t X, const char* fn) {
+  DF_REQUIRE(in != nullptr, DF_EINVAL, "%s: null input", fn);
+  DF_REQUIRE(B > 0 && Z > 0 && Y > 0 && X > 0, DF_EINVAL, "%s: non-positive extent", fn);
+  DF_REQUIRE(Z >= 2 && Y >= 2 && X >= 2, DF_ESHAPE, "%s: forward difference needs every extent >= 2 (got %lld,%lld,%lld)",
+             fn, (long long)Z, (long long)Y, (long long)X);
+  DF_REQUIRE(Z < (1 << 30) && Y < (1 << 30) && X < (1 << 30), DF_ESHAPE, "%s: extent too large", fn);
+  return DF_OK;
+}
+int check2(const void* in, int64_t B, int64_t Y, int64_t X, const char* fn) {
+  DF_REQUIRE(in != nullptr, DF_EINVAL, "%s: null input", fn);
+  DF_REQUIRE(B > 0 && Y > 0 && X > 0, DF_EINVAL, "%s: non-positive extent", fn);
+  DF_REQUIRE(Y >= 2 && X >= 2, DF_ESHAPE, "%s: forward difference needs every extent >= 2 (got %lld,%lld)", fn,
+             (long long)Y, (long long)X);
+  DF_REQUIRE(Y < (1 << 30) && X < (1 << 30), DF_ESHAPE, "%s: extent too large", fn);
+  return DF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int df_jacobian3d_fwd(const float* x, float* j, float* c, int64_t B, int64_t Z, int64_t Y, int64_t X,
+                      df_stream_t stream) {
+  if (int e = check3(x, B, Z, Y, X, "df_jacobian3d_fwd")) return e;
+  DF_REQUIRE(j || c, DF_EINVAL, "df_jacobian3d_fwd: both outputs null");
+  DF_REQUIRE(df::aligned16(j) && df::aligned16(c), DF_EALIGN, "df_jacobian3d_fwd: outputs must be 16-byte aligned");
+  Dims3 dm{B * Z * Y * X, (int)Z, (int)Y, (int)X};
+  dim3 grid((unsigned)ceil_div(dm.nvox, kVoxPerBlock)), block(kThreads);
+  hipStream_t s = df::as_stream(stream);
+  if (j && c) hipLaunchKernelGGL((jacobian3d_fwd_kernel<true, true>), grid, block, 0, s, x, j, c, dm);
+  else if (j) hipLaunchKernelGGL((jacobian3d_fwd_kernel<true, false>), grid, block, 0, s, x, j, c, dm);
+  else hipLaunchKernelGGL((jacobian3d_fwd_kernel<false, true>), grid, block, 0, s, x, j, c, dm);
+  return df::launched("df_jacobian3d_fwd");
+}
+
+int df_jacobian3d_bwd(const float* gj, const float* gc, float* gx, int64_t B, int64_t Z, int64_t Y, int64_t X,
+                      df_stream_t stream) {
+  if (int e = check3(gx, B, Z, Y, X, "df_jacobian3d_bwd")) return e;
+  DF_REQUIRE(gj || gc, DF_EINVAL, "df_jacobian3d_bwd: both incoming gradients null");
+  Dims3 dm{B * Z * Y * X, (int)Z, (int)Y, (int)X};
+  dim3 grid((unsigned)ceil_div(dm.nvox, kThreads)), block(kThreads);
+  hipStream_t s = df::as_stream(stream);
+  if (gj && gc) hipLaunchKernelGGL((jacobian3d_bwd_kernel<true, true>), grid, block, 0, s, gj, gc, gx, dm);
+  else if (gj) hipLaunchKernelGGL((jacobian3d_bwd_kernel<true, false>), grid, block, 0, s, gj, gc, gx, dm);
+  else hipLaunchKernelGGL((jacobian3d_bwd_kernel<false, true>), grid, block, 0, s, gj, gc, gx, dm);
+  return df::launched("df_jacobian3d_bwd");
+}
+
+int df_divergence3d(const float* x, float* d, int64_t B, int64_t Z, int64_t Y, int64_t X, df_stream_t stream) {
+  if (int e = check3(x, B, Z, Y, X, "df_divergence3d")) return e;
+  DF_REQUIRE(d != nullptr, DF_EINVAL, "df_divergence3d: null output");
+  const int64_t nout = B * (Z - 1) * (Y - 1) * (X - 1);
+  hipLaunchKernelGGL(divergence3d_kernel, dim3((unsigned)ceil_div(nout, kThreads)), dim3(kThreads), 0,
+                     df::as_stream(stream), x, d, nout, (int)Z, (int)Y, (int)X);
+  return df::launched("df_divergence3d");
+}
+
+int df_curl2d_fwd(const float* psi, float* u, int64_t B, int64_t Y, int64_t X, df_stream_t stream) {
+  if (int e = check2(psi, B, Y, X, "df_curl2d_fwd")) return e;
+  DF_REQUIRE(u != nullptr, DF_EINVAL, "df_curl2d_fwd: null output");
+  Dims2 dm{B * Y * X, (int)Y, (int)X};
+  hipLaunchKernelGGL(curl2d_fwd_kernel, dim3((unsigned)ceil_div(dm.npix, kThreads)), dim3(kThreads), 0,
+                     df::as_stream(stream), psi, reinterpret_cast<float2*>(u), dm);
+  return df::launched("df_curl2d_fwd");
+}
+
+int df_curl2d_bwd(const float* gu, float* gpsi, int64_t B, int64_t Y, int64_t X, df_stream_t stream) {
+  if (int e = check2(gu, B, Y, X, "df_curl2d_bwd")) return e;
+  DF_REQUIRE(gpsi != nullptr, DF_EINVAL, "df_curl2d_bwd: null output");
+  Dims2 dm{B * Y * X, (int)Y, (int)X};
+  hipLaunchKernelGGL(curl2d_bwd_kernel, dim3((unsigned)ceil_div(dm.npix, kThreads)), dim3(kThreads), 0,
+                     df::as_stream(stream), gu, gpsi, dm);
+  return df::launched("df_curl2d_bwd");
+}
+
+int df_jacobian2d_fwd(const float* x, float* j, float* w, int64_t B, int64_t Y, int64_t X, df_stream_t stream) {
+  if (int e = check2(x, B, Y, X, "df_jacobian2d_fwd")) return e;
+  DF_REQUIRE(j || w, DF_EINVAL, "df_jacobian2d_fwd: both outputs null");
+  DF_REQUIRE(df::aligned16(j), DF_EALIGN, "df_jacobian2d_fwd: j must be 16-byte aligned");
+  Dims2 dm{B * Y * X, (int)Y, (int)X};
+  dim3 grid((unsigned)ceil_div(dm.npix, kThreads)), block(kThreads);
+  hipStream_t s = df::as_stream(stream);
+  const float2* x2 = reinterpret_cast<const float2*>(x);
+  float4* j4 = reinterpret_cast<float4*>(j);
+  if (j && w) hipLaunchKernelGGL((jacobian2d_fwd_kernel<true, true>), grid, block, 0, s, x2, j4, w, dm);
+  else if (j) hipLaunchKernelGGL((jacobian2d_fwd_kernel<true, false>), grid, block, 0, s, x2, j4, w, dm);
+  else hipLaunchKernelGGL((jacobian2d_fwd_kernel<false, true>), grid, block, 0, s, x2, j4, w, dm);
+  return df::launched("df_jacobian2d_fwd");
+}
+
+int df_jacobian2d_bwd(const float* gj, const float* gw, float* gx, int64_t B, int64_t Y, int64_t X,
+                      df_stream_t stream) {
+  if (int e = check2(gx, B, Y, X, "df_jacobian2d_bwd")) return e;
+  DF_REQUIRE(gj || gw, DF_EINVAL, "df_jacobian2d_bwd: both incoming gradients null");
+  Dims2 dm{B * Y * X, (int)Y, (int)X};
+  dim3 grid((unsigned)ceil_div(dm.npix, kThreads)), block(kThreads);
+  hipStream_t s = df::as_stream(stream);
+  float2* g2 = reinterpret_cast<float2*>(gx);
+  if (gj && gw) hipLaunchKernelGGL((jacobian2d_bwd_kernel<true, true>), grid, block, 0, s, gj, gw, g2, dm);
+  else if (gj) hipLaunchKernelGGL((jacobian2d_bwd_kernel<true, false>), grid, block, 0, s, gj, gw, g2, dm);
+  else hipLaunchKernelGGL((jacobian2d_bwd_kernel<false, true>), grid, block, 0, s, gj, gw, g2, dm);
+  return df::launched("df_jacobian2d_bwd");
+}
+
+int df_divergence2d(const float* x, float* d, int64_t B, int64_t Y, int64_t X, df_stream_t stream) {
+  if (int e = check2(x, B, Y, X, "df_divergence2d")) return e;
+  DF_REQUIRE(d != nullptr, DF_EINVAL, "df_divergence2d: null output");
+  const int64_t nout = B * (Y - 1) * (X - 1);
+  hipLaunchKernelGGL(divergence2d_kernel, dim3((unsigned)ceil_div(nout, kThreads)), dim3(kThreads), 0,
+                     df::as_stream(stream), x, d, nout, (int)Y, (int)X);
+  return df::launched("df_divergence2d");
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""Drop-in counterpart of the reference's ``model.py`` generators (GeneratorBE / GeneratorBE3).
+
+Same signatures, defaults and ``(out, variables)`` return as ``byungsook/deep-fluids/model.py:5-87``;
+variables live in the ``ops`` registry under slim names (``G/0_fc/weights``, ``G/1_conv/biases`` ...)
+and ``reuse=True`` returns the same parameters (trainer.py:299-300).
+"""
+import numpy as np
+
+from .ops import *          # noqa: F401,F403  (the reference does `from ops import *`, model.py:3)
+from .ops import variable_scope, get_variables, add, lrelu, linear, reshape, conv2d, conv3d, upscale, upscale3
+
+__all__ = ["GeneratorBE", "GeneratorBE3"]
+
+
+def _generator(z, filters, output_shape, name, num_conv, conv_k, last_k, repeat, skip_concat, act, reuse, is_3d):
+    conv = conv3d if is_3d else conv2d
+    up = upscale3 if is_3d else upscale
+    with variable_scope(name, reuse=reuse) as vs:
+        if repeat == 0:
+            repeat_num = int(np.log2(np.max(output_shape[:-1]))) - 2          # model.py:9 / :52
+        else:
+            repeat_num = repeat
+        assert repeat_num > 0 and np.sum([i % np.power(2, repeat_num - 1) for i in output_shape[:-1]]) == 0
+
+        x0_shape = [int(i / np.power(2, repeat_num - 1)) for i in output_shape[:-1]] + [filters]
+        num_output = int(np.prod(x0_shape))
+        layer_num = 0
+        x = linear(z, num_output, name=str(layer_num) + "_fc")
+        layer_num += 1
+        if is_3d:
+            x = x.reshape([-1] + x0_shape)                                     # model.py:63
+        else:
+            x = reshape(x, x0_shape[0], x0_shape[1], x0_shape[2])              # model.py:21
+        x0 = x
+
+        for idx in range(repeat_num):
+            for _ in range(num_conv):
+                x = conv(x, filters, k=conv_k, s=1, act=act, name=str(layer_num) + "_conv")
+                layer_num += 1
+
+            if idx < repeat_num - 1:
+                if skip_concat:
+                    raise NotImplementedError("skip_concat=True is never enabled by the reference trainers "
+                                              "(model.py:30-33); not built")
+                x = add(x, x0)                                                 # model.py:35 / :77
+                x = up(x, 2)
+                x0 = x
+            elif not skip_concat:
+                x = add(x, x0)                                                 # model.py:40 / :82
+
+        out = conv(x, output_shape[-1], k=last_k, s=1, name=str(layer_num) + "_conv")
+    variables = get_variables(vs)
+    return out, variables
+
+
+def GeneratorBE(z, filters, output_shape, name="G", num_conv=4, conv_k=3, last_k=3, repeat=0, skip_concat=False,
+                act=lrelu, reuse=False):
+    """model.py:5-46."""
+    return _generator(z, filters, output_shape, name, num_conv, conv_k, last_k, repeat, skip_concat, act, reuse, False)
+
+
+def GeneratorBE3(z, filters, output_shape, name="G", num_conv=4, conv_k=3, last_k=3, repeat=0, skip_concat=False,
+                 act=lrelu, reuse=False):
+    """model.py:48-87."""
+    return _generator(z, filters, output_shape, name, num_conv, conv_k, last_k, repeat, skip_concat, act, reuse, True)

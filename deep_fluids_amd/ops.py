@@ -1,0 +1,599 @@
+"""Drop-in counterpart of the reference's ``ops.py`` call surface on MI355X.
+
+Same function names, argument order, defaults, return-tuple structure and channels-last layouts
+as ``byungsook/deep-fluids/ops.py`` (cited per function), operating on ``torch`` CUDA(=HIP) tensors.
+Every bit of arithmetic is done by hand-written gfx950 kernels in ``libdeepfluids_hip.so`` reached
+through the C-ABI of ``include/deepfluids_hip.h`` (ctypes, PyTorch's current HIP stream);  PyTorch
+supplies device memory, streams and autograd bookkeeping only.  There is no CPU / eager fallback:
+a missing library or a non-GPU tensor raises.
+
+TF-1 style hidden state (``slim`` variables inside ``tf.variable_scope``) is reproduced by a
+name-keyed registry: ``variable_scope(name, reuse)`` + ``get_variables(scope)``; variable names
+follow slim: ``<scope>/<layer>/weights`` ``[k,(k,)k,Cin,Cout]`` / ``[in,out]`` and ``.../biases``.
+"""
+import contextlib
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, query, DF_CONV_BIAS, DF_CONV_LRELU, DF_CONV_MASK, DF_CONV_RESIDUAL  # noqa: F401
+
+__all__ = [
+    "lrelu", "conv2d", "conv3d", "linear", "upscale", "upscale3", "resize_nearest_neighbor", "reshape",
+    "int_shape", "get_conv_shape", "nchw_to_nhwc", "nhwc_to_nchw", "add",
+    "jacobian", "jacobian3", "curl", "curl3", "divergence", "divergence3",
+    "vort_np", "curl_np", "grad_np", "jacobian_np3", "l1_mean",
+    "variable_scope", "get_variables", "get_variable", "reset_variables", "set_random_seed", "all_variables",
+]
+
+
+# --------------------------------------------------------------------------------------------------
+# plumbing
+# --------------------------------------------------------------------------------------------------
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _prep(t, name="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor on the MI355X (got %r)" % (name, type(t)))
+    if not t.is_cuda:
+        raise _lib.DeepFluidsHipError("%s is on %s: deep_fluids_amd has no CPU path (HIP kernels only)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32 (the reference is fp32 end-to-end), got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# --------------------------------------------------------------------------------------------------
+# variable registry (tf.variable_scope / slim variables)
+# --------------------------------------------------------------------------------------------------
+_VARS = {}            # full name -> torch.Tensor (requires_grad leaf)
+_SCOPES = []          # stack of (name, reuse)
+_RNG = np.random.RandomState(123)     # main.py:12 tf.set_random_seed(123) / config.py:69
+_DEFAULT_DEVICE = "cuda"
+
+
+class VariableScope(object):
+    def __init__(self, name):
+        self.name = name
+
+
+def set_random_seed(seed):
+    global _RNG
+    _RNG = np.random.RandomState(seed)
+
+
+def reset_variables():
+    _VARS.clear()
+
+
+def all_variables():
+    return dict(_VARS)
+
+
+@contextlib.contextmanager
+def variable_scope(name, reuse=False):
+    inherited = bool(_SCOPES and _SCOPES[-1][1])
+    _SCOPES.append((name, bool(reuse) or inherited))
+    try:
+        yield VariableScope("/".join(s[0] for s in _SCOPES))
+    finally:
+        _SCOPES.pop()
+
+
+def _scope_prefix():
+    return "/".join(s[0] for s in _SCOPES)
+
+
+def _reusing():
+    return bool(_SCOPES and _SCOPES[-1][1])
+
+
+def get_variable(name, shape, init="xavier", device=None):
+    """slim model variable: Xavier-uniform weights / zero biases, created on first use,
+    returned as-is under ``reuse=True`` (trainer.py:299-300 builds the test model that way)."""
+    full = (_scope_prefix() + "/" if _SCOPES else "") + name
+    if full in _VARS:
+        if not _reusing():
+            raise ValueError("Variable %s already exists; did you mean reuse=True?" % full)
+        v = _VARS[full]
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError("Variable %s has shape %s, requested %s" % (full, tuple(v.shape), tuple(shape)))
+        return v
+    if _reusing():
+        raise ValueError("Variable %s does not exist (reuse=True)" % full)
+    if init == "xavier":
+        rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+        lim = math.sqrt(6.0 / (rf * shape[-2] + rf * shape[-1]))
+        host = _RNG.uniform(-lim, lim, size=shape).astype(np.float32)
+    else:
+        host = np.zeros(shape, np.float32)
+    v = torch.from_numpy(host).to(device or _DEFAULT_DEVICE).requires_grad_(True)
+    _VARS[full] = v
+    return v
+
+
+def set_variable(full_name, value):
+    """Inject a variable by its full slim name (parity tests / checkpoint restore)."""
+    t = torch.as_tensor(np.asarray(value, np.float32)).to(_DEFAULT_DEVICE).contiguous().requires_grad_(True)
+    _VARS[full_name] = t
+    return t
+
+
+def get_variables(scope):
+    """tf.contrib.framework.get_variables(vs): variables under a scope, creation order."""
+    prefix = (scope.name if isinstance(scope, VariableScope) else str(scope)) + "/"
+    return [v for k, v in _VARS.items() if k.startswith(prefix)]
+
+
+_UNNAMED = {}
+
+
+def _layer_name(name, kind):
+    if name is not None:
+        return name
+    key = (_scope_prefix(), kind)
+    n = _UNNAMED.get(key, 0)
+    _UNNAMED[key] = n + 1
+    return kind if n == 0 else "%s_%d" % (kind, n)
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd bindings of the HIP kernels
+# --------------------------------------------------------------------------------------------------
+class _Lrelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, leak):
+        x = _prep(x, "x")
+        y = torch.empty_like(x)
+        call("df_lrelu_fwd", _ptr(x), _ptr(y), float(leak), x.numel(), _stream())
+        ctx.save_for_backward(y)
+        ctx.leak = float(leak)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = _prep(gy, "grad")
+        gx = torch.empty_like(gy)
+        call("df_lrelu_bwd", _ptr(gy), _ptr(y), _ptr(gx), ctx.leak, gy.numel(), _stream())
+        return gx, None
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _prep(a, "a"); b = _prep(b, "b")
+        if a.shape != b.shape:
+            raise ValueError("add: shapes differ %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        y = torch.empty_like(a)
+        call("df_add", _ptr(a), _ptr(b), _ptr(y), a.numel(), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def _pack(w, taps, cin, cout, mode):
+    n = query("df_conv_packed_elems", taps, cin, cout, mode)
+    wp = torch.empty(n, dtype=torch.float32, device=w.device)
+    call("df_conv_pack_weights", _ptr(w), _ptr(wp), taps, cin, cout, mode, _stream())
+    return wp
+
+
+def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak):
+    B, D, H, W = dims
+    y = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
+    call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, D, H, W, cin, cout,
+         kz, flags, float(leak), _stream())
+    return y
+
+
+class _ConvSame3(torch.autograd.Function):
+    """k=3, stride-1, SAME conv (+bias, + optional fused lrelu) on the fp32 MFMA kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, leak):
+        x = _prep(x, "x"); w = _prep(w, "weights"); b = _prep(b, "biases")
+        nd = x.dim() - 2
+        kz = 3 if nd == 3 else 1
+        taps = 27 if nd == 3 else 9
+        cin, cout = w.shape[-2], w.shape[-1]
+        if tuple(w.shape[:-2]) != (3,) * nd or x.shape[-1] != cin:
+            raise ValueError("conv: weights %s do not match input %s (k=3 only)" % (tuple(w.shape), tuple(x.shape)))
+        dims = (x.shape[0], x.shape[1] if nd == 3 else 1, x.shape[-3], x.shape[-2])
+        wp = _pack(w, taps, cin, cout, 0)
+        flags = DF_CONV_BIAS | (DF_CONV_LRELU if leak is not None else 0)
+        y = _conv_raw(x, wp, b, None, None, dims, cin, cout, kz, flags, leak if leak is not None else 0.0)
+        y = y.view(x.shape[:-1] + (cout,))
+        ctx.save_for_backward(x, w, y if leak is not None else None)
+        ctx.leak = leak
+        ctx.geom = (dims, cin, cout, kz, taps)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        dims, cin, cout, kz, taps = ctx.geom
+        B, D, H, W = dims
+        gy = _prep(gy, "grad")
+        if ctx.leak is not None:
+            dp = torch.empty_like(gy)
+            call("df_lrelu_bwd", _ptr(gy), _ptr(y), _ptr(dp), float(ctx.leak), gy.numel(), _stream())
+        else:
+            dp = gy
+        gw = torch.empty_like(w)
+        gb = torch.empty(cout, dtype=torch.float32, device=x.device)
+        nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, kz)
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+        call("df_conv_wgrad", _ptr(x), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, _ptr(ws), nbytes,
+             _stream())
+        gx = None
+        if ctx.needs_input_grad[0]:
+            wpd = _pack(w, taps, cin, cout, 1)
+            gx = _conv_raw(dp, wpd, None, None, None, dims, cout, cin, kz, 0, 0.0).view(x.shape)
+        return gx, gw, gb, None
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _prep(x, "x"); w = _prep(w, "weights"); b = _prep(b, "biases")
+        B, K = x.shape
+        N = w.shape[1]
+        if w.shape[0] != K:
+            raise ValueError("linear: weights %s do not match input %s" % (tuple(w.shape), tuple(x.shape)))
+        y = _empty((B, N), x)
+        call("df_linear_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, K, N, _stream())
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _prep(gy, "grad")
+        B, K = x.shape
+        N = w.shape[1]
+        gw = torch.empty_like(w)
+        gb = _empty((N,), x)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        call("df_linear_bwd", _ptr(x), _ptr(w), _ptr(gy), _ptr(gx), _ptr(gw), _ptr(gb), B, K, N, _stream())
+        return gx, gw, gb
+
+
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _prep(x, "x")
+        is3d = x.dim() == 5
+        B = x.shape[0]
+        D = x.shape[1] if is3d else 1
+        H, W, C = x.shape[-3], x.shape[-2], x.shape[-1]
+        out_shape = (B, 2 * D, 2 * H, 2 * W, C) if is3d else (B, 2 * H, 2 * W, C)
+        y = _empty(out_shape, x)
+        call("df_upsample2x_fwd", _ptr(x), _ptr(y), B, D, H, W, C, int(is3d), _stream())
+        ctx.geom = (B, D, H, W, C, is3d, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, D, H, W, C, is3d, shp = ctx.geom
+        gy = _prep(gy, "grad")
+        gx = _empty(shp, gy)
+        call("df_upsample2x_bwd", _ptr(gy), _ptr(gx), B, D, H, W, C, int(is3d), _stream())
+        return gx
+
+
+class _Curl2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, psi):
+        psi = _prep(psi, "x")
+        B, Y, X, C = psi.shape
+        if C != 1:
+            raise ValueError("curl expects a 1-channel stream function [B,Y,X,1], got %s" % (tuple(psi.shape),))
+        u = _empty((B, Y, X, 2), psi)
+        call("df_curl2d_fwd", _ptr(psi), _ptr(u), B, Y, X, _stream())
+        ctx.geom = (B, Y, X)
+        return u
+
+    @staticmethod
+    def backward(ctx, gu):
+        B, Y, X = ctx.geom
+        gu = _prep(gu, "grad")
+        g = _empty((B, Y, X, 1), gu)
+        call("df_curl2d_bwd", _ptr(gu), _ptr(g), B, Y, X, _stream())
+        return g
+
+
+class _Jacobian2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _prep(x, "x")
+        B, Y, X, C = x.shape
+        if C != 2:
+            raise ValueError("jacobian expects a 2-channel field [B,Y,X,2], got %s" % (tuple(x.shape),))
+        j = _empty((B, Y, X, 4), x); w = _empty((B, Y, X, 1), x)
+        call("df_jacobian2d_fwd", _ptr(x), _ptr(j), _ptr(w), B, Y, X, _stream())
+        ctx.geom = (B, Y, X)
+        ctx.set_materialize_grads(False)
+        return j, w
+
+    @staticmethod
+    def backward(ctx, gj, gw):
+        B, Y, X = ctx.geom
+        if gj is None and gw is None:
+            return None
+        gj = None if gj is None else _prep(gj, "grad")
+        gw = None if gw is None else _prep(gw, "grad")
+        ref = gj if gj is not None else gw
+        gx = _empty((B, Y, X, 2), ref)
+        call("df_jacobian2d_bwd", _ptr(gj), _ptr(gw), _ptr(gx), B, Y, X, _stream())
+        return gx
+
+
+class _Jacobian3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, want_j, want_c):
+        x = _prep(x, "x")
+        B, Z, Y, X, C = x.shape
+        if C != 3:
+            raise ValueError("jacobian3 expects a 3-channel field [B,Z,Y,X,3], got %s" % (tuple(x.shape),))
+        j = _empty((B, Z, Y, X, 9), x) if want_j else None
+        c = _empty((B, Z, Y, X, 3), x) if want_c else None
+        call("df_jacobian3d_fwd", _ptr(x), _ptr(j), _ptr(c), B, Z, Y, X, _stream())
+        ctx.geom = (B, Z, Y, X)
+        ctx.set_materialize_grads(False)
+        if want_j and want_c:
+            return j, c
+        return j if want_j else c
+
+    @staticmethod
+    def backward(ctx, *grads):
+        B, Z, Y, X = ctx.geom
+        if len(grads) == 2:
+            gj, gc = grads
+        else:
+            gj, gc = (grads[0], None) if grads[0] is not None and grads[0].shape[-1] == 9 else (None, grads[0])
+        if gj is None and gc is None:
+            return None, None, None
+        gj = None if gj is None else _prep(gj, "grad")
+        gc = None if gc is None else _prep(gc, "grad")
+        ref = gj if gj is not None else gc
+        gx = _empty((B, Z, Y, X, 3), ref)
+        call("df_jacobian3d_bwd", _ptr(gj), _ptr(gc), _ptr(gx), B, Z, Y, X, _stream())
+        return gx, None, None
+
+
+class _L1Mean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _prep(a, "a"); b = _prep(b, "b")
+        if a.shape != b.shape:
+            raise ValueError("l1_mean: shapes differ %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        n = a.numel()
+        out = _empty((), a)
+        nbytes = query("df_l1_mean_workspace_bytes", n)
+        ws = torch.empty(nbytes // 8, dtype=torch.float64, device=a.device)
+        call("df_l1_mean_fwd", _ptr(a), _ptr(b), n, _ptr(out), _ptr(ws), nbytes, _stream())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        gout = _prep(gout, "grad")
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = torch.empty_like(a)
+            call("df_l1_mean_bwd", _ptr(a), _ptr(b), _ptr(gout), 1.0, _ptr(ga), a.numel(), _stream())
+        if ctx.needs_input_grad[1]:
+            gb = torch.empty_like(b)
+            call("df_l1_mean_bwd", _ptr(a), _ptr(b), _ptr(gout), -1.0, _ptr(gb), a.numel(), _stream())
+        return ga, gb
+
+
+# --------------------------------------------------------------------------------------------------
+# the reference's call surface
+# --------------------------------------------------------------------------------------------------
+def lrelu(x, leak=0.2):
+    """ops.py:9-10  ``tf.maximum(x, leak*x)``."""
+    return _Lrelu.apply(x, leak)
+
+
+def add(a, b):
+    """The residual ``x += x0`` of model.py:35,40,77,82 as a HIP kernel."""
+    return _Add.apply(a, b)
+
+
+def nchw_to_nhwc(x):
+    """ops.py:108-109."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nhwc_to_nchw(x):
+    """ops.py:111-112."""
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def int_shape(tensor):
+    """ops.py:96-98."""
+    return [int(s) for s in tensor.shape]
+
+
+def get_conv_shape(tensor, data_format="NHWC"):
+    """ops.py:100-106: always returns [N,H,W,C] (for 5-D NDHWC input: the shape itself)."""
+    shape = int_shape(tensor)
+    if data_format == "NCHW":
+        return [shape[0], shape[2], shape[3], shape[1]]
+    elif data_format == "NHWC":
+        return shape
+
+
+def reshape(x, h, w, c, data_format="NHWC"):
+    """ops.py:198-203."""
+    if data_format == "NCHW":
+        return x.reshape(-1, c, h, w)
+    return x.reshape(-1, h, w, c)
+
+
+def _act_leak(act):
+    """Map the reference's ``act`` argument onto the fused epilogue: None -> linear, lrelu -> leak 0.2."""
+    if act is None:
+        return None, None
+    if act is lrelu:
+        return 0.2, None
+    return None, act          # any other callable is applied after the conv, un-fused
+
+
+def _conv(x, o_dim, nd, data_format, name, k, s, act):
+    if k != 3 or s != 1:
+        raise NotImplementedError("deep_fluids_amd convs implement the generator path only: k=3, s=1 "
+                                  "(reference call sites model.py:26,42,68,84); got k=%d s=%d" % (k, s))
+    if nd == 2 and data_format == "NCHW":
+        x = nchw_to_nhwc(x)
+    cin = int(x.shape[-1])
+    lname = _layer_name(name, "Conv")
+    w = get_variable(lname + "/weights", (3,) * nd + (cin, int(o_dim)), "xavier", x.device)
+    b = get_variable(lname + "/biases", (int(o_dim),), "zeros", x.device)
+    leak, post = _act_leak(act)
+    y = _ConvSame3.apply(x, w, b, leak)
+    if post is not None:
+        y = post(y)
+    if nd == 2 and data_format == "NCHW":
+        y = nhwc_to_nchw(y)
+    return y
+
+
+def conv2d(x, o_dim, data_format="NHWC", name=None, k=4, s=2, act=None):
+    """ops.py:12-13 (slim.conv2d, SAME).  Implemented for the generator's k=3, s=1 call sites."""
+    return _conv(x, o_dim, 2, data_format, name, k, s, act)
+
+
+def conv3d(x, o_dim, data_format="NDHWC", name=None, k=4, s=2, act=None):
+    """ops.py:15-16 (slim.conv3d, SAME)."""
+    if data_format != "NDHWC":
+        raise NotImplementedError("conv3d: NDHWC only (the reference never uses NCDHW)")
+    return _conv(x, o_dim, 3, data_format, name, k, s, act)
+
+
+def linear(x, o_dim, name=None, act=None):
+    """ops.py:23-24 (slim.fully_connected)."""
+    lname = _layer_name(name, "fully_connected")
+    w = get_variable(lname + "/weights", (int(x.shape[-1]), int(o_dim)), "xavier", x.device)
+    b = get_variable(lname + "/biases", (int(o_dim),), "zeros", x.device)
+    y = _Linear.apply(x, w, b)
+    return act(y) if act is not None else y
+
+
+def resize_nearest_neighbor(x, new_size, data_format="NHWC"):
+    """ops.py:66-73, restricted to the exact 2x the reference uses."""
+    if data_format == "NCHW":
+        x = nchw_to_nhwc(x)
+    if tuple(new_size) != (2 * x.shape[1], 2 * x.shape[2]):
+        raise NotImplementedError("resize_nearest_neighbor: exact 2x only (got %s -> %s)" % (tuple(x.shape[1:3]), tuple(new_size)))
+    y = _Upsample2x.apply(x)
+    return nhwc_to_nchw(y) if data_format == "NCHW" else y
+
+
+def upscale(x, scale, data_format="NHWC"):
+    """ops.py:75-77."""
+    _, h, w, _ = get_conv_shape(x, data_format)
+    return resize_nearest_neighbor(x, (h * scale, w * scale), data_format)
+
+
+def upscale3(x, scale):
+    """ops.py:79-91: two 2-D nearest resizes == one 3-D nearest 2x (src = dst >> 1)."""
+    if scale != 2:
+        raise NotImplementedError("upscale3: scale 2 only (model.py:78)")
+    return _Upsample2x.apply(x)
+
+
+def jacobian(x, data_format="NHCW"):
+    """ops.py:205-225 -> (j [..,4], w [..,1]).  (The reference default 'NHCW' is a typo that behaves as NHWC.)"""
+    if data_format == "NCHW":
+        x = nchw_to_nhwc(x)
+    j, w = _Jacobian2d.apply(x)
+    if data_format == "NCHW":
+        j, w = nhwc_to_nchw(j), nhwc_to_nchw(w)
+    return j, w
+
+
+def jacobian3(x):
+    """ops.py:227-262 -> (j [..,9], c [..,3]);  call-site idiom ``_, G_ = jacobian3(G_s)`` (trainer3.py:18)."""
+    return _Jacobian3d.apply(x, True, True)
+
+
+def curl3(x):
+    """North-star alias for ``jacobian3(x)[1]`` that skips the unused 9-channel output (24 B/voxel, not 60)."""
+    return _Jacobian3d.apply(x, False, True)
+
+
+def curl(x, data_format="NHWC"):
+    """ops.py:264-274."""
+    if data_format == "NCHW":
+        x = nchw_to_nhwc(x)
+    c = _Curl2d.apply(x)
+    return nhwc_to_nchw(c) if data_format == "NCHW" else c
+
+
+def divergence(x, data_format="NHWC"):
+    """ops.py:276-284 (no gradient: used as a diagnostic only)."""
+    if data_format == "NCHW":
+        x = nchw_to_nhwc(x)
+    x = _prep(x.detach(), "x")
+    B, Y, X, _ = x.shape
+    d = _empty((B, Y - 1, X - 1, 1), x)
+    call("df_divergence2d", _ptr(x), _ptr(d), B, Y, X, _stream())
+    return nhwc_to_nchw(d) if data_format == "NCHW" else d
+
+
+def divergence3(x):
+    """ops.py:286-290."""
+    x = _prep(x.detach(), "x")
+    B, Z, Y, X, _ = x.shape
+    d = _empty((B, Z - 1, Y - 1, X - 1, 1), x)
+    call("df_divergence3d", _ptr(x), _ptr(d), B, Z, Y, X, _stream())
+    return d
+
+
+def l1_mean(a, b):
+    """``tf.reduce_mean(tf.abs(a - b))`` (trainer.py:170-171) as one fused reduction."""
+    return _L1Mean.apply(a, b)
+
+
+# ---- NumPy-facing twins (ops.py:305-324, 344-374): ndarray in, ndarray out, computed on the GPU ----
+def _np_in(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(_DEFAULT_DEVICE)
+
+
+def vort_np(x):
+    """ops.py:305-310."""
+    return jacobian(_np_in(x), data_format="NHWC")[1].cpu().numpy()
+
+
+def curl_np(x):
+    """ops.py:312-317."""
+    return curl(_np_in(x)).cpu().numpy()
+
+
+def grad_np(x):
+    """ops.py:319-324: (dp/dx, dp/dy) == (-curl_v, curl_u)."""
+    c = curl(_np_in(x)).cpu().numpy()
+    return np.stack([-c[..., 1], c[..., 0]], axis=-1)
+
+
+def jacobian_np3(x):
+    """ops.py:344-374."""
+    j, c = jacobian3(_np_in(x))
+    return j.cpu().numpy(), c.cpu().numpy()

@@ -1,0 +1,190 @@
+"""Counterpart of the reference's ``Trainer`` / ``Trainer3`` for the ``arch='de'`` velocity-field path.
+
+Reproduces ``build_model`` (trainer.py:136-184; trainer3.py:14-63) and the hot loop of ``train_``
+(trainer.py:265-288) on PyTorch-ROCm + libdeepfluids_hip.so:
+
+    G_s, G_var = GeneratorBE|GeneratorBE3(y, filters, output_shape, num_conv, repeat)
+    G_         = curl(G_s) | jacobian3(G_s)[1]
+    G_jaco_, _ = jacobian(G_) | jacobian3(G_)
+    g_loss     = w1*mean|G_ - x| + w2*mean|G_jaco_ - x_jaco|           (x_jaco = jacobian(x), trainer.py:29-32)
+    Adam(g_lr, beta1=.5, beta2=.999).minimize(g_loss, var_list=G_var)  (TF1 "epsilon-hat" Adam)
+    g_lr <- lr_min + .5 (lr_max - lr_min)(cos(step*pi/max_step) + 1)   (assigned AFTER each step)
+
+Flag names and defaults are the reference's (config.py:14-70).  Parameters, gradients and Adam slots
+each live in one flat slab (one fused optimizer launch, bucketed all-reduce for data parallelism).
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import curl, curl3, jacobian, jacobian3, l1_mean, get_conv_shape, _ptr, _stream, call
+from .model import GeneratorBE, GeneratorBE3
+from .dist import GradSync
+
+
+def default_config(**over):
+    """config.py:14-70 defaults for the fields the velocity-field path reads."""
+    c = dict(is_3d=False, res_x=96, res_y=128, res_z=32, repeat=0, filters=128, num_conv=4, use_curl=True,
+             w1=1.0, w2=1.0, arch="de", batch_size=8, max_epoch=100, lr_max=1e-4, lr_min=2.5e-6,
+             optimizer="adam", beta1=0.5, beta2=0.999, lr_update="decay", lr_update_step=120000,
+             start_step=0, random_seed=123, num_samples=21000, c_num=3, use_curl3_alias=True)
+    c.update(over)
+    return SimpleNamespace(**c)
+
+
+class Trainer(object):
+    def __init__(self, config, device="cuda", name="G"):
+        self.config = config
+        self.device = torch.device(device)
+        self.is_3d = bool(config.is_3d)
+        self.name = name
+        self.b_num = config.batch_size
+        self.c_num = config.c_num
+        spatial = [config.res_z, config.res_y, config.res_x] if self.is_3d else [config.res_y, config.res_x]
+        if config.use_curl:                                     # trainer.py:48-53
+            self.output_shape = spatial + [3 if self.is_3d else 1]
+        else:
+            self.output_shape = spatial + [3 if self.is_3d else 2]
+        self.filters, self.num_conv, self.repeat = config.filters, config.num_conv, config.repeat
+        self.w1, self.w2 = config.w1, config.w2
+        self.beta1, self.beta2, self.eps = config.beta1, config.beta2, 1e-8
+        self.step = config.start_step                            # trainer.py:65
+        epochs_per_step = config.batch_size / float(config.num_samples)          # data.py:50
+        self.max_step = int(config.max_epoch // epochs_per_step)                # trainer.py:67
+        self.lr_update = config.lr_update
+        self.g_lr = config.lr_max                                # trainer.py:72
+        self._adam_t = 0
+        ops.set_random_seed(config.random_seed)
+        self._build_variables()
+        self.grad_sync = None
+
+    # ---- variables: created by one shape-only pass through the generator, then moved into flat slabs ----
+    def _build_variables(self):
+        gen = GeneratorBE3 if self.is_3d else GeneratorBE
+        z = torch.zeros((1, self.c_num), dtype=torch.float32, device=self.device)
+        prefix = self.name + "/"
+        existing = {k for k in ops.all_variables() if k.startswith(prefix)}
+        if not existing:
+            with torch.no_grad():
+                gen(z, self.filters, self.output_shape, name=self.name, num_conv=self.num_conv, repeat=self.repeat)
+        names = [k for k in ops.all_variables() if k.startswith(prefix)]
+        vars_ = ops.all_variables()
+        total = sum(vars_[k].numel() for k in names)
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=self.device)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.var_names, self.var_slices, self.G_var = names, {}, []
+        off = 0
+        for k in names:
+            old = vars_[k]
+            n = old.numel()
+            self.flat_p[off:off + n].copy_(old.detach().reshape(-1))
+            v = self.flat_p[off:off + n].view(old.shape).detach().requires_grad_(True)
+            v.grad = self.flat_g[off:off + n].view(old.shape)
+            ops._VARS[k] = v
+            self.var_slices[k] = (off, n)
+            self.G_var.append(v)
+            off += n
+        self.n_params = total
+
+    def load_variables(self, params):
+        """Inject weights by slim name (dict name -> ndarray), e.g. from the oracle's generator_init."""
+        for k, val in params.items():
+            off, n = self.var_slices[k]
+            self.flat_p[off:off + n].copy_(torch.from_numpy(np.asarray(val, np.float32).reshape(-1)))
+
+    def variables_numpy(self):
+        return {k: self.flat_p[o:o + n].view(ops._VARS[k].shape).cpu().numpy() for k, (o, n) in self.var_slices.items()}
+
+    def grads_numpy(self):
+        return {k: self.flat_g[o:o + n].view(ops._VARS[k].shape).cpu().numpy() for k, (o, n) in self.var_slices.items()}
+
+    def enable_data_parallel(self, group=None):
+        """Bucket the flat gradient slab per generator block (fc | 4 convs | ... | last conv)."""
+        groups = {}
+        for k in self.var_names:
+            layer = int(k.split("/")[1].split("_")[0])
+            gid = 0 if layer == 0 else 1 + (layer - 1) // self.num_conv
+            groups.setdefault(gid, []).append(k)
+        buckets = []
+        for gid in sorted(groups):
+            ks = groups[gid]
+            off = self.var_slices[ks[0]][0]
+            n = sum(self.var_slices[k][1] for k in ks)
+            buckets.append((off, n, [ops._VARS[k] for k in ks]))
+        self.grad_sync = GradSync(self.flat_g, buckets, group)
+        return self.grad_sync
+
+    # ---- graph (trainer.py:136-172 / trainer3.py:14-51) -------------------------------------------------
+    def build_model(self, x, y):
+        gen = GeneratorBE3 if self.is_3d else GeneratorBE
+        with torch.no_grad():                                   # trainer.py:29-32: Jacobian of the ground truth
+            x_jaco = (jacobian3(x) if self.is_3d else jacobian(x))[0]
+        out, _ = gen(y, self.filters, self.output_shape, name=self.name, num_conv=self.num_conv, repeat=self.repeat,
+                     reuse=True)
+        if self.config.use_curl:
+            if self.is_3d:
+                # `_, self.G_ = jacobian3(self.G_s)` (trainer3.py:18); TF prunes the unused j, eager cannot -> curl3
+                G_ = curl3(out) if self.config.use_curl3_alias else jacobian3(out)[1]
+            else:
+                G_ = curl(out)                                  # trainer.py:140
+            G_s = out
+        else:
+            G_, G_s = out, None
+        G_jaco_, G_vort_ = jacobian3(G_) if self.is_3d else jacobian(G_)         # trainer.py:146 / trainer3.py:24
+        g_loss_l1 = l1_mean(G_, x)                              # trainer.py:170
+        g_loss_j_l1 = l1_mean(G_jaco_, x_jaco)                  # trainer.py:171
+        g_loss = g_loss_l1 * self.w1 + g_loss_j_l1 * self.w2    # trainer.py:172
+        return SimpleNamespace(G_s=G_s, G_=G_, G_jaco_=G_jaco_, G_vort_=G_vort_, x_jaco=x_jaco,
+                               g_loss_l1=g_loss_l1, g_loss_j_l1=g_loss_j_l1, g_loss=g_loss)
+
+    def generate(self, z):
+        """Inference graph of build_test_model (trainer.py:295-303), training definition of the 3-D curl."""
+        gen = GeneratorBE3 if self.is_3d else GeneratorBE
+        with torch.no_grad():
+            out, _ = gen(z, self.filters, self.output_shape, name=self.name, num_conv=self.num_conv,
+                         repeat=self.repeat, reuse=True)
+            if self.config.use_curl:
+                out = curl3(out) if self.is_3d else curl(out)
+        return out
+
+    # ---- one `sess.run(g_optim)` + `sess.run(g_lr_update)` (trainer.py:269, 284-288) -------------------------
+    def train_step(self, x, y):
+        self.flat_g.zero_()
+        if self.grad_sync is not None:
+            self.grad_sync.begin_step()
+        m = self.build_model(x, y)
+        m.g_loss.backward()
+        gscale = self.grad_sync.finish() if self.grad_sync is not None else 1.0
+        self._apply_adam(gscale)
+        self.step += 1
+        if self.lr_update == "decay":
+            self.g_lr = self.config.lr_min + 0.5 * (self.config.lr_max - self.config.lr_min) * (
+                math.cos(self.step * math.pi / self.max_step) + 1.0)
+        elif self.lr_update == "step":
+            if (self.step - 1) % self.config.lr_update_step == self.config.lr_update_step - 1:
+                self.g_lr = max(self.g_lr * 0.5, self.config.lr_min)
+        return m
+
+    def _apply_adam(self, grad_scale):
+        if self.config.optimizer == "gd":                       # trainer.py:163-165
+            self.flat_p.add_(self.flat_g, alpha=-self.g_lr * grad_scale)
+            return
+        self._adam_t += 1
+        t = self._adam_t
+        lr_t = self.g_lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        call("df_adam_tf1_step", _ptr(self.flat_p), _ptr(self.flat_g), _ptr(self.flat_m), _ptr(self.flat_v),
+             self.n_params, float(lr_t), float(self.beta1), float(self.beta2), float(self.eps), float(grad_scale),
+             _stream())
+
+
+class Trainer3(Trainer):
+    """trainer3.py: the 3-D overrides are selected by ``config.is_3d``; kept as a name for call-site parity."""
+
+    def __init__(self, config, device="cuda", name="G"):
+        config.is_3d = True
+        super(Trainer3, self).__init__(config, device, name)

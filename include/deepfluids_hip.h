@@ -1,0 +1,151 @@
+/*
+ * deepfluids_hip.h -- C-ABI of libdeepfluids_hip.so (gfx950 / MI355X only).
+ *
+ * The drop-in boundary of the Deep Fluids velocity-field train step.  The reference
+ * (byungsook/deep-fluids, TF 1.15) has no FFI of its own: its boundary is the Python call
+ * surface of ops.py / model.py.  deep_fluids_amd/ops.py + model.py reproduce that surface and
+ * call THIS library through ctypes; each entry point below cites the reference lines whose
+ * arithmetic it replaces (paths relative to the upstream repo root).
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer to fp32, channels-last, C-contiguous data unless noted;
+ *     2-D tensors are [B,Y,X,C], 3-D tensors [B,Z,Y,X,C] ("x: bzyxd", ops.py:228);
+ *   - the caller owns and frees every buffer including workspaces (sizes via *_workspace_bytes);
+ *     the library keeps no tensor state and allocates nothing;
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*), nothing
+ *     synchronises internally, so calls compose with PyTorch's current stream and hipGraph capture;
+ *   - return 0 on success, <0 = DF_E* argument error, >0 = hipError_t; never throws, never
+ *     aborts; a message for the calling thread's last failure is kept in df_last_error();
+ *   - re-entrant; no global state besides read-only kernel handles.
+ */
+#ifndef DEEPFLUIDS_HIP_H
+#define DEEPFLUIDS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DF_VERSION 100 /* 0.1.0 */
+
+enum {
+  DF_OK = 0,
+  DF_EINVAL = -1,    /* null pointer / non-positive extent */
+  DF_ESHAPE = -2,    /* extent unsupported by this kernel (e.g. forward difference needs n >= 2) */
+  DF_EALIGN = -3,    /* pointer not 16-byte aligned */
+  DF_EWORKSPACE = -4 /* workspace too small */
+};
+
+/* flags for df_conv_fwd */
+enum {
+  DF_CONV_LRELU = 1,      /* y = max(v, leak*v)            ops.py:9-10 fused into the conv epilogue   */
+  DF_CONV_RESIDUAL = 2,   /* y += residual (after act)      model.py:35,40,77,82                       */
+  DF_CONV_MASK = 4,       /* y *= (mask_src > 0 ? 1 : leak) lrelu backward fused into the dgrad epilogue */
+  DF_CONV_BIAS = 8        /* v += bias[cout]                slim.conv* biases                          */
+};
+
+typedef void* df_stream_t; /* hipStream_t */
+
+int df_version(void);
+const char* df_last_error(void);
+
+/* ---- forward-difference stencils (HBM-bound) ---------------------------------------------- */
+
+/* curl(x) ops.py:264-274.  psi [B,Y,X,1] -> u [B,Y,X,2] = (D_y psi, -D_x psi). */
+int df_curl2d_fwd(const float* psi, float* u, int64_t B, int64_t Y, int64_t X, df_stream_t stream);
+/* adjoint of df_curl2d_fwd: gu [B,Y,X,2] -> gpsi [B,Y,X,1]. */
+int df_curl2d_bwd(const float* gu, float* gpsi, int64_t B, int64_t Y, int64_t X, df_stream_t stream);
+
+/* jacobian(x) ops.py:205-225.  x [B,Y,X,2] -> j [B,Y,X,4] = (dudx,dudy,dvdx,dvdy), w [B,Y,X,1] = dvdx-dudy.
+ * j or w may be NULL (that output is not produced). */
+int df_jacobian2d_fwd(const float* x, float* j, float* w, int64_t B, int64_t Y, int64_t X, df_stream_t stream);
+/* adjoint: gj [..,4] and/or gw [..,1] (either may be NULL, not both) -> gx [..,2]. */
+int df_jacobian2d_bwd(const float* gj, const float* gw, float* gx, int64_t B, int64_t Y, int64_t X,
+                      df_stream_t stream);
+
+/* jacobian3(x) ops.py:227-262.  x [B,Z,Y,X,3] -> j [..,9] = (dudx,dudy,dudz,dvdx,dvdy,dvdz,dwdx,dwdy,dwdz),
+ * c [..,3] = (dwdy-dvdz, dudz-dwdx, dvdx-dudy).  j or c may be NULL.
+ * `curl3(x)` of the north star == df_jacobian3d_fwd(x, NULL, c, ...)  (trainer3.py:18). */
+int df_jacobian3d_fwd(const float* x, float* j, float* c, int64_t B, int64_t Z, int64_t Y, int64_t X,
+                      df_stream_t stream);
+/* adjoint: gj [..,9] and/or gc [..,3] (either may be NULL, not both) -> gx [..,3]. */
+int df_jacobian3d_bwd(const float* gj, const float* gc, float* gx, int64_t B, int64_t Z, int64_t Y, int64_t X,
+                      df_stream_t stream);
+
+/* divergence ops.py:276-284: x [B,Y,X,2] -> [B,Y-1,X-1,1];  divergence3 ops.py:286-290: x [B,Z,Y,X,3] -> [B,Z-1,Y-1,X-1,1]. */
+int df_divergence2d(const float* x, float* d, int64_t B, int64_t Y, int64_t X, df_stream_t stream);
+int df_divergence3d(const float* x, float* d, int64_t B, int64_t Z, int64_t Y, int64_t X, df_stream_t stream);
+
+/* ---- losses (trainer.py:170-172, trainer3.py:49-51) -------------------------------------- */
+
+/* workspace for df_l1_mean_fwd (bytes). */
+int64_t df_l1_mean_workspace_bytes(int64_t n);
+/* out[0] = mean(|a-b|) over n elements; deterministic two-stage reduction (fp64 partials). */
+int df_l1_mean_fwd(const float* a, const float* b, int64_t n, float* out, void* workspace, int64_t workspace_bytes,
+                   df_stream_t stream);
+/* ga[i] = sign(a[i]-b[i]) * scale * (gout ? gout[0] : 1) / n   (tf Abs grad: sign, 0 at 0). */
+int df_l1_mean_bwd(const float* a, const float* b, const float* gout, float scale, float* ga, int64_t n,
+                   df_stream_t stream);
+
+/* ---- element-wise / small layers ---------------------------------------------------------- */
+
+/* lrelu(x, leak) ops.py:9-10 and its backward (slope 1 where y > 0 else leak; y = saved OUTPUT). */
+int df_lrelu_fwd(const float* x, float* y, float leak, int64_t n, df_stream_t stream);
+int df_lrelu_bwd(const float* gy, const float* y, float* gx, float leak, int64_t n, df_stream_t stream);
+
+/* y = a + b (residual add model.py:35,40,77,82), n elements. */
+int df_add(const float* a, const float* b, float* y, int64_t n, df_stream_t stream);
+
+/* nearest-neighbour 2x up-sampling of every spatial axis, channels-last (src = dst>>1):
+ * upscale ops.py:75-77 (D=1), upscale3 ops.py:79-91.  x [B,D,H,W,C] -> y [B,2D|1,2H,2W,C]; C % 4 == 0. */
+int df_upsample2x_fwd(const float* x, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
+                      df_stream_t stream);
+/* adjoint (2x2(x2) sum-pool): gy [B,2D|1,2H,2W,C] -> gx [B,D,H,W,C]. */
+int df_upsample2x_bwd(const float* gy, float* gx, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
+                      df_stream_t stream);
+
+/* linear ops.py:23-24 (slim.fully_connected): y[B,N] = x[B,K] . w[K,N] + bias[N]  (bias may be NULL). */
+int df_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t K, int64_t N,
+                  df_stream_t stream);
+/* backward: gw[K,N] = x^T gy, gb[N] = sum_b gy, gx[B,K] = gy w^T (gx / gw / gb may be NULL). */
+int df_linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int64_t B,
+                  int64_t K, int64_t N, df_stream_t stream);
+
+/* gb[c] = sum over rows of g[rows, C]  (conv bias gradient), deterministic. */
+int64_t df_colsum_workspace_bytes(int64_t rows, int64_t C);
+int df_colsum(const float* g, float* gb, int64_t rows, int64_t C, void* workspace, int64_t workspace_bytes,
+              df_stream_t stream);
+
+/* tf.train.AdamOptimizer update (trainer.py:160-162,184; "epsilon-hat" form), applied to one
+ * flat parameter slab:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr_t m / (sqrt(v) + eps),
+ * with lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the caller on the host. */
+int df_adam_tf1_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                     float eps, float grad_scale, df_stream_t stream);
+
+/* ---- convolutions on MFMA (exact fp32: v_mfma_f32_32x32x2_f32) ----------------------------- */
+
+/* slim.conv2d / conv3d, k=3, stride 1, padding SAME, channels-last (ops.py:12-16; model.py:26,42,68,84).
+ * Weights are given in TF layout [kz,ky,kx,Cin,Cout] (2-D: kz = 1) and are re-packed once per update into
+ * the MFMA operand order by df_conv_pack_weights:
+ *   mode 0: forward operand;  mode 1: dgrad operand (taps mirrored, Cin/Cout swapped). */
+int64_t df_conv_packed_elems(int64_t taps, int64_t cin, int64_t cout, int mode);
+int df_conv_pack_weights(const float* w, float* wp, int64_t taps, int64_t cin, int64_t cout, int mode,
+                         df_stream_t stream);
+/* y[B,D,H,W,Cout] = epilogue( conv_same(x[B,D,H,W,Cin], w) ).  D = 1 and kz = 1 for 2-D.
+ * `wp` packed with mode 0 (forward) or mode 1 (then x is dL/dy and y is dL/dx: the dgrad).
+ * flags: DF_CONV_*; bias / residual / mask_src are used only when their flag is set. */
+int df_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
+                float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int flags,
+                float leak, df_stream_t stream);
+/* gw[kz,3,3,Cin,Cout] = sum_voxels x[voxel+tap][cin] * gy[voxel][cout]   (split over voxel ranges,
+ * deterministic second-pass reduction through the workspace).  If gb != NULL it also receives the bias gradient
+ * gb[cout] = sum_voxels gy[voxel][cout] (accumulated on the fly from the operand registers). */
+int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz);
+int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
+                  int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPFLUIDS_HIP_H */

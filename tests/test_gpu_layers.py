@@ -1,0 +1,161 @@
+"""-m gpu: conv (fp32 MFMA) fwd / dgrad / wgrad, linear, up-sampling, lrelu, add, L1, Adam, column sums
+against the fp64 oracle on identical seeded inputs.  Tolerance: fp32 accumulation over K <= 3456 products
+-> relative L-inf <= 2e-5 of the oracle's dynamic range (the north star asks 1e-4 relative L1 end to end)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import df_oracle as orc
+from gpu_util import dev, host, rel_linf
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from deep_fluids_amd import ops as o
+    return o
+
+
+def _conv_case(ops, shape, cin, cout, leak, seed):
+    from deep_fluids_amd.ops import _ConvSame3
+    rng = np.random.RandomState(seed)
+    nd = len(shape) - 1
+    x = rng.uniform(-1, 1, shape + (cin,)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (3,) * nd + (cin, cout)) / np.sqrt(cin * 3 ** nd)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    go = rng.uniform(-1, 1, shape + (cout,)).astype(np.float32)
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = _ConvSame3.apply(xt, wt, bt, leak)
+    (y * dev(go)).sum().backward()
+    x64, w64, b64 = x.astype(np.float64), w.astype(np.float64), b.astype(np.float64)
+    pre = orc.conv_same(x64, w64, b64)
+    ref = orc.lrelu(pre, leak) if leak is not None else pre
+    dpre = go * (np.where(ref > 0, 1.0, leak) if leak is not None else 1.0)
+    dx, dw, db = orc.conv_same_bwd(x64, w64, dpre)
+    return {"y": rel_linf(host(y), ref), "dx": rel_linf(host(xt.grad), dx), "dw": rel_linf(host(wt.grad), dw),
+            "db": rel_linf(host(bt.grad), db)}
+
+
+CASES_3D = [
+    ((1, 4, 8, 16), 16, 128, 0.2),      # one exact tile set of the (2,4,16) shape
+    ((2, 8, 12, 8), 32, 128, 0.2),      # W < 12 -> the (4,4,8) tile shape; generator level 0 geometry
+    ((1, 5, 7, 19), 16, 128, None),     # ragged in every axis, no activation
+    ((1, 3, 6, 18), 128, 128, 0.2),     # the hot layer's channel counts
+    ((2, 4, 6, 16), 128, 3, None),      # last conv 128 -> 3 (N tile 32, masked columns)
+    ((1, 4, 5, 14), 3, 128, 0.2),       # 3 input channels (scalar staging path; dgrad of the last conv)
+    ((1, 2, 3, 4), 64, 64, 0.2),        # N tile 64
+    ((1, 7, 10, 7), 16, 32, 0.2),       # cfg4 level-0 geometry (odd extents)
+]
+
+
+@pytest.mark.parametrize("shape,cin,cout,leak", CASES_3D)
+def test_conv3d_fwd_bwd(ops, shape, cin, cout, leak):
+    errs = _conv_case(ops, shape, cin, cout, leak, seed=cin * 7 + cout + sum(shape))
+    assert max(errs.values()) < TOL, errs
+
+
+CASES_2D = [
+    ((2, 8, 16), 16, 128, 0.2),
+    ((1, 8, 6), 128, 128, 0.2),         # generator level 0 (W < 12 -> (1,16,8) tiles)
+    ((3, 11, 21), 32, 128, None),
+    ((2, 16, 24), 128, 1, None),        # last conv 128 -> 1 (2-D stream function)
+    ((1, 9, 17), 1, 128, 0.2),
+]
+
+
+@pytest.mark.parametrize("shape,cin,cout,leak", CASES_2D)
+def test_conv2d_fwd_bwd(ops, shape, cin, cout, leak):
+    errs = _conv_case(ops, shape, cin, cout, leak, seed=cin * 5 + cout + sum(shape))
+    assert max(errs.values()) < TOL, errs
+
+
+def test_conv_fused_epilogue_flags(ops):
+    """DF_CONV_RESIDUAL / DF_CONV_MASK straight through the C-ABI (used by the fused backward chain)."""
+    from deep_fluids_amd.ops import _pack, _conv_raw, DF_CONV_BIAS, DF_CONV_LRELU, DF_CONV_RESIDUAL, DF_CONV_MASK
+    rng = np.random.RandomState(5)
+    shape, cin, cout = (1, 4, 8, 16), 32, 128
+    x = rng.uniform(-1, 1, shape + (cin,)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (3, 3, 3, cin, cout)) / 30).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    res = rng.uniform(-1, 1, shape + (cout,)).astype(np.float32)
+    msk = rng.uniform(-1, 1, shape + (cout,)).astype(np.float32)
+    wp = _pack(dev(w), 27, cin, cout, 0)
+    y = _conv_raw(dev(x), wp, dev(b), dev(res), dev(msk), shape, cin, cout, 3,
+                  DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_RESIDUAL | DF_CONV_MASK, 0.2)
+    ref = orc.lrelu(orc.conv_same(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))) + res
+    ref = ref * np.where(msk > 0, 1.0, 0.2)
+    assert rel_linf(host(y), ref) < TOL
+
+
+def test_linear_upsample_lrelu_add(ops):
+    from deep_fluids_amd.ops import _Linear, _Upsample2x
+    rng = np.random.RandomState(11)
+    x = rng.uniform(-1, 1, (5, 3)).astype(np.float32)
+    w = rng.uniform(-1, 1, (3, 1000)).astype(np.float32)
+    b = rng.uniform(-1, 1, 1000).astype(np.float32)
+    go = rng.uniform(-1, 1, (5, 1000)).astype(np.float32)
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = _Linear.apply(xt, wt, bt)
+    (y * dev(go)).sum().backward()
+    assert rel_linf(host(y), x.astype(np.float64) @ w + b) < 1e-6
+    assert rel_linf(host(wt.grad), x.astype(np.float64).T @ go) < 1e-6
+    assert rel_linf(host(bt.grad), go.astype(np.float64).sum(0)) < 1e-6
+    assert rel_linf(host(xt.grad), go.astype(np.float64) @ w.T) < 1e-6
+    for shp in [(2, 3, 5, 8), (1, 2, 3, 2, 12)]:
+        a = rng.uniform(-1, 1, shp).astype(np.float32)
+        g = rng.uniform(-1, 1, tuple([shp[0]] + [2 * s for s in shp[1:-1]] + [shp[-1]])).astype(np.float32)
+        at = dev(a).requires_grad_(True)
+        up = _Upsample2x.apply(at)
+        np.testing.assert_array_equal(host(up), orc.upscale_nn(a))
+        (up * dev(g)).sum().backward()
+        assert rel_linf(host(at.grad), orc.upscale_nn_bwd(g.astype(np.float64))) < 1e-6
+    a = rng.uniform(-1, 1, (1003,)).astype(np.float32)
+    c = rng.uniform(-1, 1, (1003,)).astype(np.float32)
+    at = dev(a).requires_grad_(True)
+    y = ops.lrelu(at)
+    np.testing.assert_array_equal(host(y), orc.lrelu(a).astype(np.float32))
+    (y * dev(c)).sum().backward()
+    np.testing.assert_array_equal(host(at.grad), (c * np.where(a > 0, 1.0, 0.2).astype(np.float32)))
+    np.testing.assert_array_equal(host(ops.add(dev(a), dev(c))), a + c)
+
+
+def test_l1_mean_and_adam(ops):
+    from deep_fluids_amd._lib import call
+    from deep_fluids_amd.ops import _ptr, _stream
+    rng = np.random.RandomState(12)
+    for n in (7, 4096, 1000003):
+        a = rng.uniform(-1, 1, n).astype(np.float32)
+        b = rng.uniform(-1, 1, n).astype(np.float32)
+        b[:3] = a[:3]                                             # sign(0) == 0 branch
+        at = dev(a).requires_grad_(True)
+        l = ops.l1_mean(at, dev(b))
+        (l * 3.0).backward()
+        assert abs(float(l) - np.abs(a.astype(np.float64) - b).mean()) < 1e-7
+        np.testing.assert_allclose(host(at.grad), np.sign(a - b) * np.float32(3.0 / n), rtol=1e-6, atol=0)
+    n = 100003
+    p = rng.uniform(-1, 1, n).astype(np.float32); g = rng.uniform(-1, 1, n).astype(np.float32)
+    m = rng.uniform(-.1, .1, n).astype(np.float32); v = rng.uniform(0, .1, n).astype(np.float32)
+    pt, gt, mt, vt = dev(p), dev(g), dev(m), dev(v)
+    t, lr = 7, 1e-4
+    lr_t = lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.5 ** t)
+    call("df_adam_tf1_step", _ptr(pt), _ptr(gt), _ptr(mt), _ptr(vt), n, float(lr_t), 0.5, 0.999, 1e-8, 0.5, _stream())
+    rp, rm, rv = orc.adam_tf1(p.astype(np.float64), 0.5 * g.astype(np.float64), m.astype(np.float64),
+                              v.astype(np.float64), t, lr)
+    assert rel_linf(host(pt), rp) < 1e-6 and rel_linf(host(mt), rm) < 1e-6 and rel_linf(host(vt), rv) < 1e-6
+
+
+def test_colsum(ops):
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream
+    rng = np.random.RandomState(13)
+    g = rng.uniform(-1, 1, (5000, 128)).astype(np.float32)
+    gt = dev(g)
+    out = torch.empty(128, device="cuda")
+    nb = query("df_colsum_workspace_bytes", 5000, 128)
+    ws = torch.empty(nb // 4 + 1, device="cuda")
+    call("df_colsum", _ptr(gt), _ptr(out), 5000, 128, _ptr(ws), nb, _stream())
+    assert rel_linf(host(out), g.astype(np.float64).sum(0)) < 1e-6

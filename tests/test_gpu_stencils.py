@@ -1,0 +1,146 @@
+"""-m gpu: HIP stencil kernels (through the C-ABI via deep_fluids_amd.ops) vs the golden vectors captured from
+the reference's ops.py and vs the oracle on seeded inputs.  fp32 stencils are one subtraction per output:
+the bar is BIT-EXACT."""
+import numpy as np
+import pytest
+import torch
+
+import df_oracle as orc
+from gpu_util import dev, host
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from deep_fluids_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("tag", ["a", "edge2", "tall", "wide"])
+def test_golden_2d(ops, golden_stencils, tag):
+    g = golden_stencils
+    u = ops.curl(dev(g["curl_%s_in" % tag]))
+    np.testing.assert_array_equal(host(u), g["curl_%s_out" % tag])
+    j, w = ops.jacobian(dev(g["jacobian_%s_in" % tag]))
+    np.testing.assert_array_equal(host(j), g["jacobian_%s_j" % tag])
+    np.testing.assert_array_equal(host(w), g["jacobian_%s_w" % tag])
+    np.testing.assert_array_equal(host(ops.divergence(dev(g["jacobian_%s_in" % tag]))), g["divergence_%s_out" % tag])
+    np.testing.assert_array_equal(ops.curl_np(g["curl_%s_in" % tag]), g["curl_np_%s_out" % tag])
+    np.testing.assert_array_equal(ops.vort_np(g["jacobian_%s_in" % tag]), g["vort_np_%s_out" % tag])
+    np.testing.assert_array_equal(ops.grad_np(g["curl_%s_in" % tag]), g["grad_np_%s_out" % tag])
+
+
+def test_golden_nchw(ops, golden_stencils):
+    g = golden_stencils
+    np.testing.assert_array_equal(host(ops.curl(dev(g["curl_nchw_in"]), data_format="NCHW")), g["curl_nchw_out"])
+    j, w = ops.jacobian(dev(g["jacobian_nchw_in"]), data_format="NCHW")
+    np.testing.assert_array_equal(host(j), g["jacobian_nchw_j"])
+    np.testing.assert_array_equal(host(w), g["jacobian_nchw_w"])
+
+
+@pytest.mark.parametrize("tag", ["a", "edge2", "slab", "b"])
+def test_golden_3d(ops, golden_stencils, tag):
+    g = golden_stencils
+    x = dev(g["jacobian3_%s_in" % tag])
+    j, c = ops.jacobian3(x)
+    np.testing.assert_array_equal(host(j), g["jacobian3_%s_j" % tag])
+    np.testing.assert_array_equal(host(c), g["jacobian3_%s_c" % tag])
+    np.testing.assert_array_equal(host(ops.curl3(x)), g["jacobian3_%s_c" % tag])
+    np.testing.assert_array_equal(host(ops.divergence3(x)), g["divergence3_%s_out" % tag])
+    jn, cn = ops.jacobian_np3(g["jacobian3_%s_in" % tag])
+    np.testing.assert_array_equal(jn, g["jacobian_np3_%s_j" % tag])
+    np.testing.assert_array_equal(cn, g["jacobian_np3_%s_c" % tag])
+
+
+def test_golden_composites(ops, golden_stencils):
+    g = golden_stencils
+    u = ops.curl3(dev(g["composite3_psi"]))
+    np.testing.assert_array_equal(host(u), g["composite3_u"])
+    np.testing.assert_array_equal(host(ops.jacobian3(u)[0]), g["composite3_ju"])
+    np.testing.assert_array_equal(host(ops.divergence3(u)), g["composite3_div"])
+    u2 = ops.curl(dev(g["composite2_psi"]))
+    np.testing.assert_array_equal(host(u2), g["composite2_u"])
+    np.testing.assert_array_equal(host(ops.jacobian(u2)[0]), g["composite2_ju"])
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 9), (1, 2, 2, 2), (3, 16, 24, 16), (1, 3, 4, 1031), (2, 33, 2, 5)])
+def test_jacobian3_vs_oracle_fwd_bwd(ops, shape):
+    rng = np.random.RandomState(sum(shape))
+    x = rng.uniform(-1, 1, shape + (3,)).astype(np.float32)
+    gj = rng.uniform(-1, 1, shape + (9,)).astype(np.float32)
+    gc = rng.uniform(-1, 1, shape + (3,)).astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    j, c = ops.jacobian3(xt)
+    oj, oc = orc.jacobian3(x)
+    np.testing.assert_array_equal(host(j), oj)
+    np.testing.assert_array_equal(host(c), oc)
+    (j * dev(gj)).sum().backward(retain_graph=True)
+    np.testing.assert_array_equal(host(xt.grad), orc.jacobian3_bwd(gj=gj))            # gj only
+    xt.grad = None
+    (c * dev(gc)).sum().backward(retain_graph=True)
+    np.testing.assert_array_equal(host(xt.grad), orc.jacobian3_bwd(gc=gc))            # gc only
+    xt.grad = None
+    ((j * dev(gj)).sum() + (c * dev(gc)).sum()).backward()
+    np.testing.assert_array_equal(host(xt.grad), orc.jacobian3_bwd(gj, gc))           # both
+    xt2 = dev(x).requires_grad_(True)
+    (ops.curl3(xt2) * dev(gc)).sum().backward()
+    np.testing.assert_array_equal(host(xt2.grad), orc.jacobian3_bwd(gc=gc))
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 6), (1, 2, 2), (3, 128, 96), (1, 3, 1029), (2, 37, 2)])
+def test_2d_vs_oracle_fwd_bwd(ops, shape):
+    rng = np.random.RandomState(sum(shape))
+    s = rng.uniform(-1, 1, shape + (1,)).astype(np.float32)
+    v = rng.uniform(-1, 1, shape + (2,)).astype(np.float32)
+    gu = rng.uniform(-1, 1, shape + (2,)).astype(np.float32)
+    gj = rng.uniform(-1, 1, shape + (4,)).astype(np.float32)
+    gw = rng.uniform(-1, 1, shape + (1,)).astype(np.float32)
+    st = dev(s).requires_grad_(True)
+    u = ops.curl(st)
+    np.testing.assert_array_equal(host(u), orc.curl(s))
+    (u * dev(gu)).sum().backward()
+    np.testing.assert_array_equal(host(st.grad), orc.curl_bwd(gu))
+    vt = dev(v).requires_grad_(True)
+    j, w = ops.jacobian(vt)
+    oj, ow = orc.jacobian(v)
+    np.testing.assert_array_equal(host(j), oj)
+    np.testing.assert_array_equal(host(w), ow)
+    (j * dev(gj)).sum().backward(retain_graph=True)
+    np.testing.assert_array_equal(host(vt.grad), orc.jacobian_bwd(gj))
+    vt.grad = None
+    ((j * dev(gj)).sum() + (w * dev(gw)).sum()).backward()
+    np.testing.assert_array_equal(host(vt.grad), orc.jacobian_bwd(gj, gw))
+
+
+def test_full_size_properties_cfg3(ops):
+    """BASELINE cfg3 shape [16,64,96,64,3]: size-independent properties instead of a CPU oracle run."""
+    torch.manual_seed(0)
+    psi = torch.rand((16, 64, 96, 64, 3), device="cuda") * 2 - 1
+    u = ops.curl3(psi)
+    j, c = ops.jacobian3(psi)
+    assert torch.equal(u, c)                                             # curl3 == jacobian3[1]
+    assert float(ops.divergence3(u).abs().max()) < 1e-5                   # div(curl psi) == 0 up to roundoff
+    # c == [j7-j5, j2-j6, j3-j1] (ops.py:255-257), bit-exact
+    assert torch.equal(c, torch.stack([j[..., 7] - j[..., 5], j[..., 2] - j[..., 6], j[..., 3] - j[..., 1]], -1))
+    # replicate-the-difference boundary rule on every axis
+    assert torch.equal(j[:, :, :, -1, 0], j[:, :, :, -2, 0])
+    assert torch.equal(j[:, :, -1, :, 4], j[:, :, -2, :, 4])
+    assert torch.equal(j[:, -1, :, :, 8], j[:, -2, :, :, 8])
+    # batch independence: sample 7 alone gives the same bits
+    assert torch.equal(ops.jacobian3(psi[7:8].contiguous())[0], j[7:8])
+    # adjoint identity <J x, g> == <x, J^T g> in fp64 accumulation
+    g = torch.rand_like(j) * 2 - 1
+    xt = psi.clone().requires_grad_(True)
+    (ops.jacobian3(xt)[0] * g).sum().backward()
+    lhs = (j.double() * g.double()).sum()
+    rhs = (psi.double() * xt.grad.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * float(j.double().abs().sum())
+
+
+def test_errors_are_loud(ops):
+    from deep_fluids_amd._lib import DeepFluidsHipError
+    with pytest.raises(DeepFluidsHipError):
+        ops.curl3(torch.zeros((1, 1, 4, 4, 3), device="cuda"))           # extent 1: forward difference undefined
+    with pytest.raises(DeepFluidsHipError):
+        ops.curl(torch.zeros((1, 4, 4, 1)))                               # CPU tensor: no CPU path
