@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- the Deep Fluids velocity-field train step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (config.workload): BASELINE cfg3 = 3-D 64x96x64 grid (Z,Y,X), 3-channel stream function / velocity,
+GeneratorBE3 with filters=128, num_conv=4 (18 layers, 7,483,523 parameters), fp32 end to end, per-GPU batch 16,
+one full step = generator fwd -> curl3 -> jacobian3 -> L1 + Jacobian-L1 -> backward -> (grad all-reduce) -> TF1 Adam
+-> cosine LR.  Synthetic inputs resident in HBM, random-init (Xavier) weights.  Weak scaling: the global batch is
+16 * N.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--res", type=int, nargs=3, default=[64, 96, 64], metavar=("Z", "Y", "X"))
+    ap.add_argument("--filters", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_inputs(batch, res, seed, ops):
+    """y ~ U(-1,1) [B,3]; x = curl3(psi_gt) rescaled to max|x| = 1 (divergence-free, in [-1,1])."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    y = torch.rand((batch, 3), device="cuda", generator=g) * 2 - 1
+    psi = torch.rand((batch, res[0], res[1], res[2], 3), device="cuda", generator=g) * 2 - 1
+    x = ops.curl3(psi)
+    x = x / x.abs().max()
+    return x.contiguous(), y.contiguous()
+
+
+def select_kernel(name, args):
+    """KernelTimer filter: the three kernels whose rooflines are reported."""
+    if name == "df_conv_fwd":
+        B, D, H, W, cin, cout = args[6:12]
+        if cin >= 64 and cout >= 64:
+            return ("conv_mfma_kernel fwd/dgrad %dx%dx%d C%d->%d" % (D, H, W, cin, cout), 2.0 * 27 * cin * cout * B * D * H * W)
+    if name == "df_conv_wgrad":
+        B, D, H, W, cin, cout = args[4:10]
+        if cin >= 64 and cout >= 64:
+            return ("wgrad_kernel %dx%dx%d C%dx%d" % (D, H, W, cin, cout), 2.0 * 27 * cin * cout * B * D * H * W)
+    if name == "df_jacobian3d_fwd" and args[1] is not None and args[2] is not None:
+        B, Z, Y, X = args[3:7]
+        return ("jacobian3d_fwd_kernel<j,c>", 60.0 * B * Z * Y * X)
+    return None
+
+
+def cpu_baseline(res, filters, budget_s):
+    """The oracle's PyTorch-CPU restatement of the SAME train step, timed on this node's host cores on a bounded
+    sample (batch 1, grid halved per axis).  A reported baseline, not the optimisation target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import df_oracle as orc
+    import df_oracle_torch as ort
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sres = [max(r // 2, 8) for r in res]
+    rng = np.random.RandomState(123)
+    oshape = sres + [3]
+    p = ort.to_torch(orc.generator_init(rng, 3, oshape, filters))
+    opt = ort.new_opt(p)
+    x, y = orc.synthetic_batch(rng, 1, sres)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    ort.train_step(yt, xt, p, opt, oshape, filters, True)           # warm-up (thread pools, oneDNN primitives)
+    n, t0 = 0, time.time()
+    while True:
+        ort.train_step(yt, xt, p, opt, oshape, filters, True)
+        n += 1
+        el = time.time() - t0
+        if el >= budget_s or n >= 20:
+            break
+    vox = float(np.prod(sres))
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": vox * n / el, "unit": "voxels/s", "cores": cores, "kind": "port",
+            "sample": "PyTorch-CPU fp32 restatement of the reference graph (TF 1.15 unavailable): %d full train steps, "
+                      "batch 1, grid %dx%dx%d, filters %d, %d threads, %.1f s" % (n, sres[0], sres[1], sres[2], filters,
+                                                                                  cores, el),
+            "cpu": model}
+
+
+def l1_vs_oracle(filters):
+    """Relative L1 of the velocity field vs the fp64 oracle on identical inputs/weights (reduced grid 16x24x16)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import df_oracle as orc
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import Trainer, default_config
+    ops.reset_variables()
+    rng = np.random.RandomState(123)
+    spatial = (16, 24, 16)
+    oshape = list(spatial) + [3]
+    p = orc.generator_init(rng, 3, oshape, filters)
+    x, y = orc.synthetic_batch(rng, 1, spatial)
+    cfg = default_config(is_3d=True, res_x=16, res_y=24, res_z=16, filters=filters, batch_size=1, num_samples=100)
+    tr = Trainer(cfg)
+    tr.load_variables(p)
+    u = tr.generate(torch.from_numpy(y).cuda()).cpu().numpy().astype(np.float64)
+    psi = orc.generator_fwd(y.astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()}, oshape, filters)
+    ref = orc.curl3(psi)
+    ops.reset_variables()
+    return float(np.abs(u - ref).sum() / np.abs(ref).sum())
+
+
+def main():
+    a = parse()
+    from deep_fluids_amd import _lib, ops
+    from deep_fluids_amd.dist import init_from_env
+    from deep_fluids_amd.trainer import Trainer, default_config
+
+    rank, local_rank, world = init_from_env()
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    torch.cuda.set_device(local_rank)
+
+    rel_l1 = l1_vs_oracle(a.filters) if rank == 0 else None
+
+    Z, Y, X = a.res
+    cfg = default_config(is_3d=True, res_x=X, res_y=Y, res_z=Z, filters=a.filters, batch_size=a.batch * world,
+                         num_samples=6600, random_seed=123)     # smoke3_obs_buo: 11*4*150 samples
+    tr = Trainer(cfg)                                           # same seed on every rank -> identical init
+    if world > 1:
+        tr.enable_data_parallel()
+    x, y = make_inputs(a.batch, a.res, 123 + rank, ops)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tr.train_step(x, y)
+    timer = _lib.KernelTimer(select_kernel)
+    sync_all()
+    _lib.TIMER = timer
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(a.steps):
+        last = tr.train_step(x, y)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    _lib.TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(last.g_loss)
+    assert loss == loss, "Model diverged with loss = NaN"        # trainer.py:275
+
+    if rank != 0:
+        return
+    vox_per_step = a.batch * Z * Y * X * world
+    value = vox_per_step * a.steps / elapsed
+    ks = timer.summary()
+
+    def roof(prefix, peak, unit, scale):
+        sel = {k: v for k, v in ks.items() if k.startswith(prefix)}
+        if not sel:
+            return None
+        k = max(sel, key=lambda q: sel[q]["seconds"])          # the dominant instance (top resolution)
+        v = sel[k]
+        ach = v["work"] / v["seconds"] / scale
+        return {"kernel": k, "bound": "mfma" if unit == "TFLOP/s" else "hbm", "achieved": ach, "peak": peak, "unit": unit,
+                "frac": ach / peak, "traffic": None, "launches": v["launches"],
+                "avg_launch_ms": v["seconds"] / v["launches"] * 1e3, "work_per_launch": v["work"] / v["launches"]}
+
+    out = {
+        "metric": "velocity-field voxels/sec (3D 64x96x64 train step), whole job; per-GPU in `per_gpu`",
+        "value": value, "unit": "voxels/s", "per_gpu": value / world,
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg3: 3D smoke3 %dx%dx%d (Z,Y,X) fp32, GeneratorBE3 filters=%d num_conv=4, "
+                               "per-GPU batch %d, full train step (fwd+curl3+jacobian3+L1 losses+bwd+Adam)" % (Z, Y, X, a.filters, a.batch),
+                   "global_batch": a.batch * world, "grid": [Z, Y, X], "params": tr.n_params,
+                   "parallelism": "dp%d" % world},
+        "loss": loss,
+        "l1_vs_ref": {"value": rel_l1, "tolerance": 1e-4,
+                      "case": "relative L1 of the velocity field vs the fp64 oracle, grid 16x24x16, filters %d" % a.filters},
+        "roofline": roof("conv_mfma_kernel", PEAK_FP32_MFMA_TFLOPS, "TFLOP/s", 1e12),
+        "roofline_wgrad": roof("wgrad_kernel", PEAK_FP32_MFMA_TFLOPS, "TFLOP/s", 1e12),
+        "roofline_stencil": roof("jacobian3d_fwd_kernel", PEAK_HBM_GBS, "GB/s", 1e9),
+        "kernels": {k: {"launches": v["launches"], "ms_total": v["seconds"] * 1e3} for k, v in sorted(ks.items())},
+    }
+    out["cpu_baseline"] = None
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.res, a.filters, a.cpu_seconds)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -77,10 +77,44 @@ def lib():
     return _lib
 
 
+class KernelTimer(object):
+    """Optional HIP-event timing of selected C-ABI calls (bench.py's live roofline measurement).
+
+    ``select(name, args)`` returns None or ``(key, work)``; matching calls are bracketed by two events recorded
+    on the CURRENT torch stream -- the stream the kernels are launched on -- and summarised after a sync."""
+
+    def __init__(self, select):
+        self.select = select
+        self.records = []
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for key, work, e0, e1 in self.records:
+            d = out.setdefault(key, {"launches": 0, "seconds": 0.0, "work": 0.0})
+            d["launches"] += 1
+            d["seconds"] += e0.elapsed_time(e1) * 1e-3
+            d["work"] += work
+        return out
+
+
+TIMER = None   # set to a KernelTimer to enable
+
+
 def call(name, *args):
     """Call an int-returning df_* entry point; raise with df_last_error() on failure."""
     h = lib()
-    rc = getattr(h, name)(*args)
+    hit = TIMER.select(name, args) if TIMER is not None else None
+    if hit is not None:
+        import torch
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(h, name)(*args)
+        e1.record()
+        TIMER.records.append((hit[0], hit[1], e0, e1))
+    else:
+        rc = getattr(h, name)(*args)
     if rc != 0:
         msg = h.df_last_error()
         raise DeepFluidsHipError("%s failed (%d): %s" % (name, rc, msg.decode() if msg else ""))

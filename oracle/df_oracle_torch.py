@@ -1,0 +1,120 @@
+"""PyTorch-CPU restatement of the velocity-field train step  --  TEST INFRASTRUCTURE ONLY.
+
+Second, independent implementation of the conv / FC / up-sampling arithmetic that lives in TensorFlow 1.15 in
+the reference (absent here -> "parity unpinned", see df_oracle.py): F.conv2d/conv3d(padding=1), F.linear,
+nearest 2x repeat, leaky-relu 0.2, autograd for the reverse pass.  Used by
+  * tests: cross-check of df_oracle.py's hand-written conv forward/backward and generator gradients;
+  * bench.py's ``cpu_baseline`` leg: the train step timed on the GPU box's host cores (kind "port").
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Follows model.py:5-87, ops.py:9-24,66-91,205-274, trainer.py:136-184, trainer3.py:14-63.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _fdiff(f, axis):
+    """ops.py:214-217: forward difference, last DIFFERENCE replicated."""
+    n = f.shape[axis]
+    d = f.narrow(axis, 1, n - 1) - f.narrow(axis, 0, n - 1)
+    return torch.cat([d, d.narrow(axis, n - 2, 1)], dim=axis)
+
+
+def curl(x):
+    psi = x[..., 0]
+    return torch.stack([_fdiff(psi, 1), -_fdiff(psi, 2)], dim=-1)
+
+
+def jacobian(x):
+    u, v = x[..., 0], x[..., 1]
+    dudx, dudy, dvdx, dvdy = _fdiff(u, 2), _fdiff(u, 1), _fdiff(v, 2), _fdiff(v, 1)
+    return torch.stack([dudx, dudy, dvdx, dvdy], dim=-1), (dvdx - dudy).unsqueeze(-1)
+
+
+def jacobian3(x):
+    d = {}
+    for ci, cn in enumerate("uvw"):
+        for an, ax in (("x", 3), ("y", 2), ("z", 1)):
+            d[cn + an] = _fdiff(x[..., ci], ax)
+    j = torch.stack([d["ux"], d["uy"], d["uz"], d["vx"], d["vy"], d["vz"], d["wx"], d["wy"], d["wz"]], dim=-1)
+    c = torch.stack([d["wy"] - d["vz"], d["uz"] - d["wx"], d["vx"] - d["uy"]], dim=-1)
+    return j, c
+
+
+def conv_same(x, w, b):
+    """channels-last x [B,*S,Cin], TF weights [*k,Cin,Cout]; k=3, stride 1."""
+    nd = x.dim() - 2
+    if nd == 3:
+        y = F.conv3d(x.permute(0, 4, 1, 2, 3), w.permute(4, 3, 0, 1, 2).contiguous(), b, padding=1)
+        return y.permute(0, 2, 3, 4, 1)
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1).contiguous(), b, padding=1)
+    return y.permute(0, 2, 3, 1)
+
+
+def upscale_nn(x):
+    for a in range(1, x.dim() - 1):
+        x = x.repeat_interleave(2, dim=a)
+    return x
+
+
+def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, leak=0.2):
+    """model.py:5-87 (skip_concat=False)."""
+    spatial = list(output_shape[:-1])
+    repeat_num = int(np.log2(np.max(spatial))) - 2 if repeat == 0 else repeat
+    f = 2 ** (repeat_num - 1)
+    x0_shape = [s // f for s in spatial] + [filters]
+    x = F.linear(z, p["%s/0_fc/weights" % name].t(), p["%s/0_fc/biases" % name]).reshape([-1] + x0_shape)
+    ln = 1
+    x0 = x
+    for idx in range(repeat_num):
+        for _ in range(num_conv):
+            x = F.leaky_relu(conv_same(x, p["%s/%d_conv/weights" % (name, ln)], p["%s/%d_conv/biases" % (name, ln)]), leak)
+            ln += 1
+        x = x + x0
+        if idx < repeat_num - 1:
+            x = upscale_nn(x)
+            x0 = x
+    return conv_same(x, p["%s/%d_conv/weights" % (name, ln)], p["%s/%d_conv/biases" % (name, ln)])
+
+
+def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0):
+    if is_3d:
+        u = jacobian3(psi)[1]; ju = jacobian3(u)[0]; jx = jacobian3(x)[0]
+    else:
+        u = curl(psi); ju = jacobian(u)[0]; jx = jacobian(x)[0]
+    l1 = (u - x).abs().mean(); jl1 = (ju - jx).abs().mean()
+    return l1 * w1 + jl1 * w2, l1, jl1, u
+
+
+def train_step(z, x, p, opt, output_shape, filters, is_3d, num_conv=4, repeat=0, w1=1.0, w2=1.0, beta1=0.5,
+               beta2=0.999, eps=1e-8):
+    """One step with TF1 Adam, in place on ``p`` (dict of leaf tensors) and ``opt`` (m, v, t, lr)."""
+    for v in p.values():
+        v.requires_grad_(True)
+        v.grad = None
+    psi = generator_fwd(z, p, output_shape, filters, num_conv=num_conv, repeat=repeat)
+    loss, l1, jl1, u = velocity_loss(psi, x, is_3d, w1, w2)
+    loss.backward()
+    opt["t"] += 1
+    t = opt["t"]
+    lr_t = opt["lr"] * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    grads = {}
+    with torch.no_grad():
+        for k, v in p.items():
+            g = v.grad
+            grads[k] = g
+            opt["m"][k].mul_(beta1).add_(g, alpha=1.0 - beta1)
+            opt["v"][k].mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+            v.sub_(lr_t * opt["m"][k] / (opt["v"][k].sqrt() + eps))
+    return {"loss": float(loss), "l1": float(l1), "j_l1": float(jl1), "u": u.detach(), "psi": psi.detach(), "grads": grads}
+
+
+def to_torch(params, dtype=torch.float32):
+    return {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in params.items()}
+
+
+def new_opt(p, lr=1e-4):
+    return {"m": {k: torch.zeros_like(v) for k, v in p.items()}, "v": {k: torch.zeros_like(v) for k, v in p.items()},
+            "t": 0, "lr": lr}

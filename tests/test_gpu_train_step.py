@@ -60,11 +60,19 @@ def _run_step_case(is_3d, spatial, filters, batch, steps=2):
         out["loss_rel_step%d" % s] = abs(float(m.g_loss) - info["loss"]) / abs(info["loss"])
         if s == 0:
             gr = tr.grads_numpy()
-            out["grad_rel_linf"] = max(rel_linf(gr[k], info["grads"][k]) for k in gr)
+            # per-variable L-inf error relative to that variable's gradient scale, floored at 1e-3 of the global
+            # scale: the last conv's bias gradient is mathematically ZERO (curl kills constants), i.e. pure
+            # roundoff in any finite precision (5e-18 in the fp64 oracle, 1e-8 in fp32)
+            gmax = max(np.abs(v).max() for v in info["grads"].values())
+            out["grad_rel_linf"] = max(
+                float(np.abs(gr[k] - info["grads"][k]).max() / max(np.abs(info["grads"][k]).max(), 1e-3 * gmax)) for k in gr)
     newp = tr.variables_numpy()
-    # Adam divides by sqrt(v): the first updates are +-lr regardless of |g|, so compare the parameter DELTAS
-    out["param_delta_rel_linf"] = max(
-        float(np.abs((newp[k] - p[k]) - (p64[k] - p[k])).max() / max(np.abs(p64[k] - p[k]).max(), 1e-30)) for k in p)
+    # Adam divides by sqrt(v): early updates are ~ +-lr whatever |g| is, so compare the parameter DELTAS in the
+    # mean (elements whose gradient is roundoff-level flip sign; the zero-gradient last bias is excluded)
+    last_bias = sorted((k for k in p if k.endswith("biases")), key=lambda k: int(k.split("/")[1].split("_")[0]))[-1]
+    num = sum(np.abs((newp[k] - p[k]) - (p64[k] - p[k])).sum() for k in p if k != last_bias)
+    den = sum(np.abs(p64[k] - p[k]).sum() for k in p if k != last_bias)
+    out["param_delta_rel_l1"] = float(num / den)
     assert abs(tr.g_lr - opt["lr"]) < 1e-12
     ops.reset_variables()
     return out
@@ -75,7 +83,7 @@ def test_train_step_3d_vs_oracle():
     assert r["velocity_rel_l1_step0"] <= 1e-4 and r["velocity_rel_l1_step1"] <= 1e-4, r
     assert r["loss_rel_step0"] < 1e-5 and r["loss_rel_step1"] < 1e-4, r
     assert r["grad_rel_linf"] < 1e-3, r          # sign(a-b) gradients flip on fp32-vs-fp64 ties; see DESIGN.md
-    assert r["param_delta_rel_linf"] < 5e-2, r
+    assert r["param_delta_rel_l1"] < 1e-2, r
 
 
 def test_train_step_2d_vs_oracle():
@@ -83,7 +91,7 @@ def test_train_step_2d_vs_oracle():
     assert r["velocity_rel_l1_step0"] <= 1e-4 and r["velocity_rel_l1_step1"] <= 1e-4, r
     assert r["loss_rel_step0"] < 1e-5, r
     assert r["grad_rel_linf"] < 1e-3, r
-    assert r["param_delta_rel_linf"] < 5e-2, r
+    assert r["param_delta_rel_l1"] < 1e-2, r
 
 
 def test_train_step_cfg3_geometry_filters128():

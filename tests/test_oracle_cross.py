@@ -1,0 +1,43 @@
+"""The two oracle implementations against each other (CPU): df_oracle.py's hand-written NumPy conv / generator /
+reverse pass vs the independent PyTorch-CPU restatement (F.conv*, autograd).  This is the second opinion for the
+arithmetic whose reference implementation (TF 1.15) is unavailable ("parity unpinned")."""
+import numpy as np
+import pytest
+import torch
+
+import df_oracle as orc
+import df_oracle_torch as ort
+
+
+@pytest.mark.parametrize("is_3d,spatial,filters", [(True, (4, 8, 4), 4), (False, (16, 8), 8)])
+def test_train_step_numpy_vs_torch_fp64(is_3d, spatial, filters):
+    rng = np.random.RandomState(7)
+    oshape = list(spatial) + [3 if is_3d else 1]
+    p = {k: v.astype(np.float64) for k, v in orc.generator_init(rng, 3, oshape, filters).items()}
+    for k in p:
+        if k.endswith("biases"):
+            p[k] = rng.uniform(-0.1, 0.1, p[k].shape)
+    x, y = orc.synthetic_batch(rng, 2, spatial)
+    x = x.astype(np.float64); y = y.astype(np.float64)
+    opt = {"m": {k: np.zeros_like(v) for k, v in p.items()}, "v": {k: np.zeros_like(v) for k, v in p.items()},
+           "t": 0, "lr": 1e-4}
+    pt = ort.to_torch(p, torch.float64)
+    ot = ort.new_opt(pt)
+    for step in range(2):
+        p, opt, info = orc.train_step(y, x, p, opt, oshape, filters, is_3d)
+        it = ort.train_step(torch.tensor(y), torch.tensor(x), pt, ot, oshape, filters, is_3d)
+        assert abs(info["loss"] - it["loss"]) < 1e-12
+        np.testing.assert_allclose(info["u"], it["u"].numpy(), atol=1e-12)
+        for k in p:
+            np.testing.assert_allclose(info["grads"][k], it["grads"][k].numpy(), atol=1e-12, err_msg=k)
+            np.testing.assert_allclose(p[k], pt[k].detach().numpy(), atol=1e-12, err_msg=k)
+
+
+def test_stencils_numpy_vs_torch():
+    rng = np.random.RandomState(8)
+    v = rng.randn(2, 4, 5, 6, 3)
+    j, c = orc.jacobian3(v)
+    jt, ct = ort.jacobian3(torch.tensor(v))
+    np.testing.assert_array_equal(j, jt.numpy()); np.testing.assert_array_equal(c, ct.numpy())
+    s = rng.randn(2, 5, 6, 1)
+    np.testing.assert_array_equal(orc.curl(s), ort.curl(torch.tensor(s)).numpy())
