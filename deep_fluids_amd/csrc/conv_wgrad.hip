@@ -25,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
-constexpr int kMaxRanges = 128;
+constexpr int kMaxRanges = 256;
 
 struct WgradArgs {
   const float* x;
@@ -41,12 +41,15 @@ struct WgradArgs {
   int want_bias;
 };
 
-template <bool XVEC, bool GVEC>
+// WP8 > 0: the padded row length Wp = 8*WP8 is a compile-time constant and the whole row is unrolled, so the
+// compiler's conservative vmcnt merge at a loop header happens once per row pair instead of every 8 steps.
+template <bool XVEC, bool GVEC, int WP8>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = wave >> 1, qj = wave & 1;
+  const int Wc = WP8 > 0 ? WP8 * 8 : a.W;      // row length (compile-time when WP8 > 0: dispatch guarantees W == 8*WP8)
   const int half = lane >> 5, r = lane & 31;
 
   // workgroup -> (range, dzdy): XCD x gets a contiguous run of ranges, and the 9 (dz,dy) workgroups of one
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
     return a.x + off;
   };
   auto load_x = [&](const Row& rw, int pos) -> f32x2 {
-    const bool k = rw.xv && pos < a.W;
+    const bool k = rw.xv && pos < Wc;
     const float* p = rw.xb + static_cast<int64_t>(pos) * a.Cin;
     f32x2 v;
     if (XVEC) v = *reinterpret_cast<const f32x2*>(pick(k && ci_ok0, p));
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
     return v;
   };
   auto load_g = [&](const Row& rw, int pos) -> f32x2 {
-    const bool k = rw.gv && pos < a.W;
+    const bool k = rw.gv && pos < Wc;
     const float* p = rw.gb + static_cast<int64_t>(pos) * a.Cout;
     f32x2 v;
     if (GVEC) v = *reinterpret_cast<const f32x2*>(pick(k && co_ok0, p));
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
     f32x2 am = xr[(u + 7) & 7], a0 = xr[u], ap = xr[(u + 1) & 7];
     const f32x2 b = gr[u];
     if (x == 0) am = f32x2{0.f, 0.f};            // left zero padding (the ring slot holds the previous row's tail)
-    if (x == a.W - 1) ap = f32x2{0.f, 0.f};      // right zero padding (the ring slot may hold the next row's head)
+    if (x == Wc - 1) ap = f32x2{0.f, 0.f};      // right zero padding (the ring slot may hold the next row's head)
     bsum[0] += b[0]; bsum[1] += b[1];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -160,18 +163,31 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
       }
   };
 
+  const int Wp = WP8 > 0 ? WP8 * 8 : a.Wp;
   for (int pair = p0; pair < p1; ++pair) {
     const Row nxt = row_setup(pair + 1);
-    for (int x0 = 0; x0 < a.Wp - 8; x0 += 8) {
+    if (WP8 > 0) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        xr[(u + 6) & 7] = load_x(cur, x0 + u + 6);
-        gr[(u + 5) & 7] = load_g(cur, x0 + u + 5);
-        step(u, x0 + u);
+      for (int x0 = 0; x0 < (WP8 - 1) * 8; x0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          xr[(u + 6) & 7] = load_x(cur, x0 + u + 6);
+          gr[(u + 5) & 7] = load_g(cur, x0 + u + 5);
+          step(u, x0 + u);
+        }
+      }
+    } else {
+      for (int x0 = 0; x0 < Wp - 8; x0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          xr[(u + 6) & 7] = load_x(cur, x0 + u + 6);
+          gr[(u + 5) & 7] = load_g(cur, x0 + u + 5);
+          step(u, x0 + u);
+        }
       }
     }
     {   // last 8 positions of the row: the prefetch cursor crosses into the next row pair
-      const int x0 = a.Wp - 8;
+      const int x0 = Wp - 8;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         xr[(u + 6) & 7] = u < 2 ? load_x(cur, x0 + u + 6) : load_x(nxt, u - 2);
@@ -248,13 +264,11 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   p.npairs = (p.nrows + 1) / 2;
   p.ndzdy = kz == 3 ? 9 : 3;
   p.taps = p.ndzdy * 3;
-  // enough workgroups to fill 256 CUs x 2 twice over, but ranges long enough to amortise the 192-register epilogue
-  int want = (2 * 512 + p.ndzdy - 1) / p.ndzdy;
-  const int min_pairs = (int)ceil_div(2048, W);       // >= ~2k steps (~24k MFMAs) per workgroup
-  int maxr = p.npairs / (min_pairs > 0 ? min_pairs : 1);
-  if (maxr < 1) maxr = 1;
-  int nr = want < maxr ? want : maxr;
-  if (nr > kMaxRanges) nr = kMaxRanges;
+  // The kernel runs ONE workgroup per CU (192 accumulator registers per lane): a grid that is not a multiple
+  // of 256 leaves most of the chip idle in its last round.  256 equal voxel ranges x (9 | 3) (dz,dy) groups is
+  // exactly 9 | 3 full rounds; smaller problems get one range per row pair.
+  (void)W;
+  int nr = p.npairs >= kMaxRanges ? kMaxRanges : p.npairs;
   p.ppr = (p.npairs + nr - 1) / nr;
   p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
   p.Cinp = (int)(ceil_div(Cin, 128) * 128);
@@ -301,10 +315,15 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)(p.Cinp / 128), (unsigned)(p.Coutp / 128));
   const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
-  if (xvec && gvec) hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, dim3(kThreads), 0, s, a);
-  else if (xvec) hipLaunchKernelGGL((wgrad_kernel<true, false>), grid, dim3(kThreads), 0, s, a);
-  else if (gvec) hipLaunchKernelGGL((wgrad_kernel<false, true>), grid, dim3(kThreads), 0, s, a);
-  else hipLaunchKernelGGL((wgrad_kernel<false, false>), grid, dim3(kThreads), 0, s, a);
+  const int wp8 = a.Wp / 8;
+  const bool exact = (W % 8) == 0;
+  if (xvec && gvec && exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);
+  else if (xvec && gvec && exact && wp8 == 4) hipLaunchKernelGGL((wgrad_kernel<true, true, 4>), grid, dim3(kThreads), 0, s, a);
+  else if (xvec && gvec && exact && wp8 == 14) hipLaunchKernelGGL((wgrad_kernel<true, true, 14>), grid, dim3(kThreads), 0, s, a);
+  else if (xvec && gvec) hipLaunchKernelGGL((wgrad_kernel<true, true, 0>), grid, dim3(kThreads), 0, s, a);
+  else if (xvec) hipLaunchKernelGGL((wgrad_kernel<true, false, 0>), grid, dim3(kThreads), 0, s, a);
+  else if (gvec) hipLaunchKernelGGL((wgrad_kernel<false, true, 0>), grid, dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((wgrad_kernel<false, false, 0>), grid, dim3(kThreads), 0, s, a);
   const int64_t total = static_cast<int64_t>(p.taps) * Cin * Cout;
   int64_t rg = ceil_div(total, kThreads);
   if (rg > 2048) rg = 2048;
