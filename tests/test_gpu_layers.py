@@ -49,6 +49,10 @@ CASES_3D = [
     ((1, 4, 5, 14), 3, 128, 0.2),       # 3 input channels (scalar staging path; dgrad of the last conv)
     ((1, 2, 3, 4), 64, 64, 0.2),        # N tile 64
     ((1, 7, 10, 7), 16, 32, 0.2),       # cfg4 level-0 geometry (odd extents)
+    ((1, 2, 3, 32), 32, 64, 0.2),       # W = 32 / 64 / 112: the fully unrolled wgrad row variants
+    ((1, 2, 2, 64), 16, 16, None),
+    ((1, 2, 2, 112), 16, 16, 0.2),
+    ((3, 2, 2, 64), 128, 128, 0.2),     # odd row count (12 rows -> 6 pairs; 3 batches) at W = 64
 ]
 
 
