@@ -22,31 +22,13 @@
 // Epilogue (fused): bias, lrelu, residual add, lrelu-backward mask (dgrad).
 // The dgrad is the same kernel on mirrored/transposed packed weights (mode 1).
 #include "df_common.hpp"
+#include "conv_args.hpp"
 
 namespace {
 
 using df::ceil_div;
+using namespace dfconv;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kThreads = 256;
-constexpr int CK = 16;          // input channels per LDS chunk
-constexpr int LDS_STRIDE = 20;  // floats per staged voxel (16 + 4 pad)
-
-struct ConvArgs {
-  const float* x;
-  const f32x4* wp;
-  const float* bias;
-  const float* residual;
-  const float* mask_src;
-  float* y;
-  int B, D, H, W, Cin, Cout;
-  int Kpad, Npad;       // padded K (multiple of 16) and N (multiple of the N tile) of the packed weights
-  int nz, ny, nx;       // tiles per axis
-  int ntiles;
-  int flags;
-  float leak;
-};
 
 // ---- weight packing ---------------------------------------------------------------------------------
 // mode 0: Wp[tap][k8][half][n][s] = w[tap][k8*8+half*4+s][n]            (K = cin,  N = cout)
@@ -303,6 +285,8 @@ int df_conv_fwd(const float* x, const float* wp, const float* bias, const float*
   a.flags = flags; a.leak = leak;
   a.nz = a.ny = a.nx = a.ntiles = 0;
   hipStream_t s = df::as_stream(stream);
+  if (Cout <= 4) return launch_small_n(a, kz, s);                 // thin output: vector-ALU kernel
+  if (Cin <= 4 && Cout >= 32) return launch_small_k(a, kz, s);    // thin input (dgrad of the last layer)
   if (kz == 3) {
     if (W >= 12) return launch_n<3, 2, 4, 16>(a, s);
     return launch_n<3, 4, 4, 8>(a, s);

@@ -1,0 +1,40 @@
+// Shared argument block / constants of the convolution kernels (conv.hip, conv_small.hip).
+#pragma once
+#include "df_common.hpp"
+
+namespace dfconv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int CK = 16;          // input channels per LDS chunk
+constexpr int LDS_STRIDE = 20;  // floats per staged voxel (16 + 4 pad)
+
+struct ConvArgs {
+  const float* x;
+  const f32x4* wp;
+  const float* bias;
+  const float* residual;
+  const float* mask_src;
+  float* y;
+  int B, D, H, W, Cin, Cout;
+  int Kpad, Npad;       // padded K (multiple of 16) and N (multiple of the N tile) of the packed weights
+  int nz, ny, nx;       // tiles per axis
+  int ntiles;
+  int flags;
+  float leak;
+};
+
+
+// XCD-aware, bijective workgroup -> tile mapping (workgroup b runs on XCD b % 8; speed only)
+__device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
+  const int q = ntiles >> 3, rem = ntiles & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+}
+
+// VALU kernels for the generator's last layer (conv_small.hip); return DF_OK or an error
+int launch_small_n(const ConvArgs& a, int kz, hipStream_t s);   // Cout <= 4  (128 -> 3 | 1)
+int launch_small_k(const ConvArgs& a, int kz, hipStream_t s);   // Cin  <= 4  (dgrad of the last layer; 3 -> F)
+
+}  // namespace dfconv

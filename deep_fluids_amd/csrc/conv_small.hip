@@ -1,0 +1,236 @@
+// VALU kernels for the thin layers at the end of the generator (model.py:42,84: conv 128 -> 1|3, no activation).
+// A 32-wide MFMA column block would waste 29/32 of the matrix core on 3 output channels, so these run on the
+// vector ALU (64-wide wavefronts, the tiny operand held in SGPRs / broadcast from LDS):
+//
+//   conv_small_n : Cout <= 4.  thread = output voxel; the halo'd input tile is staged per 16-channel chunk in LDS
+//                  exactly as in conv.hip; the weights of a (tap, channel-quad) are 16 consecutive floats of the
+//                  packed filter bank at a wave-uniform address -> scalar loads, FMAs take them as SGPR operands.
+//   conv_small_k : Cin  <= 4 (the dgrad of the last layer, 3 -> 128).  thread = output channel with its 27x4
+//                  filter taps in registers; the 4-float input records of the halo tile sit in LDS and are read
+//                  at wave-uniform addresses (broadcast).  Full fused epilogue (bias, lrelu, residual, mask).
+//   wgrad_small_n: gW[tap][ci][co<=4].  thread = input channel with all 27 x CO accumulators in registers; a wave
+//                  walks image rows along x with an 8-deep register ring per (dz,dy) (9 coalesced 256-byte loads per
+//                  voxel step, 5-6 steps ahead), the gradient record G[voxel][co] is wave-uniform (scalar loads).
+#include "conv_args.hpp"
+
+namespace dfconv {
+namespace {
+
+using df::ceil_div;
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int KZ, int TZ, int TY, int TX, int CO, bool VEC>
+__global__ __launch_bounds__(kThreads) void conv_small_n_kernel(const ConvArgs a) {
+  static_assert(TZ * TY * TX == kThreads, "one thread per output voxel");
+  constexpr int PZ = KZ / 2;
+  constexpr int HZ = TZ + KZ - 1, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  constexpr int NPIECE = HV * (CK / 4);
+  constexpr int NLOAD = (NPIECE + kThreads - 1) / kThreads;
+  constexpr int NTAP = KZ * 9;
+  constexpr int S4 = LDS_STRIDE / 4;
+  __shared__ __attribute__((aligned(16))) float sA[HV * LDS_STRIDE];
+  const f32x4* sA4 = reinterpret_cast<const f32x4*>(sA);
+
+  const int tid = threadIdx.x;
+  const int tile = xcd_tile(blockIdx.x, a.ntiles);
+  const int ix = tile % a.nx;
+  int t2 = tile / a.nx;
+  const int iy = t2 % a.ny; t2 /= a.ny;
+  const int iz = t2 % a.nz;
+  const int b = t2 / a.nz;
+  const int tz0 = iz * TZ, ty0 = iy * TY, tx0 = ix * TX;
+  const int lx = tid % TX, ly = (tid / TX) % TY, lz = tid / (TX * TY);
+  const int aidx = ((lz * HY + ly) * HX + lx) * S4;
+  const int K8 = a.Kpad >> 3;
+  const float* __restrict__ wflat = reinterpret_cast<const float*>(a.wp);
+
+  float acc[CO];
+#pragma unroll
+  for (int n = 0; n < CO; ++n) acc[n] = 0.f;
+
+  const int nchunk = a.Kpad / CK;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    float4 stg[NLOAD];
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int p = it * kThreads + tid;
+      const int hv = p >> 2, q = p & 3;
+      const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+      const int gz = tz0 + hz - PZ, gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+      const int ch = chunk * CK + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool inb = p < NPIECE && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      if (inb) {
+        const int64_t vox = ((static_cast<int64_t>(b) * a.D + gz) * a.H + gy) * a.W + gx;
+        const float* src = a.x + vox * a.Cin + ch;
+        if (VEC) {
+          if (ch < a.Cin) v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (ch + 0 < a.Cin) v.x = src[0];
+          if (ch + 1 < a.Cin) v.y = src[1];
+          if (ch + 2 < a.Cin) v.z = src[2];
+          if (ch + 3 < a.Cin) v.w = src[3];
+        }
+      }
+      stg[it] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int p = it * kThreads + tid;
+      if (p < NPIECE) *reinterpret_cast<float4*>(&sA[(p >> 2) * LDS_STRIDE + (p & 3) * 4]) = stg[it];
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      const int toff = ((dz * HY + dy) * HX + dx) * S4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 xv = sA4[aidx + toff + q];
+        // packed record [tap][k8][half][n][s]: for n < 4 the 16 floats (n-major, s-minor) are contiguous
+        const int k8 = chunk * 2 + (q >> 1), half = q & 1;
+        const float* wr = wflat + ((static_cast<int64_t>(tap) * K8 + k8) * 2 + half) * a.Npad * 4;   // wave-uniform
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int n = 0; n < CO; ++n) acc[n] = fmaf(xv[s], wr[n * 4 + s], acc[n]);
+      }
+    }
+  }
+
+  const int gz = tz0 + lz, gy = ty0 + ly, gx = tx0 + lx;
+  if (gz < a.D && gy < a.H && gx < a.W) {
+    const int64_t o = (((static_cast<int64_t>(b) * a.D + gz) * a.H + gy) * a.W + gx) * a.Cout;
+#pragma unroll
+    for (int n = 0; n < CO; ++n) {
+      if (n < a.Cout) {
+        float v = acc[n];
+        if (a.flags & DF_CONV_BIAS) v += a.bias[n];
+        if (a.flags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
+        if (a.flags & DF_CONV_RESIDUAL) v += a.residual[o + n];
+        if (a.flags & DF_CONV_MASK) v = a.mask_src[o + n] > 0.f ? v : a.leak * v;
+        a.y[o + n] = v;
+      }
+    }
+  }
+}
+
+template <int KZ, int TZ, int TY, int TX>
+int launch_small_n_t(ConvArgs a, hipStream_t s) {
+  a.nz = (int)ceil_div(a.D, TZ); a.ny = (int)ceil_div(a.H, TY); a.nx = (int)ceil_div(a.W, TX);
+  const int64_t nt = static_cast<int64_t>(a.B) * a.nz * a.ny * a.nx;
+  DF_REQUIRE(nt < (1LL << 31), DF_ESHAPE, "df_conv_fwd: too many tiles");
+  a.ntiles = (int)nt;
+  dim3 grid((unsigned)nt);
+  const bool vec = (a.Cin % 4 == 0) && df::aligned16(a.x);
+#define DF_SN(CO)                                                                                                  \
+  if (vec) hipLaunchKernelGGL((conv_small_n_kernel<KZ, TZ, TY, TX, CO, true>), grid, dim3(kThreads), 0, s, a);     \
+  else hipLaunchKernelGGL((conv_small_n_kernel<KZ, TZ, TY, TX, CO, false>), grid, dim3(kThreads), 0, s, a)
+  switch (a.Cout) {
+    case 1: DF_SN(1); break;
+    case 2: DF_SN(2); break;
+    case 3: DF_SN(3); break;
+    default: DF_SN(4); break;
+  }
+#undef DF_SN
+  return df::launched("df_conv_fwd(small-N)");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int KZ, int TZ, int TY, int TX>
+__global__ __launch_bounds__(kThreads) void conv_small_k_kernel(const ConvArgs a, int nwn) {
+  constexpr int NV = TZ * TY * TX;    // 128 voxels per workgroup
+  constexpr int PZ = KZ / 2;
+  constexpr int HZ = TZ + KZ - 1, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  constexpr int NTAP = KZ * 9;
+  __shared__ f32x4 sG[HV];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_tile(blockIdx.x, a.ntiles);
+  const int ix = tile % a.nx;
+  int t2 = tile / a.nx;
+  const int iy = t2 % a.ny; t2 /= a.ny;
+  const int iz = t2 % a.nz;
+  const int b = t2 / a.nz;
+  const int tz0 = iz * TZ, ty0 = iy * TY, tx0 = ix * TX;
+
+  for (int hv = tid; hv < HV; hv += kThreads) {
+    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+    const int gz = tz0 + hz - PZ, gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+      const float* src = a.x + (((static_cast<int64_t>(b) * a.D + gz) * a.H + gy) * a.W + gx) * a.Cin;
+      v[0] = src[0];
+      if (a.Cin > 1) v[1] = src[1];
+      if (a.Cin > 2) v[2] = src[2];
+      if (a.Cin > 3) v[3] = src[3];
+    }
+    sG[hv] = v;
+  }
+
+  // waves: nwn of them side by side over the output channels (64 each), the rest are independent voxel streams
+  const int wn = wave % nwn, ws = wave / nwn, nstream = 4 / nwn;
+  const int n = blockIdx.y * (nwn * 64) + wn * 64 + lane;
+  const bool nok = n < a.Cout;
+  f32x4 w[NTAP];                      // this output channel's taps: packed record [tap][k8=0][half=0][n][k]
+#pragma unroll
+  for (int tap = 0; tap < NTAP; ++tap)
+    w[tap] = a.wp[(static_cast<int64_t>(tap) * (a.Kpad >> 3) * 2) * a.Npad + (nok ? n : 0)];
+  const float bv = (a.flags & DF_CONV_BIAS) && nok ? a.bias[n] : 0.f;
+  __syncthreads();
+
+  for (int m = ws; m < NV; m += nstream) {
+    const int lx = m % TX, ly = (m / TX) % TY, lz = m / (TX * TY);
+    const int gz = tz0 + lz, gy = ty0 + ly, gx = tx0 + lx;
+    if (gz >= a.D || gy >= a.H || gx >= a.W) continue;          // wave-uniform
+    const int h0 = (lz * HY + ly) * HX + lx;
+    float acc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      const f32x4 g = sG[h0 + (dz * HY + dy) * HX + dx];          // wave-uniform address: LDS broadcast
+      acc = fmaf(g[0], w[tap][0], acc);
+      acc = fmaf(g[1], w[tap][1], acc);
+      acc = fmaf(g[2], w[tap][2], acc);
+      acc = fmaf(g[3], w[tap][3], acc);
+    }
+    if (nok) {
+      const int64_t o = (((static_cast<int64_t>(b) * a.D + gz) * a.H + gy) * a.W + gx) * a.Cout + n;
+      float v = acc + bv;
+      if (a.flags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
+      if (a.flags & DF_CONV_RESIDUAL) v += a.residual[o];
+      if (a.flags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
+      a.y[o] = v;
+    }
+  }
+}
+
+template <int KZ, int TZ, int TY, int TX>
+int launch_small_k_t(ConvArgs a, hipStream_t s) {
+  a.nz = (int)ceil_div(a.D, TZ); a.ny = (int)ceil_div(a.H, TY); a.nx = (int)ceil_div(a.W, TX);
+  const int64_t nt = static_cast<int64_t>(a.B) * a.nz * a.ny * a.nx;
+  DF_REQUIRE(nt < (1LL << 31), DF_ESHAPE, "df_conv_fwd: too many tiles");
+  a.ntiles = (int)nt;
+  const int nwn = a.Cout > 128 ? 4 : (a.Cout > 64 ? 2 : 1);
+  dim3 grid((unsigned)nt, (unsigned)ceil_div(a.Cout, nwn * 64));
+  hipLaunchKernelGGL((conv_small_k_kernel<KZ, TZ, TY, TX>), grid, dim3(kThreads), 0, s, a, nwn);
+  return df::launched("df_conv_fwd(small-K)");
+}
+
+}  // namespace
+
+int launch_small_n(const ConvArgs& a, int kz, hipStream_t s) {
+  if (kz == 3) return a.W >= 12 ? launch_small_n_t<3, 4, 4, 16>(a, s) : launch_small_n_t<3, 4, 8, 8>(a, s);
+  return a.W >= 12 ? launch_small_n_t<1, 1, 16, 16>(a, s) : launch_small_n_t<1, 1, 32, 8>(a, s);
+}
+
+int launch_small_k(const ConvArgs& a, int kz, hipStream_t s) {
+  if (kz == 3) return a.W >= 12 ? launch_small_k_t<3, 2, 4, 16>(a, s) : launch_small_k_t<3, 4, 4, 8>(a, s);
+  return a.W >= 12 ? launch_small_k_t<1, 1, 8, 16>(a, s) : launch_small_k_t<1, 1, 16, 8>(a, s);
+}
+
+}  // namespace dfconv

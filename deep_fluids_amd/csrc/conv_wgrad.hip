@@ -26,6 +26,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
 constexpr int kMaxRanges = 256;
+constexpr int kZeroBytes = 512;      // zeroed slot at the end of the workspace (padding reads)
+constexpr int kSmallStreams = 2048;  // wave streams of the small-N kernel
 
 struct WgradArgs {
   const float* x;
@@ -253,6 +255,184 @@ __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float* __r
   }
 }
 
+// ---- small-N weight gradient (Cout <= 4: the generator's last layer) on the vector ALU ---------------------------
+// thread = input channel (64 per wave), all NTAP x CO accumulators in registers.  A wave walks whole image rows
+// along x; rows are laid end to end with >= 1 zero position between them (Wp = round_up(W + 1, 8)), so the
+// x-1 / x+1 neighbours at a row's ends are zeros WITHOUT any masking.  Per voxel step: 9 | 3 coalesced 256-byte
+// loads (one per (dz,dy), 5-6 steps ahead in an 8-deep ring), the wave-uniform gradient record via scalar loads,
+// 27*CO | 9*CO FMAs.  Out-of-image source rows and the padding read a zeroed workspace slot (address select on an
+// opaque scalar offset: no branches, no post-load selects -> counted vmcnt waits only).
+struct SmallWgradArgs {
+  const float* x;
+  const float* g;
+  float* partial;      // [nstreams][taps][Cin][CO]
+  float* bpartial;     // [nstreams][CO]
+  const float* zeros;
+  int B, D, H, W, Cin, Cout;
+  int Wp, nrows, nstreams, rows_per, ncib;
+};
+
+template <int KZ, int CO>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_small_n_kernel(const SmallWgradArgs a) {
+  constexpr int NDZDY = KZ * 3, NTAP = NDZDY * 3;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * 4 + wave;
+  const int cib = gw % a.ncib, stream = gw / a.ncib;
+  const int ci = cib * 64 + lane;
+  const int r0 = stream * a.rows_per;
+  int r1 = r0 + a.rows_per;
+  if (r1 > a.nrows) r1 = a.nrows;
+  const int64_t zoff_x = a.zeros - a.x, zoff_g = a.zeros - a.g;
+
+  struct Row { int64_t xo[NDZDY]; int64_t go; };
+  auto row_setup = [&](int row) -> Row {      // everything here is wave-uniform
+    Row rw;
+    const bool ok = row < r1;
+    const int y = row % a.H;
+    const int t = row / a.H;
+    const int z = t % a.D;
+    const int b = t / a.D;
+    rw.go = ok ? (static_cast<int64_t>(row) * a.W) * a.Cout : -1;
+#pragma unroll
+    for (int k = 0; k < NDZDY; ++k) {
+      const int zs = z + (KZ == 3 ? k / 3 - 1 : 0), ys = y + k % 3 - 1;
+      const bool v = ok && zs >= 0 && zs < a.D && ys >= 0 && ys < a.H;
+      rw.xo[k] = v ? (((static_cast<int64_t>(b) * a.D + zs) * a.H + ys) * a.W) * a.Cin + cib * 64 : -1;
+    }
+    return rw;
+  };
+  auto load_x = [&](const Row& rw, int k, int pos) -> float {
+    int64_t off = (rw.xo[k] >= 0 && pos < a.W) ? rw.xo[k] + static_cast<int64_t>(pos) * a.Cin : zoff_x;
+    asm("" : "+s"(off));
+    return a.x[off + lane];
+  };
+  struct GRec { float v[CO]; };
+  auto load_g = [&](const Row& rw, int pos) -> GRec {
+    int64_t off = (rw.go >= 0 && pos < a.W) ? rw.go + static_cast<int64_t>(pos) * a.Cout : zoff_g;
+    asm("" : "+s"(off));
+    GRec r;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) r.v[c] = a.g[off + c];
+    return r;
+  };
+
+  float acc[NTAP][CO];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[t][c] = 0.f;
+
+  float xr[NDZDY][8];
+  GRec gr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int k = 0; k < NDZDY; ++k) xr[k][i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) gr[i].v[c] = 0.f;
+  }
+  Row cur = row_setup(r0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int k = 0; k < NDZDY; ++k) xr[k][i] = load_x(cur, k, i);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) gr[i] = load_g(cur, i);
+
+  float bsum[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) bsum[c] = 0.f;
+  auto step = [&](int u) {
+    __builtin_amdgcn_sched_barrier(0);
+    const GRec g = gr[u];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) bsum[c] += g.v[c];
+#pragma unroll
+    for (int k = 0; k < NDZDY; ++k)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float xv = xr[k][(u + 7 + d) & 7];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[k * 3 + d][c] = fmaf(xv, g.v[c], acc[k * 3 + d][c]);
+      }
+  };
+
+  for (int row = r0; row < r1; ++row) {
+    const Row nxt = row_setup(row + 1);
+    for (int x0 = 0; x0 < a.Wp - 8; x0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int k = 0; k < NDZDY; ++k) xr[k][(u + 6) & 7] = load_x(cur, k, x0 + u + 6);
+        gr[(u + 5) & 7] = load_g(cur, x0 + u + 5);
+        step(u);
+      }
+    }
+    {
+      const int x0 = a.Wp - 8;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int k = 0; k < NDZDY; ++k) xr[k][(u + 6) & 7] = u < 2 ? load_x(cur, k, x0 + u + 6) : load_x(nxt, k, u - 2);
+        gr[(u + 5) & 7] = u < 3 ? load_g(cur, x0 + u + 5) : load_g(nxt, u - 3);
+        step(u);
+      }
+    }
+    cur = nxt;
+  }
+
+  float* P = a.partial + (static_cast<int64_t>(stream) * NTAP * a.Cin + ci) * CO;
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) P[static_cast<int64_t>(t) * a.Cin * CO + c] = acc[t][c];
+  if (cib == 0 && lane == 0) {
+#pragma unroll
+    for (int c = 0; c < CO; ++c) a.bpartial[stream * CO + c] = bsum[c];
+  }
+}
+
+// gw[tap][ci][co] = sum_stream partial[stream][tap][ci][co]  (fixed order)
+__global__ __launch_bounds__(kThreads) void wgrad_small_reduce_kernel(const float* __restrict__ partial,
+                                                                      const float* __restrict__ bpartial,
+                                                                      float* __restrict__ gw, float* __restrict__ gb,
+                                                                      int nstreams, int64_t per_stream, int CO,
+                                                                      int Cout) {
+  if (gb && blockIdx.x == 0 && threadIdx.x < Cout) {
+    float acc = 0.f;
+    for (int sidx = 0; sidx < nstreams; ++sidx) acc += bpartial[sidx * CO + threadIdx.x];
+    gb[threadIdx.x] = acc;
+  }
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < per_stream;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    float acc = 0.f;
+    for (int sidx = 0; sidx < nstreams; ++sidx) acc += partial[sidx * per_stream + i];
+    const int co = static_cast<int>(i % CO);
+    if (co < Cout) gw[(i / CO) * Cout + co] = acc;
+  }
+}
+
+inline bool small_n_ok(int64_t Cin, int64_t Cout) { return Cout <= 4 && Cin % 64 == 0; }
+
+struct SmallPlan { int nrows, ncib, nstreams, rows_per, taps, CO; int64_t partial_elems; };
+SmallPlan make_small_plan(int64_t B, int64_t D, int64_t H, int64_t Cin, int64_t Cout, int kz) {
+  SmallPlan p;
+  p.nrows = (int)(B * D * H);
+  p.ncib = (int)(Cin / 64);
+  int ns = kSmallStreams / p.ncib;
+  if (ns > p.nrows) ns = p.nrows;
+  ns = (ns * p.ncib + 3) / 4 * 4 / p.ncib;              // whole workgroups of 4 waves
+  if (ns < 1) ns = 1;
+  while ((ns * p.ncib) % 4 != 0) ++ns;
+  p.nstreams = ns;
+  p.rows_per = (p.nrows + ns - 1) / ns;
+  p.taps = kz == 3 ? 27 : 9;
+  p.CO = (int)Cout;
+  p.partial_elems = static_cast<int64_t>(ns) * p.taps * Cin * p.CO + static_cast<int64_t>(ns) * p.CO;
+  return p;
+}
+
 struct Plan {
   int nrows, npairs, nranges, ppr, Cinp, Coutp, taps, ndzdy;
   int64_t partial_elems, bpartial_elems;
@@ -284,8 +464,12 @@ extern "C" {
 
 int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
   if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  if (small_n_ok(Cin, Cout)) {
+    const SmallPlan sp = make_small_plan(B, D, H, Cin, Cout, kz);
+    return sp.partial_elems * static_cast<int64_t>(sizeof(float)) + kZeroBytes;
+  }
   const Plan p = make_plan(B, D, H, W, Cin, Cout, kz);
-  return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + 64;
+  return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + kZeroBytes;
 }
 
 int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
@@ -298,6 +482,29 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
   DF_REQUIRE(df::aligned16(workspace), DF_EALIGN, "df_conv_wgrad: workspace must be 16-byte aligned");
   DF_REQUIRE(workspace_bytes >= df_conv_wgrad_workspace_bytes(B, D, H, W, Cin, Cout, kz), DF_EWORKSPACE,
              "df_conv_wgrad: workspace too small");
+  if (small_n_ok(Cin, Cout)) {
+    const SmallPlan sp = make_small_plan(B, D, H, Cin, Cout, kz);
+    SmallWgradArgs sa;
+    sa.x = x; sa.g = gy; sa.partial = static_cast<float*>(workspace);
+    float* zeros = sa.partial + sp.partial_elems;
+    sa.zeros = zeros;
+    sa.bpartial = zeros - static_cast<int64_t>(sp.nstreams) * sp.CO;
+    sa.B = (int)B; sa.D = (int)D; sa.H = (int)H; sa.W = (int)W; sa.Cin = (int)Cin; sa.Cout = (int)Cout;
+    sa.Wp = (int)(ceil_div(W + 1, 8) * 8);
+    sa.nrows = sp.nrows; sa.nstreams = sp.nstreams; sa.rows_per = sp.rows_per; sa.ncib = sp.ncib;
+    hipStream_t s = df::as_stream(stream);
+    if (hipError_t e = hipMemsetAsync(zeros, 0, kZeroBytes, s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
+    dim3 grid((unsigned)(sp.nstreams * sp.ncib / 4));
+#define DF_WS(KZ, CO) hipLaunchKernelGGL((wgrad_small_n_kernel<KZ, CO>), grid, dim3(kThreads), 0, s, sa)
+    if (kz == 3) { if (Cout == 1) DF_WS(3, 1); else if (Cout == 2) DF_WS(3, 2); else if (Cout == 3) DF_WS(3, 3); else DF_WS(3, 4); }
+    else { if (Cout == 1) DF_WS(1, 1); else if (Cout == 2) DF_WS(1, 2); else if (Cout == 3) DF_WS(1, 3); else DF_WS(1, 4); }
+#undef DF_WS
+    const int64_t per = static_cast<int64_t>(sp.taps) * Cin * sp.CO;
+    int64_t rg = ceil_div(per, kThreads);
+    hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, sa.partial, sa.bpartial, gw,
+                       gb, sp.nstreams, per, sp.CO, (int)Cout);
+    return df::launched("df_conv_wgrad(small-N)");
+  }
   const Plan p = make_plan(B, D, H, W, Cin, Cout, kz);
   WgradArgs a;
   a.x = x; a.g = gy;
@@ -311,7 +518,7 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
   a.nrows = p.nrows; a.npairs = p.npairs; a.nranges = p.nranges; a.pairs_per_range = p.ppr;
   a.ndzdy = p.ndzdy; a.want_bias = gb != nullptr;
   hipStream_t s = df::as_stream(stream);
-  if (hipError_t e = hipMemsetAsync(zeros, 0, 64, s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
+  if (hipError_t e = hipMemsetAsync(zeros, 0, kZeroBytes, s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)(p.Cinp / 128), (unsigned)(p.Coutp / 128));
   const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
