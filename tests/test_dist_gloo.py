@@ -1,0 +1,83 @@
+"""world_size-2 `gloo` test (CPU) of the data-parallel gradient path (deep_fluids_amd/dist.py): bucketed,
+hook-driven all-reduce of the flat gradient slab + the 1/world scale == the gradient of the un-sharded batch
+(reduce_mean over the global batch == mean of equal-sized shard means)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from deep_fluids_amd.dist import GradSync, shard_batch
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _model_and_slabs(seed=0):
+    """A toy 3-bucket model whose parameters are views into one flat slab (exactly the Trainer's arrangement)."""
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(3, 8), (8,), (8, 8), (8,), (8, 2), (2,)]
+    total = sum(int(np.prod(s)) for s in shapes)
+    flat_p = torch.randn(total, generator=g)
+    flat_g = torch.zeros(total)
+    params, off = [], 0
+    for s in shapes:
+        n = int(np.prod(s))
+        v = flat_p[off:off + n].view(s).detach().requires_grad_(True)
+        v.grad = flat_g[off:off + n].view(s)
+        params.append((off, n, v))
+        off += n
+    buckets = [(params[0][0], params[0][1] + params[1][1], [params[0][2], params[1][2]]),
+               (params[2][0], params[2][1] + params[3][1], [params[2][2], params[3][2]]),
+               (params[4][0], params[4][1] + params[5][1], [params[4][2], params[5][2]])]
+    return [p[2] for p in params], flat_g, buckets
+
+
+def _loss(ps, x, y):
+    h = torch.nn.functional.leaky_relu(x @ ps[0] + ps[1], 0.2)
+    h = torch.nn.functional.leaky_relu(h @ ps[2] + ps[3], 0.2) + h
+    return ((h @ ps[4] + ps[5]) - y).abs().mean()
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ps, flat_g, buckets = _model_and_slabs()
+    sync = GradSync(flat_g, buckets)
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(8, 3, generator=g); Y = torch.randn(8, 2, generator=g)
+    lo, n = shard_batch(8, rank, world)
+    for step in range(2):                                   # two steps: hooks / counters must re-arm
+        flat_g.zero_()
+        sync.begin_step()
+        _loss(ps, X[lo:lo + n], Y[lo:lo + n]).backward()
+        scale = sync.finish()
+    out[rank] = (flat_g * scale).clone().numpy()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_matches_full_batch():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    ps, flat_g, _ = _model_and_slabs()
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(8, 3, generator=g); Y = torch.randn(8, 2, generator=g)
+    _loss(ps, X, Y).backward()
+    ref = flat_g.numpy()
+    np.testing.assert_allclose(out[0], ref, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out[1], out[0], rtol=0, atol=0)      # every rank holds identical reduced gradients
+
+
+def test_shard_batch_and_single_process_passthrough():
+    assert shard_batch(16, 3, 8) == (6, 2)
+    with pytest.raises(ValueError):
+        shard_batch(10, 0, 4)
+    ps, flat_g, buckets = _model_and_slabs()
+    sync = GradSync(flat_g, buckets)           # no process group: disabled, scale 1
+    assert not sync.enabled and sync.finish() == 1.0
