@@ -48,14 +48,12 @@ __device__ __forceinline__ void flush_lds(const float* __restrict__ s, float* __
   const float4* s4 = reinterpret_cast<const float4*>(s);
   float4* d4 = reinterpret_cast<float4*>(dst);
   for (int64_t q = tid; q < nq; q += kThreads) {
-    float4 val = s4[q];
     if (NT) {
-      __builtin_nontemporal_store(val.x, &dst[q * 4 + 0]);
-      __builtin_nontemporal_store(val.y, &dst[q * 4 + 1]);
-      __builtin_nontemporal_store(val.z, &dst[q * 4 + 2]);
-      __builtin_nontemporal_store(val.w, &dst[q * 4 + 3]);
+      typedef float v4 __attribute__((ext_vector_type(4)));
+      const v4 val = reinterpret_cast<const v4*>(s)[q];
+      __builtin_nontemporal_store(val, reinterpret_cast<v4*>(dst) + q);
     } else {
-      d4[q] = val;
+      d4[q] = s4[q];
     }
   }
   const int64_t done = nq << 2;
@@ -107,6 +105,86 @@ __global__ __launch_bounds__(kThreads) void jacobian3d_fwd_kernel(const float* _
   const int64_t nv = left < kVoxPerBlock ? left : kVoxPerBlock;
   if (WJ) flush_lds<false>(sj, j + v0 * 9, nv * 9, tid);
   if (WC) flush_lds<false>(sc, c + v0 * 3, nv * 3, tid);
+}
+
+// ---- fast path (X % 4 == 0): 4 consecutive voxels of one row per thread, 16-byte loads ---------------------------
+// A thread owns voxels 4t..4t+3 = 12 consecutive floats = three float4 (a fourth gives the x+1 record of its last
+// voxel); the y and z neighbours are the same three float4 one row / one slice further (16-byte aligned because
+// 3*X*4 bytes is a multiple of 16).  10 global_load_dwordx4 per 4 voxels instead of 48 dword loads; all but the
+// own records are L1/L2 hits.  Results leave through the same LDS transpose -> 1 KiB-contiguous stores.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool WJ, bool WC, bool NT>
+__global__ __launch_bounds__(kThreads) void jacobian3d_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ j,
+                                                                      float* __restrict__ c, Dims3 dm) {
+  __shared__ __attribute__((aligned(16))) float smem[(WJ ? kVoxPerBlock * 9 : 0) + (WC ? kVoxPerBlock * 3 : 0)];
+  float* sj = smem;
+  float* sc = smem + (WJ ? kVoxPerBlock * 9 : 0);
+  const int tid = threadIdx.x;
+  const int64_t v0 = static_cast<int64_t>(blockIdx.x) * kVoxPerBlock;
+  const int64_t vq = v0 + 4 * static_cast<int64_t>(tid);      // first voxel of this thread's quad
+  const int64_t sy = dm.X, sz = static_cast<int64_t>(dm.X) * dm.Y;
+  if (vq < dm.nvox) {
+    const int64_t row = vq / dm.X;
+    const int xx = static_cast<int>(vq - row * dm.X);          // multiple of 4; the quad never straddles a row
+    const int64_t slab = row / dm.Y;
+    const int yy = static_cast<int>(row - slab * dm.Y);
+    const int zz = static_cast<int>(slab % dm.Z);
+    const bool ly = yy == dm.Y - 1, lz = zz == dm.Z - 1;
+    const f32x4* p = reinterpret_cast<const f32x4*>(x + vq * 3);
+    const f32x4* py = reinterpret_cast<const f32x4*>(x + (ly ? vq - sy : vq + sy) * 3);
+    const f32x4* pz = reinterpret_cast<const f32x4*>(x + (lz ? vq - sz : vq + sz) * 3);
+    float o[16], ny[12], nz[12], jo[36], co[12];
+    const bool tail = vq + 4 >= dm.nvox;                       // very last quad: nothing to read behind it
+    const f32x4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = tail ? p[2] : p[3];
+    const f32x4 b0 = py[0], b1 = py[1], b2 = py[2];
+    const f32x4 c0 = pz[0], c1 = pz[1], c2 = pz[2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a0[e]; o[4 + e] = a1[e]; o[8 + e] = a2[e]; o[12 + e] = a3[e];
+                                  ny[e] = b0[e]; ny[4 + e] = b1[e]; ny[8 + e] = b2[e];
+                                  nz[e] = c0[e]; nz[4 + e] = c1[e]; nz[8 + e] = c2[e]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool lx = xx + i == dm.X - 1;                      // only possible for i == 3
+      float dx[3], dy[3], dz[3];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const float own = o[i * 3 + cc];
+        const float nx = (i == 3 && lx) ? o[(i - 1) * 3 + cc] : o[(i + 1) * 3 + cc];
+        dx[cc] = (i == 3 && lx) ? own - nx : nx - own;
+        dy[cc] = ly ? own - ny[i * 3 + cc] : ny[i * 3 + cc] - own;
+        dz[cc] = lz ? own - nz[i * 3 + cc] : nz[i * 3 + cc] - own;
+      }
+      if (WJ) {
+        float* q = jo + i * 9;
+        q[0] = dx[0]; q[1] = dy[0]; q[2] = dz[0];
+        q[3] = dx[1]; q[4] = dy[1]; q[5] = dz[1];
+        q[6] = dx[2]; q[7] = dy[2]; q[8] = dz[2];
+      }
+      if (WC) {
+        float* q = co + i * 3;
+        q[0] = dy[2] - dz[1];
+        q[1] = dz[0] - dx[2];
+        q[2] = dx[1] - dy[0];
+      }
+    }
+    // 16-byte LDS writes: lane stride 144 B (j) / 48 B (c) -> the 8 lanes of a ds_write_b128 group cover all 32 banks
+    if (WJ) {
+      f32x4* q = reinterpret_cast<f32x4*>(sj + tid * 36);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) q[k] = f32x4{jo[4 * k], jo[4 * k + 1], jo[4 * k + 2], jo[4 * k + 3]};
+    }
+    if (WC) {
+      f32x4* q = reinterpret_cast<f32x4*>(sc + tid * 12);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) q[k] = f32x4{co[4 * k], co[4 * k + 1], co[4 * k + 2], co[4 * k + 3]};
+    }
+  }
+  __syncthreads();
+  const int64_t left = dm.nvox - v0;
+  const int64_t nv = left < kVoxPerBlock ? left : kVoxPerBlock;
+  if (WJ) flush_lds<NT>(sj, j + v0 * 9, nv * 9, tid);
+  if (WC) flush_lds<NT>(sc, c + v0 * 3, nv * 3, tid);
 }
 
 // ---- adjoint helpers ---------------------------------------------------------------------------
@@ -279,6 +357,8 @@ __global__ __launch_bounds__(kThreads) void divergence2d_kernel(const float* __r
   d[o] = (x[(v + 1) * 2 + 0] - x[v * 2 + 0]) + (x[(v + X) * 2 + 1] - x[v * 2 + 1]);
 }
 
+int g_stencil_nt = 1;   // tuning knob (df_debug_set): non-temporal output stores
+
 int check3(const void* in, int64_t B, int64_t Z, int64_t Y, int64_t X, const char* fn) {
   DF_REQUIRE(in != nullptr, DF_EINVAL, "%s: null input", fn);
   DF_REQUIRE(B > 0 && Z > 0 && Y > 0 && X > 0, DF_EINVAL, "%s: non-positive extent", fn);
@@ -300,6 +380,9 @@ int check2(const void* in, int64_t B, int64_t Y, int64_t X, const char* fn) {
 
 extern "C" {
 
+// not part of the public header: tuning switch used by tools/gpu_probe.py
+void df_debug_set_stencil_nt(int v) { g_stencil_nt = v; }
+
 int df_jacobian3d_fwd(const float* x, float* j, float* c, int64_t B, int64_t Z, int64_t Y, int64_t X,
                       df_stream_t stream) {
   if (int e = check3(x, B, Z, Y, X, "df_jacobian3d_fwd")) return e;
@@ -308,6 +391,15 @@ int df_jacobian3d_fwd(const float* x, float* j, float* c, int64_t B, int64_t Z, 
   Dims3 dm{B * Z * Y * X, (int)Z, (int)Y, (int)X};
   dim3 grid((unsigned)ceil_div(dm.nvox, kVoxPerBlock)), block(kThreads);
   hipStream_t s = df::as_stream(stream);
+  if (X % 4 == 0 && df::aligned16(x)) {
+    const int nt = g_stencil_nt;
+#define DF_J3(WJ, WC)                                                                                              \
+  if (nt) hipLaunchKernelGGL((jacobian3d_fwd_vec_kernel<WJ, WC, true>), grid, block, 0, s, x, j, c, dm);           \
+  else hipLaunchKernelGGL((jacobian3d_fwd_vec_kernel<WJ, WC, false>), grid, block, 0, s, x, j, c, dm)
+    if (j && c) { DF_J3(true, true); } else if (j) { DF_J3(true, false); } else { DF_J3(false, true); }
+#undef DF_J3
+    return df::launched("df_jacobian3d_fwd");
+  }
   if (j && c) hipLaunchKernelGGL((jacobian3d_fwd_kernel<true, true>), grid, block, 0, s, x, j, c, dm);
   else if (j) hipLaunchKernelGGL((jacobian3d_fwd_kernel<true, false>), grid, block, 0, s, x, j, c, dm);
   else hipLaunchKernelGGL((jacobian3d_fwd_kernel<false, true>), grid, block, 0, s, x, j, c, dm);
