@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--res", type=int, nargs=3, default=[64, 96, 64], metavar=("Z", "Y", "X"))
     ap.add_argument("--filters", type=int, default=128)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"],
+                    help="cfg3 = the BASELINE metric (3-D); cfg2 = 2-D 128x96 per-GPU batch 64 (diagnostic only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -188,6 +190,11 @@ def main():
     value = vox_per_step * a.steps / elapsed
     ks = timer.summary()
 
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
+    except (OSError, ValueError, KeyError):
+        pmc = {}
+
     def roof(prefix, peak, unit, scale):
         sel = {k: v for k, v in ks.items() if k.startswith(prefix)}
         if not sel:
@@ -196,7 +203,10 @@ def main():
         v = sel[k]
         ach = v["work"] / v["seconds"] / scale
         return {"kernel": k, "bound": "mfma" if unit == "TFLOP/s" else "hbm", "achieved": ach, "peak": peak, "unit": unit,
-                "frac": ach / peak, "traffic": None, "launches": v["launches"],
+                "frac": ach / peak,
+                # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
+                # collected offline on the same kernels/shapes: profiles/pmc_latest.json
+                "traffic": pmc.get(prefix, {}).get("traffic_bytes"), "launches": v["launches"],
                 "avg_launch_ms": v["seconds"] / v["launches"] * 1e3, "work_per_launch": v["work"] / v["launches"]}
 
     out = {

@@ -527,6 +527,9 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
   if (xvec && gvec && exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);
   else if (xvec && gvec && exact && wp8 == 4) hipLaunchKernelGGL((wgrad_kernel<true, true, 4>), grid, dim3(kThreads), 0, s, a);
   else if (xvec && gvec && exact && wp8 == 14) hipLaunchKernelGGL((wgrad_kernel<true, true, 14>), grid, dim3(kThreads), 0, s, a);
+  else if (xvec && gvec && exact && wp8 == 12) hipLaunchKernelGGL((wgrad_kernel<true, true, 12>), grid, dim3(kThreads), 0, s, a);
+  else if (xvec && gvec && exact && wp8 == 7) hipLaunchKernelGGL((wgrad_kernel<true, true, 7>), grid, dim3(kThreads), 0, s, a);
+  else if (xvec && gvec && exact && wp8 == 2) hipLaunchKernelGGL((wgrad_kernel<true, true, 2>), grid, dim3(kThreads), 0, s, a);
   else if (xvec && gvec) hipLaunchKernelGGL((wgrad_kernel<true, true, 0>), grid, dim3(kThreads), 0, s, a);
   else if (xvec) hipLaunchKernelGGL((wgrad_kernel<true, false, 0>), grid, dim3(kThreads), 0, s, a);
   else if (gvec) hipLaunchKernelGGL((wgrad_kernel<false, true, 0>), grid, dim3(kThreads), 0, s, a);

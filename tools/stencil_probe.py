@@ -8,7 +8,7 @@ from deep_fluids_amd._lib import call, lib  # noqa: E402
 from deep_fluids_amd.ops import _ptr, _stream  # noqa: E402
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=60, warm=5):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -27,8 +27,8 @@ js = [torch.empty((B, Z, Y, X, 9), device="cuda") for _ in range(3)]
 cs = [torch.empty((B, Z, Y, X, 3), device="cuda") for _ in range(3)]
 s = _stream()
 h = lib()
-for nt in (0, 1):
-    h.df_debug_set_stencil_nt(nt)
+for nt in (0, 6, 12, 24, 48, 96, 384):
+    h.df_debug_set_stencil_group(nt)
     k = [0]
     def warm_fn():
         call("df_jacobian3d_fwd", _ptr(xs[0]), _ptr(js[0]), _ptr(cs[0]), B, Z, Y, X, s)
