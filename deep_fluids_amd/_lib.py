@@ -33,14 +33,23 @@ SIGNATURES = {
     "df_add": (I32, [P, P, P, I64, P]),
     "df_upsample2x_fwd": (I32, [P, P, I64, I64, I64, I64, I64, I32, P]),
     "df_upsample2x_bwd": (I32, [P, P, I64, I64, I64, I64, I64, I32, P]),
-    "df_linear_fwd": (I32, [P, P, P, P, I64, I64, I64, P]),
+    "df_linear_workspace_bytes": (I64, [I64, I64, I64]),
+    "df_linear_fwd": (I32, [P, P, P, P, I64, I64, I64, P, I64, P]),
     "df_linear_bwd": (I32, [P, P, P, P, P, P, I64, I64, I64, P]),
+    "df_concat2_fwd": (I32, [P, P, P, I64, I64, I64, P]),
+    "df_concat2_bwd": (I32, [P, P, P, I64, I64, I64, P]),
+    "df_dilate2_odd": (I32, [P, P, I64, I64, I64, I64, I64, I32, P]),
+    "df_sigmoid_fwd": (I32, [P, P, I64, P]),
+    "df_sigmoid_bwd": (I32, [P, P, P, I64, P]),
+    "df_mse_mean_fwd": (I32, [P, P, I64, P, P, I64, P]),
+    "df_mse_mean_bwd": (I32, [P, P, P, F32, P, I64, P]),
     "df_colsum_workspace_bytes": (I64, [I64, I64]),
     "df_colsum": (I32, [P, P, I64, I64, P, I64, P]),
     "df_adam_tf1_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, P]),
     "df_conv_packed_elems": (I64, [I64, I64, I64, I32]),
     "df_conv_pack_weights": (I32, [P, P, I64, I64, I64, I32, P]),
     "df_conv_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),
+    "df_conv_s2_fwd": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),
     "df_conv_wgrad_workspace_bytes": (I64, [I64, I64, I64, I64, I64, I64, I32]),
     "df_conv_wgrad": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
 }

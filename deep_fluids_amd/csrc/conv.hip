@@ -59,13 +59,16 @@ inline int ntile_for(int64_t N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 
 // ---- main kernel --------------------------------------------------------------------------------------
-template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, bool VEC>
+// S = stride (1 | 2).  Stride 2 follows TF 'SAME' on even extents: pad 0 before / 1 after, i.e.
+// out[o] = sum_k in[2o + k] w[k]; the LDS tile is the (2T+1)-wide input footprint of the output tile.
+template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, bool VEC, int S>
 __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
   static_assert(TZ * TY * TX == 128 && WM * MB * 32 == 128 && WM * WN == 4, "tile shape");
-  constexpr int PZ = KZ / 2;
-  constexpr int HZ = TZ + KZ - 1, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  constexpr int PZ = S == 1 ? KZ / 2 : 0, PY = S == 1 ? 1 : 0, PX = PY;
+  constexpr int HZ = (TZ - 1) * S + KZ, HY = (TY - 1) * S + 3, HX = (TX - 1) * S + 3, HV = HZ * HY * HX;
   constexpr int NPIECE = HV * (CK / 4);
   constexpr int NLOAD = (NPIECE + kThreads - 1) / kThreads;
+  constexpr int LBATCH = NLOAD < 8 ? NLOAD : 8;        // staging loads in flight per thread (bounds the registers)
   constexpr int NTAP = KZ * 9;
   constexpr int NTILE = WN * NB * 32;
   __shared__ __attribute__((aligned(16))) float sA[HV * LDS_STRIDE];
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
   for (int mb = 0; mb < MB; ++mb) {
     const int m = (wm * MB + mb) * 32 + r;
     const int lx = m % TX, ly = (m / TX) % TY, lz = m / (TX * TY);
-    aidx[mb] = ((lz * HY + ly) * HX + lx) * S4 + half;
+    aidx[mb] = ((lz * S * HY + ly * S) * HX + lx * S) * S4 + half;
   }
   // per-lane packed-weight pointers (float4 units): ((tapk8 * 2 + half) * Npad + col)
   const int64_t bstep = 2LL * a.Npad;            // float4s per (tap,k8) record
@@ -121,18 +124,16 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
   const int nchunk = a.Kpad / CK;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     // ---- stage the halo'd input block of this 16-channel chunk ------------------------------------
-    float4 stg[NLOAD];
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
+    auto stage_load = [&](int it) -> float4 {
       const int p = it * kThreads + tid;
       const int hv = p >> 2, q = p & 3;
       const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-      const int gz = tz0 + hz - PZ, gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+      const int gz = tz0 * S + hz - PZ, gy = ty0 * S + hy - PY, gx = tx0 * S + hx - PX;
       const int ch = chunk * CK + q * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool inb = p < NPIECE && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const bool inb = p < NPIECE && gz >= 0 && gz < a.Di && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
       if (inb) {
-        const int64_t vox = ((static_cast<int64_t>(b) * a.D + gz) * a.H + gy) * a.W + gx;
+        const int64_t vox = ((static_cast<int64_t>(b) * a.Di + gz) * a.Hi + gy) * a.Wi + gx;
         const float* src = a.x + vox * a.Cin + ch;
         if (VEC) {
           if (ch < a.Cin) v = *reinterpret_cast<const float4*>(src);
@@ -143,13 +144,28 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
           if (ch + 3 < a.Cin) v.w = src[3];
         }
       }
-      stg[it] = v;
-    }
-    __syncthreads();   // every wave has finished reading the previous chunk
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
+      return v;
+    };
+    auto stage_store = [&](int it, const float4& v) {
       const int p = it * kThreads + tid;
-      if (p < NPIECE) *reinterpret_cast<float4*>(&sA[(p >> 2) * LDS_STRIDE + (p & 3) * 4]) = stg[it];
+      if (p < NPIECE) *reinterpret_cast<float4*>(&sA[(p >> 2) * LDS_STRIDE + (p & 3) * 4]) = v;
+    };
+    if (NLOAD <= LBATCH) {
+      float4 stg[LBATCH];
+#pragma unroll
+      for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it);
+      __syncthreads();   // every wave has finished reading the previous chunk
+#pragma unroll
+      for (int it = 0; it < NLOAD; ++it) stage_store(it, stg[it]);
+    } else {
+      __syncthreads();
+      for (int it0 = 0; it0 < NLOAD; it0 += LBATCH) {
+        float4 stg[LBATCH];
+#pragma unroll
+        for (int i = 0; i < LBATCH; ++i) stg[i] = stage_load(it0 + i);
+#pragma unroll
+        for (int i = 0; i < LBATCH; ++i) stage_store(it0 + i, stg[i]);
+      }
     }
     __syncthreads();
 
@@ -219,7 +235,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
   }
 }
 
-template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB>
+template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, int S>
 int launch(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
   a.nz = (int)ceil_div(a.D, TZ); a.ny = (int)ceil_div(a.H, TY); a.nx = (int)ceil_div(a.W, TX);
@@ -228,17 +244,17 @@ int launch(const ConvArgs& a_in, hipStream_t s) {
   a.ntiles = (int)nt;
   dim3 grid((unsigned)nt, (unsigned)(a.Npad / (WN * NB * 32)));
   const bool vec = (a.Cin % 4 == 0) && df::aligned16(a.x);
-  if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, true>), grid, dim3(kThreads), 0, s, a);
-  else hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, false>), grid, dim3(kThreads), 0, s, a);
+  if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, true, S>), grid, dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, false, S>), grid, dim3(kThreads), 0, s, a);
   return df::launched("df_conv_fwd");
 }
 
-template <int KZ, int TZ, int TY, int TX>
+template <int KZ, int TZ, int TY, int TX, int S>
 int launch_n(const ConvArgs& a, hipStream_t s) {
   const int nt = ntile_for(a.Cout);
-  if (nt == 128) return launch<KZ, TZ, TY, TX, 2, 2, 2, 2>(a, s);
-  if (nt == 64) return launch<KZ, TZ, TY, TX, 2, 2, 2, 1>(a, s);
-  return launch<KZ, TZ, TY, TX, 4, 1, 1, 1>(a, s);
+  if (nt == 128) return launch<KZ, TZ, TY, TX, 2, 2, 2, 2, S>(a, s);
+  if (nt == 64) return launch<KZ, TZ, TY, TX, 2, 2, 2, 1, S>(a, s);
+  return launch<KZ, TZ, TY, TX, 4, 1, 1, 1, S>(a, s);
 }
 
 }  // namespace
@@ -265,34 +281,58 @@ int df_conv_pack_weights(const float* w, float* wp, int64_t taps, int64_t cin, i
   return df::launched("df_conv_pack_weights");
 }
 
-int df_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
-                float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int flags,
-                float leak, df_stream_t stream) {
-  DF_REQUIRE(x && wp && y, DF_EINVAL, "df_conv_fwd: null pointer");
-  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_conv_fwd: non-positive extent");
-  DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_conv_fwd: kz must be 1 (2-D) or 3 (3-D)");
-  DF_REQUIRE(kz == 3 || D == 1, DF_ESHAPE, "df_conv_fwd: D must be 1 when kz == 1");
-  DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "df_conv_fwd: DF_CONV_BIAS without bias");
-  DF_REQUIRE(!(flags & DF_CONV_RESIDUAL) || residual, DF_EINVAL, "df_conv_fwd: DF_CONV_RESIDUAL without residual");
-  DF_REQUIRE(!(flags & DF_CONV_MASK) || mask_src, DF_EINVAL, "df_conv_fwd: DF_CONV_MASK without mask_src");
-  DF_REQUIRE(df::aligned16(wp), DF_EALIGN, "df_conv_fwd: packed weights must be 16-byte aligned");
-  DF_REQUIRE(B * D * H * W * (Cin > Cout ? Cin : Cout) < (1LL << 40), DF_ESHAPE, "df_conv_fwd: tensor too large");
+static int conv_common(const char* fn, const float* x, const float* wp, const float* bias, const float* residual,
+                       const float* mask_src, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin,
+                       int64_t Cout, int kz, int stride, int flags, float leak, df_stream_t stream) {
+  DF_REQUIRE(x && wp && y, DF_EINVAL, "%s: null pointer", fn);
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "%s: non-positive extent", fn);
+  DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "%s: kz must be 1 (2-D) or 3 (3-D)", fn);
+  DF_REQUIRE(kz == 3 || D == 1, DF_ESHAPE, "%s: D must be 1 when kz == 1", fn);
+  DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "%s: DF_CONV_BIAS without bias", fn);
+  DF_REQUIRE(!(flags & DF_CONV_RESIDUAL) || residual, DF_EINVAL, "%s: DF_CONV_RESIDUAL without residual", fn);
+  DF_REQUIRE(!(flags & DF_CONV_MASK) || mask_src, DF_EINVAL, "%s: DF_CONV_MASK without mask_src", fn);
+  DF_REQUIRE(df::aligned16(wp), DF_EALIGN, "%s: packed weights must be 16-byte aligned", fn);
+  DF_REQUIRE(B * D * H * W * stride * stride * stride * (Cin > Cout ? Cin : Cout) < (1LL << 40), DF_ESHAPE,
+             "%s: tensor too large", fn);
   ConvArgs a;
   a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.bias = bias; a.residual = residual; a.mask_src = mask_src;
   a.y = y;
   a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.Di = (int)(kz == 3 ? D * stride : D); a.Hi = (int)(H * stride); a.Wi = (int)(W * stride);
   a.Kpad = (int)round_up(Cin, CK); a.Npad = (int)round_up(Cout, ntile_for(Cout));
   a.flags = flags; a.leak = leak;
   a.nz = a.ny = a.nx = a.ntiles = 0;
   hipStream_t s = df::as_stream(stream);
-  if (Cout <= 4) return launch_small_n(a, kz, s);                 // thin output: vector-ALU kernel
-  if (Cin <= 4 && Cout >= 32) return launch_small_k(a, kz, s);    // thin input (dgrad of the last layer)
-  if (kz == 3) {
-    if (W >= 12) return launch_n<3, 2, 4, 16>(a, s);
-    return launch_n<3, 4, 4, 8>(a, s);
+  if (stride == 2) {
+    if (kz == 3) {
+      if (W >= 12) return launch_n<3, 2, 4, 16, 2>(a, s);
+      return launch_n<3, 4, 4, 8, 2>(a, s);
+    }
+    if (W >= 12) return launch_n<1, 1, 8, 16, 2>(a, s);
+    return launch_n<1, 1, 16, 8, 2>(a, s);
   }
-  if (W >= 12) return launch_n<1, 1, 8, 16>(a, s);
-  return launch_n<1, 1, 16, 8>(a, s);
+  if (Cout <= 4) return launch_small_n(a, kz, s);                 // thin output: vector-ALU kernel
+  if (Cin <= 4 && Cout >= 32) return launch_small_k(a, kz, s);    // thin input (dgrad of the last layer; 3 -> F)
+  if (kz == 3) {
+    if (W >= 12) return launch_n<3, 2, 4, 16, 1>(a, s);
+    return launch_n<3, 4, 4, 8, 1>(a, s);
+  }
+  if (W >= 12) return launch_n<1, 1, 8, 16, 1>(a, s);
+  return launch_n<1, 1, 16, 8, 1>(a, s);
+}
+
+int df_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
+                float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int flags,
+                float leak, df_stream_t stream) {
+  return conv_common("df_conv_fwd", x, wp, bias, residual, mask_src, y, B, D, H, W, Cin, Cout, kz, 1, flags, leak,
+                     stream);
+}
+
+int df_conv_s2_fwd(const float* x, const float* wp, const float* bias, float* y, int64_t B, int64_t Do, int64_t Ho,
+                   int64_t Wo, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream) {
+  DF_REQUIRE(!(flags & (DF_CONV_RESIDUAL | DF_CONV_MASK)), DF_EINVAL, "df_conv_s2_fwd: only BIAS / LRELU epilogues");
+  return conv_common("df_conv_s2_fwd", x, wp, bias, nullptr, nullptr, y, B, Do, Ho, Wo, Cin, Cout, kz, 2, flags, leak,
+                     stream);
 }
 
 }  // extern "C"

@@ -17,7 +17,8 @@ struct ConvArgs {
   const float* residual;
   const float* mask_src;
   float* y;
-  int B, D, H, W, Cin, Cout;
+  int B, D, H, W, Cin, Cout;   // D,H,W: OUTPUT extents
+  int Di, Hi, Wi;              // input extents (== output for stride 1; 2x for stride 2)
   int Kpad, Npad;       // padded K (multiple of 16) and N (multiple of the N tile) of the packed weights
   int nz, ny, nx;       // tiles per axis
   int ntiles;

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void conv_small_n_kernel(const ConvArgs a
       const int gz = tz0 + hz - PZ, gy = ty0 + hy - 1, gx = tx0 + hx - 1;
       const int ch = chunk * CK + q * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool inb = p < NPIECE && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const bool inb = p < NPIECE && gz >= 0 && gz < a.Di && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
       if (inb) {
         const int64_t vox = ((static_cast<int64_t>(b) * a.D + gz) * a.H + gy) * a.W + gx;
         const float* src = a.x + vox * a.Cin + ch;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void conv_small_k_kernel(const ConvArgs a
     const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
     const int gz = tz0 + hz - PZ, gy = ty0 + hy - 1, gx = tx0 + hx - 1;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+    if (gz >= 0 && gz < a.Di && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) {
       const float* src = a.x + (((static_cast<int64_t>(b) * a.D + gz) * a.H + gy) * a.W + gx) * a.Cin;
       v[0] = src[0];
       if (a.Cin > 1) v[1] = src[1];

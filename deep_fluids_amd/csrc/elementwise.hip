@@ -116,6 +116,151 @@ __global__ __launch_bounds__(kThreads) void ew_kernel(const float* __restrict__ 
   }
 }
 
+// ---- channel concat / split (encoder skip connections, model.py:138,174) ---------------------------------------------
+// y[r][0:Ca] = a[r], y[r][Ca:Ca+Cb] = b[r]   (DIR 0)   |   the reverse scatter of the gradient (DIR 1)
+template <int DIR>
+__global__ __launch_bounds__(kThreads) void concat2_kernel(float* __restrict__ a, float* __restrict__ b,
+                                                           float* __restrict__ y, int64_t rows, int Ca4, int Cb4) {
+  const int C4 = Ca4 + Cb4;
+  const int64_t n4 = rows * C4;
+  float4* a4 = reinterpret_cast<float4*>(a);
+  float4* b4 = reinterpret_cast<float4*>(b);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int64_t r = i / C4;
+    const int c = static_cast<int>(i - r * C4);
+    float4* src = c < Ca4 ? a4 + r * Ca4 + c : b4 + r * Cb4 + (c - Ca4);
+    if (DIR == 0) y4[i] = *src; else *src = y4[i];
+  }
+}
+
+// ---- zero insertion for the stride-2 conv backward: out[2o+1] = g[o] on every spatial axis, zeros elsewhere ------------
+// (dX = SAME-conv(out, mirrored weights) and gW = wgrad(X, out) then reproduce the stride-2 adjoints exactly)
+template <bool IS3D>
+__global__ __launch_bounds__(kThreads) void dilate2_kernel(const float4* __restrict__ g, float4* __restrict__ out,
+                                                           int64_t nout4, int D, int H, int W, int C4) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < nout4;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % C4);
+    int64_t r = i / C4;
+    const int w = static_cast<int>(r % (2 * W)); r /= 2 * W;
+    const int h = static_cast<int>(r % (2 * H)); r /= 2 * H;
+    const int D2 = IS3D ? 2 * D : 1;
+    const int d = static_cast<int>(r % D2);
+    const int64_t b = r / D2;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((w & 1) && (h & 1) && (!IS3D || (d & 1)))
+      v = g[(((b * D + (IS3D ? d >> 1 : 0)) * H + (h >> 1)) * W + (w >> 1)) * C4 + c];
+    out[i] = v;
+  }
+}
+
+// ---- sigmoid (AE latent code when use_sparse, model.py:210) -------------------------------------------------------------
+template <int DIR>
+__global__ __launch_bounds__(kThreads) void sigmoid_kernel(const float* __restrict__ a, const float* __restrict__ yv,
+                                                           float* __restrict__ out, int64_t n) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    if (DIR == 0) out[i] = 1.f / (1.f + expf(-a[i]));
+    else { const float s = yv[i]; out[i] = a[i] * s * (1.f - s); }
+  }
+}
+
+// ---- mean squared difference (loss_p, trainer3.py:268-270) --------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void mse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               int64_t n, double* __restrict__ partial) {
+  double acc = 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const float d = a[i] - b[i];
+    acc += static_cast<double>(d * d);
+  }
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(kThreads) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ gout, float scale,
+                                                           float* __restrict__ ga, int64_t n) {
+  const float s = scale * (gout ? gout[0] : 1.f);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kThreads)
+    ga[i] = 2.f * (a[i] - b[i]) * s;
+}
+
+// ---- fully connected with LARGE K and small N (encoder head: 196,608 -> 16, model.py:150,186) --------------------------
+// forward: split-K.  Workgroup g owns rows [g*KC, (g+1)*KC) of W; thread t strides over them and keeps B x N partial
+// sums for ONE batch row at a time; block reduction -> partial[g][b][n]; a second kernel adds the partials in order.
+constexpr int kFcChunk = 2048;
+template <int NMAX>
+__global__ __launch_bounds__(kThreads) void linear_splitk_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 float* __restrict__ partial, int B, int64_t K, int N) {
+  __shared__ float red[kThreads / 64][NMAX];
+  const int64_t k0 = static_cast<int64_t>(blockIdx.x) * kFcChunk;
+  const int64_t k1 = k0 + kFcChunk < K ? k0 + kFcChunk : K;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int b = 0; b < B; ++b) {
+    float acc[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += kThreads) {
+      const float xv = x[b * K + k];
+      const float* wr = w + k * N;
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n)
+        if (n < N) acc[n] = fmaf(xv, wr[n], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      float v = acc[n];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) red[wid][n] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+      float v = 0.f;
+      for (int q = 0; q < kThreads / 64; ++q) v += red[q][threadIdx.x];
+      partial[(static_cast<int64_t>(blockIdx.x) * B + b) * N + threadIdx.x] = v;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(kThreads) void linear_splitk_final_kernel(const float* __restrict__ partial,
+                                                                       const float* __restrict__ bias,
+                                                                       float* __restrict__ y, int nparts, int BN, int N) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= BN) return;
+  double acc = 0.0;
+  for (int p = 0; p < nparts; ++p) acc += partial[static_cast<int64_t>(p) * BN + i];
+  y[i] = static_cast<float>(acc) + (bias ? bias[i % N] : 0.f);
+}
+// backward for small N: thread = k.  gw[k][:] = sum_b x[b][k] gy[b][:],  gx[b][k] = sum_n gy[b][n] w[k][n]
+template <int NMAX>
+__global__ __launch_bounds__(kThreads) void linear_bwd_smalln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                     const float* __restrict__ gy, float* __restrict__ gx,
+                                                                     float* __restrict__ gw, int B, int64_t K, int N) {
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; k < K;
+       k += static_cast<int64_t>(gridDim.x) * kThreads) {
+    float wr[NMAX], acc[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) { wr[n] = n < N ? w[k * N + n] : 0.f; acc[n] = 0.f; }
+    for (int b = 0; b < B; ++b) {
+      const float xv = x[b * K + k];
+      float dot = 0.f;
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n)
+        if (n < N) { const float g = gy[b * N + n]; acc[n] = fmaf(xv, g, acc[n]); dot = fmaf(g, wr[n], dot); }
+      if (gx) gx[b * K + k] = dot;
+    }
+    if (gw) {
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n)
+        if (n < N) gw[k * N + n] = acc[n];
+    }
+  }
+}
+
 // ---- nearest 2x up-sampling -----------------------------------------------------------------------
 // one thread per float4 of the SOURCE; it writes the 4 (2-D) or 8 (3-D) destination copies.
 template <bool IS3D>
@@ -356,10 +501,27 @@ int df_upsample2x_bwd(const float* gy, float* gx, int64_t B, int64_t D, int64_t 
   return df::launched("df_upsample2x_bwd");
 }
 
+int64_t df_linear_workspace_bytes(int64_t B, int64_t K, int64_t N) {
+  if (N <= 32 && K >= 1024) return ceil_div(K, kFcChunk) * B * N * static_cast<int64_t>(sizeof(float));
+  return 0;
+}
+
 int df_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t K, int64_t N,
-                  df_stream_t stream) {
+                  void* workspace, int64_t workspace_bytes, df_stream_t stream) {
   DF_REQUIRE(x && w && y, DF_EINVAL, "df_linear_fwd: null pointer");
   DF_REQUIRE(B > 0 && K > 0 && N > 0 && B < 65536, DF_EINVAL, "df_linear_fwd: bad extent");
+  if (N <= 32 && K >= 1024) {
+    DF_REQUIRE(workspace && workspace_bytes >= df_linear_workspace_bytes(B, K, N), DF_EWORKSPACE,
+               "df_linear_fwd: workspace too small for the split-K path");
+    const int nparts = (int)ceil_div(K, kFcChunk);
+    float* part = static_cast<float*>(workspace);
+    hipStream_t s = df::as_stream(stream);
+    if (N <= 16) hipLaunchKernelGGL((linear_splitk_kernel<16>), dim3((unsigned)nparts), dim3(kThreads), 0, s, x, w, part, (int)B, K, (int)N);
+    else hipLaunchKernelGGL((linear_splitk_kernel<32>), dim3((unsigned)nparts), dim3(kThreads), 0, s, x, w, part, (int)B, K, (int)N);
+    hipLaunchKernelGGL(linear_splitk_final_kernel, dim3((unsigned)ceil_div(B * N, kThreads)), dim3(kThreads), 0, s, part, bias, y,
+                       nparts, (int)(B * N), (int)N);
+    return df::launched("df_linear_fwd(split-K)");
+  }
   dim3 grid(grid_for(N), (unsigned)B);
   hipLaunchKernelGGL(linear_fwd_kernel, grid, dim3(kThreads), 0, df::as_stream(stream), x, w, bias, y, (int)B, (int)K, N);
   return df::launched("df_linear_fwd");
@@ -368,8 +530,19 @@ int df_linear_fwd(const float* x, const float* w, const float* bias, float* y, i
 int df_linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int64_t B,
                   int64_t K, int64_t N, df_stream_t stream) {
   DF_REQUIRE(x && w && gy, DF_EINVAL, "df_linear_bwd: null pointer");
-  DF_REQUIRE(B > 0 && K > 0 && N > 0 && B < 65536 && K < 65535, DF_EINVAL, "df_linear_bwd: bad extent");
+  DF_REQUIRE(B > 0 && K > 0 && N > 0 && B < 65536 && (K < 65535 || N <= 32), DF_EINVAL, "df_linear_bwd: bad extent");
   hipStream_t s = df::as_stream(stream);
+  if (N <= 32 && K >= 1024) {
+    if (gx || gw) {
+      if (N <= 16) hipLaunchKernelGGL((linear_bwd_smalln_kernel<16>), dim3(grid_for(K)), dim3(kThreads), 0, s, x, w, gy, gx, gw, (int)B, K, (int)N);
+      else hipLaunchKernelGGL((linear_bwd_smalln_kernel<32>), dim3(grid_for(K)), dim3(kThreads), 0, s, x, w, gy, gx, gw, (int)B, K, (int)N);
+    }
+    if (gb) {   // bias row only: the column-parallel kernel with k == K
+      dim3 grid(grid_for(N), 1);
+      hipLaunchKernelGGL(linear_bwd_w_kernel, grid, dim3(kThreads), 0, s, x, gy, (float*)nullptr, gb, (int)B, 0, N);
+    }
+    return df::launched("df_linear_bwd(small-N)");
+  }
   if (gw || gb) {
     dim3 grid(grid_for(N), (unsigned)(K + 1));
     hipLaunchKernelGGL(linear_bwd_w_kernel, grid, dim3(kThreads), 0, s, x, gy, gw, gb, (int)B, (int)K, N);
@@ -405,6 +578,79 @@ int df_adam_tf1_step(float* p, const float* g, float* m, float* v, int64_t n, fl
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(kThreads), 0, df::as_stream(stream), p, g, m, v, n, lr_t, beta1,
                      beta2, eps, grad_scale);
   return df::launched("df_adam_tf1_step");
+}
+
+int df_concat2_fwd(const float* a, const float* b, float* y, int64_t rows, int64_t Ca, int64_t Cb, df_stream_t stream) {
+  DF_REQUIRE(a && b && y, DF_EINVAL, "df_concat2_fwd: null pointer");
+  DF_REQUIRE(rows > 0 && Ca > 0 && Cb > 0, DF_EINVAL, "df_concat2_fwd: non-positive extent");
+  DF_REQUIRE(Ca % 4 == 0 && Cb % 4 == 0, DF_ESHAPE, "df_concat2_fwd: channel counts must be multiples of 4");
+  DF_REQUIRE(df::aligned16(a) && df::aligned16(b) && df::aligned16(y), DF_EALIGN, "df_concat2_fwd: 16-byte alignment");
+  hipLaunchKernelGGL((concat2_kernel<0>), dim3(grid_for(rows * (Ca + Cb) / 4)), dim3(kThreads), 0, df::as_stream(stream),
+                     const_cast<float*>(a), const_cast<float*>(b), y, rows, (int)(Ca / 4), (int)(Cb / 4));
+  return df::launched("df_concat2_fwd");
+}
+
+int df_concat2_bwd(const float* gy, float* ga, float* gb, int64_t rows, int64_t Ca, int64_t Cb, df_stream_t stream) {
+  DF_REQUIRE(gy && ga && gb, DF_EINVAL, "df_concat2_bwd: null pointer");
+  DF_REQUIRE(rows > 0 && Ca > 0 && Cb > 0, DF_EINVAL, "df_concat2_bwd: non-positive extent");
+  DF_REQUIRE(Ca % 4 == 0 && Cb % 4 == 0, DF_ESHAPE, "df_concat2_bwd: channel counts must be multiples of 4");
+  DF_REQUIRE(df::aligned16(ga) && df::aligned16(gb) && df::aligned16(gy), DF_EALIGN, "df_concat2_bwd: 16-byte alignment");
+  hipLaunchKernelGGL((concat2_kernel<1>), dim3(grid_for(rows * (Ca + Cb) / 4)), dim3(kThreads), 0, df::as_stream(stream),
+                     ga, gb, const_cast<float*>(gy), rows, (int)(Ca / 4), (int)(Cb / 4));
+  return df::launched("df_concat2_bwd");
+}
+
+int df_dilate2_odd(const float* g, float* out, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
+                   df_stream_t stream) {
+  DF_REQUIRE(g && out, DF_EINVAL, "df_dilate2_odd: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, DF_EINVAL, "df_dilate2_odd: non-positive extent");
+  DF_REQUIRE(C % 4 == 0, DF_ESHAPE, "df_dilate2_odd: C must be a multiple of 4");
+  DF_REQUIRE(is_3d || D == 1, DF_ESHAPE, "df_dilate2_odd: D must be 1 for 2-D");
+  DF_REQUIRE(df::aligned16(g) && df::aligned16(out), DF_EALIGN, "df_dilate2_odd: 16-byte alignment");
+  const int64_t n4 = B * (is_3d ? 2 * D : 1) * 2 * H * 2 * W * (C / 4);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  if (is_3d) hipLaunchKernelGGL((dilate2_kernel<true>), dim3(grid_for(n4)), dim3(kThreads), 0, df::as_stream(stream), g4, o4,
+                                n4, (int)D, (int)H, (int)W, (int)(C / 4));
+  else hipLaunchKernelGGL((dilate2_kernel<false>), dim3(grid_for(n4)), dim3(kThreads), 0, df::as_stream(stream), g4, o4, n4,
+                          (int)D, (int)H, (int)W, (int)(C / 4));
+  return df::launched("df_dilate2_odd");
+}
+
+int df_sigmoid_fwd(const float* x, float* y, int64_t n, df_stream_t stream) {
+  if (int e = check_n(x, n, "df_sigmoid_fwd")) return e;
+  DF_REQUIRE(y, DF_EINVAL, "df_sigmoid_fwd: null output");
+  hipLaunchKernelGGL((sigmoid_kernel<0>), dim3(grid_for(n)), dim3(kThreads), 0, df::as_stream(stream), x, x, y, n);
+  return df::launched("df_sigmoid_fwd");
+}
+
+int df_sigmoid_bwd(const float* gy, const float* y, float* gx, int64_t n, df_stream_t stream) {
+  if (int e = check_n(gy, n, "df_sigmoid_bwd")) return e;
+  DF_REQUIRE(y && gx, DF_EINVAL, "df_sigmoid_bwd: null pointer");
+  hipLaunchKernelGGL((sigmoid_kernel<1>), dim3(grid_for(n)), dim3(kThreads), 0, df::as_stream(stream), gy, y, gx, n);
+  return df::launched("df_sigmoid_bwd");
+}
+
+int df_mse_mean_fwd(const float* a, const float* b, int64_t n, float* out, void* workspace, int64_t workspace_bytes,
+                    df_stream_t stream) {
+  if (int e = check_n(a, n, "df_mse_mean_fwd")) return e;
+  DF_REQUIRE(b && out && workspace, DF_EINVAL, "df_mse_mean_fwd: null pointer");
+  DF_REQUIRE(workspace_bytes >= df_l1_mean_workspace_bytes(n), DF_EWORKSPACE, "df_mse_mean_fwd: workspace too small");
+  const unsigned grid = grid_for(n);
+  hipStream_t s = df::as_stream(stream);
+  double* part = static_cast<double*>(workspace);
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(grid), dim3(kThreads), 0, s, a, b, n, part);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(kThreads), 0, s, part, (int)grid, 1.0 / static_cast<double>(n), out);
+  return df::launched("df_mse_mean_fwd");
+}
+
+int df_mse_mean_bwd(const float* a, const float* b, const float* gout, float scale, float* ga, int64_t n,
+                    df_stream_t stream) {
+  if (int e = check_n(a, n, "df_mse_mean_bwd")) return e;
+  DF_REQUIRE(b && ga, DF_EINVAL, "df_mse_mean_bwd: null pointer");
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n)), dim3(kThreads), 0, df::as_stream(stream), a, b, gout,
+                     scale / static_cast<float>(n), ga, n);
+  return df::launched("df_mse_mean_bwd");
 }
 
 }  // extern "C"

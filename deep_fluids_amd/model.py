@@ -7,9 +7,10 @@ and ``reuse=True`` returns the same parameters (trainer.py:299-300).
 import numpy as np
 
 from .ops import *          # noqa: F401,F403  (the reference does `from ops import *`, model.py:3)
-from .ops import variable_scope, get_variables, add, lrelu, linear, reshape, conv2d, conv3d, upscale, upscale3
+from .ops import (variable_scope, get_variables, add, lrelu, linear, reshape, conv2d, conv3d, upscale, upscale3, concat,
+                  sigmoid, get_conv_shape)
 
-__all__ = ["GeneratorBE", "GeneratorBE3"]
+__all__ = ["GeneratorBE", "GeneratorBE3", "EncoderBE", "EncoderBE3", "AE", "AE3"]
 
 
 def _generator(z, filters, output_shape, name, num_conv, conv_k, last_k, repeat, skip_concat, act, reuse, is_3d):
@@ -63,3 +64,70 @@ def GeneratorBE3(z, filters, output_shape, name="G", num_conv=4, conv_k=3, last_
                  act=lrelu, reuse=False):
     """model.py:48-87."""
     return _generator(z, filters, output_shape, name, num_conv, conv_k, last_k, repeat, skip_concat, act, reuse, True)
+
+
+def _encoder(x, filters, z_num, name, num_conv, conv_k, repeat, act, reuse, is_3d):
+    conv = conv3d if is_3d else conv2d
+    with variable_scope(name, reuse=reuse) as vs:
+        x_shape = get_conv_shape(x)[1:]
+        if repeat == 0:
+            repeat_num = int(np.log2(np.max(x_shape[:-1]))) - 2                 # model.py:121 / :157
+        else:
+            repeat_num = repeat
+        assert repeat_num > 0 and np.sum([i % np.power(2, repeat_num - 1) for i in x_shape[:-1]]) == 0
+
+        ch = filters
+        layer_num = 0
+        x = conv(x, ch, k=conv_k, s=1, act=act, name=str(layer_num) + "_conv")
+        x0 = x
+        layer_num += 1
+        for idx in range(repeat_num):
+            for _ in range(num_conv):
+                x = conv(x, filters, k=conv_k, s=1, act=act, name=str(layer_num) + "_conv")
+                layer_num += 1
+            x = concat([x, x0], axis=-1)                                        # model.py:138 / :174 skip connection
+            ch += filters
+            if idx < repeat_num - 1:
+                x = conv(x, ch, k=conv_k, s=2, act=act, name=str(layer_num) + "_conv")
+                layer_num += 1
+                x0 = x
+        b = get_conv_shape(x)[0]
+        flat = x.reshape(b, -1)
+        out = linear(flat, z_num, name=str(layer_num) + "_fc")
+    variables = get_variables(vs)
+    return out, variables
+
+
+def EncoderBE(x, filters, z_num, name="enc", num_conv=4, conv_k=3, repeat=0, act=lrelu, reuse=False):
+    """model.py:118-152."""
+    return _encoder(x, filters, z_num, name, num_conv, conv_k, repeat, act, reuse, False)
+
+
+def EncoderBE3(x, filters, z_num, name="enc", num_conv=3, conv_k=3, repeat=0, act=lrelu, reuse=False):
+    """model.py:154-188."""
+    return _encoder(x, filters, z_num, name, num_conv, conv_k, repeat, act, reuse, True)
+
+
+def _ae(x, filters, z_num, name, num_conv, conv_k, last_k, repeat, act, skip_concat, use_sparse, reuse, is_3d):
+    enc = EncoderBE3 if is_3d else EncoderBE
+    dec = GeneratorBE3 if is_3d else GeneratorBE
+    with variable_scope(name, reuse=reuse) as vs:
+        z, _ = enc(x, filters, z_num, "enc", num_conv=num_conv - 1, conv_k=conv_k, repeat=repeat, act=act, reuse=reuse)
+        if use_sparse:
+            z = sigmoid(z)
+        out, _ = dec(z, filters, get_conv_shape(x)[1:], "dec", num_conv=num_conv, conv_k=conv_k, last_k=last_k,
+                     repeat=repeat, skip_concat=skip_concat, act=act, reuse=reuse)
+    variables = get_variables(vs)
+    return out, z, variables
+
+
+def AE(x, filters, z_num, name="AE", num_conv=4, conv_k=3, last_k=3, repeat=0, act=lrelu, skip_concat=False,
+       use_sparse=False, reuse=False):
+    """model.py:190-202."""
+    return _ae(x, filters, z_num, name, num_conv, conv_k, last_k, repeat, act, skip_concat, use_sparse, reuse, False)
+
+
+def AE3(x, filters, z_num, name="AE", num_conv=4, conv_k=3, last_k=3, repeat=0, act=lrelu, skip_concat=False,
+        use_sparse=False, reuse=False):
+    """model.py:204-216."""
+    return _ae(x, filters, z_num, name, num_conv, conv_k, last_k, repeat, act, skip_concat, use_sparse, reuse, True)

@@ -22,7 +22,7 @@ from ._lib import call, query, DF_CONV_BIAS, DF_CONV_LRELU, DF_CONV_MASK, DF_CON
 
 __all__ = [
     "lrelu", "conv2d", "conv3d", "linear", "upscale", "upscale3", "resize_nearest_neighbor", "reshape",
-    "int_shape", "get_conv_shape", "nchw_to_nhwc", "nhwc_to_nchw", "add",
+    "int_shape", "get_conv_shape", "nchw_to_nhwc", "nhwc_to_nchw", "add", "concat", "sigmoid", "mse_mean",
     "jacobian", "jacobian3", "curl", "curl3", "divergence", "divergence3",
     "vort_np", "curl_np", "grad_np", "jacobian_np3", "l1_mean",
     "variable_scope", "get_variables", "get_variable", "reset_variables", "set_random_seed", "all_variables",
@@ -246,6 +246,129 @@ class _ConvSame3(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _ConvSame3S2(torch.autograd.Function):
+    """k=3, stride-2, TF-'SAME' conv on even extents (pad 0 before / 1 after): the encoder's
+    down-sampling layers (model.py:141-143, 177-179).  Forward is a dedicated MFMA kernel; the backward re-uses the
+    stride-1 dgrad / wgrad kernels on the zero-inserted gradient (out[2o+1] = g[o]), which reproduces the stride-2
+    adjoints exactly (at 4x / 8x the minimal FLOPs -- four layers of the auto-encoder only)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, leak):
+        x = _prep(x, "x"); w = _prep(w, "weights"); b = _prep(b, "biases")
+        nd = x.dim() - 2
+        kz = 3 if nd == 3 else 1
+        taps = 27 if nd == 3 else 9
+        cin, cout = w.shape[-2], w.shape[-1]
+        if tuple(w.shape[:-2]) != (3,) * nd or x.shape[-1] != cin:
+            raise ValueError("conv: weights %s do not match input %s (k=3 only)" % (tuple(w.shape), tuple(x.shape)))
+        if any(int(d) % 2 for d in x.shape[1:-1]):
+            raise NotImplementedError("stride-2 conv: even spatial extents only (the encoder asserts them, model.py:125,161)")
+        idims = (x.shape[0], x.shape[1] if nd == 3 else 1, x.shape[-3], x.shape[-2])
+        odims = (idims[0], idims[1] // 2 if nd == 3 else 1, idims[2] // 2, idims[3] // 2)
+        wp = _pack(w, taps, cin, cout, 0)
+        flags = DF_CONV_BIAS | (DF_CONV_LRELU if leak is not None else 0)
+        y = torch.empty(odims + (cout,), dtype=torch.float32, device=x.device)
+        call("df_conv_s2_fwd", _ptr(x), _ptr(wp), _ptr(b), _ptr(y), odims[0], odims[1], odims[2], odims[3], cin, cout, kz,
+             flags, float(leak if leak is not None else 0.0), _stream())
+        y = y.view((x.shape[0],) + tuple(int(d) // 2 for d in x.shape[1:-1]) + (cout,))
+        ctx.save_for_backward(x, w, y if leak is not None else None)
+        ctx.leak = leak
+        ctx.geom = (idims, odims, cin, cout, kz, taps)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        idims, odims, cin, cout, kz, taps = ctx.geom
+        B, D, H, W = idims
+        gy = _prep(gy, "grad")
+        if ctx.leak is not None:
+            dp = torch.empty_like(gy)
+            call("df_lrelu_bwd", _ptr(gy), _ptr(y), _ptr(dp), float(ctx.leak), gy.numel(), _stream())
+        else:
+            dp = gy
+        up = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
+        call("df_dilate2_odd", _ptr(dp), _ptr(up), odims[0], odims[1], odims[2], odims[3], cout, int(kz == 3), _stream())
+        gw = torch.empty_like(w)
+        gb = torch.empty(cout, dtype=torch.float32, device=x.device)
+        nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, kz)
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+        call("df_conv_wgrad", _ptr(x), _ptr(up), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, _ptr(ws), nbytes, _stream())
+        gx = None
+        if ctx.needs_input_grad[0]:
+            wpd = _pack(w, taps, cin, cout, 1)
+            gx = _conv_raw(up, wpd, None, None, None, idims, cout, cin, kz, 0, 0.0).view(x.shape)
+        return gx, gw, gb, None
+
+
+class _Concat2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _prep(a, "a"); b = _prep(b, "b")
+        if a.shape[:-1] != b.shape[:-1]:
+            raise ValueError("concat: leading shapes differ %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        ca, cb = a.shape[-1], b.shape[-1]
+        rows = a.numel() // ca
+        y = _empty(tuple(a.shape[:-1]) + (ca + cb,), a)
+        call("df_concat2_fwd", _ptr(a), _ptr(b), _ptr(y), rows, ca, cb, _stream())
+        ctx.geom = (rows, ca, cb, tuple(a.shape), tuple(b.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        rows, ca, cb, sa, sb = ctx.geom
+        gy = _prep(gy, "grad")
+        ga, gb = _empty(sa, gy), _empty(sb, gy)
+        call("df_concat2_bwd", _ptr(gy), _ptr(ga), _ptr(gb), rows, ca, cb, _stream())
+        return ga, gb
+
+
+class _Sigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _prep(x, "x")
+        y = torch.empty_like(x)
+        call("df_sigmoid_fwd", _ptr(x), _ptr(y), x.numel(), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = _prep(gy, "grad")
+        gx = torch.empty_like(gy)
+        call("df_sigmoid_bwd", _ptr(gy), _ptr(y), _ptr(gx), gy.numel(), _stream())
+        return gx
+
+
+class _MseMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _prep(a, "a"); b = _prep(b, "b")
+        if a.shape != b.shape:
+            raise ValueError("mse_mean: shapes differ %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        n = a.numel()
+        out = _empty((), a)
+        nbytes = query("df_l1_mean_workspace_bytes", n)
+        ws = torch.empty(nbytes // 8, dtype=torch.float64, device=a.device)
+        call("df_mse_mean_fwd", _ptr(a), _ptr(b), n, _ptr(out), _ptr(ws), nbytes, _stream())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        gout = _prep(gout, "grad")
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = torch.empty_like(a)
+            call("df_mse_mean_bwd", _ptr(a), _ptr(b), _ptr(gout), 1.0, _ptr(ga), a.numel(), _stream())
+        if ctx.needs_input_grad[1]:
+            gb = torch.empty_like(b)
+            call("df_mse_mean_bwd", _ptr(a), _ptr(b), _ptr(gout), -1.0, _ptr(gb), a.numel(), _stream())
+        return ga, gb
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
@@ -255,7 +378,9 @@ class _Linear(torch.autograd.Function):
         if w.shape[0] != K:
             raise ValueError("linear: weights %s do not match input %s" % (tuple(w.shape), tuple(x.shape)))
         y = _empty((B, N), x)
-        call("df_linear_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, K, N, _stream())
+        nbytes = query("df_linear_workspace_bytes", B, K, N)
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+        call("df_linear_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, K, N, _ptr(ws), nbytes, _stream())
         ctx.save_for_backward(x, w)
         return y
 
@@ -301,7 +426,7 @@ class _Curl2d(torch.autograd.Function):
         psi = _prep(psi, "x")
         B, Y, X, C = psi.shape
         if C != 1:
-            raise ValueError("curl expects a 1-channel stream function [B,Y,X,1], got %s" % (tuple(psi.shape),))
+            raise ValueError("curl kernel expects the 1-channel stream function [B,Y,X,1], got %s" % (tuple(psi.shape),))
         u = _empty((B, Y, X, 2), psi)
         call("df_curl2d_fwd", _ptr(psi), _ptr(u), B, Y, X, _stream())
         ctx.geom = (B, Y, X)
@@ -416,6 +541,23 @@ def add(a, b):
     return _Add.apply(a, b)
 
 
+def concat(values, axis=-1):
+    """``tf.concat([x, x0], axis=-1)`` (model.py:138,174): channel concat of two channels-last tensors."""
+    if len(values) != 2 or axis not in (-1, values[0].dim() - 1):
+        raise NotImplementedError("concat: two tensors along the channel axis (the encoder's skip connection)")
+    return _Concat2.apply(values[0], values[1])
+
+
+def sigmoid(x):
+    """``tf.sigmoid`` (model.py:196,210)."""
+    return _Sigmoid.apply(x)
+
+
+def mse_mean(a, b):
+    """``tf.reduce_mean(tf.squared_difference(a, b))`` (trainer3.py:270)."""
+    return _MseMean.apply(a, b)
+
+
 def nchw_to_nhwc(x):
     """ops.py:108-109."""
     return x.permute(0, 2, 3, 1).contiguous()
@@ -457,9 +599,9 @@ def _act_leak(act):
 
 
 def _conv(x, o_dim, nd, data_format, name, k, s, act):
-    if k != 3 or s != 1:
-        raise NotImplementedError("deep_fluids_amd convs implement the generator path only: k=3, s=1 "
-                                  "(reference call sites model.py:26,42,68,84); got k=%d s=%d" % (k, s))
+    if k != 3 or s not in (1, 2):
+        raise NotImplementedError("deep_fluids_amd convs implement the generator / encoder call sites: k=3, s=1|2 "
+                                  "(model.py:26,42,68,84,127-143,163-179); got k=%d s=%d" % (k, s))
     if nd == 2 and data_format == "NCHW":
         x = nchw_to_nhwc(x)
     cin = int(x.shape[-1])
@@ -467,7 +609,7 @@ def _conv(x, o_dim, nd, data_format, name, k, s, act):
     w = get_variable(lname + "/weights", (3,) * nd + (cin, int(o_dim)), "xavier", x.device)
     b = get_variable(lname + "/biases", (int(o_dim),), "zeros", x.device)
     leak, post = _act_leak(act)
-    y = _ConvSame3.apply(x, w, b, leak)
+    y = (_ConvSame3 if s == 1 else _ConvSame3S2).apply(x, w, b, leak)
     if post is not None:
         y = post(y)
     if nd == 2 and data_format == "NCHW":
@@ -543,6 +685,8 @@ def curl(x, data_format="NHWC"):
     """ops.py:264-274."""
     if data_format == "NCHW":
         x = nchw_to_nhwc(x)
+    if x.shape[-1] != 1:
+        x = x[..., :1]          # the reference reads channel 0 only (x[:,1:,:,0]); e.g. the 2-channel AE output, trainer.py:361
     c = _Curl2d.apply(x)
     return nhwc_to_nchw(c) if data_format == "NCHW" else c
 

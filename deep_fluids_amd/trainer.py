@@ -20,8 +20,8 @@ import numpy as np
 import torch
 
 from . import ops
-from .ops import curl, curl3, jacobian, jacobian3, l1_mean, get_conv_shape, _ptr, _stream, call
-from .model import GeneratorBE, GeneratorBE3
+from .ops import curl, curl3, jacobian, jacobian3, l1_mean, mse_mean, get_conv_shape, _ptr, _stream, call
+from .model import GeneratorBE, GeneratorBE3, AE, AE3
 from .dist import GradSync
 
 
@@ -30,7 +30,8 @@ def default_config(**over):
     c = dict(is_3d=False, res_x=96, res_y=128, res_z=32, repeat=0, filters=128, num_conv=4, use_curl=True,
              w1=1.0, w2=1.0, arch="de", batch_size=8, max_epoch=100, lr_max=1e-4, lr_min=2.5e-6,
              optimizer="adam", beta1=0.5, beta2=0.999, lr_update="decay", lr_update_step=120000,
-             start_step=0, random_seed=123, num_samples=21000, c_num=3, use_curl3_alias=True)
+             start_step=0, random_seed=123, num_samples=21000, c_num=3, use_curl3_alias=True,
+             z_num=16, use_sparse=False, sparsity=0.01, w4=1.0, w5=1.0, p_num=2, x_channels=None)
     c.update(over)
     return SimpleNamespace(**c)
 
@@ -62,14 +63,17 @@ class Trainer(object):
         self.grad_sync = None
 
     # ---- variables: created by one shape-only pass through the generator, then moved into flat slabs ----
-    def _build_variables(self):
+    def _create_variables(self):
         gen = GeneratorBE3 if self.is_3d else GeneratorBE
         z = torch.zeros((1, self.c_num), dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            gen(z, self.filters, self.output_shape, name=self.name, num_conv=self.num_conv, repeat=self.repeat)
+
+    def _build_variables(self):
         prefix = self.name + "/"
         existing = {k for k in ops.all_variables() if k.startswith(prefix)}
         if not existing:
-            with torch.no_grad():
-                gen(z, self.filters, self.output_shape, name=self.name, num_conv=self.num_conv, repeat=self.repeat)
+            self._create_variables()
         names = [k for k in ops.all_variables() if k.startswith(prefix)]
         vars_ = ops.all_variables()
         total = sum(vars_[k].numel() for k in names)
@@ -103,15 +107,18 @@ class Trainer(object):
     def grads_numpy(self):
         return {k: self.flat_g[o:o + n].view(ops._VARS[k].shape).cpu().numpy() for k, (o, n) in self.var_slices.items()}
 
+    def _bucket_id(self, k):
+        layer = int(k.split("/")[-2].split("_")[0])
+        return 0 if layer == 0 else 1 + (layer - 1) // self.num_conv
+
     def enable_data_parallel(self, group=None):
         """Bucket the flat gradient slab per generator block (fc | 4 convs | ... | last conv)."""
         groups = {}
         for k in self.var_names:
-            layer = int(k.split("/")[1].split("_")[0])
-            gid = 0 if layer == 0 else 1 + (layer - 1) // self.num_conv
+            gid = (k.rsplit("/", 2)[0], self._bucket_id(k))
             groups.setdefault(gid, []).append(k)
         buckets = []
-        for gid in sorted(groups):
+        for gid in groups:                                   # insertion order == slab order
             ks = groups[gid]
             off = self.var_slices[ks[0]][0]
             n = sum(self.var_slices[k][1] for k in ks)
@@ -188,3 +195,48 @@ class Trainer3(Trainer):
     def __init__(self, config, device="cuda", name="G"):
         config.is_3d = True
         super(Trainer3, self).__init__(config, device, name)
+
+
+class AETrainer(Trainer):
+    """arch='ae' (SURVEY 8(f)-1): ``build_model_ae`` + the optimizer step of ``train_ae``
+    (trainer.py:357-462; trainer3.py:240-345).  x -> AE|AE3 -> (curl) -> L1 + Jacobian-L1 + w4*loss_p."""
+
+    def __init__(self, config, device="cuda", name="AE"):
+        self.z_num = config.z_num
+        self.p_num = config.p_num
+        self.use_sparse = config.use_sparse
+        if self.use_sparse:
+            raise NotImplementedError("use_sparse=True (Bernoulli-KL sparsity, trainer3.py:272-277) is not built; "
+                                      "the reference's documented runs never enable it (run.bat:56,73)")
+        self.w4 = config.w4
+        super(AETrainer, self).__init__(config, device, name)
+
+    def _x_shape(self):
+        spatial = ([self.config.res_z] if self.is_3d else []) + [self.config.res_y, self.config.res_x]
+        ch = self.config.x_channels or (3 if self.is_3d else 2)
+        return spatial + [ch]
+
+    def _create_variables(self):
+        ae = AE3 if self.is_3d else AE
+        x = torch.zeros([1] + self._x_shape(), dtype=torch.float32, device=self.device)
+        with torch.no_grad():      # one shape-only pass creates AE/enc/* and AE/dec/* (decoder output = x's own shape)
+            ae(x, self.filters, self.z_num, name=self.name, num_conv=self.num_conv, repeat=self.repeat)
+
+    def build_model(self, x, y):
+        ae = AE3 if self.is_3d else AE
+        with torch.no_grad():
+            x_jaco = (jacobian3(x) if self.is_3d else jacobian(x))[0]
+        out, z, _ = ae(x, self.filters, self.z_num, name=self.name, num_conv=self.num_conv, repeat=self.repeat,
+                       use_sparse=self.use_sparse, reuse=True)
+        if self.config.use_curl:
+            x_ = (curl3(out) if self.config.use_curl3_alias else jacobian3(out)[1]) if self.is_3d else curl(out)
+        else:
+            x_ = out
+        x_jaco_, x_vort_ = jacobian3(x_) if self.is_3d else jacobian(x_)
+        loss_l1 = l1_mean(x_, x)                                   # trainer3.py:265
+        loss_j_l1 = l1_mean(x_jaco_, x_jaco)                       # trainer3.py:266
+        y_last = y[:, :, -1] if y.dim() == 3 else y                # trainer3.py:268
+        loss_p = mse_mean(y_last.contiguous(), z[:, -self.p_num:].contiguous())   # trainer3.py:269-270
+        loss = loss_l1 * self.w1 + loss_j_l1 * self.w2 + loss_p * self.w4
+        return SimpleNamespace(s=out, G_=x_, x_=x_, z=z, G_jaco_=x_jaco_, G_vort_=x_vort_, x_jaco=x_jaco,
+                               g_loss_l1=loss_l1, g_loss_j_l1=loss_j_l1, loss_p=loss_p, g_loss=loss, loss=loss)

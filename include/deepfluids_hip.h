@@ -106,11 +106,31 @@ int df_upsample2x_bwd(const float* gy, float* gx, int64_t B, int64_t D, int64_t 
                       df_stream_t stream);
 
 /* linear ops.py:23-24 (slim.fully_connected): y[B,N] = x[B,K] . w[K,N] + bias[N]  (bias may be NULL). */
+int64_t df_linear_workspace_bytes(int64_t B, int64_t K, int64_t N); /* > 0 only for the large-K/small-N split-K path */
 int df_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t K, int64_t N,
-                  df_stream_t stream);
+                  void* workspace, int64_t workspace_bytes, df_stream_t stream);
 /* backward: gw[K,N] = x^T gy, gb[N] = sum_b gy, gx[B,K] = gy w^T (gx / gw / gb may be NULL). */
 int df_linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int64_t B,
                   int64_t K, int64_t N, df_stream_t stream);
+
+/* tf.concat([a, b], axis=-1) of two channels-last tensors with `rows` voxels (encoder skips, model.py:138,174) and the
+ * reverse split of the gradient; channel counts multiples of 4. */
+int df_concat2_fwd(const float* a, const float* b, float* y, int64_t rows, int64_t Ca, int64_t Cb, df_stream_t stream);
+int df_concat2_bwd(const float* gy, float* ga, float* gb, int64_t rows, int64_t Ca, int64_t Cb, df_stream_t stream);
+
+/* zero insertion used by the stride-2 conv backward: out[B,2D|1,2H,2W,C][2o+1] = g[B,D,H,W,C][o], zeros elsewhere. */
+int df_dilate2_odd(const float* g, float* out, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
+                   df_stream_t stream);
+
+/* tf.sigmoid (AE latent code with use_sparse, model.py:196,210) and its backward from the saved output. */
+int df_sigmoid_fwd(const float* x, float* y, int64_t n, df_stream_t stream);
+int df_sigmoid_bwd(const float* gy, const float* y, float* gx, int64_t n, df_stream_t stream);
+
+/* mean((a-b)^2) (loss_p, trainer.py:395 / trainer3.py:268-270); workspace as df_l1_mean_fwd. */
+int df_mse_mean_fwd(const float* a, const float* b, int64_t n, float* out, void* workspace, int64_t workspace_bytes,
+                    df_stream_t stream);
+int df_mse_mean_bwd(const float* a, const float* b, const float* gout, float scale, float* ga, int64_t n,
+                    df_stream_t stream);
 
 /* gb[c] = sum over rows of g[rows, C]  (conv bias gradient), deterministic. */
 int64_t df_colsum_workspace_bytes(int64_t rows, int64_t C);
@@ -138,6 +158,11 @@ int df_conv_pack_weights(const float* w, float* wp, int64_t taps, int64_t cin, i
 int df_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
                 float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int flags,
                 float leak, df_stream_t stream);
+/* k=3, stride 2, TF 'SAME' on even input extents (pad 0 before / 1 after): the encoder's down-sampling convs
+ * (model.py:141-143, 177-179).  x [B,2Do|1,2Ho,2Wo,Cin] -> y [B,Do,Ho,Wo,Cout]; `wp` packed with mode 0;
+ * flags: DF_CONV_BIAS | DF_CONV_LRELU only. */
+int df_conv_s2_fwd(const float* x, const float* wp, const float* bias, float* y, int64_t B, int64_t Do, int64_t Ho,
+                   int64_t Wo, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream);
 /* gw[kz,3,3,Cin,Cout] = sum_voxels x[voxel+tap][cin] * gy[voxel][cout]   (split over voxel ranges,
  * deterministic second-pass reduction through the workspace).  If gb != NULL it also receives the bias gradient
  * gb[cout] = sum_voxels gy[voxel][cout] (accumulated on the fly from the operand registers). */

@@ -365,6 +365,155 @@ def generator_bwd(dout, cache, p, name="G", leak=0.2):
 
 
 # ----------------------------------------------------------------------------------------
+# Encoder / auto-encoder (model.py:118-216)
+# ----------------------------------------------------------------------------------------
+
+def encoder_plan(x_shape, filters, repeat=0):
+    spatial = list(x_shape[:-1])
+    repeat_num = int(np.log2(np.max(spatial))) - 2 if repeat == 0 else repeat
+    assert repeat_num > 0 and all(s % (2 ** (repeat_num - 1)) == 0 for s in spatial), "model.py:125 / :161"
+    return repeat_num
+
+
+def encoder_init(rng, x_shape, filters, z_num, name="enc", num_conv=3, conv_k=3, repeat=0):
+    """Variables of EncoderBE / EncoderBE3 in slim naming order."""
+    nd = len(x_shape) - 1
+    repeat_num = encoder_plan(x_shape, filters, repeat)
+    p = {}
+    def add_conv(ln, cin, cout):
+        p["%s/%d_conv/weights" % (name, ln)] = xavier_uniform(rng, (conv_k,) * nd + (cin, cout))
+        p["%s/%d_conv/biases" % (name, ln)] = np.zeros(cout, np.float32)
+    ch = filters
+    add_conv(0, x_shape[-1], ch)
+    ln = 1
+    spatial = list(x_shape[:-1])
+    cin = ch
+    for idx in range(repeat_num):
+        for _ in range(num_conv):
+            add_conv(ln, cin, filters); cin = filters; ln += 1
+        ch += filters
+        cin = ch
+        if idx < repeat_num - 1:
+            add_conv(ln, ch, ch); ln += 1
+            spatial = [s // 2 for s in spatial]
+    flat = int(np.prod(spatial)) * ch
+    p["%s/%d_fc/weights" % (name, ln)] = xavier_uniform(rng, (flat, z_num))
+    p["%s/%d_fc/biases" % (name, ln)] = np.zeros(z_num, np.float32)
+    return p
+
+
+def encoder_fwd(x, p, filters, z_num, name="enc", num_conv=3, repeat=0, leak=0.2, keep=False):
+    """EncoderBE (model.py:118-152) / EncoderBE3 (model.py:154-188)."""
+    repeat_num = encoder_plan(x.shape[1:], filters, repeat)
+    W = lambda n, kind: p["%s/%d_%s/weights" % (name, n, kind)]
+    Bv = lambda n, kind: p["%s/%d_%s/biases" % (name, n, kind)]
+    tape = []                                           # (kind, payload) in execution order
+    def conv(xx, ln, stride):
+        y = lrelu(conv_same(xx, W(ln, "conv"), Bv(ln, "conv"), stride), leak)
+        tape.append(("conv", (xx, y, ln, stride)))
+        return y
+    x = conv(x, 0, 1)
+    x0 = x
+    ln = 1
+    for idx in range(repeat_num):
+        for _ in range(num_conv):
+            x = conv(x, ln, 1); ln += 1
+        tape.append(("concat", (x.shape[-1], x0.shape[-1])))
+        x = np.concatenate([x, x0], axis=-1)            # model.py:138 / :174
+        if idx < repeat_num - 1:
+            x = conv(x, ln, 2); ln += 1                # model.py:141-143
+            tape.append(("mark_x0", None))
+            x0 = x
+    flat = x.reshape(x.shape[0], -1)
+    z = linear(flat, W(ln, "fc"), Bv(ln, "fc"))
+    cache = {"tape": tape, "flat": flat, "xshape": x.shape, "fc_ln": ln}
+    return (z, cache) if keep else z
+
+
+def encoder_bwd(dz, cache, p, name="enc", leak=0.2):
+    """Reverse pass of :func:`encoder_fwd` (gradient w.r.t. the input is not needed: x is data)."""
+    g = {}
+    ln = cache["fc_ln"]
+    g["%s/%d_fc/weights" % (name, ln)] = cache["flat"].T @ dz
+    g["%s/%d_fc/biases" % (name, ln)] = dz.sum(axis=0)
+    dx = (dz @ p["%s/%d_fc/weights" % (name, ln)].T).reshape(cache["xshape"])
+    dx0 = None                                          # gradient flowing into the current skip source x0
+    for kind, payload in reversed(cache["tape"]):
+        if kind == "mark_x0":                           # x0 = x after the stride-2 conv: merge the skip gradient
+            if dx0 is not None:
+                dx = dx + dx0
+            dx0 = None
+        elif kind == "concat":
+            ca, cb = payload
+            dx0 = dx[..., ca:] if dx0 is None else dx0 + dx[..., ca:]
+            dx = dx[..., :ca]
+        else:
+            xin, y, l, stride = payload
+            if l == 0 and dx0 is not None:              # x0 = output of the first conv
+                dx = dx + dx0
+                dx0 = None
+            dpre = dx * np.where(y > 0, 1.0, leak).astype(dx.dtype)
+            dx, dw, db = conv_same_bwd(xin, p["%s/%d_conv/weights" % (name, l)], dpre, stride, need_dx=(l != 0))
+            g["%s/%d_conv/weights" % (name, l)] = dw; g["%s/%d_conv/biases" % (name, l)] = db
+    return g
+
+
+def ae_init(rng, x_shape, filters, z_num, name="AE", num_conv=4, repeat=0):
+    """AE / AE3 variables: encoder 'AE/enc/*' with num_conv-1 convs per block, decoder 'AE/dec/*' (model.py:190-216)."""
+    p = encoder_init(rng, x_shape, filters, z_num, name + "/enc", num_conv - 1, repeat=repeat)
+    p.update(generator_init(rng, z_num, list(x_shape), filters, name + "/dec", num_conv, repeat=repeat))
+    return p
+
+
+def ae_train_step(x, y_last, p, opt, filters, z_num, p_num, is_3d, num_conv=4, repeat=0, use_curl=True, w1=1.0, w2=1.0,
+                  w4=1.0, name="AE"):
+    """build_model_ae + one optimizer step (trainer.py:357-423 / trainer3.py:240-279), use_sparse=False.
+    ``y_last`` = y[:, :, -1]  [B, p_num];  loss = w1*L1 + w2*J-L1 + w4*mean((y_last - z[:, -p_num:])^2)."""
+    oshape = list(x.shape[1:])                           # model.py:197,211: the decoder emits x's own shape
+    z, ecache = encoder_fwd(x, p, filters, z_num, name + "/enc", num_conv - 1, repeat, keep=True)
+    s, dcache = generator_fwd(z, p, oshape, filters, name + "/dec", num_conv, repeat, keep=True)
+    if use_curl:
+        if is_3d:
+            res = velocity_loss(s, x, True, w1, w2)
+            ds = res["dpsi"]
+        else:                                            # curl reads channel 0 only (ops.py:267-268)
+            res = velocity_loss(s[..., :1], x, False, w1, w2)
+            ds = np.zeros_like(s); ds[..., :1] = res["dpsi"]
+    else:
+        raise NotImplementedError("oracle: AE without curl (liquid scenes) not restated")
+    zp = z[:, -p_num:]
+    loss_p = ((y_last - zp) ** 2).mean()
+    dzp = -2.0 * (y_last - zp) / zp.size * w4
+    grads = generator_bwd(ds, dcache, p, name + "/dec")
+    dz = _generator_dz(ds, dcache, p, name + "/dec").copy()      # dL/dz through the decoder (z is the encoder's output)
+    dz[:, -p_num:] += dzp
+    grads.update(encoder_bwd(dz, ecache, p, name + "/enc"))
+    t = opt["t"] + 1
+    new_p, new_m, new_v = {}, {}, {}
+    for k in p:
+        new_p[k], new_m[k], new_v[k] = adam_tf1(p[k], grads[k], opt["m"][k], opt["v"][k], t, opt["lr"])
+    info = {"loss": res["loss"] + w4 * loss_p, "l1": res["l1"], "j_l1": res["j_l1"], "loss_p": loss_p, "u": res["u"],
+            "z": z, "grads": grads}
+    return new_p, {"m": new_m, "v": new_v, "t": t, "lr": opt["lr"]}, info
+
+
+def _generator_dz(dout, cache, p, name, leak=0.2):
+    """dL/dz of the generator input (needed when z comes from an encoder): the reverse pass of generator_fwd down
+    to the FC layer's input."""
+    ln = cache["last_ln"]
+    dx, _, _ = conv_same_bwd(cache["last_in"], p["%s/%d_conv/weights" % (name, ln)], dout)
+    for blk in reversed(cache["blocks"]):
+        if blk["up"]:
+            dx = upscale_nn_bwd(dx, 2)
+        dy = dx
+        for xin, xout, l in zip(reversed(blk["ins"]), reversed(blk["outs"]), reversed(blk["ln"])):
+            dpre = dx * np.where(xout > 0, 1.0, leak).astype(dx.dtype)
+            dx, _, _ = conv_same_bwd(xin, p["%s/%d_conv/weights" % (name, l)], dpre)
+        dx = dx + dy
+    return dx.reshape(dx.shape[0], -1) @ p["%s/0_fc/weights" % name].T
+
+
+# ----------------------------------------------------------------------------------------
 # Train step (trainer.py:136-184, trainer3.py:14-63) + TF1 Adam + LR schedule
 # ----------------------------------------------------------------------------------------
 

@@ -111,6 +111,7 @@ def install_stub():
     tf.transpose = lambda x, perm: _t(np.transpose(np.asarray(x), perm))
     tf.maximum = lambda a, b: _t(np.maximum(a, b))
     tf.reshape = lambda x, shp: _t(np.reshape(np.asarray(x), shp))
+    tf.sigmoid = lambda x: _t(1.0 / (1.0 + np.exp(-np.asarray(x))))
     tf.variable_scope = _variable_scope
     tf.image = types.SimpleNamespace(resize_nearest_neighbor=_resize_nn)
     contrib = types.ModuleType("tensorflow.contrib")
@@ -217,6 +218,26 @@ def capture_generators(model):
             + 3 ** nd * 128 * oshape[-1] + oshape[-1]
         plans[tag] = {"fn": fn, "output_shape": oshape, "filters": 128, "repeat_num": rep, "x0_shape": x0,
                       "n_layers": nl, "n_params": n_params}
+    # auto-encoders (model.py:118-216): encoder with concat skips + stride-2 convs, decoder = GeneratorBE(3)
+    ae = {}
+    for tag, (fn, xshape, filters, z_num, batch, sparse) in {
+            "ae3_small": ("AE3", [8, 16, 8, 3], 4, 6, 2, False),
+            "ae2_small": ("AE", [16, 8, 1], 4, 5, 2, True)}.items():
+        rng = np.random.RandomState(123)
+        WEIGHTS.clear(); del PLAN[:]
+        WEIGHTS.update(orc.ae_init(rng, xshape, filters, z_num))
+        for k in list(WEIGHTS):
+            if k.endswith("biases"):
+                WEIGHTS[k] = rng.uniform(-0.1, 0.1, size=WEIGHTS[k].shape).astype(np.float32)
+        x = rng.uniform(-1, 1, size=[batch] + xshape).astype(np.float32)
+        out, z, var_names = getattr(model, fn)(_t(x), filters, z_num, use_sparse=sparse)
+        ae[tag + "_x"] = x; ae[tag + "_out"] = np.asarray(out); ae[tag + "_z"] = np.asarray(z)
+        for k, v in WEIGHTS.items():
+            ae[tag + "|" + k] = v
+        plans[tag] = {"fn": fn, "x_shape": xshape, "filters": filters, "z_num": z_num, "use_sparse": sparse,
+                      "layers": list(PLAN), "variables": list(var_names)}
+    np.savez_compressed(os.path.join(HERE, "autoencoders.npz"), **ae)
+
     with open(os.path.join(HERE, "layer_plans.json"), "w") as f:
         json.dump(plans, f, indent=1, sort_keys=True)
     print("generators.npz: %d arrays; layer_plans.json: %s" % (len(res), sorted(plans)))

@@ -1,0 +1,130 @@
+"""-m gpu: SURVEY 8(f)-1 -- encoder / auto-encoder path: stride-2 TF-SAME conv, channel concat, large-K FC, sigmoid,
+mean-squared loss, AE/AE3 graphs vs the reference's model.py (golden) and the AE train step vs the fp64 oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import df_oracle as orc
+from conftest import GOLDEN
+from gpu_util import dev, host, rel_l1, rel_linf
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.mark.parametrize("shape,cin,cout,leak", [
+    ((1, 4, 8, 32), 16, 128, 0.2), ((2, 8, 8, 8), 32, 64, 0.2), ((1, 6, 10, 14), 64, 192, None),
+    ((2, 16, 32), 16, 128, 0.2), ((1, 8, 8), 128, 128, None), ((1, 2, 2, 2), 16, 32, 0.2)])
+def test_conv_stride2_fwd_bwd(shape, cin, cout, leak):
+    from deep_fluids_amd.ops import _ConvSame3S2
+    rng = np.random.RandomState(cin + cout + sum(shape))
+    nd = len(shape) - 1
+    x = rng.uniform(-1, 1, shape + (cin,)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (3,) * nd + (cin, cout)) / np.sqrt(cin * 3 ** nd)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    oshape = (shape[0],) + tuple(s // 2 for s in shape[1:])
+    go = rng.uniform(-1, 1, oshape + (cout,)).astype(np.float32)
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = _ConvSame3S2.apply(xt, wt, bt, leak)
+    (y * dev(go)).sum().backward()
+    x64, w64, b64 = x.astype(np.float64), w.astype(np.float64), b.astype(np.float64)
+    pre = orc.conv_same(x64, w64, b64, stride=2)
+    ref = orc.lrelu(pre, leak) if leak is not None else pre
+    dpre = go * (np.where(ref > 0, 1.0, leak) if leak is not None else 1.0)
+    dx, dw, db = orc.conv_same_bwd(x64, w64, dpre, stride=2)
+    errs = {"y": rel_linf(host(y), ref), "dx": rel_linf(host(xt.grad), dx), "dw": rel_linf(host(wt.grad), dw),
+            "db": rel_linf(host(bt.grad), db)}
+    assert max(errs.values()) < TOL, errs
+
+
+def test_concat_sigmoid_mse_bigfc():
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.ops import _Linear
+    rng = np.random.RandomState(4)
+    a = rng.uniform(-1, 1, (2, 3, 5, 8)).astype(np.float32); b = rng.uniform(-1, 1, (2, 3, 5, 12)).astype(np.float32)
+    g = rng.uniform(-1, 1, (2, 3, 5, 20)).astype(np.float32)
+    at, bt = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+    y = ops.concat([at, bt], axis=-1)
+    np.testing.assert_array_equal(host(y), np.concatenate([a, b], -1))
+    (y * dev(g)).sum().backward()
+    np.testing.assert_array_equal(host(at.grad), g[..., :8]); np.testing.assert_array_equal(host(bt.grad), g[..., 8:])
+    z = rng.uniform(-3, 3, (4, 7)).astype(np.float32); gz = rng.uniform(-1, 1, (4, 7)).astype(np.float32)
+    zt = dev(z).requires_grad_(True)
+    s = ops.sigmoid(zt)
+    ref = 1 / (1 + np.exp(-z.astype(np.float64)))
+    assert rel_linf(host(s), ref) < 1e-6
+    (s * dev(gz)).sum().backward()
+    assert rel_linf(host(zt.grad), gz * ref * (1 - ref)) < 1e-6
+    p = rng.uniform(-1, 1, (4, 2)).astype(np.float32); q = rng.uniform(-1, 1, (4, 2)).astype(np.float32)
+    pt = dev(p).requires_grad_(True)
+    l = ops.mse_mean(pt, dev(q))
+    (l * 2.0).backward()
+    assert abs(float(l) - ((p.astype(np.float64) - q) ** 2).mean()) < 1e-7
+    np.testing.assert_allclose(host(pt.grad), 2 * 2 * (p - q) / p.size, rtol=1e-5, atol=1e-8)
+    # encoder head geometry: K = 24576 -> N = 16
+    B, K, N = 3, 24576 + 100, 16
+    x = rng.uniform(-1, 1, (B, K)).astype(np.float32); w = (rng.uniform(-1, 1, (K, N)) / 100).astype(np.float32)
+    bias = rng.uniform(-1, 1, N).astype(np.float32); go = rng.uniform(-1, 1, (B, N)).astype(np.float32)
+    xt, wt, bt2 = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(bias).requires_grad_(True)
+    yy = _Linear.apply(xt, wt, bt2)
+    (yy * dev(go)).sum().backward()
+    assert rel_linf(host(yy), x.astype(np.float64) @ w + bias) < 2e-6
+    assert rel_linf(host(wt.grad), x.astype(np.float64).T @ go) < 2e-6
+    assert rel_linf(host(xt.grad), go.astype(np.float64) @ w.T) < 2e-6
+    assert rel_linf(host(bt2.grad), go.astype(np.float64).sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize("tag", ["ae3_small", "ae2_small"])
+def test_ae_vs_reference_model_py(tag):
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.model import AE, AE3
+    g = dict(np.load(os.path.join(GOLDEN, "autoencoders.npz")))
+    pl = json.load(open(os.path.join(GOLDEN, "layer_plans.json")))[tag]
+    ops.reset_variables()
+    for k, v in g.items():
+        if k.startswith(tag + "|"):
+            ops.set_variable(k.split("|", 1)[1], v)
+    ae = AE3 if pl["fn"] == "AE3" else AE
+    out, z, variables = ae(dev(g[tag + "_x"]), pl["filters"], pl["z_num"], use_sparse=pl["use_sparse"], reuse=True)
+    assert len(variables) == len(pl["variables"])
+    assert rel_linf(host(z), g[tag + "_z"]) < 2e-5
+    assert rel_linf(host(out), g[tag + "_out"]) < 5e-5
+    ops.reset_variables()
+
+
+@pytest.mark.parametrize("is_3d,spatial,filters", [(True, (8, 16, 8), 16), (False, (16, 16), 16)])
+def test_ae_train_step_vs_oracle(is_3d, spatial, filters):
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import AETrainer, default_config
+    ops.reset_variables()
+    rng = np.random.RandomState(123)
+    z_num, p_num, batch = 8, 2, 2
+    ch = 3 if is_3d else 2
+    xshape = list(spatial) + [ch]
+    p = orc.ae_init(rng, xshape, filters, z_num)
+    for k in p:
+        if k.endswith("biases"):
+            p[k] = rng.uniform(-0.05, 0.05, p[k].shape).astype(np.float32)
+    x, _ = orc.synthetic_batch(rng, batch, spatial)
+    y = rng.uniform(-1, 1, (batch, p_num, 5)).astype(np.float32)
+    cfg = default_config(is_3d=is_3d, res_x=spatial[-1], res_y=spatial[-2], res_z=spatial[0] if is_3d else 1,
+                         filters=filters, batch_size=batch, num_samples=1000, z_num=z_num, p_num=p_num)
+    tr = AETrainer(cfg)
+    assert sorted(tr.var_names) == sorted(p)
+    tr.load_variables(p)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    opt = {"m": {k: np.zeros_like(v) for k, v in p64.items()}, "v": {k: np.zeros_like(v) for k, v in p64.items()},
+           "t": 0, "lr": cfg.lr_max}
+    m = tr.train_step(dev(x), dev(y))
+    _, _, info = orc.ae_train_step(x.astype(np.float64), y[:, :, -1].astype(np.float64), p64, opt, filters, z_num, p_num, is_3d)
+    assert rel_l1(host(m.G_), info["u"]) <= 1e-4
+    assert abs(float(m.g_loss.detach()) - info["loss"]) < 1e-5 * abs(info["loss"])
+    assert abs(float(m.loss_p.detach()) - info["loss_p"]) < 1e-5 * abs(info["loss_p"]) + 1e-8
+    gr = tr.grads_numpy()
+    gmax = max(np.abs(v).max() for v in info["grads"].values())
+    worst = max(float(np.abs(gr[k] - info["grads"][k]).max() / max(np.abs(info["grads"][k]).max(), 1e-3 * gmax)) for k in gr)
+    assert worst < 1e-3, worst
+    ops.reset_variables()
