@@ -111,6 +111,27 @@ class Trainer(object):
         layer = int(k.split("/")[-2].split("_")[0])
         return 0 if layer == 0 else 1 + (layer - 1) // self.num_conv
 
+    # ---- checkpoint / resume (reference: tf.train.Saver + Supervisor, trainer.py:107-123,291-292) ----
+    def save(self, path):
+        """Own format (.npz): variables under their slim names (G/0_fc/weights ...), Adam slots as
+        '<name>/Adam' and '<name>/Adam_1' (TF's slot names), 'step', 'g_lr', 'beta_power_t'."""
+        out = {}
+        for k, (o, n) in self.var_slices.items():
+            shp = ops._VARS[k].shape
+            out[k] = self.flat_p[o:o + n].view(shp).cpu().numpy()
+            out[k + "/Adam"] = self.flat_m[o:o + n].view(shp).cpu().numpy()
+            out[k + "/Adam_1"] = self.flat_v[o:o + n].view(shp).cpu().numpy()
+        out["step"] = np.int64(self.step); out["g_lr"] = np.float64(self.g_lr); out["beta_power_t"] = np.int64(self._adam_t)
+        np.savez(path, **out)
+
+    def load(self, path):
+        with np.load(path) as d:
+            for k, (o, n) in self.var_slices.items():
+                self.flat_p[o:o + n].copy_(torch.from_numpy(d[k].reshape(-1)))
+                self.flat_m[o:o + n].copy_(torch.from_numpy(d[k + "/Adam"].reshape(-1)))
+                self.flat_v[o:o + n].copy_(torch.from_numpy(d[k + "/Adam_1"].reshape(-1)))
+            self.step = int(d["step"]); self.g_lr = float(d["g_lr"]); self._adam_t = int(d["beta_power_t"])
+
     def enable_data_parallel(self, group=None):
         """Bucket the flat gradient slab per generator block (fc | 4 convs | ... | last conv)."""
         groups = {}
