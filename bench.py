@@ -148,7 +148,7 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
 
     rel_l1 = l1_vs_oracle(a.filters) if rank == 0 else None
 
@@ -181,7 +181,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = float(last.g_loss)
+    loss = float(last.g_loss.detach())
     assert loss == loss, "Model diverged with loss = NaN"        # trainer.py:275
 
     if rank != 0:
@@ -195,6 +195,8 @@ def main():
     except (OSError, ValueError, KeyError):
         pmc = {}
 
+    default_shape = list(a.res) == [64, 96, 64] and a.batch == 16 and a.filters == 128   # the shape the PMC passes ran on
+
     def roof(prefix, peak, unit, scale):
         sel = {k: v for k, v in ks.items() if k.startswith(prefix)}
         if not sel:
@@ -206,11 +208,11 @@ def main():
                 "frac": ach / peak,
                 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
                 # collected offline on the same kernels/shapes: profiles/pmc_latest.json
-                "traffic": pmc.get(prefix, {}).get("traffic_bytes"), "launches": v["launches"],
+                "traffic": pmc.get(prefix, {}).get("traffic_bytes") if default_shape else None, "launches": v["launches"],
                 "avg_launch_ms": v["seconds"] / v["launches"] * 1e3, "work_per_launch": v["work"] / v["launches"]}
 
     out = {
-        "metric": "velocity-field voxels/sec (3D 64x96x64 train step), whole job; per-GPU in `per_gpu`",
+        "metric": "velocity-field voxels/sec (3D %dx%dx%d train step), whole job; per-GPU in `per_gpu`" % (Z, Y, X),
         "value": value, "unit": "voxels/s", "per_gpu": value / world,
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

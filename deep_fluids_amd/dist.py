@@ -26,9 +26,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            # "nccl" IS RCCL on ROCm.  DF_DIST_BACKEND=gloo lets several ranks share one GPU (single-GPU test boxes)
+            backend = os.environ.get("DF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
