@@ -6,6 +6,7 @@ and ``reuse=True`` returns the same parameters (trainer.py:299-300).
 """
 import numpy as np
 
+from . import ops as ops_mod
 from .ops import *          # noqa: F401,F403  (the reference does `from ops import *`, model.py:3)
 from .ops import (variable_scope, get_variables, add, lrelu, linear, reshape, conv2d, conv3d, upscale, upscale3, concat,
                   sigmoid, get_conv_shape)
@@ -34,20 +35,23 @@ def _generator(z, filters, output_shape, name, num_conv, conv_k, last_k, repeat,
             x = reshape(x, x0_shape[0], x0_shape[1], x0_shape[2])              # model.py:21
         x0 = x
 
+        if skip_concat:
+            raise NotImplementedError("skip_concat=True is never enabled by the reference trainers (model.py:30-33); "
+                                      "not built")
+        fused = ops_mod.FUSED_BLOCKS and act is lrelu and conv_k == 3 and int(x.shape[-1]) == int(filters)
         for idx in range(repeat_num):
-            for _ in range(num_conv):
-                x = conv(x, filters, k=conv_k, s=1, act=act, name=str(layer_num) + "_conv")
-                layer_num += 1
-
+            if fused:       # same layers, variables and arithmetic as the loop below; one autograd node per block
+                names = [str(layer_num + i) + "_conv" for i in range(num_conv)]
+                x = ops_mod.gen_block(x, filters, names, 3 if is_3d else 2)
+                layer_num += num_conv
+            else:
+                for _ in range(num_conv):
+                    x = conv(x, filters, k=conv_k, s=1, act=act, name=str(layer_num) + "_conv")
+                    layer_num += 1
+                x = add(x, x0)                                                 # model.py:35,40 / :77,82
             if idx < repeat_num - 1:
-                if skip_concat:
-                    raise NotImplementedError("skip_concat=True is never enabled by the reference trainers "
-                                              "(model.py:30-33); not built")
-                x = add(x, x0)                                                 # model.py:35 / :77
-                x = up(x, 2)
+                x = up(x, 2)                                                   # model.py:36 / :78
                 x0 = x
-            elif not skip_concat:
-                x = add(x, x0)                                                 # model.py:40 / :82
 
         out = conv(x, output_shape[-1], k=last_k, s=1, name=str(layer_num) + "_conv")
     variables = get_variables(vs)

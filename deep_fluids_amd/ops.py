@@ -246,6 +246,69 @@ class _ConvSame3(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _GenBlock(torch.autograd.Function):
+    """One generator block as a single autograd node: n x [conv k3 s1 + bias + lrelu] and the residual add of the
+    block input (model.py:24-40 / 66-82).  Forward = the same kernels as the layer-by-layer path; the hand-written
+    reverse chain uses the fused epilogues of ``df_conv_fwd``: each dgrad multiplies by the lrelu slope of the layer
+    below (DF_CONV_MASK) and the first layer's dgrad adds the skip gradient (DF_CONV_RESIDUAL), which removes three
+    element-wise passes and one gradient-accumulation pass over the block's activations per block."""
+
+    @staticmethod
+    def forward(ctx, x0, leak, *wb):
+        x0 = _prep(x0, "x")
+        n = len(wb) // 2
+        nd = x0.dim() - 2
+        kz = 3 if nd == 3 else 1
+        taps = 27 if nd == 3 else 9
+        dims = (x0.shape[0], x0.shape[1] if nd == 3 else 1, x0.shape[-3], x0.shape[-2])
+        xs = [x0]
+        x = x0
+        for i in range(n):
+            w = _prep(wb[2 * i], "weights"); b = _prep(wb[2 * i + 1], "biases")
+            cin, cout = w.shape[-2], w.shape[-1]
+            if tuple(w.shape[:-2]) != (3,) * nd or x.shape[-1] != cin:
+                raise ValueError("gen_block: weights %s do not match input %s" % (tuple(w.shape), tuple(x.shape)))
+            wp = _pack(w, taps, cin, cout, 0)
+            x = _conv_raw(x, wp, b, None, None, dims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak).view(
+                x0.shape[:-1] + (cout,))
+            xs.append(x)
+        if x.shape != x0.shape:
+            raise ValueError("gen_block: residual add needs Cout == Cin of the block")
+        y = torch.empty_like(x)
+        call("df_add", _ptr(x), _ptr(x0), _ptr(y), x.numel(), _stream())
+        ctx.save_for_backward(*(xs + [wb[2 * i] for i in range(n)]))
+        ctx.geom = (n, dims, kz, taps, float(leak))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, dims, kz, taps, leak = ctx.geom
+        saved = ctx.saved_tensors
+        xs, ws = saved[:n + 1], saved[n + 1:]
+        B, D, H, W = dims
+        dy = _prep(dy, "grad")
+        dp = torch.empty_like(dy)
+        call("df_lrelu_bwd", _ptr(dy), _ptr(xs[n]), _ptr(dp), leak, dy.numel(), _stream())
+        grads = [None] * (2 * n)
+        dx0 = None
+        for i in range(n, 0, -1):
+            w = ws[i - 1]
+            cin, cout = w.shape[-2], w.shape[-1]
+            gw = torch.empty_like(w)
+            gb = torch.empty(cout, dtype=torch.float32, device=dy.device)
+            nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, kz)
+            wsb = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
+            call("df_conv_wgrad", _ptr(xs[i - 1]), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, _ptr(wsb),
+                 nbytes, _stream())
+            grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
+            wpd = _pack(w, taps, cin, cout, 1)
+            if i > 1:      # dgrad, times the lrelu slope of the layer below: directly the next dp
+                dp = _conv_raw(dp, wpd, None, None, xs[i - 1], dims, cout, cin, kz, DF_CONV_MASK, leak).view(xs[i - 1].shape)
+            elif ctx.needs_input_grad[0]:   # dgrad of the first layer + the skip gradient
+                dx0 = _conv_raw(dp, wpd, None, dy, None, dims, cout, cin, kz, DF_CONV_RESIDUAL, 0.0).view(xs[0].shape)
+        return (dx0, None) + tuple(grads)
+
+
 class _ConvSame3S2(torch.autograd.Function):
     """k=3, stride-2, TF-'SAME' conv on even extents (pad 0 before / 1 after): the encoder's
     down-sampling layers (model.py:141-143, 177-179).  Forward is a dedicated MFMA kernel; the backward re-uses the
@@ -556,6 +619,20 @@ def sigmoid(x):
 def mse_mean(a, b):
     """``tf.reduce_mean(tf.squared_difference(a, b))`` (trainer3.py:270)."""
     return _MseMean.apply(a, b)
+
+
+FUSED_BLOCKS = True     # GeneratorBE(3) uses one fused autograd node per block (same kernels, fused backward epilogues)
+
+
+def gen_block(x, filters, names, nd, leak=0.2):
+    """``num_conv`` x conv(k=3,s=1,act=lrelu) + ``x += x0`` (model.py:24-40 / 66-82) with slim variables ``names``."""
+    wb = []
+    cin = int(x.shape[-1])
+    for name in names:
+        wb.append(get_variable(name + "/weights", (3,) * nd + (cin, int(filters)), "xavier", x.device))
+        wb.append(get_variable(name + "/biases", (int(filters),), "zeros", x.device))
+        cin = int(filters)
+    return _GenBlock.apply(x, leak, *wb)
 
 
 def nchw_to_nhwc(x):
