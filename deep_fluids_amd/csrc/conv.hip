@@ -55,24 +55,73 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(const float* __restrict_
   }
 }
 
+// ---- weights of the up-sampling-aware conv ---------------------------------------------------------------------------
+// conv(nearest_up2x(Yc), W)[2m+p] = sum_{d in {0,1}^n} Yc[m + d + p - 1] * Wc[p][d]   with, per axis,
+//   p = 0: d=0 <- {k0}, d=1 <- {k1,k2};   p = 1: d=0 <- {k0,k1}, d=1 <- {k2}      (k = tap of the 3-wide filter)
+// i.e. 8 (3-D) / 4 (2-D) parity classes of a 2x2x2 / 2x2-tap conv on the COARSE grid: 27/8 = 3.4x fewer FLOPs than
+// convolving the materialised up-sampled tensor.  Packed per class like pack_kernel: [class][tap][k8][half][n][4];
+// mode 1 = dgrad operand (taps mirrored, Cin/Cout swapped).
+__device__ __forceinline__ bool in_set(int p, int d, int k) {   // does original tap k feed class-p tap d (one axis)?
+  return p == 0 ? (d == 0 ? k == 0 : k >= 1) : (d == 0 ? k <= 1 : k == 2);
+}
+__global__ __launch_bounds__(kThreads) void upconv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int kz,
+                                                               int cin, int cout, int Kpad, int Npad, int mode) {
+  const int ncls = kz == 3 ? 8 : 4, ntap = kz == 3 ? 8 : 4;
+  const int64_t per_class = static_cast<int64_t>(ntap) * Kpad * Npad;
+  const int64_t total = per_class * ncls;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i / per_class);
+    int64_t r = i - c * per_class;
+    const int s = static_cast<int>(r & 3); r >>= 2;
+    const int n = static_cast<int>(r % Npad); r /= Npad;
+    const int half = static_cast<int>(r & 1); r >>= 1;
+    const int k8 = static_cast<int>(r % (Kpad / 8));
+    int tap = static_cast<int>(r / (Kpad / 8));
+    const int k = k8 * 8 + half * 4 + s;
+    const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+    float v = 0.f;
+    if (k < K && n < N) {
+      if (mode == 1) tap = ntap - 1 - tap;                       // mirrored taps
+      const int dzt = kz == 3 ? (tap >> 2) & 1 : 0, dyt = (tap >> 1) & 1, dxt = tap & 1;
+      const int pz = kz == 3 ? (c >> 2) & 1 : 0, py = (c >> 1) & 1, px = c & 1;
+      const int ci = mode == 0 ? k : n, co = mode == 0 ? n : k;
+      for (int z = 0; z < kz; ++z)
+        for (int y = 0; y < 3; ++y)
+          for (int x = 0; x < 3; ++x)
+            if ((kz == 1 || in_set(pz, dzt, z)) && in_set(py, dyt, y) && in_set(px, dxt, x))
+              v += w[(static_cast<int64_t>((z * 3 + y) * 3 + x) * cin + ci) * cout + co];
+    }
+    wp[i] = v;
+  }
+}
+
 inline int ntile_for(int64_t N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 
 // ---- main kernel --------------------------------------------------------------------------------------
 // S = stride (1 | 2).  Stride 2 follows TF 'SAME' on even extents: pad 0 before / 1 after, i.e.
 // out[o] = sum_k in[2o + k] w[k]; the LDS tile is the (2T+1)-wide input footprint of the output tile.
-template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, bool VEC, int S>
-__global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
+// KT = taps per in-plane axis (3; 2 for the parity-class convs of an up-sampled input), KZ = taps along z.
+template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, bool VEC, int S, int KT>
+__global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in) {
   static_assert(TZ * TY * TX == 128 && WM * MB * 32 == 128 && WM * WN == 4, "tile shape");
-  constexpr int PZ = S == 1 ? KZ / 2 : 0, PY = S == 1 ? 1 : 0, PX = PY;
-  constexpr int HZ = (TZ - 1) * S + KZ, HY = (TY - 1) * S + 3, HX = (TX - 1) * S + 3, HV = HZ * HY * HX;
+  constexpr int HZ = (TZ - 1) * S + KZ, HY = (TY - 1) * S + KT, HX = (TX - 1) * S + KT, HV = HZ * HY * HX;
   constexpr int NPIECE = HV * (CK / 4);
   constexpr int NLOAD = (NPIECE + kThreads - 1) / kThreads;
   constexpr int LBATCH = NLOAD < 8 ? NLOAD : 8;        // staging loads in flight per thread (bounds the registers)
-  constexpr int NTAP = KZ * 9;
+  constexpr int NTAP = KZ * KT * KT;
   constexpr int NTILE = WN * NB * 32;
   __shared__ __attribute__((aligned(16))) float sA[HV * LDS_STRIDE];
 
+  ConvArgs a = a_in;
+  if (a.nclass > 1) {          // parity class of the up-sampling-aware conv (wave-uniform)
+    const int c = blockIdx.z;
+    const int bz = KZ > 1 ? (c >> 2) & 1 : 0, by = (c >> 1) & 1, bx = c & 1;
+    a.pz = KZ > 1 ? 1 - bz : 0; a.py = 1 - by; a.px = 1 - bx;
+    a.oz = bz; a.oy = by; a.ox = bx;
+    a.wp += static_cast<int64_t>(c) * a.wclass;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,12 +177,13 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
       const int p = it * kThreads + tid;
       const int hv = p >> 2, q = p & 3;
       const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-      const int gz = tz0 * S + hz - PZ, gy = ty0 * S + hy - PY, gx = tx0 * S + hx - PX;
+      const int gz = tz0 * S + hz - a.pz, gy = ty0 * S + hy - a.py, gx = tx0 * S + hx - a.px;
       const int ch = chunk * CK + q * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const bool inb = p < NPIECE && gz >= 0 && gz < a.Di && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
       if (inb) {
-        const int64_t vox = ((static_cast<int64_t>(b) * a.Di + gz) * a.Hi + gy) * a.Wi + gx;
+        const int64_t vox = ((static_cast<int64_t>(b) * a.xD + (gz * a.is + a.iz)) * a.xH + (gy * a.is + a.iy)) * a.xW +
+                            (gx * a.is + a.ix);
         const float* src = a.x + vox * a.Cin + ch;
         if (VEC) {
           if (ch < a.Cin) v = *reinterpret_cast<const float4*>(src);
@@ -179,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
     f32x4 af[2][MB], bf[3][NB];
     auto lds_a = [&](int step, f32x4 (&dst)[MB]) {
       const int tap = step >> 1, c8 = step & 1;
-      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      const int dz = tap / (KT * KT), dy = (tap / KT) % KT, dx = tap % KT;
       const int toff = ((dz * HY + dy) * HX + dx) * S4 + c8 * 2;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) dst[mb] = sA4[aidx[mb] + toff];
@@ -223,7 +273,8 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
         const int lx = m % TX, ly = (m / TX) % TY, lz = m / (TX * TY);
         const int gz = tz0 + lz, gy = ty0 + ly, gx = tx0 + lx;
         if (colok && gz < a.D && gy < a.H && gx < a.W) {
-          const int64_t o = (((static_cast<int64_t>(b) * a.D + gz) * a.H + gy) * a.W + gx) * a.Cout + col;
+          const int64_t o = (((static_cast<int64_t>(b) * a.yD + (gz * a.os + a.oz)) * a.yH + (gy * a.os + a.oy)) * a.yW +
+                             (gx * a.os + a.ox)) * a.Cout + col;
           float v = acc[mb][nb][e] + bv;
           if (a.flags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
           if (a.flags & DF_CONV_RESIDUAL) v += a.residual[o];
@@ -235,26 +286,26 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
   }
 }
 
-template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, int S>
+template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, int S, int KT = 3>
 int launch(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
   a.nz = (int)ceil_div(a.D, TZ); a.ny = (int)ceil_div(a.H, TY); a.nx = (int)ceil_div(a.W, TX);
   const int64_t nt = static_cast<int64_t>(a.B) * a.nz * a.ny * a.nx;
   DF_REQUIRE(nt < (1LL << 31), DF_ESHAPE, "df_conv_fwd: too many tiles");
   a.ntiles = (int)nt;
-  dim3 grid((unsigned)nt, (unsigned)(a.Npad / (WN * NB * 32)));
+  dim3 grid((unsigned)nt, (unsigned)(a.Npad / (WN * NB * 32)), (unsigned)(a.nclass > 1 ? a.nclass : 1));
   const bool vec = (a.Cin % 4 == 0) && df::aligned16(a.x);
-  if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, true, S>), grid, dim3(kThreads), 0, s, a);
-  else hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, false, S>), grid, dim3(kThreads), 0, s, a);
+  if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, true, S, KT>), grid, dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, false, S, KT>), grid, dim3(kThreads), 0, s, a);
   return df::launched("df_conv_fwd");
 }
 
-template <int KZ, int TZ, int TY, int TX, int S>
+template <int KZ, int TZ, int TY, int TX, int S, int KT = 3>
 int launch_n(const ConvArgs& a, hipStream_t s) {
   const int nt = ntile_for(a.Cout);
-  if (nt == 128) return launch<KZ, TZ, TY, TX, 2, 2, 2, 2, S>(a, s);
-  if (nt == 64) return launch<KZ, TZ, TY, TX, 2, 2, 2, 1, S>(a, s);
-  return launch<KZ, TZ, TY, TX, 4, 1, 1, 1, S>(a, s);
+  if (nt == 128) return launch<KZ, TZ, TY, TX, 2, 2, 2, 2, S, KT>(a, s);
+  if (nt == 64) return launch<KZ, TZ, TY, TX, 2, 2, 2, 1, S, KT>(a, s);
+  return launch<KZ, TZ, TY, TX, 4, 1, 1, 1, S, KT>(a, s);
 }
 
 }  // namespace
@@ -299,6 +350,10 @@ static int conv_common(const char* fn, const float* x, const float* wp, const fl
   a.y = y;
   a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
   a.Di = (int)(kz == 3 ? D * stride : D); a.Hi = (int)(H * stride); a.Wi = (int)(W * stride);
+  a.pz = stride == 1 ? kz / 2 : 0; a.py = a.px = stride == 1 ? 1 : 0;
+  a.is = 1; a.iz = a.iy = a.ix = 0; a.xD = a.Di; a.xH = a.Hi; a.xW = a.Wi;
+  a.os = 1; a.oz = a.oy = a.ox = 0; a.yD = a.D; a.yH = a.H; a.yW = a.W;
+  a.nclass = 1; a.wclass = 0;
   a.Kpad = (int)round_up(Cin, CK); a.Npad = (int)round_up(Cout, ntile_for(Cout));
   a.flags = flags; a.leak = leak;
   a.nz = a.ny = a.nx = a.ntiles = 0;
@@ -333,6 +388,95 @@ int df_conv_s2_fwd(const float* x, const float* wp, const float* bias, float* y,
   DF_REQUIRE(!(flags & (DF_CONV_RESIDUAL | DF_CONV_MASK)), DF_EINVAL, "df_conv_s2_fwd: only BIAS / LRELU epilogues");
   return conv_common("df_conv_s2_fwd", x, wp, bias, nullptr, nullptr, y, B, Do, Ho, Wo, Cin, Cout, kz, 2, flags, leak,
                      stream);
+}
+
+int64_t df_upconv_packed_elems(int64_t cin, int64_t cout, int kz, int mode) {
+  const int64_t K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  const int64_t nct = kz == 3 ? 64 : 16;    // classes * taps
+  return nct * round_up(K, CK) * round_up(N, ntile_for(N));
+}
+
+int df_upconv_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, int kz, int mode, df_stream_t stream) {
+  DF_REQUIRE(w && wp, DF_EINVAL, "df_upconv_pack_weights: null pointer");
+  DF_REQUIRE((kz == 1 || kz == 3) && cin > 0 && cout > 0 && (mode == 0 || mode == 1), DF_EINVAL,
+             "df_upconv_pack_weights: kz must be 1|3, mode 0|1");
+  const int64_t K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  const int Kpad = (int)round_up(K, CK), Npad = (int)round_up(N, ntile_for(N));
+  const int64_t total = df_upconv_packed_elems(cin, cout, kz, mode);
+  int64_t g = ceil_div(total, kThreads);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(upconv_pack_kernel, dim3((unsigned)g), dim3(kThreads), 0, df::as_stream(stream), w, wp, kz, (int)cin,
+                     (int)cout, Kpad, Npad, mode);
+  return df::launched("df_upconv_pack_weights");
+}
+
+static int upconv_launch(const ConvArgs& a, int kz, hipStream_t s) {
+  if (kz == 3) {
+    if (a.W >= 12) return launch_n<2, 2, 4, 16, 1, 2>(a, s);
+    return launch_n<2, 4, 4, 8, 1, 2>(a, s);
+  }
+  if (a.W >= 12) return launch_n<1, 1, 8, 16, 1, 2>(a, s);
+  return launch_n<1, 1, 16, 8, 1, 2>(a, s);
+}
+
+int df_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
+                  int64_t Wc, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream) {
+  DF_REQUIRE(xc && wp && y, DF_EINVAL, "df_upconv_fwd: null pointer");
+  DF_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_upconv_fwd: non-positive extent");
+  DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_upconv_fwd: kz must be 1 (2-D) or 3 (3-D)");
+  DF_REQUIRE(kz == 3 || Dc == 1, DF_ESHAPE, "df_upconv_fwd: Dc must be 1 when kz == 1");
+  DF_REQUIRE(Cin > 4 && Cout > 4, DF_ESHAPE, "df_upconv_fwd: MFMA path only (channels > 4)");
+  DF_REQUIRE(!(flags & (DF_CONV_RESIDUAL | DF_CONV_MASK)), DF_EINVAL, "df_upconv_fwd: only BIAS / LRELU epilogues");
+  DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "df_upconv_fwd: DF_CONV_BIAS without bias");
+  DF_REQUIRE(df::aligned16(wp), DF_EALIGN, "df_upconv_fwd: packed weights must be 16-byte aligned");
+  ConvArgs a;
+  a.x = xc; a.wp = reinterpret_cast<const f32x4*>(wp); a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y;
+  a.B = (int)B; a.D = (int)Dc; a.H = (int)Hc; a.W = (int)Wc; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.Di = a.D; a.Hi = a.H; a.Wi = a.W;
+  a.Kpad = (int)round_up(Cin, CK); a.Npad = (int)round_up(Cout, ntile_for(Cout));
+  a.flags = flags; a.leak = leak;
+  a.nz = a.ny = a.nx = a.ntiles = 0;
+  a.pz = a.py = a.px = 0;                        // set per class in the kernel
+  a.is = 1; a.iz = a.iy = a.ix = 0; a.xD = a.D; a.xH = a.H; a.xW = a.W;
+  a.os = 2; a.oz = a.oy = a.ox = 0;              // scatter to the fine grid; offsets per class in the kernel
+  a.yD = kz == 3 ? 2 * a.D : 1; a.yH = 2 * a.H; a.yW = 2 * a.W;
+  if (kz == 1) a.os = 2;                         // (z is untouched in 2-D: D == 1, oz == 0 -> 0*2+0)
+  a.nclass = kz == 3 ? 8 : 4;
+  a.wclass = static_cast<int64_t>(kz == 3 ? 8 : 4) * a.Kpad * a.Npad / 4;
+  return upconv_launch(a, kz, df::as_stream(stream));
+}
+
+int df_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
+                    int64_t Cin, int64_t Cout, int kz, df_stream_t stream) {
+  DF_REQUIRE(g && wp && acc, DF_EINVAL, "df_upconv_dgrad: null pointer");
+  DF_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_upconv_dgrad: non-positive extent");
+  DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_upconv_dgrad: kz must be 1 (2-D) or 3 (3-D)");
+  DF_REQUIRE(kz == 3 || Dc == 1, DF_ESHAPE, "df_upconv_dgrad: Dc must be 1 when kz == 1");
+  DF_REQUIRE(Cin > 4 && Cout > 4, DF_ESHAPE, "df_upconv_dgrad: MFMA path only (channels > 4)");
+  DF_REQUIRE(df::aligned16(wp), DF_EALIGN, "df_upconv_dgrad: packed weights must be 16-byte aligned");
+  // acc[n] += sum_p sum_t G_p[n + t - p] * Wd_p[t],  G_p[m] = g[2m + p]: one launch per parity class, accumulated in
+  // place through the residual epilogue (stream order makes the read-modify-write safe)
+  hipStream_t s = df::as_stream(stream);
+  const int ncls = kz == 3 ? 8 : 4;
+  for (int c = 0; c < ncls; ++c) {
+    const int bz = kz == 3 ? (c >> 2) & 1 : 0, by = (c >> 1) & 1, bx = c & 1;
+    ConvArgs a;
+    a.x = g; a.bias = nullptr; a.residual = acc; a.mask_src = nullptr; a.y = acc;
+    a.B = (int)B; a.D = (int)Dc; a.H = (int)Hc; a.W = (int)Wc; a.Cin = (int)Cout; a.Cout = (int)Cin;   // K = fwd Cout, N = fwd Cin
+    a.Di = a.D; a.Hi = a.H; a.Wi = a.W;
+    a.Kpad = (int)round_up(Cout, CK); a.Npad = (int)round_up(Cin, ntile_for(Cin));
+    a.wp = reinterpret_cast<const f32x4*>(wp) + static_cast<int64_t>(c) * (kz == 3 ? 8 : 4) * a.Kpad * a.Npad / 4;
+    a.flags = DF_CONV_RESIDUAL; a.leak = 0.f;
+    a.nz = a.ny = a.nx = a.ntiles = 0;
+    a.pz = bz; a.py = by; a.px = bx;                               // offsets {0,+1} for p = 0, {-1,0} for p = 1
+    a.is = 2; a.iz = bz; a.iy = by; a.ix = bx;                      // gather the class-p sub-grid of the fine gradient
+    a.xD = kz == 3 ? 2 * a.D : 1; a.xH = 2 * a.H; a.xW = 2 * a.W;
+    if (kz == 1) { a.iz = 0; }
+    a.os = 1; a.oz = a.oy = a.ox = 0; a.yD = a.D; a.yH = a.H; a.yW = a.W;
+    a.nclass = 1; a.wclass = 0;
+    if (int e = upconv_launch(a, kz, s)) return e;
+  }
+  return DF_OK;
 }
 
 }  // extern "C"

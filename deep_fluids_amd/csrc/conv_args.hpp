@@ -18,7 +18,16 @@ struct ConvArgs {
   const float* mask_src;
   float* y;
   int B, D, H, W, Cin, Cout;   // D,H,W: OUTPUT extents
-  int Di, Hi, Wi;              // input extents (== output for stride 1; 2x for stride 2)
+  int Di, Hi, Wi;              // LOGICAL input extents the taps slide over (== output for stride 1; 2x for stride 2)
+  // generalisation used by the up-sampling-aware first conv of a generator block (conv on the NN-upsampled
+  // input == 8 parity-class 2x2x2-tap convs on the coarse grid) and its dgrad; identity values for a plain conv:
+  int pz, py, px;              // logical input coordinate of tap 0 = out*S - p   (plain k=3: 1; stride 2: 0)
+  int is, iz, iy, ix;          // physical input voxel  = logical*is + i?  (gather stride / offset)
+  int xD, xH, xW;              // physical extents of the x tensor (addressing)
+  int os, oz, oy, ox;          // physical output voxel = logical*os + o?  (scatter stride / offset)
+  int yD, yH, yW;              // physical extents of y / residual / mask_src
+  int nclass;                  // > 1: blockIdx.z = parity class c; p = 1 - bit(c), o = bit(c), weights += c*wclass
+  int64_t wclass;              // packed-weight stride between classes (float4 units)
   int Kpad, Npad;       // padded K (multiple of 16) and N (multiple of the N tile) of the packed weights
   int nz, ny, nx;       // tiles per axis
   int ntiles;

@@ -39,8 +39,10 @@ struct WgradArgs {
   int Cinp, Coutp;     // padded to 128
   int Wp;              // W rounded up to 8
   int nrows, npairs, nranges, pairs_per_range;
-  int ndzdy;           // 9 (3-D) or 3 (2-D)
+  int ndzdy;           // 9 (3-D) or 3 (2-D); up mode: 32 | 8 combos = parity class x (dz,dy) pair
   int want_bias;
+  int up;              // 1: x is the COARSE input of an up-sampling-aware conv, g the FINE gradient (see df_upconv_wgrad)
+  int gD, gH, gW;      // physical extents of g (== D,H,W unless up)
 };
 
 // WP8 > 0: the padded row length Wp = 8*WP8 is a compile-time constant and the whole row is unrolled, so the
@@ -64,8 +66,18 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
     wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
   const int range = wg / a.ndzdy, dzdy = wg % a.ndzdy;
-  const int dz = a.ndzdy == 9 ? dzdy / 3 - 1 : 0;
-  const int dy = (a.ndzdy == 9 ? dzdy % 3 : dzdy) - 1;
+  int dz, dy, pz = 0, py = 0, px = 0, dd = 0, cls = 0;
+  if (a.up) {            // combo = class * nd2 + (deltaz, deltay);  X row offset = delta + p - 1 per axis
+    const int nd2 = a.ndzdy == 32 ? 4 : 2;
+    cls = dzdy / nd2; dd = dzdy % nd2;
+    pz = a.ndzdy == 32 ? (cls >> 2) & 1 : 0; py = (cls >> 1) & 1; px = cls & 1;
+    dz = a.ndzdy == 32 ? (dd >> 1) + pz - 1 : 0;
+    dy = (dd & 1) + py - 1;
+  } else {
+    dz = a.ndzdy == 9 ? dzdy / 3 - 1 : 0;
+    dy = (a.ndzdy == 9 ? dzdy % 3 : dzdy) - 1;
+  }
+  const int gs = a.up ? 2 : 1;
   const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
   if (ci0 >= a.Cin || co0 >= a.Cout) return;   // wave-uniform: quadrant entirely in the padding
 
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
     const int zs = z + dz, ys = y + dy;
     rw.gv = ok;
     rw.xv = ok && zs >= 0 && zs < a.D && ys >= 0 && ys < a.H;
-    const int64_t gvox = ((static_cast<int64_t>(b) * a.D + z) * a.H + y) * a.W;
+    const int64_t gvox = ((static_cast<int64_t>(b) * a.gD + (z * gs + pz)) * a.gH + (y * gs + py)) * a.gW + px;
     const int64_t xvox = ((static_cast<int64_t>(b) * a.D + zs) * a.H + ys) * a.W;
     rw.gb = a.g + gvox * a.Cout + coa;
     rw.xb = a.x + xvox * a.Cin + cia;
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
   };
   auto load_g = [&](const Row& rw, int pos) -> f32x2 {
     const bool k = rw.gv && pos < Wc;
-    const float* p = rw.gb + static_cast<int64_t>(pos) * a.Cout;
+    const float* p = rw.gb + static_cast<int64_t>(pos) * gs * a.Cout;
     f32x2 v;
     if (GVEC) v = *reinterpret_cast<const f32x2*>(pick(k && co_ok0, p));
     else { v[0] = *pick(k && co_ok0, p); v[1] = *pick(k && co_ok1, p + 1); }
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[d][s][t][e] = 0.f;
   f32x2 bsum = {0.f, 0.f};
-  const bool do_bias = a.want_bias && dzdy == a.ndzdy / 2 && blockIdx.y == 0 && qi == 0;
+  const bool do_bias = a.want_bias && (a.up ? dd == 0 : dzdy == a.ndzdy / 2) && blockIdx.y == 0 && qi == 0;
 
   // rings indexed by (position in row) % 8 (Wp % 8 == 0, so the index is continuous across rows);
   // X holds positions x-1 .. x+6, G holds x .. x+5 relative to the compute cursor x
@@ -221,7 +233,8 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
     bsum[0] += __shfl_xor(bsum[0], 32, 64);
     bsum[1] += __shfl_xor(bsum[1], 32, 64);
     if (half == 0) {
-      float* pb = a.bpartial + static_cast<int64_t>(range) * a.Coutp + co0 + 2 * r;
+      const int ncls = a.up ? (a.ndzdy == 32 ? 8 : 4) : 1;
+      float* pb = a.bpartial + (static_cast<int64_t>(range) * ncls + cls) * a.Coutp + co0 + 2 * r;
       pb[0] = bsum[0]; pb[1] = bsum[1];
     }
   }
@@ -433,6 +446,49 @@ SmallPlan make_small_plan(int64_t B, int64_t D, int64_t H, int64_t Cin, int64_t 
   return p;
 }
 
+// up mode: gw[kz][ky][kx] = sum over the (class, delta) pairs whose coarse offset the original tap k feeds (per axis:
+// k=0 <- (p0,d0),(p1,d0); k=1 <- (p0,d1),(p1,d0); k=2 <- (p0,d1),(p1,d1)); partial slot = combo*3 + (deltax + px).
+__global__ __launch_bounds__(kThreads) void wgrad_up_reduce_kernel(const float* __restrict__ partial,
+                                                                   const float* __restrict__ bpartial,
+                                                                   float* __restrict__ gw, float* __restrict__ gb,
+                                                                   int nranges, int kz, int Cin, int Cout, int Cinp,
+                                                                   int Coutp) {
+  const int taps = kz * 9, ncombo = kz == 3 ? 32 : 8, nd2 = kz == 3 ? 4 : 2, ncls = kz == 3 ? 8 : 4;
+  const int64_t total = static_cast<int64_t>(taps) * Cin * Cout;
+  const int64_t slot = static_cast<int64_t>(Cinp) * Coutp;
+  const int64_t pstride = static_cast<int64_t>(ncombo) * 3 * slot;
+  const int P[3][2] = {{0, 1}, {0, 1}, {0, 1}}, Dl[3][2] = {{0, 0}, {1, 0}, {1, 1}};   // k -> (p, delta) pairs
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int co = static_cast<int>(i % Cout);
+    const int64_t t2 = i / Cout;
+    const int ci = static_cast<int>(t2 % Cin);
+    const int tap = static_cast<int>(t2 / Cin);
+    const int kx = tap % 3, ky = (tap / 3) % 3, kzz = tap / 9;
+    float acc = 0.f;
+    for (int rg = 0; rg < nranges; ++rg) {
+      const float* pr = partial + rg * pstride + static_cast<int64_t>(ci) * Coutp + co;
+      for (int az = 0; az < (kz == 3 ? 2 : 1); ++az)
+        for (int ay = 0; ay < 2; ++ay)
+          for (int ax = 0; ax < 2; ++ax) {
+            const int pz = kz == 3 ? P[kzz][az] : 0, dzl = kz == 3 ? Dl[kzz][az] : 0;
+            const int py = P[ky][ay], dyl = Dl[ky][ay], px = P[kx][ax], dxl = Dl[kx][ax];
+            const int cls = (pz << 2) | (py << 1) | px;
+            const int combo = cls * nd2 + (kz == 3 ? (dzl << 1) | dyl : dyl);
+            acc += pr[(static_cast<int64_t>(combo) * 3 + (dxl + px)) * slot];
+          }
+    }
+    gw[i] = acc;
+  }
+  if (gb && blockIdx.x == 0) {
+    for (int co = threadIdx.x; co < Cout; co += kThreads) {
+      float acc = 0.f;
+      for (int q = 0; q < nranges * ncls; ++q) acc += bpartial[static_cast<int64_t>(q) * Coutp + co];
+      gb[co] = acc;
+    }
+  }
+}
+
 struct Plan {
   int nrows, npairs, nranges, ppr, Cinp, Coutp, taps, ndzdy;
   int64_t partial_elems, bpartial_elems;
@@ -517,6 +573,7 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
   a.Wp = (int)(ceil_div(W, 8) * 8);
   a.nrows = p.nrows; a.npairs = p.npairs; a.nranges = p.nranges; a.pairs_per_range = p.ppr;
   a.ndzdy = p.ndzdy; a.want_bias = gb != nullptr;
+  a.up = 0; a.gD = a.D; a.gH = a.H; a.gW = a.W;
   hipStream_t s = df::as_stream(stream);
   if (hipError_t e = hipMemsetAsync(zeros, 0, kZeroBytes, s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)(p.Cinp / 128), (unsigned)(p.Coutp / 128));
@@ -540,6 +597,62 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
                      p.nranges, p.taps, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
   return df::launched("df_conv_wgrad");
+}
+
+static Plan make_up_plan(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
+  Plan p = make_plan(B, Dc, Hc, Wc, Cin, Cout, kz);
+  p.ndzdy = kz == 3 ? 32 : 8;
+  p.taps = p.ndzdy * 3;                                  // partial slots per range
+  p.partial_elems = static_cast<int64_t>(p.nranges) * p.taps * p.Cinp * p.Coutp;
+  p.bpartial_elems = static_cast<int64_t>(p.nranges) * (kz == 3 ? 8 : 4) * p.Coutp;
+  return p;
+}
+
+int64_t df_upconv_wgrad_workspace_bytes(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
+  if (B <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const Plan p = make_up_plan(B, Dc, Hc, Wc, Cin, Cout, kz);
+  return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + kZeroBytes;
+}
+
+int df_upconv_wgrad(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
+                    int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {
+  DF_REQUIRE(xc && gy && gw && workspace, DF_EINVAL, "df_upconv_wgrad: null pointer");
+  DF_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_upconv_wgrad: non-positive extent");
+  DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_upconv_wgrad: kz must be 1 (2-D) or 3 (3-D)");
+  DF_REQUIRE(kz == 3 || Dc == 1, DF_ESHAPE, "df_upconv_wgrad: Dc must be 1 when kz == 1");
+  DF_REQUIRE(Cin % 2 == 0 && Cout % 2 == 0, DF_ESHAPE, "df_upconv_wgrad: even channel counts only");
+  DF_REQUIRE(df::aligned16(workspace), DF_EALIGN, "df_upconv_wgrad: workspace must be 16-byte aligned");
+  DF_REQUIRE(workspace_bytes >= df_upconv_wgrad_workspace_bytes(B, Dc, Hc, Wc, Cin, Cout, kz), DF_EWORKSPACE,
+             "df_upconv_wgrad: workspace too small");
+  const Plan p = make_up_plan(B, Dc, Hc, Wc, Cin, Cout, kz);
+  WgradArgs a;
+  a.x = xc; a.g = gy;
+  a.partial = static_cast<float*>(workspace);
+  a.bpartial = a.partial + p.partial_elems;
+  float* zeros = a.bpartial + p.bpartial_elems;
+  a.zeros = zeros;
+  a.B = (int)B; a.D = (int)Dc; a.H = (int)Hc; a.W = (int)Wc; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.Cinp = p.Cinp; a.Coutp = p.Coutp;
+  a.Wp = (int)(ceil_div(Wc, 8) * 8);
+  a.nrows = p.nrows; a.npairs = p.npairs; a.nranges = p.nranges; a.pairs_per_range = p.ppr;
+  a.ndzdy = p.ndzdy; a.want_bias = gb != nullptr;
+  a.up = 1; a.gD = kz == 3 ? 2 * a.D : 1; a.gH = 2 * a.H; a.gW = 2 * a.W;
+  hipStream_t s = df::as_stream(stream);
+  if (hipError_t e = hipMemsetAsync(zeros, 0, kZeroBytes, s)) return df::fail((int)e, "df_upconv_wgrad: memset: %s", hipGetErrorString(e));
+  dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)(p.Cinp / 128), (unsigned)(p.Coutp / 128));
+  const int wp8 = a.Wp / 8;
+  const bool exact = (Wc % 8) == 0;
+  if (exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);
+  else if (exact && wp8 == 4) hipLaunchKernelGGL((wgrad_kernel<true, true, 4>), grid, dim3(kThreads), 0, s, a);
+  else if (exact && wp8 == 2) hipLaunchKernelGGL((wgrad_kernel<true, true, 2>), grid, dim3(kThreads), 0, s, a);
+  else if (exact && wp8 == 7) hipLaunchKernelGGL((wgrad_kernel<true, true, 7>), grid, dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((wgrad_kernel<true, true, 0>), grid, dim3(kThreads), 0, s, a);
+  const int64_t total = static_cast<int64_t>(kz * 9) * Cin * Cout;
+  int64_t rg = ceil_div(total, kThreads);
+  if (rg > 2048) rg = 2048;
+  hipLaunchKernelGGL(wgrad_up_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
+                     p.nranges, kz, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
+  return df::launched("df_upconv_wgrad");
 }
 
 }  // extern "C"

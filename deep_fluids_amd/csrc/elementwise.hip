@@ -319,6 +319,25 @@ __global__ __launch_bounds__(kThreads) void upsample_bwd_kernel(const float4* __
   }
 }
 
+// y = a + nearest_up2x(bc): the block-end residual add when the block input is kept only at the coarse resolution
+template <bool IS3D>
+__global__ __launch_bounds__(kThreads) void add_up_kernel(const float4* __restrict__ a, const float4* __restrict__ bc,
+                                                          float4* __restrict__ y, int64_t n4, int D, int H, int W, int C4) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % C4);
+    int64_t r = i / C4;
+    const int w = static_cast<int>(r % (2 * W)); r /= 2 * W;
+    const int h = static_cast<int>(r % (2 * H)); r /= 2 * H;
+    const int D2 = IS3D ? 2 * D : 1;
+    const int d = static_cast<int>(r % D2);
+    const int64_t b = r / D2;
+    const float4 p = a[i];
+    const float4 q = bc[(((b * D + (IS3D ? d >> 1 : 0)) * H + (h >> 1)) * W + (w >> 1)) * C4 + c];
+    y[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+  }
+}
+
 // ---- fully connected with tiny K (K = c_num = 3 in the generator; 16 in the AE decoder) -----------
 __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y,
@@ -651,6 +670,24 @@ int df_mse_mean_bwd(const float* a, const float* b, const float* gout, float sca
   hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n)), dim3(kThreads), 0, df::as_stream(stream), a, b, gout,
                      scale / static_cast<float>(n), ga, n);
   return df::launched("df_mse_mean_bwd");
+}
+
+int df_add_up2x(const float* a, const float* bc, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
+                df_stream_t stream) {
+  DF_REQUIRE(a && bc && y, DF_EINVAL, "df_add_up2x: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, DF_EINVAL, "df_add_up2x: non-positive extent");
+  DF_REQUIRE(C % 4 == 0, DF_ESHAPE, "df_add_up2x: C must be a multiple of 4");
+  DF_REQUIRE(is_3d || D == 1, DF_ESHAPE, "df_add_up2x: D must be 1 for 2-D");
+  DF_REQUIRE(df::aligned16(a) && df::aligned16(bc) && df::aligned16(y), DF_EALIGN, "df_add_up2x: 16-byte alignment");
+  const int64_t n4 = B * (is_3d ? 2 * D : 1) * 2 * H * 2 * W * (C / 4);
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(bc);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  if (is_3d) hipLaunchKernelGGL((add_up_kernel<true>), dim3(grid_for(n4)), dim3(kThreads), 0, df::as_stream(stream), a4, b4, y4,
+                                n4, (int)D, (int)H, (int)W, (int)(C / 4));
+  else hipLaunchKernelGGL((add_up_kernel<false>), dim3(grid_for(n4)), dim3(kThreads), 0, df::as_stream(stream), a4, b4, y4, n4,
+                          (int)D, (int)H, (int)W, (int)(C / 4));
+  return df::launched("df_add_up2x");
 }
 
 }  // extern "C"

@@ -38,20 +38,26 @@ def _generator(z, filters, output_shape, name, num_conv, conv_k, last_k, repeat,
         if skip_concat:
             raise NotImplementedError("skip_concat=True is never enabled by the reference trainers (model.py:30-33); "
                                       "not built")
-        fused = ops_mod.FUSED_BLOCKS and act is lrelu and conv_k == 3 and int(x.shape[-1]) == int(filters)
+        fused = (ops_mod.FUSED_BLOCKS and act is lrelu and conv_k == 3 and int(x.shape[-1]) == int(filters)
+                 and int(filters) >= 8 and int(filters) % 4 == 0)     # (the fused kernels are MFMA-only: no thin-channel path)
+        pending_up = False      # fused path: the 2x up-sampling is folded into the NEXT block (never materialised)
         for idx in range(repeat_num):
             if fused:       # same layers, variables and arithmetic as the loop below; one autograd node per block
                 names = [str(layer_num + i) + "_conv" for i in range(num_conv)]
-                x = ops_mod.gen_block(x, filters, names, 3 if is_3d else 2)
+                if pending_up:
+                    x = ops_mod.up_gen_block(x, filters, names, 3 if is_3d else 2)      # model.py:36-40 / :78-82
+                else:
+                    x = ops_mod.gen_block(x, filters, names, 3 if is_3d else 2)
                 layer_num += num_conv
+                pending_up = idx < repeat_num - 1
             else:
                 for _ in range(num_conv):
                     x = conv(x, filters, k=conv_k, s=1, act=act, name=str(layer_num) + "_conv")
                     layer_num += 1
                 x = add(x, x0)                                                 # model.py:35,40 / :77,82
-            if idx < repeat_num - 1:
-                x = up(x, 2)                                                   # model.py:36 / :78
-                x0 = x
+                if idx < repeat_num - 1:
+                    x = up(x, 2)                                               # model.py:36 / :78
+                    x0 = x
 
         out = conv(x, output_shape[-1], k=last_k, s=1, name=str(layer_num) + "_conv")
     variables = get_variables(vs)

@@ -163,3 +163,43 @@ def test_colsum(ops):
     ws = torch.empty(nb // 4 + 1, device="cuda")
     call("df_colsum", _ptr(gt), _ptr(out), 5000, 128, _ptr(ws), nb, _stream())
     assert rel_linf(host(out), g.astype(np.float64).sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 16), ((2, 4, 6, 8), 32), ((1, 3, 5, 7), 128), ((2, 8, 16), 16),
+                                      ((1, 5, 9), 128), ((1, 2, 2, 32), 64)])
+def test_upconv_block_vs_materialised_upsample(ops, cshape, C):
+    """The up-sampling-aware fused block (parity-class convs on the coarse grid) == upscale + conv + ... + add of the
+    oracle, forward and every gradient (input, 27-tap weights, biases)."""
+    from deep_fluids_amd.ops import _UpGenBlock
+    rng = np.random.RandomState(C + sum(cshape))
+    nd = len(cshape) - 1
+    n = 2
+    xc = rng.uniform(-1, 1, cshape + (C,)).astype(np.float32)
+    ws = [(rng.uniform(-1, 1, (3,) * nd + (C, C)) / np.sqrt(C * 3 ** nd)).astype(np.float32) for _ in range(n)]
+    bs = [rng.uniform(-0.3, 0.3, C).astype(np.float32) for _ in range(n)]
+    fshape = (cshape[0],) + tuple(2 * s for s in cshape[1:])
+    go = rng.uniform(-1, 1, fshape + (C,)).astype(np.float32)
+    xt = dev(xc).requires_grad_(True)
+    wts = [dev(w).requires_grad_(True) for w in ws]; bts = [dev(b).requires_grad_(True) for b in bs]
+    args = []
+    for w, b in zip(wts, bts):
+        args += [w, b]
+    y = _UpGenBlock.apply(xt, 0.2, *args)
+    (y * dev(go)).sum().backward()
+    # oracle: materialise the up-sampled tensor, plain convs, residual add
+    x0 = orc.upscale_nn(xc.astype(np.float64))
+    x = x0; ins, outs = [], []
+    for w, b in zip(ws, bs):
+        ins.append(x)
+        x = orc.lrelu(orc.conv_same(x, w.astype(np.float64), b.astype(np.float64)))
+        outs.append(x)
+    ref = x + x0
+    assert rel_linf(host(y), ref) < TOL
+    dx = go.astype(np.float64)
+    for i in reversed(range(n)):
+        dpre = dx * np.where(outs[i] > 0, 1.0, 0.2)
+        dx, dw, db = orc.conv_same_bwd(ins[i], ws[i].astype(np.float64), dpre)
+        assert rel_linf(host(wts[i].grad), dw) < TOL, ("dw", i)
+        assert rel_linf(host(bts[i].grad), db) < TOL, ("db", i)
+    dxc = orc.upscale_nn_bwd(dx + go)
+    assert rel_linf(host(xt.grad), dxc) < TOL
