@@ -26,7 +26,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
 constexpr int kMaxRanges = 256;
-constexpr int kZeroBytes = 512;      // zeroed slot at the end of the workspace (padding reads)
+constexpr int kZeroBytes = 512;      // zeroed slot at the end of the workspace (padding reads; small-N kernel)
+// zeroed ROW at the end of the workspace of the MFMA kernel: out-of-image rows / padded channel lanes read it with the
+// same per-position offsets as a real row (2x for the strided gradient rows of the up-sampling-aware variant)
+inline int64_t zero_row_bytes(int64_t W, int64_t Cin, int64_t Cout) {
+  const int64_t Wp = ceil_div(W, 8) * 8 + 8;
+  return Wp * (Cin > 2 * Cout ? Cin : 2 * Cout) * 4 + 64;
+}
 constexpr int kSmallStreams = 2048;  // wave streams of the small-N kernel
 
 struct WgradArgs {
@@ -110,6 +116,10 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
     const int64_t xvox = ((static_cast<int64_t>(b) * a.D + zs) * a.H + ys) * a.W;
     rw.gb = a.g + gvox * a.Cout + coa;
     rw.xb = a.x + xvox * a.Cin + cia;
+    if (WP8 > 0) {       // exact-row variants: an invalid row / padded channel lane points at a zeroed row-sized region,
+      if (!(rw.gv && co_ok0)) rw.gb = zb;      // so the per-position loads need no select at all (W == Wp here)
+      if (!(rw.xv && ci_ok0)) rw.xb = zb;
+    }
     return rw;
   };
   // the empty asm makes the selected address opaque, so the compiler cannot turn `*(c ? p : z)` back into
@@ -121,6 +131,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
     return a.x + off;
   };
   auto load_x = [&](const Row& rw, int pos) -> f32x2 {
+    if (WP8 > 0) return *reinterpret_cast<const f32x2*>(rw.xb + static_cast<int64_t>(pos) * a.Cin);
     const bool k = rw.xv && pos < Wc;
     const float* p = rw.xb + static_cast<int64_t>(pos) * a.Cin;
     f32x2 v;
@@ -129,6 +140,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
     return v;
   };
   auto load_g = [&](const Row& rw, int pos) -> f32x2 {
+    if (WP8 > 0) return *reinterpret_cast<const f32x2*>(rw.gb + static_cast<int64_t>(pos) * gs * a.Cout);
     const bool k = rw.gv && pos < Wc;
     const float* p = rw.gb + static_cast<int64_t>(pos) * gs * a.Cout;
     f32x2 v;
@@ -525,7 +537,7 @@ int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W
     return sp.partial_elems * static_cast<int64_t>(sizeof(float)) + kZeroBytes;
   }
   const Plan p = make_plan(B, D, H, W, Cin, Cout, kz);
-  return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + kZeroBytes;
+  return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(W, Cin, Cout);
 }
 
 int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
@@ -575,7 +587,7 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
   a.ndzdy = p.ndzdy; a.want_bias = gb != nullptr;
   a.up = 0; a.gD = a.D; a.gH = a.H; a.gW = a.W;
   hipStream_t s = df::as_stream(stream);
-  if (hipError_t e = hipMemsetAsync(zeros, 0, kZeroBytes, s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
+  if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(W, Cin, Cout), s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)(p.Cinp / 128), (unsigned)(p.Coutp / 128));
   const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
@@ -602,6 +614,11 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
 static Plan make_up_plan(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
   Plan p = make_plan(B, Dc, Hc, Wc, Cin, Cout, kz);
   p.ndzdy = kz == 3 ? 32 : 8;
+  // 32 | 8 (class, dz/dy) combos per range: 64 ranges x 32 combos = 2048 workgroups = 8 whole rounds of 256 CUs, and the
+  // partial buffer (96 | 24 slots per range) stays 4x smaller than with 256 ranges
+  const int nr = p.npairs >= 64 ? 64 : p.npairs;
+  p.ppr = (p.npairs + nr - 1) / nr;
+  p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
   p.taps = p.ndzdy * 3;                                  // partial slots per range
   p.partial_elems = static_cast<int64_t>(p.nranges) * p.taps * p.Cinp * p.Coutp;
   p.bpartial_elems = static_cast<int64_t>(p.nranges) * (kz == 3 ? 8 : 4) * p.Coutp;
@@ -611,7 +628,7 @@ static Plan make_up_plan(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t 
 int64_t df_upconv_wgrad_workspace_bytes(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
   if (B <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || Cin <= 0 || Cout <= 0) return 0;
   const Plan p = make_up_plan(B, Dc, Hc, Wc, Cin, Cout, kz);
-  return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + kZeroBytes;
+  return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(Wc, Cin, Cout);
 }
 
 int df_upconv_wgrad(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
@@ -638,7 +655,7 @@ int df_upconv_wgrad(const float* xc, const float* gy, float* gw, float* gb, int6
   a.ndzdy = p.ndzdy; a.want_bias = gb != nullptr;
   a.up = 1; a.gD = kz == 3 ? 2 * a.D : 1; a.gH = 2 * a.H; a.gW = 2 * a.W;
   hipStream_t s = df::as_stream(stream);
-  if (hipError_t e = hipMemsetAsync(zeros, 0, kZeroBytes, s)) return df::fail((int)e, "df_upconv_wgrad: memset: %s", hipGetErrorString(e));
+  if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(Wc, Cin, Cout), s)) return df::fail((int)e, "df_upconv_wgrad: memset: %s", hipGetErrorString(e));
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)(p.Cinp / 128), (unsigned)(p.Coutp / 128));
   const int wp8 = a.Wp / 8;
   const bool exact = (Wc % 8) == 0;
