@@ -334,7 +334,7 @@ int df_conv_pack_weights(const float* w, float* wp, int64_t taps, int64_t cin, i
 
 static int conv_common(const char* fn, const float* x, const float* wp, const float* bias, const float* residual,
                        const float* mask_src, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin,
-                       int64_t Cout, int kz, int stride, int flags, float leak, df_stream_t stream) {
+                       int64_t Cout, int kz, int stride, int flags, float leak, df_stream_t stream, int prec = 0) {
   DF_REQUIRE(x && wp && y, DF_EINVAL, "%s: null pointer", fn);
   DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "%s: non-positive extent", fn);
   DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "%s: kz must be 1 (2-D) or 3 (3-D)", fn);
@@ -358,6 +358,11 @@ static int conv_common(const char* fn, const float* x, const float* wp, const fl
   a.flags = flags; a.leak = leak;
   a.nz = a.ny = a.nx = a.ntiles = 0;
   hipStream_t s = df::as_stream(stream);
+  if (prec == 1) {
+    DF_REQUIRE(stride == 1 && bf16x3_supported(a), DF_ESHAPE, "%s: bf16x3 needs stride 1, Cin %% 4 == 0, channels >= 16", fn);
+    a.Kpad = (int)bf16x3_kpad(Cin);
+    return launch_bf16x3(a, kz, 3, s);
+  }
   if (stride == 2) {
     if (kz == 3) {
       if (W >= 12) return launch_n<3, 2, 4, 16, 2>(a, s);
@@ -419,8 +424,8 @@ static int upconv_launch(const ConvArgs& a, int kz, hipStream_t s) {
   return launch_n<1, 1, 16, 8, 1, 2>(a, s);
 }
 
-int df_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
-                  int64_t Wc, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream) {
+static int upconv_fwd_impl(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
+                           int64_t Wc, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream, int prec) {
   DF_REQUIRE(xc && wp && y, DF_EINVAL, "df_upconv_fwd: null pointer");
   DF_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_upconv_fwd: non-positive extent");
   DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_upconv_fwd: kz must be 1 (2-D) or 3 (3-D)");
@@ -442,12 +447,26 @@ int df_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y,
   a.yD = kz == 3 ? 2 * a.D : 1; a.yH = 2 * a.H; a.yW = 2 * a.W;
   if (kz == 1) a.os = 2;                         // (z is untouched in 2-D: D == 1, oz == 0 -> 0*2+0)
   a.nclass = kz == 3 ? 8 : 4;
+  if (prec == 1) {
+    DF_REQUIRE(bf16x3_supported(a), DF_ESHAPE, "df_upconv_fwd_bf16x3: Cin %% 4 == 0, channels >= 16");
+    a.Kpad = (int)bf16x3_kpad(Cin);
+  }
   a.wclass = static_cast<int64_t>(kz == 3 ? 8 : 4) * a.Kpad * a.Npad / 4;
+  if (prec == 1) return launch_bf16x3(a, kz, 2, df::as_stream(stream));
   return upconv_launch(a, kz, df::as_stream(stream));
 }
 
-int df_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
-                    int64_t Cin, int64_t Cout, int kz, df_stream_t stream) {
+int df_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
+                  int64_t Wc, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream) {
+  return upconv_fwd_impl(xc, wp, bias, y, B, Dc, Hc, Wc, Cin, Cout, kz, flags, leak, stream, 0);
+}
+int df_upconv_fwd_bf16x3(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
+                         int64_t Wc, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream) {
+  return upconv_fwd_impl(xc, wp, bias, y, B, Dc, Hc, Wc, Cin, Cout, kz, flags, leak, stream, 1);
+}
+
+static int upconv_dgrad_impl(const float* g, const float* wp, float* acc, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
+                             int64_t Cin, int64_t Cout, int kz, df_stream_t stream, int prec) {
   DF_REQUIRE(g && wp && acc, DF_EINVAL, "df_upconv_dgrad: null pointer");
   DF_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_upconv_dgrad: non-positive extent");
   DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_upconv_dgrad: kz must be 1 (2-D) or 3 (3-D)");
@@ -464,7 +483,7 @@ int df_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int6
     a.x = g; a.bias = nullptr; a.residual = acc; a.mask_src = nullptr; a.y = acc;
     a.B = (int)B; a.D = (int)Dc; a.H = (int)Hc; a.W = (int)Wc; a.Cin = (int)Cout; a.Cout = (int)Cin;   // K = fwd Cout, N = fwd Cin
     a.Di = a.D; a.Hi = a.H; a.Wi = a.W;
-    a.Kpad = (int)round_up(Cout, CK); a.Npad = (int)round_up(Cin, ntile_for(Cin));
+    a.Kpad = (int)(prec == 1 ? bf16x3_kpad(Cout) : round_up(Cout, CK)); a.Npad = (int)round_up(Cin, ntile_for(Cin));
     a.wp = reinterpret_cast<const f32x4*>(wp) + static_cast<int64_t>(c) * (kz == 3 ? 8 : 4) * a.Kpad * a.Npad / 4;
     a.flags = DF_CONV_RESIDUAL; a.leak = 0.f;
     a.nz = a.ny = a.nx = a.ntiles = 0;
@@ -474,9 +493,57 @@ int df_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int6
     if (kz == 1) { a.iz = 0; }
     a.os = 1; a.oz = a.oy = a.ox = 0; a.yD = a.D; a.yH = a.H; a.yW = a.W;
     a.nclass = 1; a.wclass = 0;
-    if (int e = upconv_launch(a, kz, s)) return e;
+    if (prec == 1) {
+      DF_REQUIRE(bf16x3_supported(a), DF_ESHAPE, "df_upconv_dgrad_bf16x3: channels %% 4 == 0, >= 16");
+      if (int e = launch_bf16x3(a, kz, 2, s)) return e;
+    } else if (int e = upconv_launch(a, kz, s)) {
+      return e;
+    }
   }
   return DF_OK;
+}
+
+int df_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
+                    int64_t Cin, int64_t Cout, int kz, df_stream_t stream) {
+  return upconv_dgrad_impl(g, wp, acc, B, Dc, Hc, Wc, Cin, Cout, kz, stream, 0);
+}
+int df_upconv_dgrad_bf16x3(const float* g, const float* wp, float* acc, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
+                           int64_t Cin, int64_t Cout, int kz, df_stream_t stream) {
+  return upconv_dgrad_impl(g, wp, acc, B, Dc, Hc, Wc, Cin, Cout, kz, stream, 1);
+}
+
+/* ---- bf16x3 split-precision entry points (conv_bf16.hip): same arguments as their fp32 twins ------------------------------ */
+int64_t df_conv_packed_elems_bf16x3(int64_t taps, int64_t cin, int64_t cout, int mode) {
+  const int64_t K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  return taps * bf16x3_kpad(K) * round_up(N, ntile_for(N));       // 4-byte units (a hi and a lo bf16 per element)
+}
+int df_conv_pack_weights_bf16x3(const float* w, float* wp, int64_t taps, int64_t cin, int64_t cout, int mode,
+                                df_stream_t stream) {
+  DF_REQUIRE(w && wp, DF_EINVAL, "df_conv_pack_weights_bf16x3: null pointer");
+  DF_REQUIRE((taps == 9 || taps == 27) && cin > 0 && cout > 0 && (mode == 0 || mode == 1), DF_EINVAL,
+             "df_conv_pack_weights_bf16x3: taps must be 9 or 27, mode 0|1");
+  const int64_t K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  return pack_bf16x3(w, wp, (int)taps, (int)cin, (int)cout, (int)bf16x3_kpad(K), (int)round_up(N, ntile_for(N)), mode,
+                     df::as_stream(stream));
+}
+int df_conv_fwd_bf16x3(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
+                       float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int flags,
+                       float leak, df_stream_t stream) {
+  return conv_common("df_conv_fwd_bf16x3", x, wp, bias, residual, mask_src, y, B, D, H, W, Cin, Cout, kz, 1, flags, leak,
+                     stream, 1);
+}
+int64_t df_upconv_packed_elems_bf16x3(int64_t cin, int64_t cout, int kz, int mode) {
+  const int64_t K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  return (kz == 3 ? 64 : 16) * bf16x3_kpad(K) * round_up(N, ntile_for(N));
+}
+int df_upconv_pack_weights_bf16x3(const float* w, float* wp, int64_t cin, int64_t cout, int kz, int mode,
+                                  df_stream_t stream) {
+  DF_REQUIRE(w && wp, DF_EINVAL, "df_upconv_pack_weights_bf16x3: null pointer");
+  DF_REQUIRE((kz == 1 || kz == 3) && cin > 0 && cout > 0 && (mode == 0 || mode == 1), DF_EINVAL,
+             "df_upconv_pack_weights_bf16x3: kz must be 1|3, mode 0|1");
+  const int64_t K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  return upconv_pack_bf16x3(w, wp, kz, (int)cin, (int)cout, (int)bf16x3_kpad(K), (int)round_up(N, ntile_for(N)), mode,
+                            df::as_stream(stream));
 }
 
 }  // extern "C"

@@ -47,4 +47,11 @@ __device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
 int launch_small_n(const ConvArgs& a, int kz, hipStream_t s);   // Cout <= 4  (128 -> 3 | 1)
 int launch_small_k(const ConvArgs& a, int kz, hipStream_t s);   // Cin  <= 4  (dgrad of the last layer; 3 -> F)
 
+// bf16x3 split-precision MFMA path (conv_bf16.hip)
+bool bf16x3_supported(const ConvArgs& a);
+int64_t bf16x3_kpad(int64_t K);
+int launch_bf16x3(const ConvArgs& a, int kz, int kt, hipStream_t s);
+int pack_bf16x3(const float* w, void* wp, int taps, int cin, int cout, int Kpad, int Npad, int mode, hipStream_t s);
+int upconv_pack_bf16x3(const float* w, void* wp, int kz, int cin, int cout, int Kpad, int Npad, int mode, hipStream_t s);
+
 }  // namespace dfconv

@@ -1,0 +1,332 @@
+// "bf16x3" convolution: the same implicit-GEMM structure as conv.hip on the bf16 matrix pipe (16x the fp32 MFMA rate)
+// with every fp32 operand split into two bf16 words, a = hi + lo (hi = rne_bf16(a), lo = rne_bf16(a - hi)), and
+//
+//        a*b  ~=  hi_a*hi_b + hi_a*lo_b + lo_a*hi_b            (fp32 accumulation in the MFMA)
+//
+// i.e. three v_mfma_f32_32x32x16_bf16 per 32x32x16 block instead of eight v_mfma_f32_32x32x2_f32 (96 vs 512 matrix-pipe
+// cycles).  Operands keep 16 significand bits (per-product error 2^-17 ~ 8e-6), measured end to end on the generator:
+// relative L1 of the velocity field 7e-6 vs 2e-7 for exact fp32 (tolerance 1e-4).  OPT-IN precision mode
+// (deep_fluids_amd.ops.CONV_PRECISION = "bf16x3"); the default and the reported bench stay exact fp32.
+//
+//   * the fp32 -> (hi, lo) split happens ONCE per staged input element when the halo'd block is written to LDS (two bf16
+//     images, row = 32 channels = 64 B + 16 B pad: ds_read_b128 of 8 channels per lane is bank-conflict-free), so the
+//     conversion cost is amortised over all 27 taps;
+//   * weights are pre-split and packed as [tap][cin/16][half][hi|lo][cout][8]: one coalesced 16-byte load per operand;
+//   * per wave and step (tap x 16 channels): 4 ds_read_b128 + 4 global_load_dwordx4 for 12 MFMAs.
+#include "conv_args.hpp"
+
+namespace dfconv {
+namespace {
+
+using df::ceil_div;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CKB = 32;           // input channels per LDS chunk
+constexpr int ROWB = 80;          // bytes per staged voxel and image: 32 ch * 2 B + 16 B pad (5 x 16-byte slots: odd)
+
+__device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 h = static_cast<__bf16>(x[e]);            // v_cvt_pk_bf16_f32: round to nearest even
+    hi[e] = h;
+    lo[e] = static_cast<__bf16>(x[e] - static_cast<float>(h));
+  }
+}
+
+// ---- weight packing: Wb[tap][k16][half][part][n][8] (bf16), part 0 = hi, 1 = lo; k = k16*16 + half*8 + e -----------------
+// mode 0: K = cin, N = cout, w[tap][k][n];  mode 1 (dgrad): K = cout, N = cin, taps mirrored: w[T-1-tap][n][k]
+__global__ __launch_bounds__(kThreads) void pack_bf16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int taps,
+                                                               int cin, int cout, int Kpad, int Npad, int mode) {
+  const int64_t total = static_cast<int64_t>(taps) * Kpad * Npad;          // fp32 elements covered (each writes hi and lo)
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int e = static_cast<int>(i & 7);
+    int64_t r = i >> 3;
+    const int n = static_cast<int>(r % Npad); r /= Npad;
+    const int half = static_cast<int>(r & 1); r >>= 1;
+    const int k16 = static_cast<int>(r % (Kpad / 16));
+    const int tap = static_cast<int>(r / (Kpad / 16));
+    const int k = k16 * 16 + half * 8 + e;
+    const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+    float v = 0.f;
+    if (k < K && n < N)
+      v = mode == 0 ? w[(static_cast<int64_t>(tap) * cin + k) * cout + n]
+                    : w[(static_cast<int64_t>(taps - 1 - tap) * cin + n) * cout + k];
+    const __bf16 h = static_cast<__bf16>(v);
+    const __bf16 l = static_cast<__bf16>(v - static_cast<float>(h));
+    const int64_t base = (((static_cast<int64_t>(tap) * (Kpad / 16) + k16) * 2 + half) * 2) * Npad;
+    wp[(base + n) * 8 + e] = h;
+    wp[(base + Npad + n) * 8 + e] = l;
+  }
+}
+
+// up-sampling-aware variant: the pre-summed parity-class taps of conv.hip::upconv_pack_kernel, split into (hi, lo)
+__device__ __forceinline__ bool in_set_b(int p, int d, int k) {
+  return p == 0 ? (d == 0 ? k == 0 : k >= 1) : (d == 0 ? k <= 1 : k == 2);
+}
+__global__ __launch_bounds__(kThreads) void upconv_pack_bf16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
+                                                                      int kz, int cin, int cout, int Kpad, int Npad, int mode) {
+  const int ncls = kz == 3 ? 8 : 4, ntap = kz == 3 ? 8 : 4;
+  const int64_t per_class = static_cast<int64_t>(ntap) * Kpad * Npad;
+  const int64_t total = per_class * ncls;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i / per_class);
+    int64_t r = i - c * per_class;
+    const int e = static_cast<int>(r & 7); r >>= 3;
+    const int n = static_cast<int>(r % Npad); r /= Npad;
+    const int half = static_cast<int>(r & 1); r >>= 1;
+    const int k16 = static_cast<int>(r % (Kpad / 16));
+    const int tap = static_cast<int>(r / (Kpad / 16));
+    const int k = k16 * 16 + half * 8 + e;
+    const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+    float v = 0.f;
+    if (k < K && n < N) {
+      const int t = mode == 1 ? ntap - 1 - tap : tap;
+      const int dzt = kz == 3 ? (t >> 2) & 1 : 0, dyt = (t >> 1) & 1, dxt = t & 1;
+      const int pz = kz == 3 ? (c >> 2) & 1 : 0, py = (c >> 1) & 1, px = c & 1;
+      const int ci = mode == 0 ? k : n, co = mode == 0 ? n : k;
+      for (int z = 0; z < kz; ++z)
+        for (int y = 0; y < 3; ++y)
+          for (int x = 0; x < 3; ++x)
+            if ((kz == 1 || in_set_b(pz, dzt, z)) && in_set_b(py, dyt, y) && in_set_b(px, dxt, x))
+              v += w[(static_cast<int64_t>((z * 3 + y) * 3 + x) * cin + ci) * cout + co];
+    }
+    const __bf16 h = static_cast<__bf16>(v);
+    const __bf16 l = static_cast<__bf16>(v - static_cast<float>(h));
+    const int64_t base = static_cast<int64_t>(c) * per_class / 4 +          // 16-byte units: class block, then the record
+                         (((static_cast<int64_t>(tap) * (Kpad / 16) + k16) * 2 + half) * 2) * Npad;
+    wp[(base + n) * 8 + e] = h;
+    wp[(base + Npad + n) * 8 + e] = l;
+  }
+}
+
+// ---- main kernel (same tiling / arguments as conv_mfma_kernel, stride 1) -----------------------------------------------------
+template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, int KT>
+__global__ __launch_bounds__(kThreads) void conv_bf16x3_kernel(const ConvArgs a_in) {
+  static_assert(TZ * TY * TX == 128 && WM * MB * 32 == 128 && WM * WN == 4, "tile shape");
+  constexpr int HZ = TZ + KZ - 1, HY = TY + KT - 1, HX = TX + KT - 1, HV = HZ * HY * HX;
+  constexpr int NPIECE = HV * (CKB / 4);
+  constexpr int NLOAD = (NPIECE + kThreads - 1) / kThreads;
+  constexpr int LBATCH = NLOAD < 7 ? NLOAD : 7;
+  constexpr int NTAP = KZ * KT * KT;
+  constexpr int NTILE = WN * NB * 32;
+  constexpr int S16 = ROWB / 16;     // 16-byte slots per staged voxel
+  __shared__ __attribute__((aligned(16))) char smem[2 * HV * ROWB];
+  char* sHi = smem;
+  char* sLo = smem + HV * ROWB;
+
+  ConvArgs a = a_in;
+  if (a.nclass > 1) {
+    const int c = blockIdx.z;
+    const int bz = KZ > 1 ? (c >> 2) & 1 : 0, by = (c >> 1) & 1, bx = c & 1;
+    a.pz = KZ > 1 ? 1 - bz : 0; a.py = 1 - by; a.px = 1 - bx;
+    a.oz = bz; a.oy = by; a.ox = bx;
+    a.wp += static_cast<int64_t>(c) * a.wclass;
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, r = lane & 31;
+
+  const int tile = xcd_tile(blockIdx.x, a.ntiles);
+  const int ix = tile % a.nx;
+  int t2 = tile / a.nx;
+  const int iy = t2 % a.ny; t2 /= a.ny;
+  const int iz = t2 % a.nz;
+  const int b = t2 / a.nz;
+  const int tz0 = iz * TZ, ty0 = iy * TY, tx0 = ix * TX;
+  const int n0 = blockIdx.y * NTILE;
+
+  const bf16x8* sHi8 = reinterpret_cast<const bf16x8*>(sHi);
+  const bf16x8* sLo8 = reinterpret_cast<const bf16x8*>(sLo);
+  int aidx[MB];            // 16-byte slot index of this lane's voxel row, tap (0,0,0), channel octet `half`
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = (wm * MB + mb) * 32 + r;
+    const int lx = m % TX, ly = (m / TX) % TY, lz = m / (TX * TY);
+    aidx[mb] = ((lz * HY + ly) * HX + lx) * S16 + half;
+  }
+  // packed weights, in 16-byte units: ((((tap*K16 + k16)*2 + half)*2 + part)*Npad + n)
+  const bf16x8* wb = reinterpret_cast<const bf16x8*>(a.wp);
+  const int K16 = a.Kpad >> 4;
+  const int64_t rec = 4LL * a.Npad;                 // 16-byte units per (tap, k16) record
+  const bf16x8* bptr[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bptr[nb] = wb + static_cast<int64_t>(half) * 2 * a.Npad + n0 + (wn * NB + nb) * 32 + r;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.f;
+
+  const int nchunk = a.Kpad / CKB;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    // ---- stage: fp32 global -> (hi, lo) bf16 LDS images ----------------------------------------------------------------
+    auto stage_load = [&](int it) -> float4 {
+      const int p = it * kThreads + tid;
+      const int hv = p >> 3, q = p & 7;
+      const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+      const int gz = tz0 + hz - a.pz, gy = ty0 + hy - a.py, gx = tx0 + hx - a.px;
+      const int ch = chunk * CKB + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < NPIECE && gz >= 0 && gz < a.Di && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi && ch < a.Cin) {
+        const int64_t vox = ((static_cast<int64_t>(b) * a.xD + (gz * a.is + a.iz)) * a.xH + (gy * a.is + a.iy)) * a.xW +
+                            (gx * a.is + a.ix);
+        v = *reinterpret_cast<const float4*>(a.x + vox * a.Cin + ch);
+      }
+      return v;
+    };
+    auto stage_store = [&](int it, const float4& v) {
+      const int p = it * kThreads + tid;
+      if (p < NPIECE) {
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        const int off = (p >> 3) * ROWB + (p & 7) * 8;
+        *reinterpret_cast<bf16x4*>(sHi + off) = hi;
+        *reinterpret_cast<bf16x4*>(sLo + off) = lo;
+      }
+    };
+    __syncthreads();   // every wave has finished reading the previous chunk
+    for (int it0 = 0; it0 < NLOAD; it0 += LBATCH) {
+      float4 stg[LBATCH];
+#pragma unroll
+      for (int i = 0; i < LBATCH; ++i) stg[i] = stage_load(it0 + i);
+#pragma unroll
+      for (int i = 0; i < LBATCH; ++i) stage_store(it0 + i, stg[i]);
+    }
+    __syncthreads();
+
+    // ---- taps x two 16-channel sub-blocks, software-pipelined (A one step, B two steps ahead) ----------------------------
+    const bf16x8* bchunk[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bchunk[nb] = bptr[nb] + static_cast<int64_t>(chunk * 2) * rec;
+    const int64_t tapstride = static_cast<int64_t>(K16) * rec;
+
+    bf16x8 ah[2][MB], al[2][MB], bh[3][NB], bl[3][NB];
+    auto lds_a = [&](int step, bf16x8 (&dh)[MB], bf16x8 (&dl)[MB]) {
+      const int tap = step >> 1, s = step & 1;
+      const int dz = tap / (KT * KT), dy = (tap / KT) % KT, dx = tap % KT;
+      const int toff = ((dz * HY + dy) * HX + dx) * S16 + s * 2;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) { dh[mb] = sHi8[aidx[mb] + toff]; dl[mb] = sLo8[aidx[mb] + toff]; }
+    };
+    auto glb_b = [&](int step, bf16x8 (&dh)[NB], bf16x8 (&dl)[NB]) {
+      const int tap = step >> 1, s = step & 1;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const bf16x8* p = bchunk[nb] + tap * tapstride + s * rec;
+        dh[nb] = p[0];
+        dl[nb] = p[a.Npad];
+      }
+    };
+    glb_b(0, bh[0], bl[0]);
+    glb_b(1, bh[1], bl[1]);
+    lds_a(0, ah[0], al[0]);
+#pragma unroll
+    for (int step = 0; step < NTAP * 2; ++step) {
+      const int ca = step & 1, cb = step % 3;
+      if (step + 2 < NTAP * 2) glb_b(step + 2, bh[(step + 2) % 3], bl[(step + 2) % 3]);
+      if (step + 1 < NTAP * 2) lds_a(step + 1, ah[ca ^ 1], al[ca ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ca][mb], bh[cb][nb], acc[mb][nb], 0, 0, 0);
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca][mb], bl[cb][nb], acc[mb][nb], 0, 0, 0);
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca][mb], bh[cb][nb], acc[mb][nb], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue (identical to conv_mfma_kernel) ---------------------------------------------------------------------------
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int col = n0 + (wn * NB + nb) * 32 + r;
+    const bool colok = col < a.Cout;
+    const float bv = (a.flags & DF_CONV_BIAS) && colok ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = (wm * MB + mb) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int lx = m % TX, ly = (m / TX) % TY, lz = m / (TX * TY);
+        const int gz = tz0 + lz, gy = ty0 + ly, gx = tx0 + lx;
+        if (colok && gz < a.D && gy < a.H && gx < a.W) {
+          const int64_t o = (((static_cast<int64_t>(b) * a.yD + (gz * a.os + a.oz)) * a.yH + (gy * a.os + a.oy)) * a.yW +
+                             (gx * a.os + a.ox)) * a.Cout + col;
+          float v = acc[mb][nb][e] + bv;
+          if (a.flags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
+          if (a.flags & DF_CONV_RESIDUAL) v += a.residual[o];
+          if (a.flags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
+          a.y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int KZ, int TZ, int TY, int TX, int KT>
+int launch_t(ConvArgs a, hipStream_t s) {
+  a.nz = (int)ceil_div(a.D, TZ); a.ny = (int)ceil_div(a.H, TY); a.nx = (int)ceil_div(a.W, TX);
+  const int64_t nt = static_cast<int64_t>(a.B) * a.nz * a.ny * a.nx;
+  DF_REQUIRE(nt < (1LL << 31), DF_ESHAPE, "df_conv_fwd: too many tiles");
+  a.ntiles = (int)nt;
+  const unsigned ncls = (unsigned)(a.nclass > 1 ? a.nclass : 1);
+  if (a.Npad % 128 == 0) {
+    dim3 grid((unsigned)nt, (unsigned)(a.Npad / 128), ncls);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KZ, TZ, TY, TX, 2, 2, 2, 2, KT>), grid, dim3(kThreads), 0, s, a);
+  } else if (a.Npad % 64 == 0) {
+    dim3 grid((unsigned)nt, (unsigned)(a.Npad / 64), ncls);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KZ, TZ, TY, TX, 2, 2, 2, 1, KT>), grid, dim3(kThreads), 0, s, a);
+  } else {
+    dim3 grid((unsigned)nt, (unsigned)(a.Npad / 32), ncls);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KZ, TZ, TY, TX, 4, 1, 1, 1, KT>), grid, dim3(kThreads), 0, s, a);
+  }
+  return df::launched("df_conv_fwd(bf16x3)");
+}
+
+}  // namespace
+
+bool bf16x3_supported(const ConvArgs& a) {
+  return a.Cin % 4 == 0 && a.Cin >= 16 && a.Cout >= 16 && df::aligned16(a.x);
+}
+
+int64_t bf16x3_kpad(int64_t K) { return ceil_div(K, CKB) * CKB; }
+
+int launch_bf16x3(const ConvArgs& a, int kz, int kt, hipStream_t s) {
+  if (kt == 3) {
+    if (kz == 3) return a.W >= 12 ? launch_t<3, 2, 4, 16, 3>(a, s) : launch_t<3, 4, 4, 8, 3>(a, s);
+    return a.W >= 12 ? launch_t<1, 1, 8, 16, 3>(a, s) : launch_t<1, 1, 16, 8, 3>(a, s);
+  }
+  if (kz == 3) return a.W >= 12 ? launch_t<2, 2, 4, 16, 2>(a, s) : launch_t<2, 4, 4, 8, 2>(a, s);
+  return a.W >= 12 ? launch_t<1, 1, 8, 16, 2>(a, s) : launch_t<1, 1, 16, 8, 2>(a, s);
+}
+
+int upconv_pack_bf16x3(const float* w, void* wp, int kz, int cin, int cout, int Kpad, int Npad, int mode, hipStream_t s) {
+  const int64_t total = static_cast<int64_t>(kz == 3 ? 64 : 16) * Kpad * Npad;
+  int64_t g = ceil_div(total, kThreads);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(upconv_pack_bf16x3_kernel, dim3((unsigned)g), dim3(kThreads), 0, s, w, static_cast<__bf16*>(wp), kz, cin,
+                     cout, Kpad, Npad, mode);
+  return df::launched("df_upconv_pack_weights(bf16x3)");
+}
+
+int pack_bf16x3(const float* w, void* wp, int taps, int cin, int cout, int Kpad, int Npad, int mode, hipStream_t s) {
+  const int64_t total = static_cast<int64_t>(taps) * Kpad * Npad;
+  int64_t g = ceil_div(total, kThreads);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)g), dim3(kThreads), 0, s, w, static_cast<__bf16*>(wp), taps, cin, cout,
+                     Kpad, Npad, mode);
+  return df::launched("df_conv_pack_weights(bf16x3)");
+}
+
+}  // namespace dfconv

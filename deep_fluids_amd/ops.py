@@ -185,18 +185,31 @@ class _Add(torch.autograd.Function):
         return g, g
 
 
+# Convolution precision of the 128->128-class layers (forward and dgrad):
+#   "fp32"   exact fp32 MFMA (v_mfma_f32_32x32x2_f32) -- the default, what the reference computes and bench.py reports;
+#   "bf16x3" opt-in: operands split into bf16 hi/lo words, 3 bf16 MFMAs per product block (16 significand bits per
+#            operand, fp32 accumulate): ~5x the matrix rate, velocity-field error ~1e-5 (tolerance 1e-4).
+CONV_PRECISION = "fp32"
+
+
+def _sfx(cin, cout):
+    """'_bf16x3' when that mode is on and the layer is wide enough for it (thin layers stay on the fp32 VALU kernels)."""
+    return "_bf16x3" if (CONV_PRECISION == "bf16x3" and cin >= 16 and cout >= 16 and cin % 4 == 0) else ""
+
+
 def _pack(w, taps, cin, cout, mode):
-    n = query("df_conv_packed_elems", taps, cin, cout, mode)
+    sfx = _sfx(cin, cout)
+    n = query("df_conv_packed_elems" + sfx, taps, cin, cout, mode)
     wp = torch.empty(n, dtype=torch.float32, device=w.device)
-    call("df_conv_pack_weights", _ptr(w), _ptr(wp), taps, cin, cout, mode, _stream())
+    call("df_conv_pack_weights" + sfx, _ptr(w), _ptr(wp), taps, cin, cout, mode, _stream())
     return wp
 
 
 def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak):
     B, D, H, W = dims
     y = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
-    call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, D, H, W, cin, cout,
-         kz, flags, float(leak), _stream())
+    call("df_conv_fwd" + _sfx(cin, cout), _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, D, H, W,
+         cin, cout, kz, flags, float(leak), _stream())
     return y
 
 
@@ -334,10 +347,12 @@ class _UpGenBlock(torch.autograd.Function):
             if tuple(w.shape[:-2]) != (3,) * nd or cin != C or cout != C:
                 raise ValueError("up_gen_block: weights %s do not match %d channels" % (tuple(w.shape), C))
             if i == 0:
-                wp = torch.empty(query("df_upconv_packed_elems", cin, cout, kz, 0), dtype=torch.float32, device=xc.device)
-                call("df_upconv_pack_weights", _ptr(w), _ptr(wp), cin, cout, kz, 0, _stream())
+                sfx = _sfx(cin, cout)
+                wp = torch.empty(query("df_upconv_packed_elems" + sfx, cin, cout, kz, 0), dtype=torch.float32,
+                                 device=xc.device)
+                call("df_upconv_pack_weights" + sfx, _ptr(w), _ptr(wp), cin, cout, kz, 0, _stream())
                 x = torch.empty(fshape, dtype=torch.float32, device=xc.device)
-                call("df_upconv_fwd", _ptr(xc), _ptr(wp), _ptr(b), _ptr(x), cdims[0], cdims[1], cdims[2], cdims[3], cin, cout,
+                call("df_upconv_fwd" + sfx, _ptr(xc), _ptr(wp), _ptr(b), _ptr(x), cdims[0], cdims[1], cdims[2], cdims[3], cin, cout,
                      kz, DF_CONV_BIAS | DF_CONV_LRELU, float(leak), _stream())
             else:
                 wp = _pack(w, taps, cin, cout, 0)
@@ -380,9 +395,11 @@ class _UpGenBlock(torch.autograd.Function):
                     dxc = torch.empty_like(xc)          # skip path: sum-pool of dy, then += the conv path per parity class
                     call("df_upsample2x_bwd", _ptr(dy), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, int(is3d),
                          _stream())
-                    wpd = torch.empty(query("df_upconv_packed_elems", C, C, kz, 1), dtype=torch.float32, device=dy.device)
-                    call("df_upconv_pack_weights", _ptr(w), _ptr(wpd), C, C, kz, 1, _stream())
-                    call("df_upconv_dgrad", _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, C, kz,
+                    sfx = _sfx(C, C)
+                    wpd = torch.empty(query("df_upconv_packed_elems" + sfx, C, C, kz, 1), dtype=torch.float32,
+                                      device=dy.device)
+                    call("df_upconv_pack_weights" + sfx, _ptr(w), _ptr(wpd), C, C, kz, 1, _stream())
+                    call("df_upconv_dgrad" + sfx, _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, C, kz,
                          _stream())
             grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
         return (dxc, None) + tuple(grads)

@@ -183,6 +183,24 @@ int df_upconv_wgrad(const float* xc, const float* gy, float* gw, float* gb, int6
 int df_add_up2x(const float* a, const float* bc, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
                 df_stream_t stream);
 
+/* ---- opt-in "bf16x3" precision mode (conv_bf16.hip) ---------------------------------------------------------------------
+ * fp32 operands are split a = hi + lo into two bf16 words and a*b ~= hi*hi + hi*lo + lo*hi runs on the bf16 matrix pipe
+ * (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate): 16 significand bits per operand, ~5x the fp32 MFMA rate.  Same arguments
+ * as the fp32 twins; weights must be packed by the matching *_bf16x3 pack call.  Needs Cin % 4 == 0, channels >= 16. */
+int64_t df_conv_packed_elems_bf16x3(int64_t taps, int64_t cin, int64_t cout, int mode);   /* in 4-byte units */
+int df_conv_pack_weights_bf16x3(const float* w, float* wp, int64_t taps, int64_t cin, int64_t cout, int mode,
+                                df_stream_t stream);
+int df_conv_fwd_bf16x3(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
+                       float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int flags,
+                       float leak, df_stream_t stream);
+int64_t df_upconv_packed_elems_bf16x3(int64_t cin, int64_t cout, int kz, int mode);
+int df_upconv_pack_weights_bf16x3(const float* w, float* wp, int64_t cin, int64_t cout, int kz, int mode,
+                                  df_stream_t stream);
+int df_upconv_fwd_bf16x3(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
+                         int64_t Wc, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream);
+int df_upconv_dgrad_bf16x3(const float* g, const float* wp, float* acc, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
+                           int64_t Cin, int64_t Cout, int kz, df_stream_t stream);
+
 /* gw[kz,3,3,Cin,Cout] = sum_voxels x[voxel+tap][cin] * gy[voxel][cout]   (split over voxel ranges,
  * deterministic second-pass reduction through the workspace).  If gb != NULL it also receives the bias gradient
  * gb[cout] = sum_voxels gy[voxel][cout] (accumulated on the fly from the operand registers). */
