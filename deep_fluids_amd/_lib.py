@@ -64,6 +64,8 @@ SIGNATURES = {
     "df_upconv_pack_weights_bf16x3": (I32, [P, P, I64, I64, I32, I32, P]),
     "df_upconv_fwd_bf16x3": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),
     "df_upconv_dgrad_bf16x3": (I32, [P, P, P, I64, I64, I64, I64, I64, I64, I32, P]),
+    "df_conv_wgrad_bf16x3": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
+    "df_upconv_wgrad_bf16x3": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
     "df_conv_wgrad_workspace_bytes": (I64, [I64, I64, I64, I64, I64, I64, I32]),
     "df_conv_wgrad": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
 }

@@ -252,6 +252,202 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
+// ---- bf16x3 weight gradient (opt-in precision mode, see conv_bf16.hip) ---------------------------------------------------
+// Same decomposition as wgrad_kernel (workgroup = (voxel range, (dz,dy) group), wave = 64x64 (ci,co) quadrant x 3 dx taps,
+// operands straight from L1/L2), on v_mfma_f32_32x32x16_bf16: K = 16 consecutive voxels of ONE image row per instruction
+// (half-wave 0: x0..x0+7, half-wave 1: x0+8..x0+15).  A lane's 8 k-values of a channel are 8 row positions, i.e. 8 separate
+// coalesced loads -- so the x-1 / x / x+1 windows are just different registers of ONE set of 10 position loads (no
+// alignment problem), converted to (hi, lo) bf16 in registers: 3 MFMAs (lo*hi, hi*lo, hi*hi) per 32x32x16 block.
+// Loads run 3 steps ahead in a 4-deep register ring, continuous across rows.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = static_cast<__bf16>(x[e]);
+    hi[e] = h;
+    lo[e] = static_cast<__bf16>(x[e] - static_cast<float>(h));
+  }
+}
+
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+
+template <int W16>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_bf16x3_kernel(const WgradArgs a) {
+  constexpr int U = 4 / cgcd(W16, 4);          // rows per unrolled iteration: U*W16 steps, a multiple of the ring depth 4
+  constexpr int NS = U * W16;
+  constexpr int E = (3 + W16 - 1) / W16;       // extra rows the 3-step-ahead loads can reach into
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = wave >> 1, qj = wave & 1;
+  const int half = lane >> 5, r = lane & 31;
+
+  const int nwg = a.nranges * a.ndzdy;
+  int wg;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, rem = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int range = wg / a.ndzdy, dzdy = wg % a.ndzdy;
+  int dz, dy, pz = 0, py = 0, px = 0, dd = 0, cls = 0;
+  if (a.up) {
+    const int nd2 = a.ndzdy == 32 ? 4 : 2;
+    cls = dzdy / nd2; dd = dzdy % nd2;
+    pz = a.ndzdy == 32 ? (cls >> 2) & 1 : 0; py = (cls >> 1) & 1; px = cls & 1;
+    dz = a.ndzdy == 32 ? (dd >> 1) + pz - 1 : 0;
+    dy = (dd & 1) + py - 1;
+  } else {
+    dz = a.ndzdy == 9 ? dzdy / 3 - 1 : 0;
+    dy = (a.ndzdy == 9 ? dzdy % 3 : dzdy) - 1;
+  }
+  const int gs = a.up ? 2 : 1;
+  const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
+  if (ci0 >= a.Cin || co0 >= a.Cout) return;
+
+  const int row0 = 2 * range * a.pairs_per_range;
+  int row1 = row0 + 2 * a.pairs_per_range;
+  if (row1 > a.nrows) row1 = a.nrows;
+  const int cia = ci0 + 2 * r, coa = co0 + 2 * r;
+  const bool ci_ok = cia < a.Cin, co_ok = coa < a.Cout;
+  const float* zb = a.zeros;
+
+  struct Row { const float* xb; const float* gb; bool xz; };
+  auto row_setup = [&](int row) -> Row {
+    Row rw;
+    const bool ok = row < row1;
+    const int y = row % a.H;
+    const int t = row / a.H;
+    const int z = t % a.D;
+    const int b = t / a.D;
+    const int zs = z + dz, ys = y + dy;
+    const bool xv = ok && zs >= 0 && zs < a.D && ys >= 0 && ys < a.H && ci_ok;
+    const bool gv = ok && co_ok;
+    const int64_t gvox = ((static_cast<int64_t>(b) * a.gD + (z * gs + pz)) * a.gH + (y * gs + py)) * a.gW + px;
+    const int64_t xvox = ((static_cast<int64_t>(b) * a.D + zs) * a.H + ys) * a.W;
+    rw.xb = xv ? a.x + (xvox + 8 * half) * a.Cin + cia : zb;            // the +8*half: half-wave 1 holds k = 8..15
+    rw.gb = gv ? a.g + (gvox + 8 * half * gs) * a.Cout + coa : zb;
+    rw.xz = !xv;
+    return rw;
+  };
+  struct Raw { f32x2 x[10]; f32x2 g[8]; };
+  auto issue = [&](const Row& rw, int k16, Raw& dst) {
+    const int x0 = 16 * k16;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {            // positions u = x0 - 1 + j (+8 in half-wave 1)
+      const float* p = rw.xb + static_cast<int64_t>(x0 - 1 + j) * a.Cin;
+      if (k16 == 0 && j == 0) p = (half == 0 || rw.xz) ? zb : p;               // x = -1: left zero padding
+      if (k16 == W16 - 1 && j == 9) p = (half == 1 || rw.xz) ? zb : p;         // x = W: right zero padding
+      dst.x[j] = *reinterpret_cast<const f32x2*>(p);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      dst.g[j] = *reinterpret_cast<const f32x2*>(rw.gb + static_cast<int64_t>(x0 + j) * gs * a.Cout);
+  };
+
+  f32x16 acc[3][2][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][s][t][e] = 0.f;
+  f32x2 bsum = {0.f, 0.f};
+  const bool do_bias = a.want_bias && (a.up ? dd == 0 : dzdy == a.ndzdy / 2) && blockIdx.y == 0 && qi == 0;
+
+  auto compute = [&](const Raw& rw) {
+    bf16x8 bh[2], bl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = rw.g[e][t];
+      split8(v, bh[t], bl[t]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bsum[0] += rw.g[e][0]; bsum[1] += rw.g[e][1]; }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rw.x[d + e][s];
+        bf16x8 ah, al;
+        split8(v, ah, al);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[d][s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[d][s][t], 0, 0, 0);
+          acc[d][s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[d][s][t], 0, 0, 0);
+          acc[d][s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[d][s][t], 0, 0, 0);
+        }
+      }
+  };
+
+  Row rows[U + E];
+#pragma unroll
+  for (int i = 0; i < U + E; ++i) rows[i] = row_setup(row0 + i);
+  Raw ring[4];
+#pragma unroll
+  for (int sidx = 0; sidx < 3; ++sidx) issue(rows[sidx / W16], sidx % W16, ring[sidx]);
+
+  for (int rbase = row0; rbase < row1; rbase += U) {
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      issue(rows[(sidx + 3) / W16], (sidx + 3) % W16, ring[(sidx + 3) & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(ring[sidx & 3]);
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) rows[i] = rows[i + U];
+#pragma unroll
+    for (int i = E; i < U + E; ++i) rows[i] = row_setup(rbase + U + i);
+  }
+
+  const int taps = a.ndzdy * 3;
+  float* P = a.partial + static_cast<int64_t>(range) * taps * a.Cinp * a.Coutp;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int tap = dzdy * 3 + d;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int ci = ci0 + 2 * i + s, co = co0 + 2 * r + t;
+          P[(static_cast<int64_t>(tap) * a.Cinp + ci) * a.Coutp + co] = acc[d][s][t][e];
+        }
+  }
+  if (do_bias) {
+    bsum[0] += __shfl_xor(bsum[0], 32, 64);
+    bsum[1] += __shfl_xor(bsum[1], 32, 64);
+    if (half == 0) {
+      const int ncls = a.up ? (a.ndzdy == 32 ? 8 : 4) : 1;
+      float* pb = a.bpartial + (static_cast<int64_t>(range) * ncls + cls) * a.Coutp + co0 + 2 * r;
+      pb[0] = bsum[0]; pb[1] = bsum[1];
+    }
+  }
+}
+
+inline bool wgrad_bf16x3_ok(int64_t W, int64_t Cin, int64_t Cout) {
+  return (W == 16 || W == 32 || W == 64 || W == 96 || W == 112) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 16 && Cout >= 16;
+}
+template <typename A>
+inline void launch_wgrad_bf16x3(int64_t W, dim3 grid, hipStream_t s, const A& a) {
+  switch (W / 16) {
+    case 1: hipLaunchKernelGGL((wgrad_bf16x3_kernel<1>), grid, dim3(kThreads), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((wgrad_bf16x3_kernel<2>), grid, dim3(kThreads), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((wgrad_bf16x3_kernel<4>), grid, dim3(kThreads), 0, s, a); break;
+    case 6: hipLaunchKernelGGL((wgrad_bf16x3_kernel<6>), grid, dim3(kThreads), 0, s, a); break;
+    default: hipLaunchKernelGGL((wgrad_bf16x3_kernel<7>), grid, dim3(kThreads), 0, s, a); break;
+  }
+}
+
 // gw[tap][ci][co] = sum_range partial[range][tap][ci][co]  (fixed order);  gb likewise
 __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                                 const float* __restrict__ bpartial,
@@ -540,8 +736,9 @@ int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W
   return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(W, Cin, Cout);
 }
 
-int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
-                  int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {
+static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
+                           int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream,
+                           int prec) {
   DF_REQUIRE(x && gy && gw && workspace, DF_EINVAL, "df_conv_wgrad: null pointer");
   DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_conv_wgrad: non-positive extent");
   DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_conv_wgrad: kz must be 1 (2-D) or 3 (3-D)");
@@ -591,6 +788,9 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)(p.Cinp / 128), (unsigned)(p.Coutp / 128));
   const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
+  if (prec == 1 && xvec && gvec && wgrad_bf16x3_ok(W, Cin, Cout)) {
+    launch_wgrad_bf16x3(W, grid, s, a);
+  } else {
   const int wp8 = a.Wp / 8;
   const bool exact = (W % 8) == 0;
   if (xvec && gvec && exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);
@@ -603,12 +803,22 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
   else if (xvec) hipLaunchKernelGGL((wgrad_kernel<true, false, 0>), grid, dim3(kThreads), 0, s, a);
   else if (gvec) hipLaunchKernelGGL((wgrad_kernel<false, true, 0>), grid, dim3(kThreads), 0, s, a);
   else hipLaunchKernelGGL((wgrad_kernel<false, false, 0>), grid, dim3(kThreads), 0, s, a);
+  }
   const int64_t total = static_cast<int64_t>(p.taps) * Cin * Cout;
   int64_t rg = ceil_div(total, kThreads);
   if (rg > 2048) rg = 2048;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
                      p.nranges, p.taps, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
   return df::launched("df_conv_wgrad");
+}
+
+int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
+                  int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {
+  return conv_wgrad_impl(x, gy, gw, gb, B, D, H, W, Cin, Cout, kz, workspace, workspace_bytes, stream, 0);
+}
+int df_conv_wgrad_bf16x3(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
+                         int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {
+  return conv_wgrad_impl(x, gy, gw, gb, B, D, H, W, Cin, Cout, kz, workspace, workspace_bytes, stream, 1);
 }
 
 static Plan make_up_plan(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
@@ -631,8 +841,9 @@ int64_t df_upconv_wgrad_workspace_bytes(int64_t B, int64_t Dc, int64_t Hc, int64
   return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(Wc, Cin, Cout);
 }
 
-int df_upconv_wgrad(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
-                    int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {
+static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc,
+                             int64_t Wc, int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes,
+                             df_stream_t stream, int prec) {
   DF_REQUIRE(xc && gy && gw && workspace, DF_EINVAL, "df_upconv_wgrad: null pointer");
   DF_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_upconv_wgrad: non-positive extent");
   DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_upconv_wgrad: kz must be 1 (2-D) or 3 (3-D)");
@@ -659,7 +870,8 @@ int df_upconv_wgrad(const float* xc, const float* gy, float* gw, float* gb, int6
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)(p.Cinp / 128), (unsigned)(p.Coutp / 128));
   const int wp8 = a.Wp / 8;
   const bool exact = (Wc % 8) == 0;
-  if (exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);
+  if (prec == 1 && wgrad_bf16x3_ok(Wc, Cin, Cout)) launch_wgrad_bf16x3(Wc, grid, s, a);
+  else if (exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 4) hipLaunchKernelGGL((wgrad_kernel<true, true, 4>), grid, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 2) hipLaunchKernelGGL((wgrad_kernel<true, true, 2>), grid, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 7) hipLaunchKernelGGL((wgrad_kernel<true, true, 7>), grid, dim3(kThreads), 0, s, a);
@@ -670,6 +882,16 @@ int df_upconv_wgrad(const float* xc, const float* gy, float* gw, float* gb, int6
   hipLaunchKernelGGL(wgrad_up_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
                      p.nranges, kz, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
   return df::launched("df_upconv_wgrad");
+}
+
+int df_upconv_wgrad(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
+                    int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {
+  return upconv_wgrad_impl(xc, gy, gw, gb, B, Dc, Hc, Wc, Cin, Cout, kz, workspace, workspace_bytes, stream, 0);
+}
+int df_upconv_wgrad_bf16x3(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc,
+                           int64_t Wc, int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes,
+                           df_stream_t stream) {
+  return upconv_wgrad_impl(xc, gy, gw, gb, B, Dc, Hc, Wc, Cin, Cout, kz, workspace, workspace_bytes, stream, 1);
 }
 
 }  // extern "C"

@@ -250,8 +250,8 @@ class _ConvSame3(torch.autograd.Function):
         gb = torch.empty(cout, dtype=torch.float32, device=x.device)
         nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, kz)
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
-        call("df_conv_wgrad", _ptr(x), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, _ptr(ws), nbytes,
-             _stream())
+        call("df_conv_wgrad" + _sfx(cin, cout), _ptr(x), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, _ptr(ws),
+             nbytes, _stream())
         gx = None
         if ctx.needs_input_grad[0]:
             wpd = _pack(w, taps, cin, cout, 1)
@@ -311,8 +311,8 @@ class _GenBlock(torch.autograd.Function):
             gb = torch.empty(cout, dtype=torch.float32, device=dy.device)
             nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, kz)
             wsb = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
-            call("df_conv_wgrad", _ptr(xs[i - 1]), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, _ptr(wsb),
-                 nbytes, _stream())
+            call("df_conv_wgrad" + _sfx(cin, cout), _ptr(xs[i - 1]), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz,
+                 _ptr(wsb), nbytes, _stream())
             grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
             wpd = _pack(w, taps, cin, cout, 1)
             if i > 1:      # dgrad, times the lrelu slope of the layer below: directly the next dp
@@ -382,15 +382,15 @@ class _UpGenBlock(torch.autograd.Function):
             if i > 1:
                 nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, C, kz)
                 wsb = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
-                call("df_conv_wgrad", _ptr(xs[i - 2]), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, C, C, kz, _ptr(wsb), nbytes,
-                     _stream())
+                call("df_conv_wgrad" + _sfx(C, C), _ptr(xs[i - 2]), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, C, C, kz, _ptr(wsb),
+                     nbytes, _stream())
                 wpd = _pack(w, taps, C, C, 1)
                 dp = _conv_raw(dp, wpd, None, None, xs[i - 2], fdims, C, C, kz, DF_CONV_MASK, leak).view(dy.shape)
             else:
                 nbytes = query("df_upconv_wgrad_workspace_bytes", cdims[0], cdims[1], cdims[2], cdims[3], C, C, kz)
                 wsb = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
-                call("df_upconv_wgrad", _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2], cdims[3], C, C,
-                     kz, _ptr(wsb), nbytes, _stream())
+                call("df_upconv_wgrad" + _sfx(C, C), _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
+                     cdims[3], C, C, kz, _ptr(wsb), nbytes, _stream())
                 if ctx.needs_input_grad[0]:
                     dxc = torch.empty_like(xc)          # skip path: sum-pool of dy, then += the conv path per parity class
                     call("df_upsample2x_bwd", _ptr(dy), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, int(is3d),

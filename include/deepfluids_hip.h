@@ -200,6 +200,13 @@ int df_upconv_fwd_bf16x3(const float* xc, const float* wp, const float* bias, fl
                          int64_t Wc, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream);
 int df_upconv_dgrad_bf16x3(const float* g, const float* wp, float* acc, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
                            int64_t Cin, int64_t Cout, int kz, df_stream_t stream);
+/* weight gradients in the same mode (workspaces: the fp32 *_workspace_bytes); rows with W not in {16,32,64,96,112} or thin
+ * channels fall back to the exact fp32 kernels. */
+int df_conv_wgrad_bf16x3(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
+                         int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream);
+int df_upconv_wgrad_bf16x3(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc,
+                           int64_t Wc, int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes,
+                           df_stream_t stream);
 
 /* gw[kz,3,3,Cin,Cout] = sum_voxels x[voxel+tap][cin] * gy[voxel][cout]   (split over voxel ranges,
  * deterministic second-pass reduction through the workspace).  If gb != NULL it also receives the bias gradient

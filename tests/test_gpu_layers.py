@@ -217,10 +217,11 @@ def bf16x3(ops):
 
 @pytest.mark.parametrize("shape,cin,cout,leak", [((1, 4, 8, 16), 32, 128, 0.2), ((2, 8, 12, 8), 64, 128, 0.2),
                                                   ((1, 5, 7, 19), 16, 32, None), ((1, 3, 6, 18), 128, 128, 0.2),
-                                                  ((2, 8, 16), 32, 128, 0.2), ((1, 9, 17), 128, 64, None)])
+                                                  ((2, 8, 16), 32, 128, 0.2), ((1, 9, 17), 128, 64, None), ((1, 3, 2, 64), 128, 128, 0.2),
+                                                  ((2, 2, 3, 32), 64, 64, None), ((1, 5, 96), 32, 64, 0.2)])
 def test_conv_bf16x3_mode(ops, bf16x3, shape, cin, cout, leak):
     """Opt-in split-precision mode: forward and dgrad on the bf16 matrix pipe (hi*hi + hi*lo + lo*hi); 16 significand
-    bits per operand -> relative L-inf ~1e-5 (bound 1e-4); wgrad stays exact fp32."""
+    bits per operand -> relative L-inf ~1e-5 (bound 1e-4); rows of 16/32/64/96/112 voxels use the bf16x3 wgrad kernel."""
     errs = _conv_case(ops, shape, cin, cout, leak, seed=cin + cout + sum(shape), mask_from_gpu=True)
     assert errs["y"] < 1e-4 and errs["dx"] < 1e-4, errs
     assert errs["y"] > 1e-7, "suspiciously exact: is the bf16x3 kernel really running?"
