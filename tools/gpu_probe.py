@@ -105,5 +105,34 @@ def main():
     print("lrelu_bwd 3x3GiB    : %9.3f ms  %7.1f GB/s" % (t * 1e3, up.numel() * 12 / t / 1e9))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def probe_bf16x3():
+    """Kernel-level timing of the opt-in bf16x3 mode at the top-resolution shape."""
+    from deep_fluids_amd import ops as _ops
+    s = _stream()
+    F = 128
+    bz, d, h, w = 16, 64, 96, 64
+    xin = torch.rand((bz, d, h, w, F), device="cuda") - 0.5
+    wt = (torch.rand((3, 3, 3, F, F), device="cuda") - 0.5) * 0.05
+    bias = torch.zeros(F, device="cuda")
+    y = torch.empty_like(xin)
+    n = query("df_conv_packed_elems_bf16x3", 27, F, F, 0)
+    wp = torch.empty(n, device="cuda")
+    call("df_conv_pack_weights_bf16x3", _ptr(wt), _ptr(wp), 27, F, F, 0, s)
+    flops = 2.0 * 27 * F * F * bz * d * h * w
+    t = timeit(lambda: call("df_conv_fwd_bf16x3", _ptr(xin), _ptr(wp), _ptr(bias), None, None, _ptr(y), bz, d, h, w, F, F, 3,
+                            9, 0.2, s), iters=5, warm=2)
+    print("bf16x3 conv3d fwd  top-res: %8.3f ms  %6.1f TFLOP/s fp32-equivalent (%.0f bf16 TFLOP/s on the matrix pipe)" % (t * 1e3, flops / t / 1e12, 3 * flops / t / 1e12))
+    gw = torch.empty_like(wt); gb = torch.empty(F, device="cuda")
+    nb = query("df_conv_wgrad_workspace_bytes", bz, d, h, w, F, F, 3)
+    ws = torch.empty(nb // 4 + 1, device="cuda")
+    t = timeit(lambda: call("df_conv_wgrad_bf16x3", _ptr(xin), _ptr(y), _ptr(gw), _ptr(gb), bz, d, h, w, F, F, 3, _ptr(ws), nb, s),
+               iters=5, warm=2)
+    print("bf16x3 conv3d wgrad top-res: %8.3f ms  %6.1f TFLOP/s fp32-equivalent (%.0f bf16 TFLOP/s on the matrix pipe)" % (t * 1e3, flops / t / 1e12, 3 * flops / t / 1e12))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "bf16x3":
+    probe_bf16x3()
