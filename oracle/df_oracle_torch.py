@@ -108,7 +108,7 @@ def train_step(z, x, p, opt, output_shape, filters, is_3d, num_conv=4, repeat=0,
             opt["m"][k].mul_(beta1).add_(g, alpha=1.0 - beta1)
             opt["v"][k].mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
             v.sub_(lr_t * opt["m"][k] / (opt["v"][k].sqrt() + eps))
-    return {"loss": float(loss), "l1": float(l1), "j_l1": float(jl1), "u": u.detach(), "psi": psi.detach(), "grads": grads}
+    return {"loss": float(loss.detach()), "l1": float(l1.detach()), "j_l1": float(jl1.detach()), "u": u.detach(), "psi": psi.detach(), "grads": grads}
 
 
 def to_torch(params, dtype=torch.float32):
