@@ -155,12 +155,14 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in
     const int lx = m % TX, ly = (m / TX) % TY, lz = m / (TX * TY);
     aidx[mb] = ((lz * S * HY + ly * S) * HX + lx * S) * S4 + half;
   }
-  // per-lane packed-weight pointers (float4 units): ((tapk8 * 2 + half) * Npad + col)
+  // packed weights (float4 units): ((tapk8 * 2 + half) * Npad + col) = wave-uniform base + 32-bit per-lane offset, so every
+  // B load is `global_load_dwordx4 v, v_off, s[base]` and no per-step 64-bit address lives in VGPRs
   const int64_t bstep = 2LL * a.Npad;            // float4s per (tap,k8) record
   const int K8 = a.Kpad >> 3;
-  const f32x4* bptr[NB];
+  int boff[NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) bptr[nb] = a.wp + static_cast<int64_t>(half) * a.Npad + n0 + (wn * NB + nb) * 32 + r;
+  for (int nb = 0; nb < NB; ++nb) boff[nb] = half * a.Npad + (wn * NB + nb) * 32 + r;
+  const f32x4* wbase = a.wp + n0;
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -220,9 +222,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in
     __syncthreads();
 
     // ---- 9 / 27 taps x 2 channel-octets, software-pipelined by one step ---------------------------
-    const f32x4* bchunk[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bchunk[nb] = bptr[nb] + static_cast<int64_t>(chunk * 2) * bstep;
+    const f32x4* bchunk = wbase + static_cast<int64_t>(chunk * 2) * bstep;      // wave-uniform
     const int64_t tapstride = static_cast<int64_t>(K8) * bstep;
 
     // A fragments: one step ahead (LDS);  B fragments: two steps ahead (L2), ring of three
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in
     auto glb_b = [&](int step, f32x4 (&dst)[NB]) {
       const int tap = step >> 1, c8 = step & 1;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) dst[nb] = bchunk[nb][tap * tapstride + c8 * bstep];
+      for (int nb = 0; nb < NB; ++nb) dst[nb] = (bchunk + (tap * tapstride + c8 * bstep))[boff[nb]];
     };
     glb_b(0, bf[0]);
     glb_b(1, bf[1]);

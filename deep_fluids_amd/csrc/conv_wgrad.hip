@@ -47,6 +47,7 @@ struct WgradArgs {
   int nrows, npairs, nranges, pairs_per_range;
   int ndzdy;           // 9 (3-D) or 3 (2-D); up mode: 32 | 8 combos = parity class x (dz,dy) pair
   int want_bias;
+  int nqi, nqj, nsub;  // live 64x64 quadrants per 128x128 block (1|2 each); the 4/(nqi*nqj) spare waves split the voxel range
   int up;              // 1: x is the COARSE input of an up-sampling-aware conv, g the FINE gradient (see df_upconv_wgrad)
   int gD, gH, gW;      // physical extents of g (== D,H,W unless up)
 };
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qi = wave >> 1, qj = wave & 1;
+  const int nq = a.nqi * a.nqj;
+  const int qi = (wave % nq) / a.nqj, qj = (wave % nq) % a.nqj, sub = wave / nq;
   const int Wc = WP8 > 0 ? WP8 * 8 : a.W;      // row length (compile-time when WP8 > 0: dispatch guarantees W == 8*WP8)
   const int half = lane >> 5, r = lane & 31;
 
@@ -87,9 +89,12 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
   const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
   if (ci0 >= a.Cin || co0 >= a.Cout) return;   // wave-uniform: quadrant entirely in the padding
 
-  const int p0 = range * a.pairs_per_range;
-  int p1 = p0 + a.pairs_per_range;
+  const int ppe = (a.pairs_per_range + a.nsub - 1) / a.nsub;       // pairs per (range, sub-range)
+  const int p0 = range * a.pairs_per_range + sub * ppe;
+  int p1 = p0 + ppe;
+  if (p1 > (range + 1) * a.pairs_per_range) p1 = (range + 1) * a.pairs_per_range;
   if (p1 > a.npairs) p1 = a.npairs;
+  const int erange = range * a.nsub + sub;
 
   const int cia = ci0 + 2 * r, coa = co0 + 2 * r;   // this lane's first ci / co
   const bool ci_ok0 = cia < a.Cin, ci_ok1 = cia + 1 < a.Cin;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
 
   // ---- write the partial: D layout col = r (co = co0+2r+t), row i = (e&3)+8(e>>2)+4*half (ci = ci0+2i+s) ------
   const int taps = a.ndzdy * 3;
-  float* P = a.partial + static_cast<int64_t>(range) * taps * a.Cinp * a.Coutp;
+  float* P = a.partial + static_cast<int64_t>(erange) * taps * a.Cinp * a.Coutp;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int tap = dzdy * 3 + d;
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
     bsum[1] += __shfl_xor(bsum[1], 32, 64);
     if (half == 0) {
       const int ncls = a.up ? (a.ndzdy == 32 ? 8 : 4) : 1;
-      float* pb = a.bpartial + (static_cast<int64_t>(range) * ncls + cls) * a.Coutp + co0 + 2 * r;
+      float* pb = a.bpartial + (static_cast<int64_t>(erange) * ncls + cls) * a.Coutp + co0 + 2 * r;
       pb[0] = bsum[0]; pb[1] = bsum[1];
     }
   }
@@ -280,7 +285,8 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_bf16x3_kernel(const WgradAr
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qi = wave >> 1, qj = wave & 1;
+  const int nq = a.nqi * a.nqj;
+  const int qi = (wave % nq) / a.nqj, qj = (wave % nq) % a.nqj, sub = wave / nq;
   const int half = lane >> 5, r = lane & 31;
 
   const int nwg = a.nranges * a.ndzdy;
@@ -306,9 +312,12 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_bf16x3_kernel(const WgradAr
   const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
   if (ci0 >= a.Cin || co0 >= a.Cout) return;
 
-  const int row0 = 2 * range * a.pairs_per_range;
-  int row1 = row0 + 2 * a.pairs_per_range;
+  const int ppe = (a.pairs_per_range + a.nsub - 1) / a.nsub;
+  const int row0 = 2 * (range * a.pairs_per_range + sub * ppe);
+  int row1 = row0 + 2 * ppe;
+  if (row1 > 2 * (range + 1) * a.pairs_per_range) row1 = 2 * (range + 1) * a.pairs_per_range;
   if (row1 > a.nrows) row1 = a.nrows;
+  const int erange = range * a.nsub + sub;
   const int cia = ci0 + 2 * r, coa = co0 + 2 * r;
   const bool ci_ok = cia < a.Cin, co_ok = coa < a.Cout;
   const float* zb = a.zeros;
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_bf16x3_kernel(const WgradAr
   }
 
   const int taps = a.ndzdy * 3;
-  float* P = a.partial + static_cast<int64_t>(range) * taps * a.Cinp * a.Coutp;
+  float* P = a.partial + static_cast<int64_t>(erange) * taps * a.Cinp * a.Coutp;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int tap = dzdy * 3 + d;
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_bf16x3_kernel(const WgradAr
     bsum[1] += __shfl_xor(bsum[1], 32, 64);
     if (half == 0) {
       const int ncls = a.up ? (a.ndzdy == 32 ? 8 : 4) : 1;
-      float* pb = a.bpartial + (static_cast<int64_t>(range) * ncls + cls) * a.Coutp + co0 + 2 * r;
+      float* pb = a.bpartial + (static_cast<int64_t>(erange) * ncls + cls) * a.Coutp + co0 + 2 * r;
       pb[0] = bsum[0]; pb[1] = bsum[1];
     }
   }
@@ -698,7 +707,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_up_reduce_kernel(const float* 
 }
 
 struct Plan {
-  int nrows, npairs, nranges, ppr, Cinp, Coutp, taps, ndzdy;
+  int nrows, npairs, nranges, ppr, Cinp, Coutp, taps, ndzdy, nqi, nqj, nsub;
   int64_t partial_elems, bpartial_elems;
 };
 
@@ -715,10 +724,12 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   int nr = p.npairs >= kMaxRanges ? kMaxRanges : p.npairs;
   p.ppr = (p.npairs + nr - 1) / nr;
   p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
-  p.Cinp = (int)(ceil_div(Cin, 128) * 128);
-  p.Coutp = (int)(ceil_div(Cout, 128) * 128);
-  p.partial_elems = static_cast<int64_t>(p.nranges) * p.taps * p.Cinp * p.Coutp;
-  p.bpartial_elems = static_cast<int64_t>(p.nranges) * p.Coutp;
+  p.Cinp = (int)(ceil_div(Cin, 64) * 64);
+  p.Coutp = (int)(ceil_div(Cout, 64) * 64);
+  p.nqi = Cin <= 64 ? 1 : 2; p.nqj = Cout <= 64 ? 1 : 2;
+  p.nsub = 4 / (p.nqi * p.nqj);
+  p.partial_elems = static_cast<int64_t>(p.nranges) * p.nsub * p.taps * p.Cinp * p.Coutp;
+  p.bpartial_elems = static_cast<int64_t>(p.nranges) * p.nsub * p.Coutp;
   return p;
 }
 
@@ -782,10 +793,11 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   a.Wp = (int)(ceil_div(W, 8) * 8);
   a.nrows = p.nrows; a.npairs = p.npairs; a.nranges = p.nranges; a.pairs_per_range = p.ppr;
   a.ndzdy = p.ndzdy; a.want_bias = gb != nullptr;
+  a.nqi = p.nqi; a.nqj = p.nqj; a.nsub = p.nsub;
   a.up = 0; a.gD = a.D; a.gH = a.H; a.gW = a.W;
   hipStream_t s = df::as_stream(stream);
   if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(W, Cin, Cout), s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
-  dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)(p.Cinp / 128), (unsigned)(p.Coutp / 128));
+  dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)ceil_div(Cin, 128), (unsigned)ceil_div(Cout, 128));
   const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
   if (prec == 1 && xvec && gvec && wgrad_bf16x3_ok(W, Cin, Cout)) {
@@ -808,7 +820,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   int64_t rg = ceil_div(total, kThreads);
   if (rg > 2048) rg = 2048;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
-                     p.nranges, p.taps, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
+                     p.nranges * p.nsub, p.taps, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
   return df::launched("df_conv_wgrad");
 }
 
@@ -830,8 +842,8 @@ static Plan make_up_plan(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t 
   p.ppr = (p.npairs + nr - 1) / nr;
   p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
   p.taps = p.ndzdy * 3;                                  // partial slots per range
-  p.partial_elems = static_cast<int64_t>(p.nranges) * p.taps * p.Cinp * p.Coutp;
-  p.bpartial_elems = static_cast<int64_t>(p.nranges) * (kz == 3 ? 8 : 4) * p.Coutp;
+  p.partial_elems = static_cast<int64_t>(p.nranges) * p.nsub * p.taps * p.Cinp * p.Coutp;
+  p.bpartial_elems = static_cast<int64_t>(p.nranges) * p.nsub * (kz == 3 ? 8 : 4) * p.Coutp;
   return p;
 }
 
@@ -864,10 +876,11 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   a.Wp = (int)(ceil_div(Wc, 8) * 8);
   a.nrows = p.nrows; a.npairs = p.npairs; a.nranges = p.nranges; a.pairs_per_range = p.ppr;
   a.ndzdy = p.ndzdy; a.want_bias = gb != nullptr;
+  a.nqi = p.nqi; a.nqj = p.nqj; a.nsub = p.nsub;
   a.up = 1; a.gD = kz == 3 ? 2 * a.D : 1; a.gH = 2 * a.H; a.gW = 2 * a.W;
   hipStream_t s = df::as_stream(stream);
   if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(Wc, Cin, Cout), s)) return df::fail((int)e, "df_upconv_wgrad: memset: %s", hipGetErrorString(e));
-  dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)(p.Cinp / 128), (unsigned)(p.Coutp / 128));
+  dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)ceil_div(Cin, 128), (unsigned)ceil_div(Cout, 128));
   const int wp8 = a.Wp / 8;
   const bool exact = (Wc % 8) == 0;
   if (prec == 1 && wgrad_bf16x3_ok(Wc, Cin, Cout)) launch_wgrad_bf16x3(Wc, grid, s, a);
@@ -880,7 +893,7 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   int64_t rg = ceil_div(total, kThreads);
   if (rg > 2048) rg = 2048;
   hipLaunchKernelGGL(wgrad_up_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
-                     p.nranges, kz, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
+                     p.nranges * p.nsub, kz, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
   return df::launched("df_upconv_wgrad");
 }
 
