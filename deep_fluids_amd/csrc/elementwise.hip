@@ -135,6 +135,21 @@ __global__ __launch_bounds__(kThreads) void concat2_kernel(float* __restrict__ a
   }
 }
 
+// scalar variant for channel counts that are not multiples of 4 (discriminator input: 2+1 / 3+3 channels)
+template <int DIR>
+__global__ __launch_bounds__(kThreads) void concat2_scalar_kernel(float* __restrict__ a, float* __restrict__ b,
+                                                                  float* __restrict__ y, int64_t rows, int Ca, int Cb) {
+  const int C = Ca + Cb;
+  const int64_t n = rows * C;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int64_t r = i / C;
+    const int c = static_cast<int>(i - r * C);
+    float* src = c < Ca ? a + r * Ca + c : b + r * Cb + (c - Ca);
+    if (DIR == 0) y[i] = *src; else *src = y[i];
+  }
+}
+
 // ---- zero insertion for the stride-2 conv backward: out[2o+1] = g[o] on every spatial axis, zeros elsewhere ------------
 // (dX = SAME-conv(out, mirrored weights) and gW = wgrad(X, out) then reproduce the stride-2 adjoints exactly)
 template <bool IS3D>
@@ -602,8 +617,11 @@ int df_adam_tf1_step(float* p, const float* g, float* m, float* v, int64_t n, fl
 int df_concat2_fwd(const float* a, const float* b, float* y, int64_t rows, int64_t Ca, int64_t Cb, df_stream_t stream) {
   DF_REQUIRE(a && b && y, DF_EINVAL, "df_concat2_fwd: null pointer");
   DF_REQUIRE(rows > 0 && Ca > 0 && Cb > 0, DF_EINVAL, "df_concat2_fwd: non-positive extent");
-  DF_REQUIRE(Ca % 4 == 0 && Cb % 4 == 0, DF_ESHAPE, "df_concat2_fwd: channel counts must be multiples of 4");
-  DF_REQUIRE(df::aligned16(a) && df::aligned16(b) && df::aligned16(y), DF_EALIGN, "df_concat2_fwd: 16-byte alignment");
+  if (Ca % 4 != 0 || Cb % 4 != 0 || !df::aligned16(a) || !df::aligned16(b) || !df::aligned16(y)) {
+    hipLaunchKernelGGL((concat2_scalar_kernel<0>), dim3(grid_for(rows * (Ca + Cb))), dim3(kThreads), 0, df::as_stream(stream),
+                       const_cast<float*>(a), const_cast<float*>(b), y, rows, (int)Ca, (int)Cb);
+    return df::launched("df_concat2_fwd");
+  }
   hipLaunchKernelGGL((concat2_kernel<0>), dim3(grid_for(rows * (Ca + Cb) / 4)), dim3(kThreads), 0, df::as_stream(stream),
                      const_cast<float*>(a), const_cast<float*>(b), y, rows, (int)(Ca / 4), (int)(Cb / 4));
   return df::launched("df_concat2_fwd");
@@ -612,8 +630,11 @@ int df_concat2_fwd(const float* a, const float* b, float* y, int64_t rows, int64
 int df_concat2_bwd(const float* gy, float* ga, float* gb, int64_t rows, int64_t Ca, int64_t Cb, df_stream_t stream) {
   DF_REQUIRE(gy && ga && gb, DF_EINVAL, "df_concat2_bwd: null pointer");
   DF_REQUIRE(rows > 0 && Ca > 0 && Cb > 0, DF_EINVAL, "df_concat2_bwd: non-positive extent");
-  DF_REQUIRE(Ca % 4 == 0 && Cb % 4 == 0, DF_ESHAPE, "df_concat2_bwd: channel counts must be multiples of 4");
-  DF_REQUIRE(df::aligned16(ga) && df::aligned16(gb) && df::aligned16(gy), DF_EALIGN, "df_concat2_bwd: 16-byte alignment");
+  if (Ca % 4 != 0 || Cb % 4 != 0 || !df::aligned16(ga) || !df::aligned16(gb) || !df::aligned16(gy)) {
+    hipLaunchKernelGGL((concat2_scalar_kernel<1>), dim3(grid_for(rows * (Ca + Cb))), dim3(kThreads), 0, df::as_stream(stream),
+                       ga, gb, const_cast<float*>(gy), rows, (int)Ca, (int)Cb);
+    return df::launched("df_concat2_bwd");
+  }
   hipLaunchKernelGGL((concat2_kernel<1>), dim3(grid_for(rows * (Ca + Cb) / 4)), dim3(kThreads), 0, df::as_stream(stream),
                      ga, gb, const_cast<float*>(gy), rows, (int)(Ca / 4), (int)(Cb / 4));
   return df::launched("df_concat2_bwd");

@@ -11,7 +11,8 @@ from .ops import *          # noqa: F401,F403  (the reference does `from ops imp
 from .ops import (variable_scope, get_variables, add, lrelu, linear, reshape, conv2d, conv3d, upscale, upscale3, concat,
                   sigmoid, get_conv_shape)
 
-__all__ = ["GeneratorBE", "GeneratorBE3", "EncoderBE", "EncoderBE3", "AE", "AE3"]
+__all__ = ["GeneratorBE", "GeneratorBE3", "EncoderBE", "EncoderBE3", "AE", "AE3", "DiscriminatorPatch",
+           "DiscriminatorPatch3"]
 
 
 def _generator(z, filters, output_shape, name, num_conv, conv_k, last_k, repeat, skip_concat, act, reuse, is_3d):
@@ -141,3 +142,27 @@ def AE3(x, filters, z_num, name="AE", num_conv=4, conv_k=3, last_k=3, repeat=0, 
         use_sparse=False, reuse=False):
     """model.py:204-216."""
     return _ae(x, filters, z_num, name, num_conv, conv_k, last_k, repeat, act, skip_concat, use_sparse, reuse, True)
+
+
+def _discriminator(x, filters, name, reuse, is_3d):
+    conv = conv3d if is_3d else conv2d
+    with variable_scope(name, reuse=reuse) as vs:
+        repeat_num = 3                                         # model.py:91 / :107
+        d = int(filters / 2)
+        for _ in range(repeat_num):
+            x = conv(x, d, k=3, act=lrelu)                     # the wrapper's default stride 2 (ops.py:12,15)
+            d *= 2
+        x = conv(x, d, k=3, s=1, act=lrelu)
+        out = conv(x, 1, k=3, s=1)
+    variables = get_variables(vs)
+    return out, variables
+
+
+def DiscriminatorPatch(x, filters, name="D", train=True, reuse=False):
+    """model.py:89-103 (PatchGAN-style, used by arch='dg')."""
+    return _discriminator(x, filters, name, reuse, False)
+
+
+def DiscriminatorPatch3(x, filters, name="D", train=True, reuse=False):
+    """model.py:105-116."""
+    return _discriminator(x, filters, name, reuse, True)

@@ -58,6 +58,7 @@ def _empty(shape, like):
 # variable registry (tf.variable_scope / slim variables)
 # --------------------------------------------------------------------------------------------------
 _VARS = {}            # full name -> torch.Tensor (requires_grad leaf)
+_UNNAMED = {}         # (scope prefix, layer kind) -> how many unnamed layers of that kind were created in this scope entry
 _SCOPES = []          # stack of (name, reuse)
 _RNG = np.random.RandomState(123)     # main.py:12 tf.set_random_seed(123) / config.py:69
 _DEFAULT_DEVICE = "cuda"
@@ -85,6 +86,9 @@ def all_variables():
 def variable_scope(name, reuse=False):
     inherited = bool(_SCOPES and _SCOPES[-1][1])
     _SCOPES.append((name, bool(reuse) or inherited))
+    prefix = "/".join(s[0] for s in _SCOPES)
+    for key in [k for k in _UNNAMED if k[0] == prefix]:      # slim's default layer names (Conv, Conv_1, ...) restart on
+        del _UNNAMED[key]                                     # every entry of the scope, so reuse=True finds the same names
     try:
         yield VariableScope("/".join(s[0] for s in _SCOPES))
     finally:
@@ -134,9 +138,6 @@ def get_variables(scope):
     """tf.contrib.framework.get_variables(vs): variables under a scope, creation order."""
     prefix = (scope.name if isinstance(scope, VariableScope) else str(scope)) + "/"
     return [v for k, v in _VARS.items() if k.startswith(prefix)]
-
-
-_UNNAMED = {}
 
 
 def _layer_name(name, kind):

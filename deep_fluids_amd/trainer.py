@@ -21,7 +21,8 @@ import torch
 
 from . import ops
 from .ops import curl, curl3, jacobian, jacobian3, l1_mean, mse_mean, get_conv_shape, _ptr, _stream, call
-from .model import GeneratorBE, GeneratorBE3, AE, AE3
+from .model import GeneratorBE, GeneratorBE3, AE, AE3, DiscriminatorPatch, DiscriminatorPatch3
+from .ops import concat
 from .dist import GradSync
 
 
@@ -31,7 +32,7 @@ def default_config(**over):
              w1=1.0, w2=1.0, arch="de", batch_size=8, max_epoch=100, lr_max=1e-4, lr_min=2.5e-6,
              optimizer="adam", beta1=0.5, beta2=0.999, lr_update="decay", lr_update_step=120000,
              start_step=0, random_seed=123, num_samples=21000, c_num=3, use_curl3_alias=True,
-             z_num=16, use_sparse=False, sparsity=0.01, w4=1.0, w5=1.0, p_num=2, x_channels=None)
+             z_num=16, use_sparse=False, sparsity=0.01, w4=1.0, w5=1.0, p_num=2, x_channels=None, w3=0.005)
     c.update(over)
     return SimpleNamespace(**c)
 
@@ -261,3 +262,73 @@ class AETrainer(Trainer):
         loss = loss_l1 * self.w1 + loss_j_l1 * self.w2 + loss_p * self.w4
         return SimpleNamespace(s=out, G_=x_, x_=x_, z=z, G_jaco_=x_jaco_, G_vort_=x_vort_, x_jaco=x_jaco,
                                g_loss_l1=loss_l1, g_loss_j_l1=loss_j_l1, loss_p=loss_p, g_loss=loss, loss=loss)
+
+
+class _Slab(object):
+    """Flat parameter / gradient / Adam-slot slabs over a set of registry variables (views re-registered in place)."""
+
+    def __init__(self, names, device):
+        vars_ = ops.all_variables()
+        total = sum(vars_[k].numel() for k in names)
+        self.p = torch.empty(total, dtype=torch.float32, device=device)
+        self.g = torch.zeros(total, dtype=torch.float32, device=device)
+        self.m = torch.zeros(total, dtype=torch.float32, device=device)
+        self.v = torch.zeros(total, dtype=torch.float32, device=device)
+        self.names, self.slices, self.vars = list(names), {}, []
+        off = 0
+        for k in names:
+            old = vars_[k]
+            n = old.numel()
+            self.p[off:off + n].copy_(old.detach().reshape(-1))
+            v = self.p[off:off + n].view(old.shape).detach().requires_grad_(True)
+            v.grad = self.g[off:off + n].view(old.shape)
+            ops._VARS[k] = v
+            self.slices[k] = (off, n)
+            self.vars.append(v)
+            off += n
+        self.n = total
+
+
+class GANTrainer(Trainer):
+    """arch='dg' (SURVEY 8(f)-4): generator + PatchGAN discriminator with LSGAN terms, both updated from the same
+    forward pass like ``sess.run([g_optim, d_optim])`` (trainer.py:149-156, 174-184, 265-267; trainer3.py:26-33,53-63)."""
+
+    def __init__(self, config, device="cuda", name="G"):
+        self.w3 = config.w3
+        super(GANTrainer, self).__init__(config, device, name)
+        disc = DiscriminatorPatch3 if self.is_3d else DiscriminatorPatch
+        cin = 6 if self.is_3d else 3                              # concat([x, x_vort]): 3+3 | 2+1 channels
+        spatial = ([config.res_z] if self.is_3d else []) + [config.res_y, config.res_x]
+        if not any(k.startswith("D/") for k in ops.all_variables()):
+            with torch.no_grad():
+                disc(torch.zeros([1] + spatial + [cin], device=self.device), self.filters)
+        self.D = _Slab([k for k in ops.all_variables() if k.startswith("D/")], self.device)
+        self._adam_t_d = 0
+
+    def train_step(self, x, y):
+        disc = DiscriminatorPatch3 if self.is_3d else DiscriminatorPatch
+        self.flat_g.zero_(); self.D.g.zero_()
+        m = self.build_model(x, y)
+        with torch.no_grad():
+            x_vort = (jacobian3(x) if self.is_3d else jacobian(x))[1]                 # trainer.py:30,32
+        D_x, _ = disc(concat([x, x_vort], axis=-1), self.filters, reuse=True)         # trainer.py:153-154
+        D_G, _ = disc(concat([m.G_, m.G_vort_], axis=-1), self.filters, reuse=True)   # trainer.py:155-156
+        ones_g, zeros_g, ones_x = torch.ones_like(D_G), torch.zeros_like(D_G), torch.ones_like(D_x)
+        m.g_loss_real = ops.mse_mean(D_G, ones_g)                                      # trainer.py:175
+        m.d_loss_fake = ops.mse_mean(D_G, zeros_g)                                     # trainer.py:176
+        m.d_loss_real = ops.mse_mean(D_x, ones_x)                                      # trainer.py:177
+        m.g_loss = m.g_loss + m.g_loss_real * self.w3                                  # trainer.py:179
+        m.d_loss = m.d_loss_real + m.d_loss_fake                                       # trainer.py:181
+        m.g_loss.backward(inputs=self.G_var, retain_graph=True)
+        m.d_loss.backward(inputs=self.D.vars)
+        self._apply_adam(1.0)
+        self._adam_t_d += 1
+        t = self._adam_t_d
+        lr_t = self.g_lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        call("df_adam_tf1_step", _ptr(self.D.p), _ptr(self.D.g), _ptr(self.D.m), _ptr(self.D.v), self.D.n, float(lr_t),
+             float(self.beta1), float(self.beta2), float(self.eps), 1.0, _stream())
+        self.step += 1
+        if self.lr_update == "decay":
+            self.g_lr = self.config.lr_min + 0.5 * (self.config.lr_max - self.config.lr_min) * (
+                math.cos(self.step * math.pi / self.max_step) + 1.0)
+        return m

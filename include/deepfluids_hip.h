@@ -114,7 +114,7 @@ int df_linear_bwd(const float* x, const float* w, const float* gy, float* gx, fl
                   int64_t K, int64_t N, df_stream_t stream);
 
 /* tf.concat([a, b], axis=-1) of two channels-last tensors with `rows` voxels (encoder skips, model.py:138,174) and the
- * reverse split of the gradient; channel counts multiples of 4. */
+ * reverse split of the gradient (16-byte vectorised when both channel counts are multiples of 4). */
 int df_concat2_fwd(const float* a, const float* b, float* y, int64_t rows, int64_t Ca, int64_t Cb, df_stream_t stream);
 int df_concat2_bwd(const float* gy, float* ga, float* gb, int64_t rows, int64_t Ca, int64_t Cb, df_stream_t stream);
 

@@ -514,6 +514,77 @@ def _generator_dz(dout, cache, p, name, leak=0.2):
 
 
 # ----------------------------------------------------------------------------------------
+# Discriminator (model.py:89-116) and the LSGAN terms of arch='dg' (trainer.py:149-156,174-182)
+# ----------------------------------------------------------------------------------------
+
+def discriminator_init(rng, cin, filters, nd, name="D"):
+    p = {}
+    d = int(filters / 2)
+    c = cin
+    names = ["Conv", "Conv_1", "Conv_2", "Conv_3", "Conv_4"]          # slim's default scope names (no `name=` given)
+    chans = [d, 2 * d, 4 * d, 8 * d, 1]
+    for n, co in zip(names, chans):
+        p["%s/%s/weights" % (name, n)] = xavier_uniform(rng, (3,) * nd + (c, co))
+        p["%s/%s/biases" % (name, n)] = np.zeros(co, np.float32)
+        c = co
+    return p
+
+
+_D_LAYERS = [("Conv", 2, True), ("Conv_1", 2, True), ("Conv_2", 2, True), ("Conv_3", 1, True), ("Conv_4", 1, False)]
+
+
+def discriminator_fwd(x, p, name="D", leak=0.2, keep=False):
+    tape = []
+    for n, stride, act in _D_LAYERS:
+        pre = conv_same(x, p["%s/%s/weights" % (name, n)], p["%s/%s/biases" % (name, n)], stride)
+        y = lrelu(pre, leak) if act else pre
+        tape.append((n, stride, act, x, y))
+        x = y
+    return (x, tape) if keep else x
+
+
+def discriminator_bwd(dout, tape, p, name="D", leak=0.2, need_dx=True):
+    g = {}
+    dx = dout
+    for n, stride, act, xin, y in reversed(tape):
+        dpre = dx * np.where(y > 0, 1.0, leak).astype(dx.dtype) if act else dx
+        dx, dw, db = conv_same_bwd(xin, p["%s/%s/weights" % (name, n)], dpre, stride)
+        g["%s/%s/weights" % (name, n)] = dw; g["%s/%s/biases" % (name, n)] = db
+    return g, (dx if need_dx else None)
+
+
+def gan_losses_and_grads(z, x, pG, pD, output_shape, filters, is_3d, w1=1.0, w2=1.0, w3=0.005, num_conv=4, repeat=0):
+    """arch='dg' (trainer.py:136-184 / trainer3.py:14-63): losses and the gradients the two `minimize` calls apply:
+    g_loss w.r.t. G_var (through the discriminator), d_loss w.r.t. D_var."""
+    psi, cache = generator_fwd(z, pG, output_shape, filters, "G", num_conv, repeat, keep=True)
+    if is_3d:
+        u = curl3(psi); ju, vu = jacobian3(u); jx, vx = jacobian3(x)
+    else:
+        u = curl(psi); ju, vu = jacobian(u); jx, vx = jacobian(x)
+    l1 = l1_mean(u, x); jl1 = l1_mean(ju, jx)
+    D_x, tape_x = discriminator_fwd(np.concatenate([x, vx], -1), pD, keep=True)
+    D_G, tape_G = discriminator_fwd(np.concatenate([u, vu], -1), pD, keep=True)
+    g_real = ((D_G - 1) ** 2).mean(); d_fake = (D_G ** 2).mean(); d_real = ((D_x - 1) ** 2).mean()
+    g_loss = w1 * l1 + w2 * jl1 + w3 * g_real
+    d_loss = d_real + d_fake
+    gD1, _ = discriminator_bwd(2 * (D_x - 1) / D_x.size, tape_x, pD, need_dx=False)
+    gD2, _ = discriminator_bwd(2 * D_G / D_G.size, tape_G, pD, need_dx=False)
+    gD = {k: gD1[k] + gD2[k] for k in gD1}
+    _, dGin = discriminator_bwd(w3 * 2 * (D_G - 1) / D_G.size, tape_G, pD)
+    c = u.shape[-1]
+    du = l1_mean_bwd(u, x, w1) + dGin[..., :c]
+    dj = l1_mean_bwd(ju, jx, w2)
+    if is_3d:
+        du = du + jacobian3_bwd(gj=dj, gc=dGin[..., c:])
+        dpsi = jacobian3_bwd(gc=du)
+    else:
+        du = du + jacobian_bwd(dj, dGin[..., c:])
+        dpsi = curl_bwd(du)
+    gG = generator_bwd(dpsi, cache, pG, "G")
+    return {"g_loss": g_loss, "d_loss": d_loss, "l1": l1, "j_l1": jl1, "g_loss_real": g_real, "u": u, "gG": gG, "gD": gD}
+
+
+# ----------------------------------------------------------------------------------------
 # Train step (trainer.py:136-184, trainer3.py:14-63) + TF1 Adam + LR schedule
 # ----------------------------------------------------------------------------------------
 

@@ -72,8 +72,20 @@ def _variable_scope(name, reuse=False):
     _SCOPE.pop()
 
 
+_UNNAMED = {}
+
+
+def _default_name(scope, kind):
+    if scope is not None:
+        return scope
+    key = ("/".join(_SCOPE), kind)
+    n = _UNNAMED.get(key, 0)
+    _UNNAMED[key] = n + 1
+    return kind if n == 0 else "%s_%d" % (kind, n)
+
+
 def _conv(x, o_dim, k, stride=1, activation_fn=None, scope=None, data_format=None):
-    full = _scope_name(scope)
+    full = _scope_name(_default_name(scope, "Conv"))
     w = WEIGHTS[full + "/weights"]; b = WEIGHTS[full + "/biases"]
     nd = x.ndim - 2
     assert w.shape == (k,) * nd + (x.shape[-1], o_dim), (full, w.shape)
@@ -236,6 +248,20 @@ def capture_generators(model):
             ae[tag + "|" + k] = v
         plans[tag] = {"fn": fn, "x_shape": xshape, "filters": filters, "z_num": z_num, "use_sparse": sparse,
                       "layers": list(PLAN), "variables": list(var_names)}
+    for tag, (fn, xshape, filters, batch) in {"d2_small": ("DiscriminatorPatch", [16, 16, 3], 8, 2),
+                                              "d3_small": ("DiscriminatorPatch3", [8, 16, 8, 6], 8, 1)}.items():
+        rng = np.random.RandomState(123)
+        WEIGHTS.clear(); del PLAN[:]; _UNNAMED.clear()
+        WEIGHTS.update(orc.discriminator_init(rng, xshape[-1], filters, len(xshape) - 1))
+        for k in list(WEIGHTS):
+            if k.endswith("biases"):
+                WEIGHTS[k] = rng.uniform(-0.1, 0.1, size=WEIGHTS[k].shape).astype(np.float32)
+        x = rng.uniform(-1, 1, size=[batch] + xshape).astype(np.float32)
+        out, var_names = getattr(model, fn)(_t(x), filters)
+        ae[tag + "_x"] = x; ae[tag + "_out"] = np.asarray(out)
+        for k, v in WEIGHTS.items():
+            ae[tag + "|" + k] = v
+        plans[tag] = {"fn": fn, "x_shape": xshape, "filters": filters, "layers": list(PLAN), "variables": list(var_names)}
     np.savez_compressed(os.path.join(HERE, "autoencoders.npz"), **ae)
 
     with open(os.path.join(HERE, "layer_plans.json"), "w") as f:

@@ -128,3 +128,61 @@ def test_ae_train_step_vs_oracle(is_3d, spatial, filters):
     worst = max(float(np.abs(gr[k] - info["grads"][k]).max() / max(np.abs(info["grads"][k]).max(), 1e-3 * gmax)) for k in gr)
     assert worst < 1e-3, worst
     ops.reset_variables()
+
+
+@pytest.mark.parametrize("tag", ["d2_small", "d3_small"])
+def test_discriminator_vs_reference_model_py(tag):
+    """DiscriminatorPatch(3) (three stride-2 convs from the wrapper default, slim default layer names)."""
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.model import DiscriminatorPatch, DiscriminatorPatch3
+    g = dict(np.load(os.path.join(GOLDEN, "autoencoders.npz")))
+    pl = json.load(open(os.path.join(GOLDEN, "layer_plans.json")))[tag]
+    ops.reset_variables()
+    for k, v in g.items():
+        if k.startswith(tag + "|"):
+            ops.set_variable(k.split("|", 1)[1], v)
+    d = DiscriminatorPatch3 if pl["fn"].endswith("3") else DiscriminatorPatch
+    out, variables = d(dev(g[tag + "_x"]), pl["filters"], reuse=True)
+    assert len(variables) == len(pl["variables"])
+    assert rel_linf(host(out), g[tag + "_out"]) < 2e-5
+    ops.reset_variables()
+
+
+@pytest.mark.parametrize("is_3d,spatial", [(False, (16, 16)), (True, (8, 16, 8))])
+def test_gan_train_step_vs_oracle(is_3d, spatial):
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import GANTrainer, default_config
+    ops.reset_variables()
+    rng = np.random.RandomState(5)
+    filters, batch = 16, 2
+    oshape = list(spatial) + [3 if is_3d else 1]
+    pG = orc.generator_init(rng, 3, oshape, filters)
+    pD = orc.discriminator_init(rng, 6 if is_3d else 3, filters, len(spatial))
+    for p in (pG, pD):
+        for k in p:
+            if k.endswith("biases"):
+                p[k] = rng.uniform(-0.05, 0.05, p[k].shape).astype(np.float32)
+    x, y = orc.synthetic_batch(rng, batch, spatial)
+    cfg = default_config(is_3d=is_3d, res_x=spatial[-1], res_y=spatial[-2], res_z=spatial[0] if is_3d else 1,
+                         filters=filters, batch_size=batch, num_samples=1000, arch="dg", w3=0.5)
+    tr = GANTrainer(cfg)
+    tr.load_variables(pG)
+    for k, v in pD.items():
+        o, n = tr.D.slices[k]
+        tr.D.p[o:o + n].copy_(torch.from_numpy(v.reshape(-1)))
+    m = tr.train_step(dev(x), dev(y))
+    ref = orc.gan_losses_and_grads(y.astype(np.float64), x.astype(np.float64), {k: v.astype(np.float64) for k, v in pG.items()},
+                                   {k: v.astype(np.float64) for k, v in pD.items()}, oshape, filters, is_3d, w3=0.5)
+    assert abs(float(m.g_loss.detach()) - ref["g_loss"]) < 1e-5 * abs(ref["g_loss"])
+    assert abs(float(m.d_loss.detach()) - ref["d_loss"]) < 1e-5 * abs(ref["d_loss"])
+    assert rel_l1(host(m.G_), ref["u"]) <= 1e-4
+    gG = tr.grads_numpy()
+    gmax = max(np.abs(v).max() for v in ref["gG"].values())
+    worst = max(float(np.abs(gG[k] - ref["gG"][k]).max() / max(np.abs(ref["gG"][k]).max(), 1e-3 * gmax)) for k in gG)
+    assert worst < 2e-3, ("G", worst)
+    dmax = max(np.abs(v).max() for v in ref["gD"].values())
+    for k, (o, n) in tr.D.slices.items():
+        got = tr.D.g[o:o + n].view(ops._VARS[k].shape).cpu().numpy()
+        err = float(np.abs(got - ref["gD"][k]).max() / max(np.abs(ref["gD"][k]).max(), 1e-3 * dmax))
+        assert err < 2e-3, (k, err)
+    ops.reset_variables()
