@@ -1,0 +1,468 @@
+// 3x3x3 SAME stride-1 convolution as Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores
+// (reference: slim.conv3d behind ops.py:12-16, called from model.py:68,84 -- the 128->128 layers of GeneratorBE3).
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        per 2x2x2 output tile / 4x4x4 input tile, 64 transform points xi
+// = 64 independent GEMMs  M_xi[tile][cout] = sum_cin V_xi[tile][cin] * U_xi[cin][cout]:   8 MFMA MACs per output voxel
+// and (cin,cout) pair instead of 27 -> 3.375x fewer matrix-core FLOPs than the direct kernel (conv.hip); all arithmetic
+// stays fp32 (v_mfma_f32_32x32x2_f32 + exact +-1 / 0.5 transform factors), results differ from the direct sum only by
+// fp32 rounding order (tests: same tolerance as the direct kernel against the fp64 oracle).
+//
+// Workgroup = 4 waves = one block of 2x4x4 tiles (4x8x8 output voxels) x 32 output channels.  Wave w owns the 16
+// transform points with xi_z = w (256 accumulator registers: the whole AGPR file at one wave per SIMD).
+//   * input: the 6x10x10 halo block of a 16-channel chunk is staged in LDS channel-major ([c][z*144 + y*12 + x], the
+//     pitches make every wave-wide ds_read_b64 below bank-conflict free), double buffered, one barrier per chunk.
+//   * A operand: lane = (tile, cin parity) reads the 2 z-planes x 4 x 4 inputs of its tile it needs for xi_z (16
+//     ds_read_b64), runs the separable B^T transform in registers (48 VALU ops) and so produces the 16 A values of one
+//     k-step (2 input channels) directly in MFMA A layout -- the transformed input never touches memory.
+//   * B operand: transformed weights U are packed [cout/32][xi_z][cin/2][xi_y][cin parity][cout%32][xi_x] so that a lane
+//     needs 4 coalesced 16-byte global loads (L2 hits) per k-step; nothing is staged for B.
+//   => per wave and k-step: 16 MFMA (1024 matrix-core cycles) + 48 VALU + 16 ds_read_b64 + 4 global_load_dwordx4.
+//   * epilogue: inverse transform in y,x in registers, the four xi_z partial planes are combined through LDS, then
+//     bias / lrelu / residual / lrelu-mask as in conv.hip.  The dgrad is the same kernel on mode-1 packed weights.
+#include "df_common.hpp"
+#include "conv_args.hpp"
+
+namespace {
+
+using df::ceil_div;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kT = 256;
+constexpr int CKW = 16;                   // input channels per LDS chunk (8 k-steps)
+constexpr int PY = 12, PZ = 144;          // LDS pitches (dwords) of a channel plane: 6 z x 10 y x 10 x, padded
+constexpr int CP = 866;                   // dwords per channel plane (6*144 = 864, +2: staging writes spread over banks)
+constexpr int HY = 10, HX = 10, HV = 600; // halo block 6 x 10 x 10
+constexpr int NLOAD = 10;                 // ceil(600 * 4 float4 pieces / 256 threads)
+constexpr int BUF = CKW * CP;             // dwords per LDS buffer
+constexpr int kZeroFloats = 64;           // zeroed tail of the packed weights (SAME padding reads it)
+
+struct WinoArgs {
+  const float* x;
+  const f32x4* wp;
+  const float* zeros;
+  const float* bias;
+  const float* residual;
+  const float* mask_src;
+  float* y;
+  int B, D, H, W, Cin, Cout;
+  int nbz, nby, nbx, ntb, ncs;
+  int flags;
+  float leak;
+  int dbg;
+};
+
+// ---- weight transform + packing ------------------------------------------------------------------------------------------
+// mode 0: g[tap][k][n] = w[tap][k][n]          (K = cin,  N = cout)
+// mode 1: g[tap][k][n] = w[26 - tap][n][k]     (K = cout, N = cin; taps mirrored)  -> dgrad operand
+// Up[cs][xz][kk][xy][kp][j][xx] = sum_taps G[xz][tz] G[xy][ty] G[xx][tx] g[tap][2kk+kp][32cs+j]
+__device__ __forceinline__ double gmat(int xi, int t) {
+  return xi == 0 ? (t == 0 ? 1.0 : 0.0) : xi == 3 ? (t == 2 ? 1.0 : 0.0) : (xi == 2 && t == 1 ? -0.5 : 0.5);
+}
+__global__ __launch_bounds__(kT) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout,
+                                                       int mode, int64_t total) {
+  const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x; i < total + kZeroFloats;
+       i += static_cast<int64_t>(gridDim.x) * kT) {
+    if (i >= total) { wp[i] = 0.f; continue; }
+    int64_t r = i;
+    const int xx = static_cast<int>(r & 3); r >>= 2;
+    const int j = static_cast<int>(r & 31); r >>= 5;
+    const int kp = static_cast<int>(r & 1); r >>= 1;
+    const int xy = static_cast<int>(r & 3); r >>= 2;
+    const int kk = static_cast<int>(r % (K / 2)); r /= (K / 2);
+    const int xz = static_cast<int>(r & 3); r >>= 2;
+    const int cs = static_cast<int>(r);
+    const int k = 2 * kk + kp, n = cs * 32 + j;
+    double acc = 0.0;
+    for (int tz = 0; tz < 3; ++tz)
+      for (int ty = 0; ty < 3; ++ty)
+        for (int tx = 0; tx < 3; ++tx) {
+          const double c = gmat(xz, tz) * gmat(xy, ty) * gmat(xx, tx);
+          if (c == 0.0) continue;
+          const int tap = (tz * 3 + ty) * 3 + tx;
+          const float v = mode == 0 ? w[(static_cast<int64_t>(tap) * cin + k) * cout + n]
+                                    : w[(static_cast<int64_t>(26 - tap) * cin + n) * cout + k];
+          acc += c * static_cast<double>(v);
+        }
+    (void)N;
+    wp[i] = static_cast<float>(acc);
+  }
+}
+
+// ---- packed-fp32 helpers (VOP3P): one instruction = two lanes of the separable B^T transform --------------------------------
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// P = (x0,x1), Q = (x2,x3):  (x0 - x2, x1 + x2)
+__device__ __forceinline__ f32x2 pk_bt01(f32x2 p, f32x2 q) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(p), "v"(q));
+  return d;
+}
+// (x2 - x1, x1 - x3)
+__device__ __forceinline__ f32x2 pk_bt23(f32x2 p, f32x2 q) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(p), "v"(q));
+  return d;
+}
+
+__device__ unsigned long long g_wino_prof[32];
+
+struct BlockInfo {
+  const float* xh;     // &x[b][z0-1][y0-1][x0-1][0]: origin of the block's halo (may lie outside the tensor; masked)
+  int b, z0, y0, x0;
+};
+
+template <int DBG>
+__global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
+  __shared__ __attribute__((aligned(16))) float sIn[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = xi_z
+  const int r = lane & 31, kp = lane >> 5;
+
+  // ---- persistent worker -> (cout slice, sequence of tile blocks) ------------------------------------------------------------
+  // Workgroup g runs on XCD g % 8.  When the slice count divides 8 an XCD only ever sees ONE slice (its 1 MB of transformed
+  // weights stays L2-resident), its 32 workers walk 32 neighbouring tile blocks at a time (shared halos hit the L2) and the
+  // other slices of those blocks run at the same time on the neighbouring XCDs (Infinity Cache serves the repeats).
+  int cs, tb, tstride;
+  {
+    const int g = blockIdx.x, G = gridDim.x;
+    if ((8 % a.ncs) == 0 && (G & 7) == 0) {
+      const int xcd = g & 7, slot = g >> 3, per = 8 / a.ncs, wx = G >> 3;
+      cs = xcd % a.ncs;
+      tb = (xcd / a.ncs) * wx + slot;
+      tstride = per * wx;
+    } else {
+      const int nw = G / a.ncs;
+      cs = g % a.ncs;
+      tb = g / a.ncs;
+      tstride = nw;
+      if (tb >= nw) return;
+    }
+  }
+  if (tb >= a.ntb) return;
+  const int n0 = cs * 32;
+
+  auto decode = [&](int t) -> BlockInfo {
+    BlockInfo bi;
+    const int bx = t % a.nbx;
+    int t2 = t / a.nbx;
+    const int by = t2 % a.nby; t2 /= a.nby;
+    const int bz = t2 % a.nbz;
+    bi.b = t2 / a.nbz;
+    bi.z0 = bz * 4; bi.y0 = by * 8; bi.x0 = bx * 8;
+    bi.xh = a.x + (((static_cast<int64_t>(bi.b) * a.D + (bi.z0 - 1)) * a.H + (bi.y0 - 1)) * a.W + (bi.x0 - 1)) * a.Cin;
+    return bi;
+  };
+
+  // ---- staging plan (per thread: 10 float4 pieces of the 600-voxel x 16-channel halo block) ------------------------------
+  int roff[NLOAD], ldst[NLOAD], hpk[NLOAD];
+#pragma unroll
+  for (int it = 0; it < NLOAD; ++it) {
+    int p = it * kT + tid;
+    if (p > HV * 4 - 1) p = HV * 4 - 1;     // the tail threads of the last pass duplicate the last piece (same data, same slot)
+    const int hv = p >> 2, q4 = p & 3;
+    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+    roff[it] = ((hz * a.H + hy) * a.W + hx) * a.Cin + q4 * 4;
+    ldst[it] = (q4 * 4) * CP + hz * PZ + hy * PY + hx;
+    hpk[it] = hz | (hy << 8) | (hx << 16);
+  }
+  auto block_mask = [&](const BlockInfo& bi) -> unsigned {
+    unsigned m = 0;
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int gz = bi.z0 - 1 + (hpk[it] & 255), gy = bi.y0 - 1 + ((hpk[it] >> 8) & 255), gx = bi.x0 - 1 + (hpk[it] >> 16);
+      const bool ok = static_cast<unsigned>(gz) < static_cast<unsigned>(a.D) && static_cast<unsigned>(gy) < static_cast<unsigned>(a.H) &&
+                      static_cast<unsigned>(gx) < static_cast<unsigned>(a.W);
+      m |= ok ? (1u << it) : 0u;
+    }
+    return ((DBG & 4) || (a.dbg & 2)) ? 0u : m;
+  };
+  auto stage_load = [&](int it, const float* base, unsigned m) -> f32x4 {
+    const float* src = ((m >> it) & 1u) ? base + roff[it] : a.zeros;
+    return *reinterpret_cast<const f32x4*>(src);
+  };
+  auto stage_store = [&](int it, int bufoff, const f32x4& v) {
+    float* d = sIn + bufoff + ldst[it];
+    d[0] = v[0]; d[CP] = v[1]; d[2 * CP] = v[2]; d[3 * CP] = v[3];
+  };
+
+  // ---- A operand: this lane's tile, planes (za, zb) of xi_z ---------------------------------------------------------------
+  const int tx = r & 3, ty = (r >> 2) & 3, tz = r >> 4;
+  const int za = wave == 0 ? 0 : wave == 2 ? 2 : 1;
+  const int zb = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
+  const float qs = wave == 1 ? 1.f : -1.f;
+  const f32x2 qs2 = {qs, qs};
+  const int abase = kp * CP + (2 * tz) * PZ + (2 * ty) * PY + 2 * tx;
+  const int offA = abase + za * PZ, offB = abase + zb * PZ;
+
+  f32x2 ra[8], rb[8];      // raw inputs [y][x pair] of planes za / zb
+  f32x2 T[8], U[8];        // after the z / y transform
+  f32x2 A2[2][8];          // A operands of a k-step: A2[.][xi_y*2 + h] = (xi_x = 2h, 2h+1)
+  // one row (y) of raw reads for k-step `ks` of the buffer at dword offset `bo`
+  auto raw_row = [&](int ia, int ib, int y) {
+    ra[y * 2 + 0] = *reinterpret_cast<const f32x2*>(&sIn[ia + y * PY]);
+    ra[y * 2 + 1] = *reinterpret_cast<const f32x2*>(&sIn[ia + y * PY + 2]);
+    rb[y * 2 + 0] = *reinterpret_cast<const f32x2*>(&sIn[ib + y * PY]);
+    rb[y * 2 + 1] = *reinterpret_cast<const f32x2*>(&sIn[ib + y * PY + 2]);
+  };
+  auto stage1 = [&](int j) { T[j] = pk_fma(rb[j], qs2, ra[j]); };                       // j = y*2 + h
+  auto stage2 = [&](int k, int h) {                                                      // xi_y = k
+    U[k * 2 + h] = k == 0 ? pk_sub(T[0 + h], T[4 + h]) : k == 1 ? pk_add(T[2 + h], T[4 + h])
+                 : k == 2 ? pk_sub(T[4 + h], T[2 + h]) : pk_sub(T[2 + h], T[6 + h]);
+  };
+  auto stage3 = [&](int dst, int k) {
+    A2[dst][k * 2 + 0] = pk_bt01(U[k * 2], U[k * 2 + 1]);
+    A2[dst][k * 2 + 1] = pk_bt23(U[k * 2], U[k * 2 + 1]);
+  };
+
+  // ---- B operand ------------------------------------------------------------------------------------------------------------
+  const int nkk = a.Cin >> 1;
+  const f32x4* wbase = a.wp + (static_cast<int64_t>(cs) * 4 + wave) * nkk * 256;
+  f32x4 bq[2][4];
+  auto issue_b = [&](int slot, int kk) {
+    int k2 = kk < nkk ? kk : 0;             // wraps to the first k-step of the next tile block
+    const f32x4* p = wbase + static_cast<int64_t>(k2) * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[slot][q] = p[q * 64 + lane];
+  };
+
+  f32x16 acc[16];
+  const int nchunk = a.Cin / CKW;
+
+  // ---- prologue: first block's chunk 0 -> buffer 0, first A operands -----------------------------------------------------------
+  BlockInfo cur = decode(tb);
+  unsigned cmask = block_mask(cur);
+  {
+    f32x4 stg[NLOAD];
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, cur.xh, cmask);
+    issue_b(0, 0);
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) stage_store(it, 0, stg[it]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int y = 0; y < 4; ++y) raw_row(offA, offB, y);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) stage1(j);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { stage2(k, 0); stage2(k, 1); }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) stage3(0, k);
+#pragma unroll
+  for (int y = 0; y < 4; ++y) raw_row(offA + 2 * CP, offB + 2 * CP, y);
+
+  int pb = 0;          // buffer parity of the block's chunk 0
+  for (; tb < a.ntb; tb += tstride) {
+    const unsigned long long tp0 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
+    const int tbn = tb + tstride < a.ntb ? tb + tstride : tb;
+    const BlockInfo nxt = decode(tbn);
+    const unsigned nmask = block_mask(nxt);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    const unsigned long long tp1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      const int bo = ((chunk + pb) & 1) * BUF, bn = BUF - bo;        // dword offsets of this / the other buffer
+      const bool lastc = chunk + 1 == nchunk;
+      const float* sbase = lastc ? nxt.xh : cur.xh + (chunk + 1) * CKW;
+      const unsigned smask = lastc ? nmask : cmask;
+      f32x4 stg[NLOAD];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int c = ks & 1;
+        // LDS dword index of the raw reads issued in this k-step (k-step ks+2: this chunk, or the next one's first two)
+        // (kept opaque and in 8-byte units: the row reads become ds_read2_b64 with small immediate offsets)
+        int ia = ((ks < 6 ? bo + (ks + 2) * 2 * CP : bn + (ks - 6) * 2 * CP) + offA) >> 1;
+        int ib = ((ks < 6 ? bo + (ks + 2) * 2 * CP : bn + (ks - 6) * 2 * CP) + offB) >> 1;
+        asm volatile("" : "+v"(ia), "+v"(ib));
+        ia *= 2; ib *= 2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[c][i >> 1][i & 1], bq[c][i >> 2][i & 3], acc[i], 0, 0, 0);
+          if (i == 0 && !(DBG & 8)) issue_b(c ^ 1, chunk * 8 + ks + 1);
+          if (!(DBG & 1)) {
+            if (i < 4) { stage1(2 * i); stage1(2 * i + 1); }
+            else if (i < 8) { stage2(i - 4, 0); stage2(i - 4, 1); }
+            else if (i < 12) stage3(c ^ 1, i - 8);
+          }
+          if (ks == 6 && i == 3) __syncthreads();   // next chunk staged by everyone; everyone done reading this chunk's planes
+          if (i >= 4 && i < 8 && !(DBG & 2)) raw_row(ia, ib, i - 4);
+          if (i >= 12 && !(DBG & 4)) {
+            const int j = i - 12;
+            if (ks == 0) {
+              stg[j] = stage_load(j, sbase, smask);
+              stg[4 + j] = stage_load(4 + j, sbase, smask);
+              if (j < 2) stg[8 + j] = stage_load(8 + j, sbase, smask);
+            }
+            if (ks == 4 && j < 3) stage_store(j, bn, stg[j]);
+            if (ks == 4 && j == 3) { stage_store(3, bn, stg[3]); stage_store(4, bn, stg[4]); }
+            if (ks == 5 && j < 3) stage_store(5 + j, bn, stg[5 + j]);
+            if (ks == 5 && j == 3) { stage_store(8, bn, stg[8]); stage_store(9, bn, stg[9]); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+
+    const unsigned long long tp2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
+    // ---- epilogue: inverse transform in x, y per accumulator element; z across the waves through the idle LDS buffer ---------
+    // (the buffer of the last chunk is free since that chunk's ks = 6 barrier; the other one holds the next block's chunk 0)
+    {
+      const int lb = ((nchunk - 1 + pb) & 1) * BUF;
+      f32x4* sO = reinterpret_cast<f32x4*>(sIn + lb);      // [xi_z][e % 8][lane] float4 = (oy0ox0, oy0ox1, oy1ox0, oy1ox1)
+      const int col = n0 + r;
+      const float bv = (a.flags & DF_CONV_BIAS) ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+          const int e = half * 8 + e8;
+          float px[4][2];
+#pragma unroll
+          for (int yy = 0; yy < 4; ++yy) {
+            px[yy][0] = acc[yy * 4 + 0][e] + acc[yy * 4 + 1][e] + acc[yy * 4 + 2][e];
+            px[yy][1] = acc[yy * 4 + 1][e] - acc[yy * 4 + 2][e] - acc[yy * 4 + 3][e];
+          }
+          f32x4 o;
+          o[0] = px[0][0] + px[1][0] + px[2][0];
+          o[1] = px[0][1] + px[1][1] + px[2][1];
+          o[2] = px[1][0] - px[2][0] - px[3][0];
+          o[3] = px[1][1] - px[2][1] - px[3][1];
+          sO[(wave * 8 + e8) * 64 + lane] = o;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ee = 0; ee < 2; ++ee) {
+          const int e8 = wave * 2 + ee, e = half * 8 + e8;
+          const f32x4 m0 = sO[(0 * 8 + e8) * 64 + lane], m1 = sO[(1 * 8 + e8) * 64 + lane];
+          const f32x4 m2 = sO[(2 * 8 + e8) * 64 + lane], m3 = sO[(3 * 8 + e8) * 64 + lane];
+          const int tile = (e & 3) + 8 * (e >> 2) + 4 * kp;
+          const int ox0 = cur.x0 + 2 * (tile & 3), oy0 = cur.y0 + 2 * ((tile >> 2) & 3), oz0 = cur.z0 + 2 * (tile >> 4);
+#pragma unroll
+          for (int oz = 0; oz < 2; ++oz) {
+            const f32x4 v4 = oz == 0 ? m0 + m1 + m2 : m1 - m2 - m3;
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+              const int gz = oz0 + oz, gy = oy0 + (sx >> 1), gx = ox0 + (sx & 1);
+              if (gz < a.D && gy < a.H && gx < a.W) {
+                const int64_t o = (((static_cast<int64_t>(cur.b) * a.D + gz) * a.H + gy) * a.W + gx) * a.Cout + col;
+                float v = v4[sx] + bv;
+                if (a.flags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
+                if (a.flags & DF_CONV_RESIDUAL) v += a.residual[o];
+                if (a.flags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
+                a.y[o] = v;
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if ((DBG & 16) && blockIdx.x == 8 && tid == 0) {
+      const unsigned long long tp3 = __builtin_readcyclecounter();
+      g_wino_prof[0] += tp1 - tp0; g_wino_prof[1] += tp2 - tp1; g_wino_prof[2] += tp3 - tp2; g_wino_prof[3] += 1;
+    }
+    pb = (pb + nchunk) & 1;
+    cur = nxt;
+    cmask = nmask;
+  }
+}
+
+int g_wino_dbg = 0;
+}  // namespace
+
+extern "C" {
+
+void df_debug_set_wino(int v) { g_wino_dbg = v; }
+int df_debug_wino_prof(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_prof), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_prof), 32 * sizeof(unsigned long long));
+}
+
+int64_t df_wino_packed_elems(int64_t cin, int64_t cout, int mode) {
+  (void)mode;
+  return 64 * cin * cout + kZeroFloats;
+}
+
+int df_wino_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, int mode, df_stream_t stream) {
+  DF_REQUIRE(w && wp, DF_EINVAL, "df_wino_pack_weights: null pointer");
+  DF_REQUIRE(cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 && (mode == 0 || mode == 1), DF_ESHAPE,
+             "df_wino_pack_weights: cin, cout must be multiples of 32; mode 0|1");
+  const int64_t total = 64 * cin * cout;
+  int64_t g = ceil_div(total + kZeroFloats, kT);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)g), dim3(kT), 0, df::as_stream(stream), w, wp, (int)cin, (int)cout, mode,
+                     total);
+  return df::launched("df_wino_pack_weights");
+}
+
+int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
+                     float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak,
+                     df_stream_t stream) {
+  DF_REQUIRE(x && wp && y, DF_EINVAL, "df_wino_conv_fwd: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, DF_EINVAL, "df_wino_conv_fwd: non-positive extent");
+  DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE,
+             "df_wino_conv_fwd: Cin, Cout must be multiples of 32 (use df_conv_fwd otherwise)");
+  DF_REQUIRE(D * H * W * (Cin > Cout ? Cin : Cout) < (1LL << 31), DF_ESHAPE, "df_wino_conv_fwd: volume too large");
+  DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_BIAS without bias");
+  DF_REQUIRE(!(flags & DF_CONV_RESIDUAL) || residual, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_RESIDUAL without residual");
+  DF_REQUIRE(!(flags & DF_CONV_MASK) || mask_src, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_MASK without mask_src");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x), DF_EALIGN, "df_wino_conv_fwd: x and packed weights must be 16-byte aligned");
+  WinoArgs a;
+  a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
+  a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y;
+  a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.nbz = (int)ceil_div(D, 4); a.nby = (int)ceil_div(H, 8); a.nbx = (int)ceil_div(W, 8);
+  const int64_t ntb = B * a.nbz * a.nby * a.nbx;
+  a.ncs = (int)(Cout / 32);
+  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_conv_fwd: too many workgroups");
+  a.ntb = (int)ntb;
+  a.flags = flags; a.leak = leak; a.dbg = g_wino_dbg;
+  // persistent workers: one workgroup per CU (a workgroup owns a CU's whole register file and 111 KB of its LDS)
+  int64_t grid = df::kCUs;
+  if (8 % a.ncs == 0) {
+    const int64_t need = ceil_div(ntb, 8 / a.ncs) * 8;      // workers that get at least one tile block
+    if (need < grid) grid = need;
+  } else {
+    grid = (grid / a.ncs) * a.ncs;
+    if (ntb * a.ncs < grid) grid = ntb * a.ncs;
+  }
+  switch (g_wino_dbg >> 2) {
+    case 0: hipLaunchKernelGGL(wino3d_kernel<0>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 1: hipLaunchKernelGGL(wino3d_kernel<1>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 2: hipLaunchKernelGGL(wino3d_kernel<2>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 3: hipLaunchKernelGGL(wino3d_kernel<3>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 7: hipLaunchKernelGGL(wino3d_kernel<7>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 17: hipLaunchKernelGGL(wino3d_kernel<17>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 19: hipLaunchKernelGGL(wino3d_kernel<19>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 23: hipLaunchKernelGGL(wino3d_kernel<23>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 31: hipLaunchKernelGGL(wino3d_kernel<31>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 16: hipLaunchKernelGGL(wino3d_kernel<16>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 20: hipLaunchKernelGGL(wino3d_kernel<20>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 15: hipLaunchKernelGGL(wino3d_kernel<15>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    default: return df::fail(DF_EINVAL, "df_wino_conv_fwd: unknown debug variant");
+  }
+  return df::launched("df_wino_conv_fwd");
+}
+
+}  // extern "C"

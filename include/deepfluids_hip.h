@@ -183,6 +183,16 @@ int df_upconv_wgrad(const float* xc, const float* gy, float* gw, float* gb, int6
 int df_add_up2x(const float* a, const float* bc, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
                 df_stream_t stream);
 
+/* ---- Winograd F(2x2x2, 3x3x3) form of the 3-D stride-1 convolution (conv_wino.hip) ------------------------------------
+ * Same result as df_conv_fwd with kz = 3 up to fp32 rounding order (all arithmetic fp32, 3.4x fewer matrix-core FLOPs);
+ * same epilogue flags.  Needs Cin % 32 == 0 and Cout % 32 == 0.  Weights: TF layout [3,3,3,Cin,Cout], transformed and
+ * packed once per update by df_wino_pack_weights (mode 0: forward operand, mode 1: dgrad operand). */
+int64_t df_wino_packed_elems(int64_t cin, int64_t cout, int mode);
+int df_wino_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, int mode, df_stream_t stream);
+int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
+                     float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak,
+                     df_stream_t stream);
+
 /* ---- opt-in "bf16x3" precision mode (conv_bf16.hip) ---------------------------------------------------------------------
  * fp32 operands are split a = hi + lo into two bf16 words and a*b ~= hi*hi + hi*lo + lo*hi runs on the bf16 matrix pipe
  * (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate): 16 significand bits per operand, ~5x the fp32 MFMA rate.  Same arguments
