@@ -4,21 +4,23 @@
 //   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        per 2x2x2 output tile / 4x4x4 input tile, 64 transform points xi
 // = 64 independent GEMMs  M_xi[tile][cout] = sum_cin V_xi[tile][cin] * U_xi[cin][cout]:   8 MFMA MACs per output voxel
 // and (cin,cout) pair instead of 27 -> 3.375x fewer matrix-core FLOPs than the direct kernel (conv.hip); all arithmetic
-// stays fp32 (v_mfma_f32_32x32x2_f32 + exact +-1 / 0.5 transform factors), results differ from the direct sum only by
+// stays fp32 (v_mfma_f32_16x16x4_f32 + exact +-1 / 0.5 transform factors), results differ from the direct sum only by
 // fp32 rounding order (tests: same tolerance as the direct kernel against the fp64 oracle).
 //
-// Workgroup = 4 waves = one block of 2x4x4 tiles (4x8x8 output voxels) x 32 output channels.  Wave w owns the 16
-// transform points with xi_z = w (256 accumulator registers: the whole AGPR file at one wave per SIMD).
+// Persistent workgroup = 8 waves (two per SIMD: measured on gfx950, a wave's own VALU / LDS / VMEM instructions do NOT
+// overlap its own MFMAs -- a second wave on the SIMD is what keeps the matrix pipe busy) = one block of 2x4x4 tiles
+// (4x8x8 output voxels) x 32 output channels at a time.  Wave (xi_z, tz) owns the 16 transform points with that xi_z
+// for the 16 tiles of z-row tz: 32 MFMA 16x16x4 per k-step (4 input channels), 128 accumulator registers.
 //   * input: the 6x10x10 halo block of a 16-channel chunk is staged in LDS channel-major ([c][z*144 + y*12 + x], the
-//     pitches make every wave-wide ds_read_b64 below bank-conflict free), double buffered, one barrier per chunk.
-//   * A operand: lane = (tile, cin parity) reads the 2 z-planes x 4 x 4 inputs of its tile it needs for xi_z (16
-//     ds_read_b64), runs the separable B^T transform in registers (48 VALU ops) and so produces the 16 A values of one
-//     k-step (2 input channels) directly in MFMA A layout -- the transformed input never touches memory.
-//   * B operand: transformed weights U are packed [cout/32][xi_z][cin/2][xi_y][cin parity][cout%32][xi_x] so that a lane
-//     needs 4 coalesced 16-byte global loads (L2 hits) per k-step; nothing is staged for B.
-//   => per wave and k-step: 16 MFMA (1024 matrix-core cycles) + 48 VALU + 16 ds_read_b64 + 4 global_load_dwordx4.
-//   * epilogue: inverse transform in y,x in registers, the four xi_z partial planes are combined through LDS, then
-//     bias / lrelu / residual / lrelu-mask as in conv.hip.  The dgrad is the same kernel on mode-1 packed weights.
+//     pitches make every wave-wide ds_read2_b64 below bank-conflict free), double buffered, one barrier per chunk;
+//     the next tile block's first chunk is staged during the last chunk of the current one.
+//   * A operand: lane = (tile, cin%4) reads the 2 z-planes x 4 x 4 inputs of its tile that xi_z needs (8 ds_read2_b64),
+//     runs the separable B^T transform in registers (24 packed-fp32 VALU ops) and so produces the 16 A values of one
+//     k-step directly in MFMA A layout -- the transformed input never touches memory.
+//   * B operand: transformed weights U are packed [cout/32][xi_z][cin/4][cout/16%2][xi_y][cin%4][cout%16][xi_x] so that
+//     a lane needs 8 coalesced 16-byte global loads per k-step (L2 / L1 hits: the two tz waves read the same words).
+//   * epilogue: inverse transform in y,x in registers, the four xi_z partial planes are combined through the idle LDS
+//     buffer, then bias / lrelu / residual / lrelu-mask as in conv.hip.  The dgrad is the same kernel on mode-1 weights.
 #include "df_common.hpp"
 #include "conv_args.hpp"
 
@@ -29,12 +31,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kT = 256;
-constexpr int CKW = 16;                   // input channels per LDS chunk (8 k-steps)
+constexpr int kT = 512;                   // 8 waves: (xi_z, tile z-row)
+constexpr int kPackT = 256;
+constexpr int CKW = 16;                   // input channels per LDS chunk (4 k-steps)
 constexpr int PY = 12, PZ = 144;          // LDS pitches (dwords) of a channel plane: 6 z x 10 y x 10 x, padded
 constexpr int CP = 866;                   // dwords per channel plane (6*144 = 864, +2: staging writes spread over banks)
 constexpr int HY = 10, HX = 10, HV = 600; // halo block 6 x 10 x 10
-constexpr int NLOAD = 10;                 // ceil(600 * 4 float4 pieces / 256 threads)
+constexpr int NLOAD = 5;                  // ceil(600 * 4 float4 pieces / 512 threads)
 constexpr int BUF = CKW * CP;             // dwords per LDS buffer
 constexpr int kZeroFloats = 64;           // zeroed tail of the packed weights (SAME padding reads it)
 
@@ -56,25 +59,26 @@ struct WinoArgs {
 // ---- weight transform + packing ------------------------------------------------------------------------------------------
 // mode 0: g[tap][k][n] = w[tap][k][n]          (K = cin,  N = cout)
 // mode 1: g[tap][k][n] = w[26 - tap][n][k]     (K = cout, N = cin; taps mirrored)  -> dgrad operand
-// Up[cs][xz][kk][xy][kp][j][xx] = sum_taps G[xz][tz] G[xy][ty] G[xx][tx] g[tap][2kk+kp][32cs+j]
+// Up[cs][xz][k4][nb][xy][kq][j][xx] = sum_taps G[xz][tz] G[xy][ty] G[xx][tx] g[tap][4 k4 + kq][32 cs + 16 nb + j]
 __device__ __forceinline__ double gmat(int xi, int t) {
   return xi == 0 ? (t == 0 ? 1.0 : 0.0) : xi == 3 ? (t == 2 ? 1.0 : 0.0) : (xi == 2 && t == 1 ? -0.5 : 0.5);
 }
-__global__ __launch_bounds__(kT) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout,
-                                                       int mode, int64_t total) {
-  const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x; i < total + kZeroFloats;
-       i += static_cast<int64_t>(gridDim.x) * kT) {
+__global__ __launch_bounds__(kPackT) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout,
+                                                           int mode, int64_t total) {
+  const int K = mode == 0 ? cin : cout;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kPackT + threadIdx.x; i < total + kZeroFloats;
+       i += static_cast<int64_t>(gridDim.x) * kPackT) {
     if (i >= total) { wp[i] = 0.f; continue; }
     int64_t r = i;
     const int xx = static_cast<int>(r & 3); r >>= 2;
-    const int j = static_cast<int>(r & 31); r >>= 5;
-    const int kp = static_cast<int>(r & 1); r >>= 1;
+    const int j = static_cast<int>(r & 15); r >>= 4;
+    const int kq = static_cast<int>(r & 3); r >>= 2;
     const int xy = static_cast<int>(r & 3); r >>= 2;
-    const int kk = static_cast<int>(r % (K / 2)); r /= (K / 2);
+    const int nb = static_cast<int>(r & 1); r >>= 1;
+    const int k4 = static_cast<int>(r % (K / 4)); r /= (K / 4);
     const int xz = static_cast<int>(r & 3); r >>= 2;
     const int cs = static_cast<int>(r);
-    const int k = 2 * kk + kp, n = cs * 32 + j;
+    const int k = 4 * k4 + kq, n = cs * 32 + nb * 16 + j;
     double acc = 0.0;
     for (int tz = 0; tz < 3; ++tz)
       for (int ty = 0; ty < 3; ++ty)
@@ -86,7 +90,6 @@ __global__ __launch_bounds__(kT) void wino_pack_kernel(const float* __restrict__
                                     : w[(static_cast<int64_t>(26 - tap) * cin + n) * cout + k];
           acc += c * static_cast<double>(v);
         }
-    (void)N;
     wp[i] = static_cast<float>(acc);
   }
 }
@@ -133,8 +136,9 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = xi_z
-  const int r = lane & 31, kp = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xz = wave & 3, th = wave >> 2;      // xi_z; tile z-row
+  const int tl = lane & 15, kq = lane >> 4;     // tile within the row block (ty = tl >> 2, tx = tl & 3); cin % 4
 
   // ---- persistent worker -> (cout slice, sequence of tile blocks) ------------------------------------------------------------
   // Workgroup g runs on XCD g % 8.  When the slice count divides 8 an XCD only ever sees ONE slice (its 1 MB of transformed
@@ -171,8 +175,8 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     return bi;
   };
 
-  // ---- staging plan (per thread: 10 float4 pieces of the 600-voxel x 16-channel halo block) ------------------------------
-  int roff[NLOAD], ldst[NLOAD], hpk[NLOAD];
+  // ---- staging plan (per thread: 5 float4 pieces of the 600-voxel x 16-channel halo block) ---------------------------------
+  int roff[NLOAD], ldst[NLOAD];
 #pragma unroll
   for (int it = 0; it < NLOAD; ++it) {
     int p = it * kT + tid;
@@ -181,13 +185,16 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
     roff[it] = ((hz * a.H + hy) * a.W + hx) * a.Cin + q4 * 4;
     ldst[it] = (q4 * 4) * CP + hz * PZ + hy * PY + hx;
-    hpk[it] = hz | (hy << 8) | (hx << 16);
   }
   auto block_mask = [&](const BlockInfo& bi) -> unsigned {
     unsigned m = 0;
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
-      const int gz = bi.z0 - 1 + (hpk[it] & 255), gy = bi.y0 - 1 + ((hpk[it] >> 8) & 255), gx = bi.x0 - 1 + (hpk[it] >> 16);
+      int p = it * kT + tid;
+      if (p > HV * 4 - 1) p = HV * 4 - 1;
+      const int hv = p >> 2;
+      const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+      const int gz = bi.z0 - 1 + hz, gy = bi.y0 - 1 + hy, gx = bi.x0 - 1 + hx;
       const bool ok = static_cast<unsigned>(gz) < static_cast<unsigned>(a.D) && static_cast<unsigned>(gy) < static_cast<unsigned>(a.H) &&
                       static_cast<unsigned>(gx) < static_cast<unsigned>(a.W);
       m |= ok ? (1u << it) : 0u;
@@ -204,70 +211,71 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   };
 
   // ---- A operand: this lane's tile, planes (za, zb) of xi_z ---------------------------------------------------------------
-  const int tx = r & 3, ty = (r >> 2) & 3, tz = r >> 4;
-  const int za = wave == 0 ? 0 : wave == 2 ? 2 : 1;
-  const int zb = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
-  const float qs = wave == 1 ? 1.f : -1.f;
+  const int tx = tl & 3, ty = tl >> 2;
+  const int za = xz == 0 ? 0 : xz == 2 ? 2 : 1;
+  const int zb = xz == 0 ? 2 : xz == 1 ? 2 : xz == 2 ? 1 : 3;
+  const float qs = xz == 1 ? 1.f : -1.f;
   const f32x2 qs2 = {qs, qs};
-  const int abase = kp * CP + (2 * tz) * PZ + (2 * ty) * PY + 2 * tx;
+  const int abase = kq * CP + (2 * th) * PZ + (2 * ty) * PY + 2 * tx;
   const int offA = abase + za * PZ, offB = abase + zb * PZ;
 
   f32x2 ra[8], rb[8];      // raw inputs [y][x pair] of planes za / zb
   f32x2 T[8], U[8];        // after the z / y transform
-  f32x2 A2[2][8];          // A operands of a k-step: A2[.][xi_y*2 + h] = (xi_x = 2h, 2h+1)
-  // one row (y) of raw reads for k-step `ks` of the buffer at dword offset `bo`
-  auto raw_row = [&](int ia, int ib, int y) {
-    ra[y * 2 + 0] = *reinterpret_cast<const f32x2*>(&sIn[ia + y * PY]);
-    ra[y * 2 + 1] = *reinterpret_cast<const f32x2*>(&sIn[ia + y * PY + 2]);
-    rb[y * 2 + 0] = *reinterpret_cast<const f32x2*>(&sIn[ib + y * PY]);
-    rb[y * 2 + 1] = *reinterpret_cast<const f32x2*>(&sIn[ib + y * PY + 2]);
+  f32x2 A2[8];             // A operands of a k-step: A2[xi_y*2 + h] = (xi_x = 2h, 2h+1)
+  auto raw_read = [&](int idx) {     // idx: LDS dword index of plane (4 ks + kq) of the right buffer, without offA / offB
+    int ia = (idx + offA) >> 1, ib = (idx + offB) >> 1;
+    asm volatile("" : "+v"(ia), "+v"(ib));     // opaque, in 8-byte units: the reads become ds_read2_b64 with small immediates
+    ia *= 2; ib *= 2;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      ra[y * 2 + 0] = *reinterpret_cast<const f32x2*>(&sIn[ia + y * PY]);
+      ra[y * 2 + 1] = *reinterpret_cast<const f32x2*>(&sIn[ia + y * PY + 2]);
+      rb[y * 2 + 0] = *reinterpret_cast<const f32x2*>(&sIn[ib + y * PY]);
+      rb[y * 2 + 1] = *reinterpret_cast<const f32x2*>(&sIn[ib + y * PY + 2]);
+    }
   };
-  auto stage1 = [&](int j) { T[j] = pk_fma(rb[j], qs2, ra[j]); };                       // j = y*2 + h
-  auto stage2 = [&](int k, int h) {                                                      // xi_y = k
-    U[k * 2 + h] = k == 0 ? pk_sub(T[0 + h], T[4 + h]) : k == 1 ? pk_add(T[2 + h], T[4 + h])
-                 : k == 2 ? pk_sub(T[4 + h], T[2 + h]) : pk_sub(T[2 + h], T[6 + h]);
-  };
-  auto stage3 = [&](int dst, int k) {
-    A2[dst][k * 2 + 0] = pk_bt01(U[k * 2], U[k * 2 + 1]);
-    A2[dst][k * 2 + 1] = pk_bt23(U[k * 2], U[k * 2 + 1]);
+  auto transform = [&]() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) T[j] = pk_fma(rb[j], qs2, ra[j]);          // z
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                                           // y
+      U[0 + h] = pk_sub(T[0 + h], T[4 + h]);
+      U[2 + h] = pk_add(T[2 + h], T[4 + h]);
+      U[4 + h] = pk_sub(T[4 + h], T[2 + h]);
+      U[6 + h] = pk_sub(T[2 + h], T[6 + h]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                           // x
+      A2[k * 2 + 0] = pk_bt01(U[k * 2], U[k * 2 + 1]);
+      A2[k * 2 + 1] = pk_bt23(U[k * 2], U[k * 2 + 1]);
+    }
   };
 
   // ---- B operand ------------------------------------------------------------------------------------------------------------
-  const int nkk = a.Cin >> 1;
-  const f32x4* wbase = a.wp + (static_cast<int64_t>(cs) * 4 + wave) * nkk * 256;
-  f32x4 bq[2][4];
-  auto issue_b = [&](int slot, int kk) {
-    int k2 = kk < nkk ? kk : 0;             // wraps to the first k-step of the next tile block
-    const f32x4* p = wbase + static_cast<int64_t>(k2) * 256;
+  const int nk4 = a.Cin >> 2;
+  const f32x4* wbase = a.wp + (static_cast<int64_t>(cs) * 4 + xz) * nk4 * 512;
+  f32x4 bq[2][4];          // [cout 16-block][xi_y] = (xi_x 0..3)
+  auto issue_b = [&](int nb, int k4) {
+    const int k2 = k4 < nk4 ? k4 : 0;        // wraps to the first k-step of the next tile block
+    const f32x4* p = wbase + static_cast<int64_t>(k2) * 512 + nb * 256;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bq[slot][q] = p[q * 64 + lane];
+    for (int q = 0; q < 4; ++q) bq[nb][q] = p[q * 64 + lane];
   };
 
-  f32x16 acc[16];
+  f32x4 acc[2][16];
   const int nchunk = a.Cin / CKW;
 
-  // ---- prologue: first block's chunk 0 -> buffer 0, first A operands -----------------------------------------------------------
+  // ---- prologue: first block's chunk 0 -> buffer 0 ------------------------------------------------------------------------------
   BlockInfo cur = decode(tb);
   unsigned cmask = block_mask(cur);
   {
     f32x4 stg[NLOAD];
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, cur.xh, cmask);
-    issue_b(0, 0);
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) stage_store(it, 0, stg[it]);
   }
   __syncthreads();
-#pragma unroll
-  for (int y = 0; y < 4; ++y) raw_row(offA, offB, y);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) stage1(j);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { stage2(k, 0); stage2(k, 1); }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) stage3(0, k);
-#pragma unroll
-  for (int y = 0; y < 4; ++y) raw_row(offA + 2 * CP, offB + 2 * CP, y);
 
   int pb = 0;          // buffer parity of the block's chunk 0
   for (; tb < a.ntb; tb += tstride) {
@@ -276,9 +284,13 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const BlockInfo nxt = decode(tbn);
     const unsigned nmask = block_mask(nxt);
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+      for (int i = 0; i < 16; ++i) acc[nb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // nothing is prefetched across the epilogue (registers): first raw inputs / weights of this block
+    raw_read(pb * BUF);
+    issue_b(0, 0);
+    issue_b(1, 0);
 
     const unsigned long long tp1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -288,91 +300,88 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       const unsigned smask = lastc ? nmask : cmask;
       f32x4 stg[NLOAD];
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int c = ks & 1;
-        // LDS dword index of the raw reads issued in this k-step (k-step ks+2: this chunk, or the next one's first two)
-        // (kept opaque and in 8-byte units: the row reads become ds_read2_b64 with small immediate offsets)
-        int ia = ((ks < 6 ? bo + (ks + 2) * 2 * CP : bn + (ks - 6) * 2 * CP) + offA) >> 1;
-        int ib = ((ks < 6 ? bo + (ks + 2) * 2 * CP : bn + (ks - 6) * 2 * CP) + offB) >> 1;
-        asm volatile("" : "+v"(ia), "+v"(ib));
-        ia *= 2; ib *= 2;
+      for (int ks = 0; ks < 4; ++ks) {
+        // -- A operands of this k-step (its raw inputs were requested at the end of the previous one) --
+        if (!(DBG & 1)) transform();
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0 && !(DBG & 4)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[c][i >> 1][i & 1], bq[c][i >> 2][i & 3], acc[i], 0, 0, 0);
-          if (i == 0 && !(DBG & 8)) issue_b(c ^ 1, chunk * 8 + ks + 1);
-          if (!(DBG & 1)) {
-            if (i < 4) { stage1(2 * i); stage1(2 * i + 1); }
-            else if (i < 8) { stage2(i - 4, 0); stage2(i - 4, 1); }
-            else if (i < 12) stage3(c ^ 1, i - 8);
-          }
-          if (ks == 6 && i == 3) __syncthreads();   // next chunk staged by everyone; everyone done reading this chunk's planes
-          if (i >= 4 && i < 8 && !(DBG & 2)) raw_row(ia, ib, i - 4);
-          if (i >= 12 && !(DBG & 4)) {
-            const int j = i - 12;
-            if (ks == 0) {
-              stg[j] = stage_load(j, sbase, smask);
-              stg[4 + j] = stage_load(4 + j, sbase, smask);
-              if (j < 2) stg[8 + j] = stage_load(8 + j, sbase, smask);
-            }
-            if (ks == 4 && j < 3) stage_store(j, bn, stg[j]);
-            if (ks == 4 && j == 3) { stage_store(3, bn, stg[3]); stage_store(4, bn, stg[4]); }
-            if (ks == 5 && j < 3) stage_store(5 + j, bn, stg[5 + j]);
-            if (ks == 5 && j == 3) { stage_store(8, bn, stg[8]); stage_store(9, bn, stg[9]); }
-          }
-          __builtin_amdgcn_sched_barrier(0);
+          for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, sbase, smask);
         }
+        if (ks == 2 && !(DBG & 4)) {
+#pragma unroll
+          for (int it = 0; it < NLOAD; ++it) stage_store(it, bn, stg[it]);
+        }
+        if (ks == 3) __syncthreads();       // next chunk staged by everyone; everyone is done reading the planes it overwrote
+        if (!(DBG & 2)) raw_read(ks < 3 ? bo + (ks + 1) * 4 * CP : bn);     // raw inputs of the next k-step
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 8)) issue_b(0, chunk * 4 + ks + 1);       // weights of the next k-step, as each register block frees up
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 8)) issue_b(1, chunk * 4 + ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 
     const unsigned long long tp2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
     // ---- epilogue: inverse transform in x, y per accumulator element; z across the waves through the idle LDS buffer ---------
-    // (the buffer of the last chunk is free since that chunk's ks = 6 barrier; the other one holds the next block's chunk 0)
+    // (the buffer of the last chunk is free since that chunk's barrier; the other one holds the next block's chunk 0)
     {
       const int lb = ((nchunk - 1 + pb) & 1) * BUF;
-      f32x4* sO = reinterpret_cast<f32x4*>(sIn + lb);      // [xi_z][e % 8][lane] float4 = (oy0ox0, oy0ox1, oy1ox0, oy1ox1)
-      const int col = n0 + r;
-      const float bv = (a.flags & DF_CONV_BIAS) ? a.bias[col] : 0.f;
+      f32x4* sO = reinterpret_cast<f32x4*>(sIn + lb);      // [xi_z][tz][e][lane] float4 = (oy0ox0, oy0ox1, oy1ox0, oy1ox1)
+      // this wave combines accumulator element e = xi_z of its own z-row:  tile (ty = lane>>4, tx = e), cout = lane & 15
+      const int oz0 = cur.z0 + 2 * th, oy0 = cur.y0 + 2 * kq, ox0 = cur.x0 + 2 * xz;
+      const int64_t sW = a.Cout, sH = static_cast<int64_t>(a.W) * a.Cout, sD = sH * a.H;
+      const int64_t obase = (((static_cast<int64_t>(cur.b) * a.D + oz0) * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl;
+      const bool full = cur.z0 + 4 <= a.D && cur.y0 + 8 <= a.H && cur.x0 + 8 <= a.W;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int nb = 0; nb < 2; ++nb) {
+        const int col = n0 + nb * 16 + tl;
+        const float bv = (a.flags & DF_CONV_BIAS) ? a.bias[col] : 0.f;
+        float rres[8], rmask[8];
+        if (full) {
 #pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-          const int e = half * 8 + e8;
-          float px[4][2];
+          for (int s = 0; s < 8; ++s) {
+            const int64_t o = obase + nb * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW;
+            rres[s] = (a.flags & DF_CONV_RESIDUAL) ? a.residual[o] : 0.f;
+            rmask[s] = (a.flags & DF_CONV_MASK) ? a.mask_src[o] : 1.f;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f32x2 px[4];
 #pragma unroll
           for (int yy = 0; yy < 4; ++yy) {
-            px[yy][0] = acc[yy * 4 + 0][e] + acc[yy * 4 + 1][e] + acc[yy * 4 + 2][e];
-            px[yy][1] = acc[yy * 4 + 1][e] - acc[yy * 4 + 2][e] - acc[yy * 4 + 3][e];
+            px[yy][0] = acc[nb][yy * 4 + 0][e] + acc[nb][yy * 4 + 1][e] + acc[nb][yy * 4 + 2][e];
+            px[yy][1] = acc[nb][yy * 4 + 1][e] - acc[nb][yy * 4 + 2][e] - acc[nb][yy * 4 + 3][e];
           }
-          f32x4 o;
-          o[0] = px[0][0] + px[1][0] + px[2][0];
-          o[1] = px[0][1] + px[1][1] + px[2][1];
-          o[2] = px[1][0] - px[2][0] - px[3][0];
-          o[3] = px[1][1] - px[2][1] - px[3][1];
-          sO[(wave * 8 + e8) * 64 + lane] = o;
+          const f32x2 o01 = px[0] + px[1] + px[2], o23 = px[1] - px[2] - px[3];
+          sO[((xz * 2 + th) * 4 + e) * 64 + lane] = f32x4{o01[0], o01[1], o23[0], o23[1]};
         }
         __syncthreads();
+        const f32x4 m0 = sO[((0 * 2 + th) * 4 + xz) * 64 + lane], m1 = sO[((1 * 2 + th) * 4 + xz) * 64 + lane];
+        const f32x4 m2 = sO[((2 * 2 + th) * 4 + xz) * 64 + lane], m3 = sO[((3 * 2 + th) * 4 + xz) * 64 + lane];
+        const f32x4 lo = m0 + m1 + m2, hi = m1 - m2 - m3;
 #pragma unroll
-        for (int ee = 0; ee < 2; ++ee) {
-          const int e8 = wave * 2 + ee, e = half * 8 + e8;
-          const f32x4 m0 = sO[(0 * 8 + e8) * 64 + lane], m1 = sO[(1 * 8 + e8) * 64 + lane];
-          const f32x4 m2 = sO[(2 * 8 + e8) * 64 + lane], m3 = sO[(3 * 8 + e8) * 64 + lane];
-          const int tile = (e & 3) + 8 * (e >> 2) + 4 * kp;
-          const int ox0 = cur.x0 + 2 * (tile & 3), oy0 = cur.y0 + 2 * ((tile >> 2) & 3), oz0 = cur.z0 + 2 * (tile >> 4);
-#pragma unroll
-          for (int oz = 0; oz < 2; ++oz) {
-            const f32x4 v4 = oz == 0 ? m0 + m1 + m2 : m1 - m2 - m3;
-#pragma unroll
-            for (int sx = 0; sx < 4; ++sx) {
-              const int gz = oz0 + oz, gy = oy0 + (sx >> 1), gx = ox0 + (sx & 1);
-              if (gz < a.D && gy < a.H && gx < a.W) {
-                const int64_t o = (((static_cast<int64_t>(cur.b) * a.D + gz) * a.H + gy) * a.W + gx) * a.Cout + col;
-                float v = v4[sx] + bv;
-                if (a.flags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
-                if (a.flags & DF_CONV_RESIDUAL) v += a.residual[o];
-                if (a.flags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
-                a.y[o] = v;
-              }
-            }
+        for (int s = 0; s < 8; ++s) {
+          float v = (s < 4 ? lo[s & 3] : hi[s & 3]) + bv;
+          if (a.flags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
+          const int64_t o = obase + nb * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW;
+          if (full) {
+            if (a.flags & DF_CONV_RESIDUAL) v += rres[s];
+            if (a.flags & DF_CONV_MASK) v = rmask[s] > 0.f ? v : a.leak * v;
+            a.y[o] = v;
+          } else if (oz0 + (s >> 2) < a.D && oy0 + ((s >> 1) & 1) < a.H && ox0 + (s & 1) < a.W) {
+            if (a.flags & DF_CONV_RESIDUAL) v += a.residual[o];
+            if (a.flags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
+            a.y[o] = v;
           }
         }
         __syncthreads();
@@ -409,9 +418,9 @@ int df_wino_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, i
   DF_REQUIRE(cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 && (mode == 0 || mode == 1), DF_ESHAPE,
              "df_wino_pack_weights: cin, cout must be multiples of 32; mode 0|1");
   const int64_t total = 64 * cin * cout;
-  int64_t g = ceil_div(total + kZeroFloats, kT);
+  int64_t g = ceil_div(total + kZeroFloats, kPackT);
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)g), dim3(kT), 0, df::as_stream(stream), w, wp, (int)cin, (int)cout, mode,
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)g), dim3(kPackT), 0, df::as_stream(stream), w, wp, (int)cin, (int)cout, mode,
                      total);
   return df::launched("df_wino_pack_weights");
 }

@@ -198,7 +198,27 @@ def _sfx(cin, cout):
     return "_bf16x3" if (CONV_PRECISION == "bf16x3" and cin >= 16 and cout >= 16 and cin % 4 == 0) else ""
 
 
-def _pack(w, taps, cin, cout, mode):
+# Algorithm of the wide 3-D stride-1 convs (forward and dgrad), fp32 mode only:
+#   "auto"     Winograd F(2x2x2,3x3x3) (conv_wino.hip: same fp32 arithmetic, 3.4x fewer matrix FLOPs) where it applies
+#              (3-D, Cin and Cout multiples of 32, extents >= 8) and the direct implicit-GEMM kernel everywhere else;
+#   "direct"   always the direct kernel;   "winograd"  Winograd wherever the channel counts allow (tests).
+CONV_ALGO = "auto"
+
+
+def _use_wino(cin, cout, dims, kz):
+    if kz != 3 or CONV_ALGO == "direct" or CONV_PRECISION != "fp32" or cin % 32 or cout % 32:
+        return False
+    if CONV_ALGO == "winograd":
+        return True
+    return min(dims[1], dims[2], dims[3]) >= 8
+
+
+def _pack(w, taps, cin, cout, mode, dims=None):
+    """Packed MFMA operand of w for the stride-1 conv on `dims` (mode 0: forward, mode 1: dgrad)."""
+    if dims is not None and _use_wino(cin, cout, dims, 3 if taps == 27 else 1):
+        wp = torch.empty(query("df_wino_packed_elems", cin, cout, mode), dtype=torch.float32, device=w.device)
+        call("df_wino_pack_weights", _ptr(w), _ptr(wp), cin, cout, mode, _stream())
+        return wp
     sfx = _sfx(cin, cout)
     n = query("df_conv_packed_elems" + sfx, taps, cin, cout, mode)
     wp = torch.empty(n, dtype=torch.float32, device=w.device)
@@ -207,8 +227,13 @@ def _pack(w, taps, cin, cout, mode):
 
 
 def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak):
+    """`wp` must come from ``_pack(..., dims)`` with the same dims (the two agree on the algorithm)."""
     B, D, H, W = dims
     y = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
+    if _use_wino(cin, cout, dims, kz):
+        call("df_wino_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, D, H, W, cin, cout,
+             flags, float(leak), _stream())
+        return y
     call("df_conv_fwd" + _sfx(cin, cout), _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, D, H, W,
          cin, cout, kz, flags, float(leak), _stream())
     return y
@@ -227,7 +252,7 @@ class _ConvSame3(torch.autograd.Function):
         if tuple(w.shape[:-2]) != (3,) * nd or x.shape[-1] != cin:
             raise ValueError("conv: weights %s do not match input %s (k=3 only)" % (tuple(w.shape), tuple(x.shape)))
         dims = (x.shape[0], x.shape[1] if nd == 3 else 1, x.shape[-3], x.shape[-2])
-        wp = _pack(w, taps, cin, cout, 0)
+        wp = _pack(w, taps, cin, cout, 0, dims)
         flags = DF_CONV_BIAS | (DF_CONV_LRELU if leak is not None else 0)
         y = _conv_raw(x, wp, b, None, None, dims, cin, cout, kz, flags, leak if leak is not None else 0.0)
         y = y.view(x.shape[:-1] + (cout,))
@@ -255,7 +280,7 @@ class _ConvSame3(torch.autograd.Function):
              nbytes, _stream())
         gx = None
         if ctx.needs_input_grad[0]:
-            wpd = _pack(w, taps, cin, cout, 1)
+            wpd = _pack(w, taps, cin, cout, 1, dims)
             gx = _conv_raw(dp, wpd, None, None, None, dims, cout, cin, kz, 0, 0.0).view(x.shape)
         return gx, gw, gb, None
 
@@ -282,7 +307,7 @@ class _GenBlock(torch.autograd.Function):
             cin, cout = w.shape[-2], w.shape[-1]
             if tuple(w.shape[:-2]) != (3,) * nd or x.shape[-1] != cin:
                 raise ValueError("gen_block: weights %s do not match input %s" % (tuple(w.shape), tuple(x.shape)))
-            wp = _pack(w, taps, cin, cout, 0)
+            wp = _pack(w, taps, cin, cout, 0, dims)
             x = _conv_raw(x, wp, b, None, None, dims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak).view(
                 x0.shape[:-1] + (cout,))
             xs.append(x)
@@ -315,7 +340,7 @@ class _GenBlock(torch.autograd.Function):
             call("df_conv_wgrad" + _sfx(cin, cout), _ptr(xs[i - 1]), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz,
                  _ptr(wsb), nbytes, _stream())
             grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
-            wpd = _pack(w, taps, cin, cout, 1)
+            wpd = _pack(w, taps, cin, cout, 1, dims)
             if i > 1:      # dgrad, times the lrelu slope of the layer below: directly the next dp
                 dp = _conv_raw(dp, wpd, None, None, xs[i - 1], dims, cout, cin, kz, DF_CONV_MASK, leak).view(xs[i - 1].shape)
             elif ctx.needs_input_grad[0]:   # dgrad of the first layer + the skip gradient
@@ -356,7 +381,7 @@ class _UpGenBlock(torch.autograd.Function):
                 call("df_upconv_fwd" + sfx, _ptr(xc), _ptr(wp), _ptr(b), _ptr(x), cdims[0], cdims[1], cdims[2], cdims[3], cin, cout,
                      kz, DF_CONV_BIAS | DF_CONV_LRELU, float(leak), _stream())
             else:
-                wp = _pack(w, taps, cin, cout, 0)
+                wp = _pack(w, taps, cin, cout, 0, fdims)
                 x = _conv_raw(x, wp, b, None, None, fdims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak).view(fshape)
             xs.append(x)
         y = torch.empty_like(x)
@@ -385,7 +410,7 @@ class _UpGenBlock(torch.autograd.Function):
                 wsb = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
                 call("df_conv_wgrad" + _sfx(C, C), _ptr(xs[i - 2]), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, C, C, kz, _ptr(wsb),
                      nbytes, _stream())
-                wpd = _pack(w, taps, C, C, 1)
+                wpd = _pack(w, taps, C, C, 1, fdims)
                 dp = _conv_raw(dp, wpd, None, None, xs[i - 2], fdims, C, C, kz, DF_CONV_MASK, leak).view(dy.shape)
             else:
                 nbytes = query("df_upconv_wgrad_workspace_bytes", cdims[0], cdims[1], cdims[2], cdims[3], C, C, kz)
@@ -456,7 +481,7 @@ class _ConvSame3S2(torch.autograd.Function):
         call("df_conv_wgrad", _ptr(x), _ptr(up), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, _ptr(ws), nbytes, _stream())
         gx = None
         if ctx.needs_input_grad[0]:
-            wpd = _pack(w, taps, cin, cout, 1)
+            wpd = _pack(w, taps, cin, cout, 1, idims)
             gx = _conv_raw(up, wpd, None, None, None, idims, cout, cin, kz, 0, 0.0).view(x.shape)
         return gx, gw, gb, None
 

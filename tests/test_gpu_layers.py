@@ -74,6 +74,53 @@ CASES_2D = [
 ]
 
 
+WINO_CASES = [
+    ((1, 4, 8, 8), 32, 32, 0.2),        # exactly one tile block
+    ((2, 8, 16, 8), 64, 32, 0.2),       # Cin != Cout (forward and dgrad swap them)
+    ((1, 6, 10, 12), 32, 64, None),     # partial tile blocks in z, y and x; no activation
+    ((1, 5, 7, 9), 32, 32, 0.2),        # odd extents: half-filled 2x2x2 tiles at the upper faces
+    ((1, 8, 12, 8), 128, 128, 0.2),     # the hot layer's channel counts (8 chunks, 4 cout slices)
+    ((3, 4, 8, 16), 96, 96, 0.2),       # 3 cout slices: the generic (non XCD-pinned) worker mapping; odd chunk count
+]
+
+
+@pytest.mark.parametrize("shape,cin,cout,leak", WINO_CASES)
+def test_conv3d_winograd_fwd_bwd(ops, shape, cin, cout, leak):
+    """conv_wino.hip (forward and dgrad through _ConvSame3; the wgrad stays direct) against the fp64 oracle, same tolerance
+    as the direct kernel."""
+    old = ops.CONV_ALGO
+    ops.CONV_ALGO = "winograd"
+    try:
+        errs = _conv_case(ops, shape, cin, cout, leak, seed=cin * 3 + cout + sum(shape), mask_from_gpu=True)
+    finally:
+        ops.CONV_ALGO = old
+    assert max(errs.values()) < TOL, errs
+
+
+def test_winograd_fused_epilogues_match_direct(ops):
+    """bias / lrelu / residual / lrelu-mask epilogues of df_wino_conv_fwd vs df_conv_fwd on the same inputs."""
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream
+    rng = np.random.RandomState(11)
+    B, D, H, W, C, N = 2, 6, 8, 12, 64, 32
+    x = dev(rng.uniform(-1, 1, (B, D, H, W, C)).astype(np.float32))
+    w = dev((rng.uniform(-1, 1, (3, 3, 3, C, N)) / np.sqrt(27 * C)).astype(np.float32))
+    bias = dev(rng.uniform(-0.5, 0.5, N).astype(np.float32))
+    res = dev(rng.uniform(-1, 1, (B, D, H, W, N)).astype(np.float32))
+    msk = dev(rng.uniform(-1, 1, (B, D, H, W, N)).astype(np.float32))
+    wd = torch.empty(query("df_conv_packed_elems", 27, C, N, 0), device="cuda")
+    call("df_conv_pack_weights", _ptr(w), _ptr(wd), 27, C, N, 0, _stream())
+    ww = torch.empty(query("df_wino_packed_elems", C, N, 0), device="cuda")
+    call("df_wino_pack_weights", _ptr(w), _ptr(ww), C, N, 0, _stream())
+    for flags in (0, 8, 8 | 1, 2, 4, 8 | 1 | 2, 2 | 4, 8 | 1 | 2 | 4):
+        y0 = torch.empty((B, D, H, W, N), device="cuda"); y1 = torch.full_like(y0, float("nan"))
+        call("df_conv_fwd", _ptr(x), _ptr(wd), _ptr(bias), _ptr(res), _ptr(msk), _ptr(y0), B, D, H, W, C, N, 3, flags, 0.2, _stream())
+        call("df_wino_conv_fwd", _ptr(x), _ptr(ww), _ptr(bias), _ptr(res), _ptr(msk), _ptr(y1), B, D, H, W, C, N, flags, 0.2, _stream())
+        err = rel_linf(host(y1), host(y0))
+        # (an lrelu applied to a pre-activation within rounding of zero may pick the other branch: difference <= 1e-6 * scale)
+        assert err < 2e-5, (flags, err)
+
+
 @pytest.mark.parametrize("shape,cin,cout,leak", CASES_2D)
 def test_conv2d_fwd_bwd(ops, shape, cin, cout, leak):
     errs = _conv_case(ops, shape, cin, cout, leak, seed=cin * 5 + cout + sum(shape))
