@@ -30,6 +30,7 @@ using df::ceil_div;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kT = 512;                   // 8 waves: (xi_z, tile z-row)
 constexpr int kPackT = 256;
@@ -39,7 +40,7 @@ constexpr int CP = 866;                   // dwords per channel plane (6*144 = 8
 constexpr int HY = 10, HX = 10, HV = 600; // halo block 6 x 10 x 10
 constexpr int NLOAD = 5;                  // ceil(600 * 4 float4 pieces / 512 threads)
 constexpr int BUF = CKW * CP;             // dwords per LDS buffer
-constexpr int kZeroFloats = 64;           // zeroed tail of the packed weights (SAME padding reads it)
+constexpr int kZeroFloats = 1024;         // zeroed tail of the packed weights: SAME padding reads it, one 64-byte step per chunk
 
 struct WinoArgs {
   const float* x;
@@ -126,9 +127,18 @@ __device__ __forceinline__ f32x2 pk_bt23(f32x2 p, f32x2 q) {
 __device__ unsigned long long g_wino_prof[32];
 
 struct BlockInfo {
-  const float* xh;     // &x[b][z0-1][y0-1][x0-1][0]: origin of the block's halo (may lie outside the tensor; masked)
+  const float* xb;     // &x[b][0][0][0][0]
+  int hoff;            // element offset of the block's halo origin (z0-1, y0-1, x0-1) inside the batch volume (may be < 0)
   int b, z0, y0, x0;
 };
+
+// raw buffer descriptor (gfx9 data format word): out-of-range offsets read as zero -- the SAME padding of the staging loads
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
 
 template <int DBG>
 __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
@@ -171,42 +181,45 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const int bz = t2 % a.nbz;
     bi.b = t2 / a.nbz;
     bi.z0 = bz * 4; bi.y0 = by * 8; bi.x0 = bx * 8;
-    bi.xh = a.x + (((static_cast<int64_t>(bi.b) * a.D + (bi.z0 - 1)) * a.H + (bi.y0 - 1)) * a.W + (bi.x0 - 1)) * a.Cin;
+    bi.xb = a.x + static_cast<int64_t>(bi.b) * a.D * a.H * a.W * a.Cin;
+    bi.hoff = (((bi.z0 - 1) * a.H + (bi.y0 - 1)) * a.W + (bi.x0 - 1)) * a.Cin;
     return bi;
   };
 
   // ---- staging plan (per thread: 5 float4 pieces of the 600-voxel x 16-channel halo block) ---------------------------------
-  int roff[NLOAD], ldst[NLOAD];
+  // so[it] = byte offset of piece `it` inside the batch volume, or an out-of-range offset for halo voxels outside the tensor:
+  // the buffer load's range check then returns the zeros of the SAME padding.  Set once per tile block; a staging pass adds
+  // only the chunk's scalar offset.
+  int ldst[NLOAD];
+  unsigned so[NLOAD];
 #pragma unroll
   for (int it = 0; it < NLOAD; ++it) {
     int p = it * kT + tid;
     if (p > HV * 4 - 1) p = HV * 4 - 1;     // the tail threads of the last pass duplicate the last piece (same data, same slot)
     const int hv = p >> 2, q4 = p & 3;
     const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-    roff[it] = ((hz * a.H + hy) * a.W + hx) * a.Cin + q4 * 4;
-    ldst[it] = (q4 * 4) * CP + hz * PZ + hy * PY + hx;
+    ldst[it] = ((q4 * 4) * CP + hz * PZ + hy * PY + hx) * 4;          // bytes, buffer 0
   }
-  auto block_mask = [&](const BlockInfo& bi) -> unsigned {
-    unsigned m = 0;
+  const unsigned vol_bytes = static_cast<unsigned>(a.D) * a.H * a.W * a.Cin * 4u;
+  auto set_offs = [&](const BlockInfo& bi) {
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
       int p = it * kT + tid;
       if (p > HV * 4 - 1) p = HV * 4 - 1;
-      const int hv = p >> 2;
+      const int hv = p >> 2, q4 = p & 3;
       const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+      const int roff = ((hz * a.H + hy) * a.W + hx) * a.Cin + q4 * 4;
       const int gz = bi.z0 - 1 + hz, gy = bi.y0 - 1 + hy, gx = bi.x0 - 1 + hx;
-      const bool ok = static_cast<unsigned>(gz) < static_cast<unsigned>(a.D) && static_cast<unsigned>(gy) < static_cast<unsigned>(a.H) &&
-                      static_cast<unsigned>(gx) < static_cast<unsigned>(a.W);
-      m |= ok ? (1u << it) : 0u;
+      bool ok = static_cast<unsigned>(gz) < static_cast<unsigned>(a.D) && static_cast<unsigned>(gy) < static_cast<unsigned>(a.H) &&
+                static_cast<unsigned>(gx) < static_cast<unsigned>(a.W);
+      if ((DBG & 4) || (a.dbg & 2)) ok = false;
+      so[it] = ok ? static_cast<unsigned>(bi.hoff + roff) * 4u : 0x80000000u;
     }
-    return ((DBG & 4) || (a.dbg & 2)) ? 0u : m;
   };
-  auto stage_load = [&](int it, const float* base, unsigned m) -> f32x4 {
-    const float* src = ((m >> it) & 1u) ? base + roff[it] : a.zeros;
-    return *reinterpret_cast<const f32x4*>(src);
-  };
-  auto stage_store = [&](int it, int bufoff, const f32x4& v) {
-    float* d = sIn + bufoff + ldst[it];
+  auto stage_load = [&](int it, __amdgpu_buffer_rsrc_t srd, unsigned chunkbytes) -> f32x4 { return buf_load16(srd, so[it], chunkbytes); };
+  char* sInB = reinterpret_cast<char*>(sIn);
+  auto stage_store = [&](int it, int bufbytes, const f32x4& v) {
+    float* d = reinterpret_cast<float*>(sInB + (ldst[it] + bufbytes));
     d[0] = v[0]; d[CP] = v[1]; d[2 * CP] = v[2]; d[3 * CP] = v[3];
   };
 
@@ -222,16 +235,18 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   f32x2 ra[8], rb[8];      // raw inputs [y][x pair] of planes za / zb
   f32x2 T[8], U[8];        // after the z / y transform
   f32x2 A2[8];             // A operands of a k-step: A2[xi_y*2 + h] = (xi_x = 2h, 2h+1)
-  auto raw_read = [&](int idx) {     // idx: LDS dword index of plane (4 ks + kq) of the right buffer, without offA / offB
-    int ia = (idx + offA) >> 1, ib = (idx + offB) >> 1;
-    asm volatile("" : "+v"(ia), "+v"(ib));     // opaque, in 8-byte units: the reads become ds_read2_b64 with small immediates
-    ia *= 2; ib *= 2;
+  const int offAb = offA * 4, offBb = offB * 4;      // bytes (multiples of 8)
+  auto raw_read = [&](int idxbytes) {   // idxbytes: LDS byte offset of plane 4 ks (+ buffer), without this lane's offset
+    int ia = idxbytes + offAb, ib = idxbytes + offBb;
+    asm volatile("" : "+v"(ia), "+v"(ib));     // opaque: the 16 row reads become 8 ds_read2_b64 with small immediate offsets
+    __builtin_assume((ia & 7) == 0);
+    __builtin_assume((ib & 7) == 0);
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
-      ra[y * 2 + 0] = *reinterpret_cast<const f32x2*>(&sIn[ia + y * PY]);
-      ra[y * 2 + 1] = *reinterpret_cast<const f32x2*>(&sIn[ia + y * PY + 2]);
-      rb[y * 2 + 0] = *reinterpret_cast<const f32x2*>(&sIn[ib + y * PY]);
-      rb[y * 2 + 1] = *reinterpret_cast<const f32x2*>(&sIn[ib + y * PY + 2]);
+      ra[y * 2 + 0] = *reinterpret_cast<const f32x2*>(sInB + ia + (y * PY) * 4);
+      ra[y * 2 + 1] = *reinterpret_cast<const f32x2*>(sInB + ia + (y * PY + 2) * 4);
+      rb[y * 2 + 0] = *reinterpret_cast<const f32x2*>(sInB + ib + (y * PY) * 4);
+      rb[y * 2 + 1] = *reinterpret_cast<const f32x2*>(sInB + ib + (y * PY + 2) * 4);
     }
   };
   auto transform = [&]() {
@@ -253,13 +268,15 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
   // ---- B operand ------------------------------------------------------------------------------------------------------------
   const int nk4 = a.Cin >> 2;
-  const f32x4* wbase = a.wp + (static_cast<int64_t>(cs) * 4 + xz) * nk4 * 512;
   f32x4 bq[2][4];          // [cout 16-block][xi_y] = (xi_x 0..3)
+  const unsigned laneb = static_cast<unsigned>(lane) * 16u;
+  const __amdgpu_buffer_rsrc_t wsrd = make_srd(a.wp, static_cast<unsigned>(a.Cin) * a.Cout * 256u);
+  const unsigned wbase_b = static_cast<unsigned>((cs * 4 + xz) * nk4) * 8192u;
   auto issue_b = [&](int nb, int k4) {
     const int k2 = k4 < nk4 ? k4 : 0;        // wraps to the first k-step of the next tile block
-    const f32x4* p = wbase + static_cast<int64_t>(k2) * 512 + nb * 256;
+    const unsigned sb = wbase_b + static_cast<unsigned>(k2) * 8192u + nb * 4096u;      // wave-uniform
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bq[nb][q] = p[q * 64 + lane];
+    for (int q = 0; q < 4; ++q) bq[nb][q] = buf_load16(wsrd, laneb + q * 1024u, sb);
   };
 
   f32x4 acc[2][16];
@@ -267,11 +284,12 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
   // ---- prologue: first block's chunk 0 -> buffer 0 ------------------------------------------------------------------------------
   BlockInfo cur = decode(tb);
-  unsigned cmask = block_mask(cur);
+  set_offs(cur);
   {
+    const __amdgpu_buffer_rsrc_t srd0 = make_srd(cur.xb, vol_bytes);
     f32x4 stg[NLOAD];
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, cur.xh, cmask);
+    for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, srd0, 0u);
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) stage_store(it, 0, stg[it]);
   }
@@ -282,51 +300,69 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const unsigned long long tp0 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
     const int tbn = tb + tstride < a.ntb ? tb + tstride : tb;
     const BlockInfo nxt = decode(tbn);
-    const unsigned nmask = block_mask(nxt);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // nothing is prefetched across the epilogue (registers): first raw inputs / weights of this block
-    raw_read(pb * BUF);
+    raw_read(pb * BUF * 4);
     issue_b(0, 0);
     issue_b(1, 0);
 
     const unsigned long long tp1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long ph[4] = {0, 0, 0, 0};
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-      const int bo = ((chunk + pb) & 1) * BUF, bn = BUF - bo;        // dword offsets of this / the other buffer
+      const int bo = ((chunk + pb) & 1) * BUF * 4, bn = BUF * 4 - bo;        // byte offsets of this / the other buffer
       const bool lastc = chunk + 1 == nchunk;
-      const float* sbase = lastc ? nxt.xh : cur.xh + (chunk + 1) * CKW;
-      const unsigned smask = lastc ? nmask : cmask;
+      if (lastc) set_offs(nxt);                      // the last chunk stages the next tile block's first chunk
+      const __amdgpu_buffer_rsrc_t ssrd = make_srd(lastc ? nxt.xb : cur.xb, vol_bytes);
+      const unsigned schunk = lastc ? 0u : static_cast<unsigned>(chunk + 1) * (CKW * 4u);
       f32x4 stg[NLOAD];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        // -- A operands of this k-step (its raw inputs were requested at the end of the previous one) --
+        // -- A operands of this k-step (its raw inputs were requested during the previous one) --
+        const unsigned long long q0 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
+        if (DBG & 16) asm volatile("s_waitcnt lgkmcnt(0)");
+        const unsigned long long q1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (!(DBG & 1)) transform();
         __builtin_amdgcn_sched_barrier(0);
-        if (ks == 0 && !(DBG & 4)) {
-#pragma unroll
-          for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, sbase, smask);
-        }
-        if (ks == 2 && !(DBG & 4)) {
+        if (ks == 2 && !(DBG & 4) && !(DBG & 64)) {
 #pragma unroll
           for (int it = 0; it < NLOAD; ++it) stage_store(it, bn, stg[it]);
         }
+        if (ks == 2 && (DBG & 64)) {       // keep the loads alive without the LDS writes
+#pragma unroll
+          for (int it = 0; it < NLOAD; ++it) asm volatile("" :: "v"(stg[it]));
+        }
         if (ks == 3) __syncthreads();       // next chunk staged by everyone; everyone is done reading the planes it overwrote
-        if (!(DBG & 2)) raw_read(ks < 3 ? bo + (ks + 1) * 4 * CP : bn);     // raw inputs of the next k-step
+        if (!(DBG & 2)) raw_read(ks < 3 ? bo + (ks + 1) * 16 * CP : bn);     // raw inputs of the next k-step
         __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long q2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
+        if (DBG & 16) asm volatile("s_waitcnt vmcnt(4)");
+        const unsigned long long q3 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
+        if (DBG & 32) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (!(DBG & 8)) issue_b(0, chunk * 4 + ks + 1);       // weights of the next k-step, as each register block frees up
+        if (ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk: right behind a weight batch, so that the in-order vmcnt
+                                         // wait that first covers them is the one for the batch issued 16 MFMAs later
+#pragma unroll
+          for (int it = 0; it < NLOAD; ++it) stg[it] = (DBG & 128) ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (DBG & 32) __builtin_amdgcn_s_setprio(0);
         if (!(DBG & 8)) issue_b(1, chunk * 4 + ks + 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (DBG & 16) {
+          const unsigned long long q4 = __builtin_readcyclecounter();
+          ph[0] += q1 - q0; ph[1] += q2 - q1; ph[2] += q3 - q2; ph[3] += q4 - q3;
+        }
       }
     }
 
@@ -390,10 +426,10 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     if ((DBG & 16) && blockIdx.x == 8 && tid == 0) {
       const unsigned long long tp3 = __builtin_readcyclecounter();
       g_wino_prof[0] += tp1 - tp0; g_wino_prof[1] += tp2 - tp1; g_wino_prof[2] += tp3 - tp2; g_wino_prof[3] += 1;
+      for (int i = 0; i < 4; ++i) g_wino_prof[4 + i] += ph[i];
     }
     pb = (pb + nchunk) & 1;
     cur = nxt;
-    cmask = nmask;
   }
 }
 
@@ -432,7 +468,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
   DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, DF_EINVAL, "df_wino_conv_fwd: non-positive extent");
   DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE,
              "df_wino_conv_fwd: Cin, Cout must be multiples of 32 (use df_conv_fwd otherwise)");
-  DF_REQUIRE(D * H * W * (Cin > Cout ? Cin : Cout) < (1LL << 31), DF_ESHAPE, "df_wino_conv_fwd: volume too large");
+  DF_REQUIRE(D * H * W * (Cin > Cout ? Cin : Cout) < (1LL << 31) && Cin <= kZeroFloats, DF_ESHAPE, "df_wino_conv_fwd: volume too large");
   DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_BIAS without bias");
   DF_REQUIRE(!(flags & DF_CONV_RESIDUAL) || residual, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_RESIDUAL without residual");
   DF_REQUIRE(!(flags & DF_CONV_MASK) || mask_src, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_MASK without mask_src");
@@ -466,6 +502,14 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 19: hipLaunchKernelGGL(wino3d_kernel<19>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 23: hipLaunchKernelGGL(wino3d_kernel<23>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 31: hipLaunchKernelGGL(wino3d_kernel<31>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 18: hipLaunchKernelGGL(wino3d_kernel<18>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 24: hipLaunchKernelGGL(wino3d_kernel<24>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 25: hipLaunchKernelGGL(wino3d_kernel<25>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 27: hipLaunchKernelGGL(wino3d_kernel<27>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 32: hipLaunchKernelGGL(wino3d_kernel<32>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 48: hipLaunchKernelGGL(wino3d_kernel<48>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 80: hipLaunchKernelGGL(wino3d_kernel<80>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 144: hipLaunchKernelGGL(wino3d_kernel<144>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 16: hipLaunchKernelGGL(wino3d_kernel<16>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 20: hipLaunchKernelGGL(wino3d_kernel<20>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 15: hipLaunchKernelGGL(wino3d_kernel<15>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
