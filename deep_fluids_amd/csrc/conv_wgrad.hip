@@ -257,6 +257,209 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
+// ---- Winograd-in-x weight gradient ---------------------------------------------------------------------------------------------
+// F(2,3) along the image rows:  for an x-tile of two output positions (2t, 2t+1) and its four inputs d = X[2t-1 .. 2t+2],
+//   dU_xi += (B^T d)_xi * (A dy)_xi ,  xi = 0..3,    B^T d = (d0-d2, d1+d2, d2-d1, d1-d3),  A dy = (g0, g0+g1, g0-g1, -g1)
+//   gW[dx] = G^T dU :  gW0 = U0 + (U1+U2)/2,  gW1 = (U1-U2)/2,  gW2 = (U1+U2)/2 + U3
+// i.e. FOUR transform-domain products per two positions instead of 3 taps x 2 positions: 16 instead of 24 MFMAs per tile
+// (1.5x fewer matrix FLOPs), for 6 packed-fp32 transform ops per tile and lane.  Same decomposition, operand streaming and
+// register rings as wgrad_kernel (exact-row variants only: W == 8*WP8); the sign of U3 and the G^T combination are applied by
+// wgrad_wx_reduce_kernel.  All arithmetic fp32; differs from the direct sum by rounding order only.
+__device__ __forceinline__ f32x2 wpk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 wpk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+// CS > 0: Cin == Cout == CS at compile time (the operand position offsets become load immediates)
+template <int WP8, int CS>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_wx_kernel(const WgradArgs a) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nq = a.nqi * a.nqj;
+  const int qi = (wave % nq) / a.nqj, qj = (wave % nq) % a.nqj, sub = wave / nq;
+  constexpr int Wc = WP8 * 8;
+  const int half = lane >> 5, r = lane & 31;
+
+  const int nwg = a.nranges * a.ndzdy;
+  int wg;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, rem = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int range = wg / a.ndzdy, dzdy = wg % a.ndzdy;
+  const int dz = a.ndzdy == 9 ? dzdy / 3 - 1 : 0;
+  const int dy = (a.ndzdy == 9 ? dzdy % 3 : dzdy) - 1;
+  const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
+  if (ci0 >= a.Cin || co0 >= a.Cout) return;   // wave-uniform: quadrant entirely in the padding
+
+  const int ppe = (a.pairs_per_range + a.nsub - 1) / a.nsub;
+  const int p0 = range * a.pairs_per_range + sub * ppe;
+  int p1 = p0 + ppe;
+  if (p1 > (range + 1) * a.pairs_per_range) p1 = (range + 1) * a.pairs_per_range;
+  if (p1 > a.npairs) p1 = a.npairs;
+  const int erange = range * a.nsub + sub;
+
+  const int cia = ci0 + 2 * r, coa = co0 + 2 * r;
+  const bool ci_ok0 = cia < a.Cin, co_ok0 = coa < a.Cout;
+  const float* zb = a.zeros;
+  struct Row { const float* xb; const float* gb; };
+  auto row_setup = [&](int pair) -> Row {      // invalid rows / padded channel lanes point at the zeroed row-sized region
+    Row rw;
+    const int row = 2 * pair + half;
+    const bool ok = pair < p1 && row < a.nrows;
+    const int y = row % a.H;
+    const int t = row / a.H;
+    const int z = t % a.D;
+    const int b = t / a.D;
+    const int zs = z + dz, ys = y + dy;
+    const bool xv = ok && zs >= 0 && zs < a.D && ys >= 0 && ys < a.H;
+    const int64_t gvox = ((static_cast<int64_t>(b) * a.D + z) * a.H + y) * a.W;
+    const int64_t xvox = ((static_cast<int64_t>(b) * a.D + zs) * a.H + ys) * a.W;
+    rw.gb = (ok && co_ok0) ? a.g + gvox * a.Cout + coa : zb;
+    rw.xb = (xv && ci_ok0) ? a.x + xvox * a.Cin + cia : zb;
+    return rw;
+  };
+  const int xs = CS ? CS : a.Cin, gs = CS ? CS : a.Cout;
+  auto load_x = [&](const Row& rw, int pos) -> f32x2 { return *reinterpret_cast<const f32x2*>(rw.xb + static_cast<int64_t>(pos) * xs); };
+  auto load_g = [&](const Row& rw, int pos) -> f32x2 { return *reinterpret_cast<const f32x2*>(rw.gb + static_cast<int64_t>(pos) * gs); };
+
+  f32x16 acc[4][2][2];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][s][t][e] = 0.f;
+  f32x2 bsum = {0.f, 0.f};
+  const bool do_bias = a.want_bias && dzdy == a.ndzdy / 2 && blockIdx.y == 0 && qi == 0;
+
+  // rings indexed by (position in row) % 8: X holds positions x-1 .. x+5 (+ the two being fetched), G x .. x+5
+  f32x2 xr[8], gr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { xr[i] = f32x2{0.f, 0.f}; gr[i] = f32x2{0.f, 0.f}; }
+  Row cur = row_setup(p0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { xr[i] = load_x(cur, i); gr[i] = load_g(cur, i); }
+
+  // one x-tile: positions x, x+1 (ring slots u, u+1; u even).  `nx`/`ng` = the four loads issued behind the transform.
+  auto tile = [&](int u, int x, const Row& lr, int lpos) {
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 dm = xr[(u + 7) & 7], d0 = xr[u], d1 = xr[(u + 1) & 7], d2 = xr[(u + 2) & 7];
+    const f32x2 g0 = gr[u], g1 = gr[(u + 1) & 7];
+    if (x == 0) dm = f32x2{0.f, 0.f};            // left zero padding (the slot holds the previous row's tail)
+    if (x == Wc - 2) d2 = f32x2{0.f, 0.f};       // right zero padding (the slot holds the next row's head)
+    const f32x2 v0 = wpk_sub(dm, d1), v1 = wpk_add(d0, d1), v2 = wpk_sub(d1, d0), v3 = wpk_sub(d0, d2);
+    const f32x2 m1 = wpk_add(g0, g1), m2 = wpk_sub(g0, g1);
+    bsum = wpk_add(bsum, m1);
+    __builtin_amdgcn_sched_barrier(0);
+    xr[(u + 6) & 7] = load_x(lr, lpos);          // positions x+6, x+7 (slot u+7 held d[-1], consumed above)
+    xr[(u + 7) & 7] = load_x(lr, lpos + 1);
+    gr[(u + 6) & 7] = load_g(lr, lpos);
+    gr[(u + 7) & 7] = load_g(lr, lpos + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[0][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[s], g0[t], acc[0][s][t], 0, 0, 0);
+        acc[1][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[s], m1[t], acc[1][s][t], 0, 0, 0);
+        acc[2][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[s], m2[t], acc[2][s][t], 0, 0, 0);
+        acc[3][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3[s], g1[t], acc[3][s][t], 0, 0, 0);
+      }
+  };
+
+  for (int pair = p0; pair < p1; ++pair) {
+    const Row nxt = row_setup(pair + 1);
+#pragma unroll
+    for (int x0 = 0; x0 < Wc - 8; x0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) tile(u, x0 + u, cur, x0 + u + 6);
+    }
+    {   // last 8 positions of the row: the prefetch cursor crosses into the next row pair
+      constexpr int x0 = Wc - 8;
+      tile(0, x0, cur, x0 + 6);
+#pragma unroll
+      for (int u = 2; u < 8; u += 2) tile(u, x0 + u, nxt, u - 2);
+    }
+    cur = nxt;
+  }
+
+  // ---- partial: 4 transform-domain slots per (dz,dy); D layout as in wgrad_kernel ---------------------------------------------
+  float* P = a.partial + static_cast<int64_t>(erange) * a.ndzdy * 4 * a.Cinp * a.Coutp;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int slot = dzdy * 4 + d;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int ci = ci0 + 2 * i + s, co = co0 + 2 * r + t;
+          P[(static_cast<int64_t>(slot) * a.Cinp + ci) * a.Coutp + co] = acc[d][s][t][e];
+        }
+  }
+  if (do_bias) {
+    bsum[0] += __shfl_xor(bsum[0], 32, 64);
+    bsum[1] += __shfl_xor(bsum[1], 32, 64);
+    if (half == 0) {
+      float* pb = a.bpartial + static_cast<int64_t>(erange) * a.Coutp + co0 + 2 * r;
+      pb[0] = bsum[0]; pb[1] = bsum[1];
+    }
+  }
+}
+
+// gw[dzdy][dx][ci][co] from the summed (fixed order) transform-domain partials U0..U3 (U3 was accumulated with +g1)
+__global__ __launch_bounds__(kThreads) void wgrad_wx_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
+                                                                   float* __restrict__ gw, float* __restrict__ gb, int nranges,
+                                                                   int ndzdy, int Cin, int Cout, int Cinp, int Coutp) {
+  const int64_t total = static_cast<int64_t>(ndzdy) * Cin * Cout;
+  const int64_t slot = static_cast<int64_t>(Cinp) * Coutp;
+  const int64_t pstride = static_cast<int64_t>(ndzdy) * 4 * slot;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int co = static_cast<int>(i % Cout);
+    const int64_t t2 = i / Cout;
+    const int ci = static_cast<int>(t2 % Cin);
+    const int dzdy = static_cast<int>(t2 / Cin);
+    const float* p = partial + (static_cast<int64_t>(dzdy) * 4 * Cinp + ci) * Coutp + co;
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+    for (int rg = 0; rg < nranges; ++rg) {
+      const float* q = p + rg * pstride;
+      u0 += q[0]; u1 += q[slot]; u2 += q[2 * slot]; u3 += q[3 * slot];
+    }
+    const float h = 0.5f * (u1 + u2);
+    float* o = gw + (static_cast<int64_t>(dzdy) * 3 * Cin + ci) * Cout + co;
+    o[0] = u0 + h;
+    o[static_cast<int64_t>(Cin) * Cout] = 0.5f * (u1 - u2);
+    o[2 * static_cast<int64_t>(Cin) * Cout] = h - u3;
+  }
+  if (gb && blockIdx.x == 0) {
+    for (int co = threadIdx.x; co < Cout; co += kThreads) {
+      float acc = 0.f;
+      for (int rg = 0; rg < nranges; ++rg) acc += bpartial[static_cast<int64_t>(rg) * Coutp + co];
+      gb[co] = acc;
+    }
+  }
+}
+
+// the Winograd-in-x variant exists for the fully unrolled row lengths below (even channel counts: float2 operand loads)
+inline bool wx_ok(int64_t W, int64_t Cin, int64_t Cout) {
+  return (W == 16 || W == 32 || W == 64) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
+}
+int g_wgrad_algo = 0;     // 0: Winograd-in-x where available, 1: always the direct kernel (df_debug_set_wgrad_algo)
+
 // ---- bf16x3 weight gradient (opt-in precision mode, see conv_bf16.hip) ---------------------------------------------------
 // Same decomposition as wgrad_kernel (workgroup = (voxel range, (dz,dy) group), wave = 64x64 (ci,co) quadrant x 3 dx taps,
 // operands straight from L1/L2), on v_mfma_f32_32x32x16_bf16: K = 16 consecutive voxels of ONE image row per instruction
@@ -720,7 +923,6 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   // The kernel runs ONE workgroup per CU (192 accumulator registers per lane): a grid that is not a multiple
   // of 256 leaves most of the chip idle in its last round.  256 equal voxel ranges x (9 | 3) (dz,dy) groups is
   // exactly 9 | 3 full rounds; smaller problems get one range per row pair.
-  (void)W;
   int nr = p.npairs >= kMaxRanges ? kMaxRanges : p.npairs;
   p.ppr = (p.npairs + nr - 1) / nr;
   p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
@@ -728,7 +930,8 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   p.Coutp = (int)(ceil_div(Cout, 64) * 64);
   p.nqi = Cin <= 64 ? 1 : 2; p.nqj = Cout <= 64 ? 1 : 2;
   p.nsub = 4 / (p.nqi * p.nqj);
-  p.partial_elems = static_cast<int64_t>(p.nranges) * p.nsub * p.taps * p.Cinp * p.Coutp;
+  const int slots = wx_ok(W, Cin, Cout) ? p.ndzdy * 4 : p.taps;       // the Winograd-in-x kernel writes 4 slots per (dz,dy)
+  p.partial_elems = static_cast<int64_t>(p.nranges) * p.nsub * slots * p.Cinp * p.Coutp;
   p.bpartial_elems = static_cast<int64_t>(p.nranges) * p.nsub * p.Coutp;
   return p;
 }
@@ -802,6 +1005,20 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
   if (prec == 1 && xvec && gvec && wgrad_bf16x3_ok(W, Cin, Cout)) {
     launch_wgrad_bf16x3(W, grid, s, a);
+  } else if (prec == 0 && g_wgrad_algo == 0 && xvec && gvec && wx_ok(W, Cin, Cout)) {
+    const bool c128 = Cin == 128 && Cout == 128;
+    if (W == 64 && c128) hipLaunchKernelGGL((wgrad_wx_kernel<8, 128>), grid, dim3(kThreads), 0, s, a);
+    else if (W == 64) hipLaunchKernelGGL((wgrad_wx_kernel<8, 0>), grid, dim3(kThreads), 0, s, a);
+    else if (W == 32 && c128) hipLaunchKernelGGL((wgrad_wx_kernel<4, 128>), grid, dim3(kThreads), 0, s, a);
+    else if (W == 32) hipLaunchKernelGGL((wgrad_wx_kernel<4, 0>), grid, dim3(kThreads), 0, s, a);
+    else if (c128) hipLaunchKernelGGL((wgrad_wx_kernel<2, 128>), grid, dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_wx_kernel<2, 0>), grid, dim3(kThreads), 0, s, a);
+    const int64_t tot = static_cast<int64_t>(p.ndzdy) * Cin * Cout;
+    int64_t rgx = ceil_div(tot, kThreads);
+    if (rgx > 2048) rgx = 2048;
+    hipLaunchKernelGGL(wgrad_wx_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
+                       p.nranges * p.nsub, p.ndzdy, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
+    return df::launched("df_conv_wgrad(winograd-x)");
   } else {
   const int wp8 = a.Wp / 8;
   const bool exact = (W % 8) == 0;
@@ -823,6 +1040,8 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
                      p.nranges * p.nsub, p.taps, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
   return df::launched("df_conv_wgrad");
 }
+
+void df_debug_set_wgrad_algo(int v) { g_wgrad_algo = v; }
 
 int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
                   int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {

@@ -56,6 +56,8 @@ CASES_3D = [
     ((1, 2, 2, 64), 16, 16, None),
     ((1, 2, 2, 112), 16, 16, 0.2),
     ((3, 2, 2, 64), 128, 128, 0.2),     # odd row count (12 rows -> 6 pairs; 3 batches) at W = 64
+    ((2, 3, 5, 16), 32, 96, 0.2),       # W = 16: the third Winograd-in-x wgrad row variant; Cout not a multiple of 64
+    ((1, 4, 4, 64), 64, 64, None),      # single 64x64 quadrant (the spare waves split the voxel range)
 ]
 
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Direct vs Winograd-in-x weight gradient: difference and timing (gpurun tuning aid)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deep_fluids_amd._lib import call, query, lib  # noqa: E402
+from deep_fluids_amd.ops import _ptr, _stream  # noqa: E402
+from tools.gpu_probe import timeit  # noqa: E402
+
+
+def run(B, D, H, W, C, N, kz=3, iters=3):
+    torch.manual_seed(0)
+    s = _stream()
+    x = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    g = torch.rand((B, D, H, W, N), device="cuda") * 2 - 1
+    taps = 27 if kz == 3 else 9
+    nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, N, kz)
+    ws = torch.empty((nb + 3) // 4, device="cuda")
+    out = []
+    for algo in (1, 0):
+        lib().df_debug_set_wgrad_algo(ctypes.c_int(algo))
+        gw = torch.empty((taps, C, N), device="cuda"); gb = torch.empty(N, device="cuda")
+        f = lambda: call("df_conv_wgrad", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, N, kz, _ptr(ws), nb, s)
+        f(); torch.cuda.synchronize()
+        t = timeit(f, iters, 1)
+        out.append((gw.clone(), gb.clone(), t))
+    lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+    (w0, b0, t0), (w1, b1, t1) = out
+    fl = 2.0 * taps * C * N * B * D * H * W
+    print("B%d %dx%dx%d C%d N%d: gw rel-linf %.2e  gb %.2e | direct %.3f ms (%.0f TF)  wino-x %.3f ms (%.0f TF-eq)" % (
+        B, D, H, W, C, N, ((w0 - w1).abs().max() / w0.abs().max()).item(), ((b0 - b1).abs().max() / b0.abs().max()).item(),
+        t0 * 1e3, fl / t0 / 1e12, t1 * 1e3, fl / t1 / 1e12), flush=True)
+
+
+if __name__ == "__main__":
+    run(1, 4, 6, 16, 32, 32)
+    run(2, 16, 24, 16, 128, 128)
+    run(2, 32, 48, 32, 128, 128)
+    run(4, 64, 96, 64, 128, 128)
+    run(16, 1, 96, 64, 128, 128, kz=1)
