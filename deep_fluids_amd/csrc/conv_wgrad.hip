@@ -454,11 +454,248 @@ __global__ __launch_bounds__(kThreads) void wgrad_wx_reduce_kernel(const float* 
   }
 }
 
+// ---- Winograd-in-(x,y) weight gradient -------------------------------------------------------------------------------------------
+// F(2x2,3x3) over the image plane, direct in z: tile = 2x2 output positions, 4x4 inputs.  A workgroup owns ONE (dz, xi_y) and the
+// four xi_x of wgrad_wx_kernel; the y part of both transforms is a two-row combination with workgroup-uniform coefficients,
+//   X_c = X[row a] + sx * X[row b],   G_c = G[row a] + sg * G[row b]
+//   xi_y = 0: X rows (2t-1, 2t+1, -1), G (2t, -, 0) | 1: (2t, 2t+1, +1), (2t, 2t+1, +1) | 2: (2t+1, 2t, -1), (2t, 2t+1, -1)
+//          3: (2t, 2t+2, -1), (2t+1, -, 0)   [true (A dy)_3 = -g1: the sign is applied by the reduce kernel, as for xi_x = 3]
+// after which a tile row is processed exactly like an image row of the x-only kernel: 3*16 = 48 transform-domain products per 2x2
+// positions instead of 27*4 = 108 (2.25x fewer matrix FLOPs), 11 packed-fp32 ops and 8 8-byte loads per x-tile and lane.
+// The two half-waves walk two different tile rows.  H, W even; exact-row variants only.
+struct WxyArgs {
+  WgradArgs w;
+  int Ht, ntrows;      // tile rows per (b,z) = H/2; B*D*Ht
+};
+
+template <int WP8, int CS>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_wxy_kernel(const WxyArgs aa) {
+  const WgradArgs& a = aa.w;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nq = a.nqi * a.nqj;
+  const int qi = (wave % nq) / a.nqj, qj = (wave % nq) % a.nqj, sub = wave / nq;
+  constexpr int Wc = WP8 * 8;
+  const int half = lane >> 5, r = lane & 31;
+
+  const int nwg = a.nranges * a.ndzdy;          // ndzdy = (3 | 1) dz x 4 xi_y
+  int wg;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, rem = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int range = wg / a.ndzdy, dzxy = wg % a.ndzdy;
+  const int dz = a.ndzdy == 12 ? dzxy / 4 - 1 : 0;
+  const int xiy = dzxy & 3;
+  const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
+  if (ci0 >= a.Cin || co0 >= a.Cout) return;
+
+  const int ppe = (a.pairs_per_range + a.nsub - 1) / a.nsub;
+  const int p0 = range * a.pairs_per_range + sub * ppe;
+  int p1 = p0 + ppe;
+  if (p1 > (range + 1) * a.pairs_per_range) p1 = (range + 1) * a.pairs_per_range;
+  if (p1 > a.npairs) p1 = a.npairs;
+  const int erange = range * a.nsub + sub;
+
+  const int cia = ci0 + 2 * r, coa = co0 + 2 * r;
+  const bool ci_ok0 = cia < a.Cin, co_ok0 = coa < a.Cout;
+  const float* zb = a.zeros;
+  // row offsets (relative to 2t) and coefficients of this workgroup's xi_y
+  const int xoa = xiy == 0 ? -1 : xiy == 2 ? 1 : 0, xob = xiy == 0 ? 1 : xiy == 1 ? 1 : xiy == 2 ? 0 : 2;
+  const float sxf = xiy == 1 ? 1.f : -1.f;
+  const int goa = xiy == 3 ? 1 : 0;
+  const float sgf = xiy == 1 ? 1.f : xiy == 2 ? -1.f : 0.f;
+  const f32x2 sx2 = {sxf, sxf}, sg2 = {sgf, sgf};
+  struct Row { const float* xa; const float* xb; const float* ga; const float* gb; };
+  auto row_setup = [&](int pair) -> Row {
+    Row rw;
+    const int trow = 2 * pair + half;
+    const bool ok = pair < p1 && trow < aa.ntrows;
+    const int yt = trow % aa.Ht;
+    const int t = trow / aa.Ht;
+    const int z = t % a.D;
+    const int b = t / a.D;
+    const int zs = z + dz, y0 = 2 * yt;
+    const bool zv = ok && zs >= 0 && zs < a.D;
+    const int ya = y0 + xoa, yb = y0 + xob;
+    const int64_t gbase = (static_cast<int64_t>(b) * a.D + z) * a.H;
+    const int64_t xbase = (static_cast<int64_t>(b) * a.D + zs) * a.H;
+    rw.xa = (zv && ya >= 0 && ya < a.H && ci_ok0) ? a.x + (xbase + ya) * a.W * a.Cin + cia : zb;
+    rw.xb = (zv && yb >= 0 && yb < a.H && ci_ok0) ? a.x + (xbase + yb) * a.W * a.Cin + cia : zb;
+    rw.ga = (ok && co_ok0) ? a.g + (gbase + y0 + goa) * a.W * a.Cout + coa : zb;
+    rw.gb = (ok && co_ok0 && sgf != 0.f) ? a.g + (gbase + y0 + 1) * a.W * a.Cout + coa : zb;
+    return rw;
+  };
+  const int xs = CS ? CS : a.Cin, gs = CS ? CS : a.Cout;
+  auto ld = [&](const float* base, int pos, int stride) -> f32x2 {
+    return *reinterpret_cast<const f32x2*>(base + static_cast<int64_t>(pos) * stride);
+  };
+  auto pkfma = [&](f32x2 x, f32x2 y, f32x2 z) -> f32x2 {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+  };
+
+  f32x16 acc[4][2][2];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][s][t][e] = 0.f;
+  f32x2 bsum = {0.f, 0.f};
+  const bool do_bias = a.want_bias && dz == 0 && xiy == 1 && blockIdx.y == 0 && qi == 0;     // G_c = g(2t) + g(2t+1)
+
+  // raw rings by (position in row) % 8 and the ring of y-combined X values
+  f32x2 xra[8], xrb[8], gra[8], grb[8], xc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { xra[i] = xrb[i] = gra[i] = grb[i] = xc[i] = f32x2{0.f, 0.f}; }
+  Row cur = row_setup(p0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    xra[i] = ld(cur.xa, i, xs); xrb[i] = ld(cur.xb, i, xs);
+    gra[i] = ld(cur.ga, i, gs); grb[i] = ld(cur.gb, i, gs);
+  }
+  xc[0] = pkfma(xrb[0], sx2, xra[0]);
+
+  auto tile = [&](int u, int x, const Row& lr, int lpos) {
+    __builtin_amdgcn_sched_barrier(0);
+    // y-combination of the two positions this tile is the first to need, and of its two gradient positions
+    xc[(u + 1) & 7] = pkfma(xrb[(u + 1) & 7], sx2, xra[(u + 1) & 7]);
+    xc[(u + 2) & 7] = pkfma(xrb[(u + 2) & 7], sx2, xra[(u + 2) & 7]);
+    const f32x2 g0 = pkfma(grb[u], sg2, gra[u]), g1 = pkfma(grb[(u + 1) & 7], sg2, gra[(u + 1) & 7]);
+    f32x2 dm = xc[(u + 7) & 7], d0 = xc[u], d1 = xc[(u + 1) & 7], d2 = xc[(u + 2) & 7];
+    if (x == 0) dm = f32x2{0.f, 0.f};
+    if (x == Wc - 2) d2 = f32x2{0.f, 0.f};
+    const f32x2 v0 = wpk_sub(dm, d1), v1 = wpk_add(d0, d1), v2 = wpk_sub(d1, d0), v3 = wpk_sub(d0, d2);
+    const f32x2 m1 = wpk_add(g0, g1), m2 = wpk_sub(g0, g1);
+    bsum = wpk_add(bsum, m1);
+    __builtin_amdgcn_sched_barrier(0);
+    xra[(u + 6) & 7] = ld(lr.xa, lpos, xs); xra[(u + 7) & 7] = ld(lr.xa, lpos + 1, xs);
+    xrb[(u + 6) & 7] = ld(lr.xb, lpos, xs); xrb[(u + 7) & 7] = ld(lr.xb, lpos + 1, xs);
+    gra[(u + 6) & 7] = ld(lr.ga, lpos, gs); gra[(u + 7) & 7] = ld(lr.ga, lpos + 1, gs);
+    grb[(u + 6) & 7] = ld(lr.gb, lpos, gs); grb[(u + 7) & 7] = ld(lr.gb, lpos + 1, gs);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[0][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[s], g0[t], acc[0][s][t], 0, 0, 0);
+        acc[1][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[s], m1[t], acc[1][s][t], 0, 0, 0);
+        acc[2][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[s], m2[t], acc[2][s][t], 0, 0, 0);
+        acc[3][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3[s], g1[t], acc[3][s][t], 0, 0, 0);
+      }
+  };
+
+  for (int pair = p0; pair < p1; ++pair) {
+    const Row nxt = row_setup(pair + 1);
+#pragma unroll
+    for (int x0 = 0; x0 < Wc - 8; x0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) tile(u, x0 + u, cur, x0 + u + 6);
+    }
+    {
+      constexpr int x0 = Wc - 8;
+      tile(0, x0, cur, x0 + 6);
+#pragma unroll
+      for (int u = 2; u < 8; u += 2) tile(u, x0 + u, nxt, u - 2);
+    }
+    cur = nxt;
+  }
+
+  // ---- partial: slot = (dz, xi_y) * 4 + xi_x ------------------------------------------------------------------------------------
+  float* P = a.partial + static_cast<int64_t>(erange) * a.ndzdy * 4 * a.Cinp * a.Coutp;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int slot = dzxy * 4 + d;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int ci = ci0 + 2 * i + s, co = co0 + 2 * r + t;
+          P[(static_cast<int64_t>(slot) * a.Cinp + ci) * a.Coutp + co] = acc[d][s][t][e];
+        }
+  }
+  if (do_bias) {
+    bsum[0] += __shfl_xor(bsum[0], 32, 64);
+    bsum[1] += __shfl_xor(bsum[1], 32, 64);
+    if (half == 0) {
+      float* pb = a.bpartial + static_cast<int64_t>(erange) * a.Coutp + co0 + 2 * r;
+      pb[0] = bsum[0]; pb[1] = bsum[1];
+    }
+  }
+}
+
+// gw[dz][dy][dx][ci][co] = G^T_y G^T_x of the summed (fixed order) partials U[xi_y][xi_x]; U[3][.] and U[.][3] carry a flipped sign
+__global__ __launch_bounds__(kThreads) void wgrad_wxy_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
+                                                                    float* __restrict__ gw, float* __restrict__ gb, int nranges, int ndz,
+                                                                    int Cin, int Cout, int Cinp, int Coutp) {
+  const int64_t total = static_cast<int64_t>(ndz) * Cin * Cout;
+  const int64_t slot = static_cast<int64_t>(Cinp) * Coutp;
+  const int64_t pstride = static_cast<int64_t>(ndz) * 16 * slot;
+  const int64_t tapstride = static_cast<int64_t>(Cin) * Cout;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int co = static_cast<int>(i % Cout);
+    const int64_t t2 = i / Cout;
+    const int ci = static_cast<int>(t2 % Cin);
+    const int dzi = static_cast<int>(t2 / Cin);
+    const float* p = partial + (static_cast<int64_t>(dzi) * 16 * Cinp + ci) * Coutp + co;
+    float u[4][4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u[k >> 2][k & 3] = 0.f;
+    for (int rg = 0; rg < nranges; ++rg) {
+      const float* q = p + rg * pstride;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) u[k >> 2][k & 3] += q[k * slot];
+    }
+    float w[3][4];      // G^T along y
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float h = 0.5f * (u[1][k] + u[2][k]);
+      w[0][k] = u[0][k] + h;
+      w[1][k] = 0.5f * (u[1][k] - u[2][k]);
+      w[2][k] = h - u[3][k];
+    }
+    float* o = gw + (static_cast<int64_t>(dzi) * 9 * Cin + ci) * Cout + co;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const float h = 0.5f * (w[dy][1] + w[dy][2]);
+      o[(dy * 3 + 0) * tapstride] = w[dy][0] + h;
+      o[(dy * 3 + 1) * tapstride] = 0.5f * (w[dy][1] - w[dy][2]);
+      o[(dy * 3 + 2) * tapstride] = h - w[dy][3];
+    }
+  }
+  if (gb && blockIdx.x == 0) {
+    for (int co = threadIdx.x; co < Cout; co += kThreads) {
+      float acc = 0.f;
+      for (int rg = 0; rg < nranges; ++rg) acc += bpartial[static_cast<int64_t>(rg) * Coutp + co];
+      gb[co] = acc;
+    }
+  }
+}
+
 // the Winograd-in-x variant exists for the fully unrolled row lengths below (even channel counts: float2 operand loads)
 inline bool wx_ok(int64_t W, int64_t Cin, int64_t Cout) {
   return (W == 16 || W == 32 || W == 64) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
 }
-int g_wgrad_algo = 0;     // 0: Winograd-in-x where available, 1: always the direct kernel (df_debug_set_wgrad_algo)
+inline bool wxy_ok(int64_t H, int64_t W, int64_t Cin, int64_t Cout) { return wx_ok(W, Cin, Cout) && H % 2 == 0 && H >= 4; }
+int g_wgrad_ranges = 0;   // debug: override the number of voxel ranges (0 = default)
+int g_wgrad_algo = 0;     // 0: best available, 1: always the direct kernel, 2: at most Winograd-in-x (df_debug_set_wgrad_algo)
+// 0 direct | 1 Winograd in x | 2 Winograd in (x,y)
+inline int wgrad_algo(int64_t rows, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
+  if (g_wgrad_algo == 1) return 0;
+  // (x,y) pays a larger partial buffer: worth it from ~4096 tile rows (measured: 16x24x16x16 ties, 32x48x32x16 wins 1.2x)
+  if (g_wgrad_algo != 2 && wxy_ok(H, W, Cin, Cout) && (rows >= 8192 || g_wgrad_algo == 3)) return 2;
+  return wx_ok(W, Cin, Cout) ? 1 : 0;
+}
 
 // ---- bf16x3 weight gradient (opt-in precision mode, see conv_bf16.hip) ---------------------------------------------------
 // Same decomposition as wgrad_kernel (workgroup = (voxel range, (dz,dy) group), wave = 64x64 (ci,co) quadrant x 3 dx taps,
@@ -914,23 +1151,27 @@ struct Plan {
   int64_t partial_elems, bpartial_elems;
 };
 
-Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
+Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int algo = 0) {
   Plan p;
-  p.nrows = (int)(B * D * H);
+  p.nrows = (int)(algo == 2 ? B * D * (H / 2) : B * D * H);       // image rows, or 2-row tile rows
   p.npairs = (p.nrows + 1) / 2;
-  p.ndzdy = kz == 3 ? 9 : 3;
-  p.taps = p.ndzdy * 3;
-  // The kernel runs ONE workgroup per CU (192 accumulator registers per lane): a grid that is not a multiple
-  // of 256 leaves most of the chip idle in its last round.  256 equal voxel ranges x (9 | 3) (dz,dy) groups is
-  // exactly 9 | 3 full rounds; smaller problems get one range per row pair.
-  int nr = p.npairs >= kMaxRanges ? kMaxRanges : p.npairs;
+  p.ndzdy = algo == 2 ? (kz == 3 ? 12 : 4) : (kz == 3 ? 9 : 3);  // workgroup types: (dz,dy) or (dz,xi_y)
+  p.taps = kz == 3 ? 27 : 9;
+  // The kernel runs ONE workgroup per CU (192-256 accumulator registers per lane): a grid that is not a multiple
+  // of 256 leaves most of the chip idle in its last round.  256 equal voxel ranges x (9 | 3 | 12 | 4) groups is
+  // a whole number of rounds; smaller problems get one range per row pair.
+  (void)W;
+  // (the (x,y) Winograd kernel has 12 | 4 workgroup types and 16 partial slots per dz: 128 ranges = 6 | 2 whole rounds and half
+  //  the partial traffic of 256)
+  const int maxr = g_wgrad_ranges > 0 ? g_wgrad_ranges : (algo == 2 ? 128 : kMaxRanges);
+  int nr = p.npairs >= maxr ? maxr : p.npairs;
   p.ppr = (p.npairs + nr - 1) / nr;
   p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
   p.Cinp = (int)(ceil_div(Cin, 64) * 64);
   p.Coutp = (int)(ceil_div(Cout, 64) * 64);
   p.nqi = Cin <= 64 ? 1 : 2; p.nqj = Cout <= 64 ? 1 : 2;
   p.nsub = 4 / (p.nqi * p.nqj);
-  const int slots = wx_ok(W, Cin, Cout) ? p.ndzdy * 4 : p.taps;       // the Winograd-in-x kernel writes 4 slots per (dz,dy)
+  const int slots = algo == 0 ? p.taps : p.ndzdy * 4;             // the Winograd kernels write 4 xi_x slots per group
   p.partial_elems = static_cast<int64_t>(p.nranges) * p.nsub * slots * p.Cinp * p.Coutp;
   p.bpartial_elems = static_cast<int64_t>(p.nranges) * p.nsub * p.Coutp;
   return p;
@@ -946,8 +1187,14 @@ int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W
     const SmallPlan sp = make_small_plan(B, D, H, Cin, Cout, kz);
     return sp.partial_elems * static_cast<int64_t>(sizeof(float)) + kZeroBytes;
   }
-  const Plan p = make_plan(B, D, H, W, Cin, Cout, kz);
-  return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(W, Cin, Cout);
+  int64_t best = 0;
+  for (int algo = 0; algo <= 2; ++algo) {       // the launch may fall back (operand alignment), so size for the largest
+    if ((algo == 1 && !wx_ok(W, Cin, Cout)) || (algo == 2 && !wxy_ok(H, W, Cin, Cout))) continue;
+    const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, algo);
+    const int64_t n = (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float));
+    if (n > best) best = n;
+  }
+  return best + zero_row_bytes(W, Cin, Cout);
 }
 
 static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
@@ -984,7 +1231,10 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
                        gb, sp.nstreams, per, sp.CO, (int)Cout);
     return df::launched("df_conv_wgrad(small-N)");
   }
-  const Plan p = make_plan(B, D, H, W, Cin, Cout, kz);
+  const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
+  const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
+  const int algo = (prec == 0 && xvec && gvec) ? wgrad_algo(B * D * H, H, W, Cin, Cout) : 0;
+  const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, algo);
   WgradArgs a;
   a.x = x; a.g = gy;
   a.partial = static_cast<float*>(workspace);
@@ -1001,11 +1251,25 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   hipStream_t s = df::as_stream(stream);
   if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(W, Cin, Cout), s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)ceil_div(Cin, 128), (unsigned)ceil_div(Cout, 128));
-  const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
-  const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
   if (prec == 1 && xvec && gvec && wgrad_bf16x3_ok(W, Cin, Cout)) {
     launch_wgrad_bf16x3(W, grid, s, a);
-  } else if (prec == 0 && g_wgrad_algo == 0 && xvec && gvec && wx_ok(W, Cin, Cout)) {
+  } else if (algo == 2) {
+    WxyArgs aa;
+    aa.w = a; aa.Ht = (int)(H / 2); aa.ntrows = p.nrows;
+    const bool c128 = Cin == 128 && Cout == 128;
+    if (W == 64 && c128) hipLaunchKernelGGL((wgrad_wxy_kernel<8, 128>), grid, dim3(kThreads), 0, s, aa);
+    else if (W == 64) hipLaunchKernelGGL((wgrad_wxy_kernel<8, 0>), grid, dim3(kThreads), 0, s, aa);
+    else if (W == 32 && c128) hipLaunchKernelGGL((wgrad_wxy_kernel<4, 128>), grid, dim3(kThreads), 0, s, aa);
+    else if (W == 32) hipLaunchKernelGGL((wgrad_wxy_kernel<4, 0>), grid, dim3(kThreads), 0, s, aa);
+    else if (c128) hipLaunchKernelGGL((wgrad_wxy_kernel<2, 128>), grid, dim3(kThreads), 0, s, aa);
+    else hipLaunchKernelGGL((wgrad_wxy_kernel<2, 0>), grid, dim3(kThreads), 0, s, aa);
+    const int ndz = kz == 3 ? 3 : 1;
+    const int64_t tot = static_cast<int64_t>(ndz) * Cin * Cout;
+    int64_t rgx = ceil_div(tot, kThreads);
+    hipLaunchKernelGGL(wgrad_wxy_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
+                       p.nranges * p.nsub, ndz, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
+    return df::launched("df_conv_wgrad(winograd-xy)");
+  } else if (algo == 1) {
     const bool c128 = Cin == 128 && Cout == 128;
     if (W == 64 && c128) hipLaunchKernelGGL((wgrad_wx_kernel<8, 128>), grid, dim3(kThreads), 0, s, a);
     else if (W == 64) hipLaunchKernelGGL((wgrad_wx_kernel<8, 0>), grid, dim3(kThreads), 0, s, a);
@@ -1041,7 +1305,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   return df::launched("df_conv_wgrad");
 }
 
-void df_debug_set_wgrad_algo(int v) { g_wgrad_algo = v; }
+void df_debug_set_wgrad_algo(int v) { g_wgrad_algo = v & 3; g_wgrad_ranges = v >> 2; }
 
 int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
                   int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {

@@ -76,6 +76,21 @@ CASES_2D = [
 ]
 
 
+@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("shape,cin,cout,leak", [((3, 2, 2, 64), 128, 128, 0.2), ((1, 2, 6, 32), 32, 64, 0.2), ((2, 3, 4, 16), 32, 96, None),
+                                                 ((2, 8, 32), 64, 64, 0.2)])
+def test_conv_wgrad_algorithms(ops, shape, cin, cout, leak, algo):
+    """df_conv_wgrad forced to the direct kernel (1), Winograd in x (2) and Winograd in (x,y) (3) -- the default picks by size --
+    against the fp64 oracle; the last case is 2-D (kz = 1)."""
+    from deep_fluids_amd._lib import lib
+    lib().df_debug_set_wgrad_algo(ctypes.c_int(algo))
+    try:
+        errs = _conv_case(ops, shape, cin, cout, leak, seed=algo + cin + cout)
+    finally:
+        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+    assert max(errs.values()) < TOL, errs
+
+
 WINO_CASES = [
     ((1, 4, 8, 8), 32, 32, 0.2),        # exactly one tile block
     ((2, 8, 16, 8), 64, 32, 0.2),       # Cin != Cout (forward and dgrad swap them)

@@ -22,7 +22,7 @@ def run(B, D, H, W, C, N, kz=3, iters=3):
     nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, N, kz)
     ws = torch.empty((nb + 3) // 4, device="cuda")
     out = []
-    for algo in (1, 0):
+    for algo in (1, 2, 0):
         lib().df_debug_set_wgrad_algo(ctypes.c_int(algo))
         gw = torch.empty((taps, C, N), device="cuda"); gb = torch.empty(N, device="cuda")
         f = lambda: call("df_conv_wgrad", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, N, kz, _ptr(ws), nb, s)
@@ -30,16 +30,24 @@ def run(B, D, H, W, C, N, kz=3, iters=3):
         t = timeit(f, iters, 1)
         out.append((gw.clone(), gb.clone(), t))
     lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
-    (w0, b0, t0), (w1, b1, t1) = out
+    (w0, b0, t0), (w1, b1, t1), (w2, b2, t2) = out
     fl = 2.0 * taps * C * N * B * D * H * W
-    print("B%d %dx%dx%d C%d N%d: gw rel-linf %.2e  gb %.2e | direct %.3f ms (%.0f TF)  wino-x %.3f ms (%.0f TF-eq)" % (
+    print("B%d %dx%dx%d C%d N%d: x: gw %.2e gb %.2e  xy: gw %.2e gb %.2e | direct %.3f ms (%.0f TF)  wino-x %.3f ms (%.0f TF-eq)  wino-xy %.3f ms (%.0f TF-eq)" % (
         B, D, H, W, C, N, ((w0 - w1).abs().max() / w0.abs().max()).item(), ((b0 - b1).abs().max() / b0.abs().max()).item(),
-        t0 * 1e3, fl / t0 / 1e12, t1 * 1e3, fl / t1 / 1e12), flush=True)
+        ((w0 - w2).abs().max() / w0.abs().max()).item(), ((b0 - b2).abs().max() / b0.abs().max()).item(),
+        t0 * 1e3, fl / t0 / 1e12, t1 * 1e3, fl / t1 / 1e12, t2 * 1e3, fl / t2 / 1e12), flush=True)
 
 
 if __name__ == "__main__":
-    run(1, 4, 6, 16, 32, 32)
-    run(2, 16, 24, 16, 128, 128)
-    run(2, 32, 48, 32, 128, 128)
+    if len(sys.argv) > 1:
+        R = int(sys.argv[1])
+        import deep_fluids_amd._lib as L
+        orig = lib().df_debug_set_wgrad_algo
+        class _W:  # route the algo setter through a range override
+            pass
+        _set = lambda v: orig(ctypes.c_int(v.value | (R << 2)))
+        lib().df_debug_set_wgrad_algo = _set
+    run(16, 16, 24, 16, 128, 128)
+    run(16, 32, 48, 32, 128, 128)
     run(4, 64, 96, 64, 128, 128)
-    run(16, 1, 96, 64, 128, 128, kz=1)
+    run(16, 64, 96, 64, 128, 128, iters=2)
