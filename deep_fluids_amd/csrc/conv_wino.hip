@@ -186,6 +186,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     return bi;
   };
 
+  const __amdgpu_buffer_rsrc_t wsrd_dbg = make_srd(a.wp, 4096u);
   // ---- staging plan (per thread: 5 float4 pieces of the 600-voxel x 16-channel halo block) ---------------------------------
   // so[it] = byte offset of piece `it` inside the batch volume, or an out-of-range offset for halo voxels outside the tensor:
   // the buffer load's range check then returns the zeros of the SAME padding.  Set once per tile block; a staging pass adds
@@ -216,7 +217,10 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       so[it] = ok ? static_cast<unsigned>(bi.hoff + roff) * 4u : 0x80000000u;
     }
   };
-  auto stage_load = [&](int it, __amdgpu_buffer_rsrc_t srd, unsigned chunkbytes) -> f32x4 { return buf_load16(srd, so[it], chunkbytes); };
+  auto stage_load = [&](int it, __amdgpu_buffer_rsrc_t srd, unsigned chunkbytes) -> f32x4 {
+    if (DBG & 256) return buf_load16(wsrd_dbg, static_cast<unsigned>(lane) * 16u, 0u);      // always-cached address (latency experiment)
+    return buf_load16(srd, so[it], chunkbytes);
+  };
   char* sInB = reinterpret_cast<char*>(sIn);
   auto stage_store = [&](int it, int bufbytes, const f32x4& v) {
     float* d = reinterpret_cast<float*>(sInB + (ldst[it] + bufbytes));
@@ -510,6 +514,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 48: hipLaunchKernelGGL(wino3d_kernel<48>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 80: hipLaunchKernelGGL(wino3d_kernel<80>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 144: hipLaunchKernelGGL(wino3d_kernel<144>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 272: hipLaunchKernelGGL(wino3d_kernel<272>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 16: hipLaunchKernelGGL(wino3d_kernel<16>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 20: hipLaunchKernelGGL(wino3d_kernel<20>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 15: hipLaunchKernelGGL(wino3d_kernel<15>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
