@@ -172,6 +172,9 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   }
   if (tb >= a.ntb) return;
   const int n0 = cs * 32;
+  const int tb0 = tb;
+  const int niter = (a.ntb - tb0 + tstride - 1) / tstride;
+  auto seq = [&](int k) -> int { return tb0 + k * tstride; };
 
   auto decode = [&](int t) -> BlockInfo {
     BlockInfo bi;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   const int nchunk = a.Cin / CKW;
 
   // ---- prologue: first block's chunk 0 -> buffer 0 ------------------------------------------------------------------------------
-  BlockInfo cur = decode(tb);
+  BlockInfo cur = decode(seq(0));
   set_offs(cur);
   {
     const __amdgpu_buffer_rsrc_t srd0 = make_srd(cur.xb, vol_bytes);
@@ -300,10 +303,9 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   __syncthreads();
 
   int pb = 0;          // buffer parity of the block's chunk 0
-  for (; tb < a.ntb; tb += tstride) {
+  for (int it = 0; it < niter; ++it) {
     const unsigned long long tp0 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
-    const int tbn = tb + tstride < a.ntb ? tb + tstride : tb;
-    const BlockInfo nxt = decode(tbn);
+    const BlockInfo nxt = decode(seq(it + 1 < niter ? it + 1 : it));
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
