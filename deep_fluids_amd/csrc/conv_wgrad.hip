@@ -257,14 +257,6 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
-// ---- Winograd-in-x weight gradient ---------------------------------------------------------------------------------------------
-// F(2,3) along the image rows:  for an x-tile of two output positions (2t, 2t+1) and its four inputs d = X[2t-1 .. 2t+2],
-//   dU_xi += (B^T d)_xi * (A dy)_xi ,  xi = 0..3,    B^T d = (d0-d2, d1+d2, d2-d1, d1-d3),  A dy = (g0, g0+g1, g0-g1, -g1)
-//   gW[dx] = G^T dU :  gW0 = U0 + (U1+U2)/2,  gW1 = (U1-U2)/2,  gW2 = (U1+U2)/2 + U3
-// i.e. FOUR transform-domain products per two positions instead of 3 taps x 2 positions: 16 instead of 24 MFMAs per tile
-// (1.5x fewer matrix FLOPs), for 6 packed-fp32 transform ops per tile and lane.  Same decomposition, operand streaming and
-// register rings as wgrad_kernel (exact-row variants only: W == 8*WP8); the sign of U3 and the G^T combination are applied by
-// wgrad_wx_reduce_kernel.  All arithmetic fp32; differs from the direct sum by rounding order only.
 __device__ __forceinline__ f32x2 wpk_add(f32x2 a, f32x2 b) {
   f32x2 d;
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -276,6 +268,175 @@ __device__ __forceinline__ f32x2 wpk_sub(f32x2 a, f32x2 b) {
   return d;
 }
 
+
+// ---- up-sampling-aware weight gradient, both x-parity classes in one workgroup ----------------------------------------------------
+// In up mode (df_upconv_wgrad) a parity class has TWO taps per axis: for px = 0 the coarse offsets (-1, 0), for px = 1 (0, +1); the
+// generic kernel computes three and discards one.  Here a workgroup owns the two classes that differ only in px: one coarse X ring,
+// two fine-gradient rings (fine positions 2x and 2x+1), and exactly the four useful products per position
+//   X[x-1] g0 -> (px=0, slot 0)   X[x] g0 -> (px=0, slot 1)   X[x] g1 -> (px=1, slot 1)   X[x+1] g1 -> (px=1, slot 2)
+// = 16 MFMAs for 3 loads (instead of 2 x 12 MFMAs for 2 x 2 loads, a third of them wasted).  Partial layout and reduce unchanged.
+template <int WP8>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_up2_kernel(const WgradArgs a) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nq = a.nqi * a.nqj;
+  const int qi = (wave % nq) / a.nqj, qj = (wave % nq) % a.nqj, sub = wave / nq;
+  constexpr int Wc = WP8 * 8;
+  const int half = lane >> 5, r = lane & 31;
+  const bool is3d = a.ndzdy == 32;
+  const int nhc = a.ndzdy / 2;                   // half-combos: (pz,py) class pair x (dz,dy) delta
+  const int nd2 = is3d ? 4 : 2;
+
+  const int nwg = a.nranges * nhc;
+  int wg;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, rem = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int range = wg / nhc, hc = wg % nhc;
+  const int clsh = hc / nd2, dd = hc % nd2;
+  const int pz = is3d ? (clsh >> 1) & 1 : 0, py = clsh & 1;
+  const int dz = is3d ? (dd >> 1) + pz - 1 : 0;
+  const int dy = (dd & 1) + py - 1;
+  const int cls0 = clsh * 2, cls1 = clsh * 2 + 1;
+  const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
+  if (ci0 >= a.Cin || co0 >= a.Cout) return;
+
+  const int ppe = (a.pairs_per_range + a.nsub - 1) / a.nsub;
+  const int p0 = range * a.pairs_per_range + sub * ppe;
+  int p1 = p0 + ppe;
+  if (p1 > (range + 1) * a.pairs_per_range) p1 = (range + 1) * a.pairs_per_range;
+  if (p1 > a.npairs) p1 = a.npairs;
+  const int erange = range * a.nsub + sub;
+
+  const int cia = ci0 + 2 * r, coa = co0 + 2 * r;
+  const bool ci_ok0 = cia < a.Cin, co_ok0 = coa < a.Cout;
+  const float* zb = a.zeros;
+  struct Row { const float* xb; const float* gb; };
+  auto row_setup = [&](int pair) -> Row {
+    Row rw;
+    const int row = 2 * pair + half;
+    const bool ok = pair < p1 && row < a.nrows;
+    const int y = row % a.H;
+    const int t = row / a.H;
+    const int z = t % a.D;
+    const int b = t / a.D;
+    const int zs = z + dz, ys = y + dy;
+    const bool xv = ok && zs >= 0 && zs < a.D && ys >= 0 && ys < a.H;
+    const int64_t gvox = ((static_cast<int64_t>(b) * a.gD + (z * 2 + pz)) * a.gH + (y * 2 + py)) * a.gW;
+    const int64_t xvox = ((static_cast<int64_t>(b) * a.D + zs) * a.H + ys) * a.W;
+    rw.gb = (ok && co_ok0) ? a.g + gvox * a.Cout + coa : zb;
+    rw.xb = (xv && ci_ok0) ? a.x + xvox * a.Cin + cia : zb;
+    return rw;
+  };
+  auto load_x = [&](const Row& rw, int pos) -> f32x2 { return *reinterpret_cast<const f32x2*>(rw.xb + static_cast<int64_t>(pos) * a.Cin); };
+  auto load_g = [&](const Row& rw, int pos, int px) -> f32x2 {
+    return *reinterpret_cast<const f32x2*>(rw.gb + static_cast<int64_t>(2 * pos + px) * a.Cout);
+  };
+
+  f32x16 acc[4][2][2];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][s][t][e] = 0.f;
+  f32x2 bsum0 = {0.f, 0.f}, bsum1 = {0.f, 0.f};
+  const bool do_bias = a.want_bias && dd == 0 && blockIdx.y == 0 && qi == 0;
+
+  f32x2 xr[8], g0r[8], g1r[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { xr[i] = g0r[i] = g1r[i] = f32x2{0.f, 0.f}; }
+  Row cur = row_setup(p0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) xr[i] = load_x(cur, i);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { g0r[i] = load_g(cur, i, 0); g1r[i] = load_g(cur, i, 1); }
+
+  auto step = [&](int u, int x) {
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 am = xr[(u + 7) & 7], a0 = xr[u], ap = xr[(u + 1) & 7];
+    const f32x2 g0 = g0r[u], g1 = g1r[u];
+    if (x == 0) am = f32x2{0.f, 0.f};
+    if (x == Wc - 1) ap = f32x2{0.f, 0.f};
+    bsum0 = wpk_add(bsum0, g0); bsum1 = wpk_add(bsum1, g1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[0][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(am[s], g0[t], acc[0][s][t], 0, 0, 0);
+        acc[1][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], g0[t], acc[1][s][t], 0, 0, 0);
+        acc[2][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], g1[t], acc[2][s][t], 0, 0, 0);
+        acc[3][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s], g1[t], acc[3][s][t], 0, 0, 0);
+      }
+  };
+
+  for (int pair = p0; pair < p1; ++pair) {
+    const Row nxt = row_setup(pair + 1);
+#pragma unroll
+    for (int x0 = 0; x0 < Wc - 8; x0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        xr[(u + 6) & 7] = load_x(cur, x0 + u + 6);
+        g0r[(u + 5) & 7] = load_g(cur, x0 + u + 5, 0);
+        g1r[(u + 5) & 7] = load_g(cur, x0 + u + 5, 1);
+        step(u, x0 + u);
+      }
+    }
+    {
+      constexpr int x0 = Wc - 8;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        xr[(u + 6) & 7] = u < 2 ? load_x(cur, x0 + u + 6) : load_x(nxt, u - 2);
+        g0r[(u + 5) & 7] = u < 3 ? load_g(cur, x0 + u + 5, 0) : load_g(nxt, u - 3, 0);
+        g1r[(u + 5) & 7] = u < 3 ? load_g(cur, x0 + u + 5, 1) : load_g(nxt, u - 3, 1);
+        step(u, x0 + u);
+      }
+    }
+    cur = nxt;
+  }
+
+  // partial slot = (class * nd2 + dd) * 3 + (coarse offset + 1): (cls0: 0, 1), (cls1: 1, 2)
+  float* P = a.partial + static_cast<int64_t>(erange) * a.ndzdy * 3 * a.Cinp * a.Coutp;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int slot = ((d < 2 ? cls0 : cls1) * nd2 + dd) * 3 + (d < 2 ? d : d - 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int ci = ci0 + 2 * i + s, co = co0 + 2 * r + t;
+          P[(static_cast<int64_t>(slot) * a.Cinp + ci) * a.Coutp + co] = acc[d][s][t][e];
+        }
+  }
+  if (do_bias) {
+    bsum0[0] += __shfl_xor(bsum0[0], 32, 64); bsum0[1] += __shfl_xor(bsum0[1], 32, 64);
+    bsum1[0] += __shfl_xor(bsum1[0], 32, 64); bsum1[1] += __shfl_xor(bsum1[1], 32, 64);
+    if (half == 0) {
+      const int ncls = is3d ? 8 : 4;
+      float* pb0 = a.bpartial + (static_cast<int64_t>(erange) * ncls + cls0) * a.Coutp + co0 + 2 * r;
+      float* pb1 = a.bpartial + (static_cast<int64_t>(erange) * ncls + cls1) * a.Coutp + co0 + 2 * r;
+      pb0[0] = bsum0[0]; pb0[1] = bsum0[1];
+      pb1[0] = bsum1[0]; pb1[1] = bsum1[1];
+    }
+  }
+}
+
+// ---- Winograd-in-x weight gradient ---------------------------------------------------------------------------------------------
+// F(2,3) along the image rows:  for an x-tile of two output positions (2t, 2t+1) and its four inputs d = X[2t-1 .. 2t+2],
+//   dU_xi += (B^T d)_xi * (A dy)_xi ,  xi = 0..3,    B^T d = (d0-d2, d1+d2, d2-d1, d1-d3),  A dy = (g0, g0+g1, g0-g1, -g1)
+//   gW[dx] = G^T dU :  gW0 = U0 + (U1+U2)/2,  gW1 = (U1-U2)/2,  gW2 = (U1+U2)/2 + U3
+// i.e. FOUR transform-domain products per two positions instead of 3 taps x 2 positions: 16 instead of 24 MFMAs per tile
+// (1.5x fewer matrix FLOPs), for 6 packed-fp32 transform ops per tile and lane.  Same decomposition, operand streaming and
+// register rings as wgrad_kernel (exact-row variants only: W == 8*WP8); the sign of U3 and the G^T combination are applied by
+// wgrad_wx_reduce_kernel.  All arithmetic fp32; differs from the direct sum by rounding order only.
 // CS > 0: Cin == Cout == CS at compile time (the operand position offsets become load immediates)
 template <int WP8, int CS>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_wx_kernel(const WgradArgs a) {
@@ -1366,7 +1527,12 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)ceil_div(Cin, 128), (unsigned)ceil_div(Cout, 128));
   const int wp8 = a.Wp / 8;
   const bool exact = (Wc % 8) == 0;
+  const bool aligned8 = ((reinterpret_cast<uintptr_t>(xc) | reinterpret_cast<uintptr_t>(gy)) & 7u) == 0;
+  const dim3 grid2((unsigned)(p.nranges * (p.ndzdy / 2)), grid.y, grid.z);     // one workgroup per x-parity class PAIR
   if (prec == 1 && wgrad_bf16x3_ok(Wc, Cin, Cout)) launch_wgrad_bf16x3(Wc, grid, s, a);
+  else if (prec == 0 && aligned8 && exact && wp8 == 4 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<4>), grid2, dim3(kThreads), 0, s, a);
+  else if (prec == 0 && aligned8 && exact && wp8 == 2 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<2>), grid2, dim3(kThreads), 0, s, a);
+  else if (prec == 0 && aligned8 && exact && wp8 == 1 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<1>), grid2, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 4) hipLaunchKernelGGL((wgrad_kernel<true, true, 4>), grid, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 2) hipLaunchKernelGGL((wgrad_kernel<true, true, 2>), grid, dim3(kThreads), 0, s, a);
