@@ -55,6 +55,7 @@ struct WinoArgs {
   int flags;
   float leak;
   int dbg;
+  int spx;
 };
 
 // ---- weight transform + packing ------------------------------------------------------------------------------------------
@@ -158,10 +159,15 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   {
     const int g = blockIdx.x, G = gridDim.x;
     if ((8 % a.ncs) == 0 && (G & 7) == 0) {
-      const int xcd = g & 7, slot = g >> 3, per = 8 / a.ncs, wx = G >> 3;
-      cs = xcd % a.ncs;
-      tb = (xcd / a.ncs) * wx + slot;
-      tstride = per * wx;
+      // spx slices per XCD (spx | ncs): the XCD's weights are spx MB, and the spx workgroups of a tile block that share its L2
+      // run at the same time on neighbouring CUs, so that block's input is fetched from the fabric once per XCD, not per slice
+      const int spx = a.spx, xpg = a.ncs / spx;            // XCDs per group (a group covers all slices of its tile blocks)
+      const int xcd = g & 7, slot = g >> 3, wx = G >> 3;   // wx workers per XCD
+      const int ngroups = 8 / xpg, tw = wx / spx;          // tile workers per XCD
+      cs = (xcd % xpg) * spx + slot % spx;
+      tb = (xcd / xpg) * tw + slot / spx;
+      tstride = ngroups * tw;
+      if (slot / spx >= tw) return;
     } else {
       const int nw = G / a.ncs;
       cs = g % a.ncs;
@@ -352,11 +358,6 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (!(DBG & 8)) issue_b(0, chunk * 4 + ks + 1);       // weights of the next k-step, as each register block frees up
-        if (ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk: right behind a weight batch, so that the in-order vmcnt
-                                         // wait that first covers them is the one for the batch issued 16 MFMAs later
-#pragma unroll
-          for (int it = 0; it < NLOAD; ++it) stg[it] = (DBG & 128) ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
-        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -364,6 +365,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (DBG & 32) __builtin_amdgcn_s_setprio(0);
         if (!(DBG & 8)) issue_b(1, chunk * 4 + ks + 1);
+        if (ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
+                                         // the first wait that covers them is the one for the NEXT weight batch (1.5 k-steps away)
+#pragma unroll
+          for (int it = 0; it < NLOAD; ++it) stg[it] = (DBG & 128) ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (DBG & 16) {
           const unsigned long long q4 = __builtin_readcyclecounter();
@@ -440,11 +446,12 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 }
 
 int g_wino_dbg = 0;
+int g_wino_spx = 0;     // debug: slices per XCD override
 }  // namespace
 
 extern "C" {
 
-void df_debug_set_wino(int v) { g_wino_dbg = v; }
+void df_debug_set_wino(int v) { g_wino_dbg = v & 0xffff; g_wino_spx = v >> 16; }
 int df_debug_wino_prof(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_prof), z, sizeof(z)); }
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_prof), 32 * sizeof(unsigned long long));
@@ -491,9 +498,14 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
   a.flags = flags; a.leak = leak; a.dbg = g_wino_dbg;
   // persistent workers: one workgroup per CU (a workgroup owns a CU's whole register file and 111 KB of its LDS)
   int64_t grid = df::kCUs;
+  a.spx = 1;
   if (8 % a.ncs == 0) {
-    const int64_t need = ceil_div(ntb, 8 / a.ncs) * 8;      // workers that get at least one tile block
+    a.spx = (g_wino_spx > 0 && a.ncs % g_wino_spx == 0) ? g_wino_spx : (a.ncs % 2 == 0 ? 2 : 1);
+    const int xpg = a.ncs / a.spx, ngroups = 8 / xpg;
+    const int64_t need = ceil_div(ceil_div(ntb, ngroups) * a.spx, 1) * 8;      // workers that get at least one tile block
     if (need < grid) grid = need;
+    if ((grid >> 3) % a.spx) grid = ((grid >> 3) / a.spx + 1) * a.spx * 8;
+    if (grid > df::kCUs) grid = df::kCUs;
   } else {
     grid = (grid / a.ncs) * a.ncs;
     if (ntb * a.ncs < grid) grid = ntb * a.ncs;

@@ -17,6 +17,10 @@ bias = torch.zeros(F, device="cuda"); y = torch.empty_like(xin)
 wp = _pack(wt, 27, F, F, 0)
 for _ in range(2):
     call("df_conv_fwd", _ptr(xin), _ptr(wp), _ptr(bias), None, None, _ptr(y), B, Z, Y, X, F, F, 3, 9, 0.2, s)
+ww = torch.empty(query("df_wino_packed_elems", F, F, 0), device="cuda")
+call("df_wino_pack_weights", _ptr(wt), _ptr(ww), F, F, 0, s)
+for _ in range(2):
+    call("df_wino_conv_fwd", _ptr(xin), _ptr(ww), _ptr(bias), None, None, _ptr(y), B, Z, Y, X, F, F, 9, 0.2, s)
 gw = torch.empty_like(wt); gb = torch.empty(F, device="cuda")
 nb = query("df_conv_wgrad_workspace_bytes", B, Z, Y, X, F, F, 3)
 ws = torch.empty(nb // 4 + 1, device="cuda")
