@@ -17,6 +17,7 @@ namespace dfconv {
 namespace {
 
 using df::ceil_div;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int KZ, int TZ, int TY, int TX, int CO, bool VEC>
@@ -44,9 +45,10 @@ __global__ __launch_bounds__(kThreads) void conv_small_n_kernel(const ConvArgs a
   const int K8 = a.Kpad >> 3;
   const float* __restrict__ wflat = reinterpret_cast<const float*>(a.wp);
 
-  float acc[CO];
+  // two partial sums per output channel (even / odd input channel of a pair): the inner product runs as packed fp32 FMAs
+  f32x2 acc2[CO];
 #pragma unroll
-  for (int n = 0; n < CO; ++n) acc[n] = 0.f;
+  for (int n = 0; n < CO; ++n) acc2[n] = f32x2{0.f, 0.f};
 
   const int nchunk = a.Kpad / CK;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -92,13 +94,19 @@ __global__ __launch_bounds__(kThreads) void conv_small_n_kernel(const ConvArgs a
         // packed record [tap][k8][half][n][s]: for n < 4 the 16 floats (n-major, s-minor) are contiguous
         const int k8 = chunk * 2 + (q >> 1), half = q & 1;
         const float* wr = wflat + ((static_cast<int64_t>(tap) * K8 + k8) * 2 + half) * a.Npad * 4;   // wave-uniform
+        const f32x2 x01 = {xv[0], xv[1]}, x23 = {xv[2], xv[3]};
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int n = 0; n < CO; ++n) acc[n] = fmaf(xv[s], wr[n * 4 + s], acc[n]);
+        for (int n = 0; n < CO; ++n) {
+          const f32x2 w01 = {wr[n * 4 + 0], wr[n * 4 + 1]}, w23 = {wr[n * 4 + 2], wr[n * 4 + 3]};
+          acc2[n] = __builtin_elementwise_fma(x01, w01, acc2[n]);
+          acc2[n] = __builtin_elementwise_fma(x23, w23, acc2[n]);
+        }
       }
     }
   }
+  float acc[CO];
+#pragma unroll
+  for (int n = 0; n < CO; ++n) acc[n] = acc2[n][0] + acc2[n][1];
 
   const int gz = tz0 + lz, gy = ty0 + ly, gx = tx0 + lx;
   if (gz < a.D && gy < a.H && gx < a.W) {
@@ -188,16 +196,15 @@ __global__ __launch_bounds__(kThreads) void conv_small_k_kernel(const ConvArgs a
     const int gz = tz0 + lz, gy = ty0 + ly, gx = tx0 + lx;
     if (gz >= a.D || gy >= a.H || gx >= a.W) continue;          // wave-uniform
     const int h0 = (lz * HY + ly) * HX + lx;
-    float acc = 0.f;
+    f32x2 acc2 = {0.f, 0.f};            // packed fp32 FMAs: (k = 0, 2) and (k = 1, 3) partial sums
 #pragma unroll
     for (int tap = 0; tap < NTAP; ++tap) {
       const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
       const f32x4 g = sG[h0 + (dz * HY + dy) * HX + dx];          // wave-uniform address: LDS broadcast
-      acc = fmaf(g[0], w[tap][0], acc);
-      acc = fmaf(g[1], w[tap][1], acc);
-      acc = fmaf(g[2], w[tap][2], acc);
-      acc = fmaf(g[3], w[tap][3], acc);
+      acc2 = __builtin_elementwise_fma(f32x2{g[0], g[1]}, f32x2{w[tap][0], w[tap][1]}, acc2);
+      acc2 = __builtin_elementwise_fma(f32x2{g[2], g[3]}, f32x2{w[tap][2], w[tap][3]}, acc2);
     }
+    const float acc = acc2[0] + acc2[1];
     if (nok) {
       const int64_t o = (((static_cast<int64_t>(b) * a.D + gz) * a.H + gy) * a.W + gx) * a.Cout + n;
       float v = acc + bv;
