@@ -794,36 +794,54 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxy_kernel(const WxyArgs aa
   }
 }
 
-// gw[dz][dy][dx][ci][co] = G^T_y G^T_x of the summed (fixed order) partials U[xi_y][xi_x]; U[3][.] and U[.][3] carry a flipped sign
+// gw[dz][dy][dx][ci][co] = G^T_y G^T_x of the summed (fixed order) partials U[xi_y][xi_x]; U[3][.] and U[.][3] carry a flipped sign.
+// Workgroup = 32 consecutive (dz,ci,co) elements x 8 range groups: each thread sums every 8th range, the 8 group sums are combined
+// in a fixed order through LDS (deterministic), then one thread per element applies the two G^T.
 __global__ __launch_bounds__(kThreads) void wgrad_wxy_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
                                                                     float* __restrict__ gw, float* __restrict__ gb, int nranges, int ndz,
                                                                     int Cin, int Cout, int Cinp, int Coutp) {
+  __shared__ float sU[8][16][32];
   const int64_t total = static_cast<int64_t>(ndz) * Cin * Cout;
   const int64_t slot = static_cast<int64_t>(Cinp) * Coutp;
   const int64_t pstride = static_cast<int64_t>(ndz) * 16 * slot;
   const int64_t tapstride = static_cast<int64_t>(Cin) * Cout;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kThreads) {
-    const int co = static_cast<int>(i % Cout);
-    const int64_t t2 = i / Cout;
-    const int ci = static_cast<int>(t2 % Cin);
-    const int dzi = static_cast<int>(t2 / Cin);
-    const float* p = partial + (static_cast<int64_t>(dzi) * 16 * Cinp + ci) * Coutp + co;
-    float u[4][4];
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 32 + el;
+  const bool ok = i < total;
+  const int co = ok ? static_cast<int>(i % Cout) : 0;
+  const int64_t t2 = ok ? i / Cout : 0;
+  const int ci = static_cast<int>(t2 % Cin);
+  const int dzi = static_cast<int>(t2 / Cin);
+  const float* p = partial + (static_cast<int64_t>(dzi) * 16 * Cinp + ci) * Coutp + co;
+  float u[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) u[k >> 2][k & 3] = 0.f;
-    for (int rg = 0; rg < nranges; ++rg) {
+  for (int k = 0; k < 16; ++k) u[k] = 0.f;
+  if (ok) {
+    for (int rg = grp; rg < nranges; rg += 8) {
       const float* q = p + rg * pstride;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) u[k >> 2][k & 3] += q[k * slot];
+      for (int k = 0; k < 16; ++k) u[k] += q[k * slot];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sU[grp][k][el] = u[k];
+  __syncthreads();
+  if (grp == 0 && ok) {
+    float v[4][4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float acc = sU[0][k][el];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) acc += sU[g][k][el];
+      v[k >> 2][k & 3] = acc;
     }
     float w[3][4];      // G^T along y
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float h = 0.5f * (u[1][k] + u[2][k]);
-      w[0][k] = u[0][k] + h;
-      w[1][k] = 0.5f * (u[1][k] - u[2][k]);
-      w[2][k] = h - u[3][k];
+      const float h = 0.5f * (v[1][k] + v[2][k]);
+      w[0][k] = v[0][k] + h;
+      w[1][k] = 0.5f * (v[1][k] - v[2][k]);
+      w[2][k] = h - v[3][k];
     }
     float* o = gw + (static_cast<int64_t>(dzi) * 9 * Cin + ci) * Cout + co;
 #pragma unroll
@@ -835,10 +853,10 @@ __global__ __launch_bounds__(kThreads) void wgrad_wxy_reduce_kernel(const float*
     }
   }
   if (gb && blockIdx.x == 0) {
-    for (int co = threadIdx.x; co < Cout; co += kThreads) {
+    for (int c = threadIdx.x; c < Cout; c += kThreads) {
       float acc = 0.f;
-      for (int rg = 0; rg < nranges; ++rg) acc += bpartial[static_cast<int64_t>(rg) * Coutp + co];
-      gb[co] = acc;
+      for (int rg = 0; rg < nranges; ++rg) acc += bpartial[static_cast<int64_t>(rg) * Coutp + c];
+      gb[c] = acc;
     }
   }
 }
@@ -1426,7 +1444,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     else hipLaunchKernelGGL((wgrad_wxy_kernel<2, 0>), grid, dim3(kThreads), 0, s, aa);
     const int ndz = kz == 3 ? 3 : 1;
     const int64_t tot = static_cast<int64_t>(ndz) * Cin * Cout;
-    int64_t rgx = ceil_div(tot, kThreads);
+    const int64_t rgx = ceil_div(tot, 32);
     hipLaunchKernelGGL(wgrad_wxy_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
                        p.nranges * p.nsub, ndz, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
     return df::launched("df_conv_wgrad(winograd-xy)");
