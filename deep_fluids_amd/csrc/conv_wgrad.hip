@@ -1289,20 +1289,24 @@ __global__ __launch_bounds__(kThreads) void wgrad_up_reduce_kernel(const float* 
                                                                    float* __restrict__ gw, float* __restrict__ gb,
                                                                    int nranges, int kz, int Cin, int Cout, int Cinp,
                                                                    int Coutp) {
+  // workgroup = 32 consecutive output elements x 8 range groups (fixed-order combine through LDS: deterministic)
+  __shared__ float sP[8][32];
   const int taps = kz * 9, ncombo = kz == 3 ? 32 : 8, nd2 = kz == 3 ? 4 : 2, ncls = kz == 3 ? 8 : 4;
   const int64_t total = static_cast<int64_t>(taps) * Cin * Cout;
   const int64_t slot = static_cast<int64_t>(Cinp) * Coutp;
   const int64_t pstride = static_cast<int64_t>(ncombo) * 3 * slot;
   const int P[3][2] = {{0, 1}, {0, 1}, {0, 1}}, Dl[3][2] = {{0, 0}, {1, 0}, {1, 1}};   // k -> (p, delta) pairs
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 32 + el;
+  const bool ok = i < total;
+  float acc = 0.f;
+  if (ok) {
     const int co = static_cast<int>(i % Cout);
     const int64_t t2 = i / Cout;
     const int ci = static_cast<int>(t2 % Cin);
     const int tap = static_cast<int>(t2 / Cin);
     const int kx = tap % 3, ky = (tap / 3) % 3, kzz = tap / 9;
-    float acc = 0.f;
-    for (int rg = 0; rg < nranges; ++rg) {
+    for (int rg = grp; rg < nranges; rg += 8) {
       const float* pr = partial + rg * pstride + static_cast<int64_t>(ci) * Coutp + co;
       for (int az = 0; az < (kz == 3 ? 2 : 1); ++az)
         for (int ay = 0; ay < 2; ++ay)
@@ -1314,13 +1318,20 @@ __global__ __launch_bounds__(kThreads) void wgrad_up_reduce_kernel(const float* 
             acc += pr[(static_cast<int64_t>(combo) * 3 + (dxl + px)) * slot];
           }
     }
-    gw[i] = acc;
+  }
+  sP[grp][el] = acc;
+  __syncthreads();
+  if (grp == 0 && ok) {
+    float t = sP[0][el];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += sP[g][el];
+    gw[i] = t;
   }
   if (gb && blockIdx.x == 0) {
     for (int co = threadIdx.x; co < Cout; co += kThreads) {
-      float acc = 0.f;
-      for (int q = 0; q < nranges * ncls; ++q) acc += bpartial[static_cast<int64_t>(q) * Coutp + co];
-      gb[co] = acc;
+      float a2 = 0.f;
+      for (int q = 0; q < nranges * ncls; ++q) a2 += bpartial[static_cast<int64_t>(q) * Coutp + co];
+      gb[co] = a2;
     }
   }
 }
@@ -1557,8 +1568,7 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   else if (exact && wp8 == 7) hipLaunchKernelGGL((wgrad_kernel<true, true, 7>), grid, dim3(kThreads), 0, s, a);
   else hipLaunchKernelGGL((wgrad_kernel<true, true, 0>), grid, dim3(kThreads), 0, s, a);
   const int64_t total = static_cast<int64_t>(kz * 9) * Cin * Cout;
-  int64_t rg = ceil_div(total, kThreads);
-  if (rg > 2048) rg = 2048;
+  const int64_t rg = ceil_div(total, 32);
   hipLaunchKernelGGL(wgrad_up_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
                      p.nranges * p.nsub, kz, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
   return df::launched("df_upconv_wgrad");
