@@ -141,10 +141,12 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-template <int DBG>
+// FL >= 0: the epilogue flags are the compile-time constant FL (no per-element flag tests); FL < 0: run-time a.flags
+template <int DBG, int FL = -1>
 __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   __shared__ __attribute__((aligned(16))) float sIn[2 * BUF];
 
+  const int eflags = FL >= 0 ? FL : a.flags;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -392,14 +394,14 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         const int col = n0 + nb * 16 + tl;
-        const float bv = (a.flags & DF_CONV_BIAS) ? a.bias[col] : 0.f;
+        const float bv = (eflags & DF_CONV_BIAS) ? a.bias[col] : 0.f;
         float rres[8], rmask[8];
         if (full) {
 #pragma unroll
           for (int s = 0; s < 8; ++s) {
             const int64_t o = obase + nb * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW;
-            rres[s] = (a.flags & DF_CONV_RESIDUAL) ? a.residual[o] : 0.f;
-            rmask[s] = (a.flags & DF_CONV_MASK) ? a.mask_src[o] : 1.f;
+            rres[s] = (eflags & DF_CONV_RESIDUAL) ? a.residual[o] : 0.f;
+            rmask[s] = (eflags & DF_CONV_MASK) ? a.mask_src[o] : 1.f;
           }
         }
 #pragma unroll
@@ -420,15 +422,15 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           float v = (s < 4 ? lo[s & 3] : hi[s & 3]) + bv;
-          if (a.flags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
+          if (eflags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
           const int64_t o = obase + nb * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW;
           if (full) {
-            if (a.flags & DF_CONV_RESIDUAL) v += rres[s];
-            if (a.flags & DF_CONV_MASK) v = rmask[s] > 0.f ? v : a.leak * v;
+            if (eflags & DF_CONV_RESIDUAL) v += rres[s];
+            if (eflags & DF_CONV_MASK) v = rmask[s] > 0.f ? v : a.leak * v;
             a.y[o] = v;
           } else if (oz0 + (s >> 2) < a.D && oy0 + ((s >> 1) & 1) < a.H && ox0 + (s & 1) < a.W) {
-            if (a.flags & DF_CONV_RESIDUAL) v += a.residual[o];
-            if (a.flags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
+            if (eflags & DF_CONV_RESIDUAL) v += a.residual[o];
+            if (eflags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
             a.y[o] = v;
           }
         }
@@ -511,27 +513,33 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     if (ntb * a.ncs < grid) grid = ntb * a.ncs;
   }
   switch (g_wino_dbg >> 2) {
-    case 0: hipLaunchKernelGGL(wino3d_kernel<0>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 1: hipLaunchKernelGGL(wino3d_kernel<1>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 2: hipLaunchKernelGGL(wino3d_kernel<2>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 3: hipLaunchKernelGGL(wino3d_kernel<3>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 7: hipLaunchKernelGGL(wino3d_kernel<7>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 17: hipLaunchKernelGGL(wino3d_kernel<17>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 19: hipLaunchKernelGGL(wino3d_kernel<19>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 23: hipLaunchKernelGGL(wino3d_kernel<23>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 31: hipLaunchKernelGGL(wino3d_kernel<31>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 18: hipLaunchKernelGGL(wino3d_kernel<18>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 24: hipLaunchKernelGGL(wino3d_kernel<24>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 25: hipLaunchKernelGGL(wino3d_kernel<25>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 27: hipLaunchKernelGGL(wino3d_kernel<27>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 32: hipLaunchKernelGGL(wino3d_kernel<32>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 48: hipLaunchKernelGGL(wino3d_kernel<48>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 80: hipLaunchKernelGGL(wino3d_kernel<80>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 144: hipLaunchKernelGGL(wino3d_kernel<144>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 272: hipLaunchKernelGGL(wino3d_kernel<272>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 16: hipLaunchKernelGGL(wino3d_kernel<16>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 20: hipLaunchKernelGGL(wino3d_kernel<20>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 15: hipLaunchKernelGGL(wino3d_kernel<15>, dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 0:
+      if (flags == (DF_CONV_BIAS | DF_CONV_LRELU)) hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+      else if (flags == DF_CONV_MASK) hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_MASK>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+      else if (flags == DF_CONV_RESIDUAL) hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_RESIDUAL>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+      else if (flags == 0) hipLaunchKernelGGL((wino3d_kernel<0, 0>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+      else hipLaunchKernelGGL((wino3d_kernel<0, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+      break;
+    case 1: hipLaunchKernelGGL((wino3d_kernel<1, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 2: hipLaunchKernelGGL((wino3d_kernel<2, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 3: hipLaunchKernelGGL((wino3d_kernel<3, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 7: hipLaunchKernelGGL((wino3d_kernel<7, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 17: hipLaunchKernelGGL((wino3d_kernel<17, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 19: hipLaunchKernelGGL((wino3d_kernel<19, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 23: hipLaunchKernelGGL((wino3d_kernel<23, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 31: hipLaunchKernelGGL((wino3d_kernel<31, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 18: hipLaunchKernelGGL((wino3d_kernel<18, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 24: hipLaunchKernelGGL((wino3d_kernel<24, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 25: hipLaunchKernelGGL((wino3d_kernel<25, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 27: hipLaunchKernelGGL((wino3d_kernel<27, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 32: hipLaunchKernelGGL((wino3d_kernel<32, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 48: hipLaunchKernelGGL((wino3d_kernel<48, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 80: hipLaunchKernelGGL((wino3d_kernel<80, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 144: hipLaunchKernelGGL((wino3d_kernel<144, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 272: hipLaunchKernelGGL((wino3d_kernel<272, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 16: hipLaunchKernelGGL((wino3d_kernel<16, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 20: hipLaunchKernelGGL((wino3d_kernel<20, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 15: hipLaunchKernelGGL((wino3d_kernel<15, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     default: return df::fail(DF_EINVAL, "df_wino_conv_fwd: unknown debug variant");
   }
   return df::launched("df_wino_conv_fwd");
