@@ -315,3 +315,53 @@ def test_upconv_block_bf16x3_mode(ops, bf16x3):
     for i in reversed(range(n)):
         dx, _, _ = orc.conv_same_bwd(ins[i], ws[i].astype(np.float64), dx * np.where(outs[i] > 0, 1.0, 0.2))
     assert rel_linf(host(xt.grad), orc.upscale_nn_bwd(dx + go)) < 1e-4
+
+
+def test_full_size_conv_algorithms_agree_cfg3(ops):
+    """BASELINE cfg3 spatial size (64x96x64, F = 128, one batch element): too large for the NumPy oracle, so the parity check is a
+    property -- three independently written algorithms must agree: the direct MFMA kernels (pinned against the oracle above) vs the
+    Winograd forward / dgrad (conv_wino.hip) and the direct vs Winograd-x vs Winograd-(x,y) weight gradients (conv_wgrad.hip);
+    plus linearity of the Winograd conv in its input."""
+    from deep_fluids_amd._lib import call, query, lib
+    from deep_fluids_amd.ops import _ptr, _stream
+    torch.manual_seed(3)
+    B, D, H, W, C = 1, 64, 96, 64, 128
+    s = _stream()
+    x = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    x2 = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    g = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    w = (torch.rand((3, 3, 3, C, C), device="cuda") * 2 - 1) * (1.0 / (27 * C)) ** 0.5
+    bias = torch.rand(C, device="cuda") - 0.5
+    for mode in (0, 1):
+        wd = torch.empty(query("df_conv_packed_elems", 27, C, C, mode), device="cuda")
+        call("df_conv_pack_weights", _ptr(w), _ptr(wd), 27, C, C, mode, s)
+        ww = torch.empty(query("df_wino_packed_elems", C, C, mode), device="cuda")
+        call("df_wino_pack_weights", _ptr(w), _ptr(ww), C, C, mode, s)
+        y0 = torch.empty_like(x); y1 = torch.full_like(x, float("nan"))
+        call("df_conv_fwd", _ptr(x), _ptr(wd), _ptr(bias), None, None, _ptr(y0), B, D, H, W, C, C, 3, 8, 0.0, s)
+        call("df_wino_conv_fwd", _ptr(x), _ptr(ww), _ptr(bias), None, None, _ptr(y1), B, D, H, W, C, C, 8, 0.0, s)
+        assert ((y0 - y1).abs().max() / y0.abs().max()).item() < 2e-5, mode
+        assert ((y0 - y1).abs().sum() / y0.abs().sum()).item() < 5e-6, mode
+        if mode == 0:       # linearity: conv(2 x - 3 x2) = 2 conv(x) - 3 conv(x2) (no bias)
+            ya = torch.empty_like(x); yb = torch.empty_like(x); yc = torch.empty_like(x)
+            xc = 2 * x - 3 * x2
+            for src, dst in ((x, ya), (x2, yb), (xc, yc)):
+                call("df_wino_conv_fwd", _ptr(src), _ptr(ww), None, None, None, _ptr(dst), B, D, H, W, C, C, 0, 0.0, s)
+            lin = 2 * ya - 3 * yb
+            assert ((lin - yc).abs().max() / yc.abs().max()).item() < 2e-5
+            del ya, yb, yc, xc, lin
+    nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, C, 3)
+    ws = torch.empty((nb + 3) // 4, device="cuda")
+    res = []
+    for algo in (1, 2, 3):
+        lib().df_debug_set_wgrad_algo(ctypes.c_int(algo))
+        gw = torch.full((27, C, C), float("nan"), device="cuda"); gb = torch.full((C,), float("nan"), device="cuda")
+        call("df_conv_wgrad", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, s)
+        res.append((gw, gb))
+    lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+    for gw, gb in res[1:]:
+        assert ((gw - res[0][0]).abs().max() / res[0][0].abs().max()).item() < 2e-5
+        assert ((gb - res[0][1]).abs().max() / res[0][1].abs().max()).item() < 2e-5
+    # the bias gradient is a plain column sum: check it against torch in fp64
+    ref = g.double().sum(dim=(0, 1, 2, 3))
+    assert ((res[0][1].double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
