@@ -863,7 +863,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_wxy_reduce_kernel(const float*
 
 // the Winograd-in-x variant exists for the fully unrolled row lengths below (even channel counts: float2 operand loads)
 inline bool wx_ok(int64_t W, int64_t Cin, int64_t Cout) {
-  return (W == 16 || W == 32 || W == 64) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
+  return (W == 16 || W == 32 || W == 64 || W == 56 || W == 112) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
 }
 inline bool wxy_ok(int64_t H, int64_t W, int64_t Cin, int64_t Cout) { return wx_ok(W, Cin, Cout) && H % 2 == 0 && H >= 4; }
 int g_wgrad_ranges = 0;   // debug: override the number of voxel ranges (0 = default)
@@ -1449,6 +1449,8 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     const bool c128 = Cin == 128 && Cout == 128;
     if (W == 64 && c128) hipLaunchKernelGGL((wgrad_wxy_kernel<8, 128>), grid, dim3(kThreads), 0, s, aa);
     else if (W == 64) hipLaunchKernelGGL((wgrad_wxy_kernel<8, 0>), grid, dim3(kThreads), 0, s, aa);
+    else if (W == 112) hipLaunchKernelGGL((wgrad_wxy_kernel<14, 0>), grid, dim3(kThreads), 0, s, aa);      // cfg4 row lengths
+    else if (W == 56) hipLaunchKernelGGL((wgrad_wxy_kernel<7, 0>), grid, dim3(kThreads), 0, s, aa);
     else if (W == 32 && c128) hipLaunchKernelGGL((wgrad_wxy_kernel<4, 128>), grid, dim3(kThreads), 0, s, aa);
     else if (W == 32) hipLaunchKernelGGL((wgrad_wxy_kernel<4, 0>), grid, dim3(kThreads), 0, s, aa);
     else if (c128) hipLaunchKernelGGL((wgrad_wxy_kernel<2, 128>), grid, dim3(kThreads), 0, s, aa);
@@ -1463,6 +1465,8 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     const bool c128 = Cin == 128 && Cout == 128;
     if (W == 64 && c128) hipLaunchKernelGGL((wgrad_wx_kernel<8, 128>), grid, dim3(kThreads), 0, s, a);
     else if (W == 64) hipLaunchKernelGGL((wgrad_wx_kernel<8, 0>), grid, dim3(kThreads), 0, s, a);
+    else if (W == 112) hipLaunchKernelGGL((wgrad_wx_kernel<14, 0>), grid, dim3(kThreads), 0, s, a);
+    else if (W == 56) hipLaunchKernelGGL((wgrad_wx_kernel<7, 0>), grid, dim3(kThreads), 0, s, a);
     else if (W == 32 && c128) hipLaunchKernelGGL((wgrad_wx_kernel<4, 128>), grid, dim3(kThreads), 0, s, a);
     else if (W == 32) hipLaunchKernelGGL((wgrad_wx_kernel<4, 0>), grid, dim3(kThreads), 0, s, a);
     else if (c128) hipLaunchKernelGGL((wgrad_wx_kernel<2, 128>), grid, dim3(kThreads), 0, s, a);
