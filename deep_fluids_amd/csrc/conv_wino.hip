@@ -483,7 +483,9 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
   DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, DF_EINVAL, "df_wino_conv_fwd: non-positive extent");
   DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE,
              "df_wino_conv_fwd: Cin, Cout must be multiples of 32 (use df_conv_fwd otherwise)");
-  DF_REQUIRE(D * H * W * (Cin > Cout ? Cin : Cout) < (1LL << 31) && Cin <= kZeroFloats, DF_ESHAPE, "df_wino_conv_fwd: volume too large");
+  // (staging goes through 32-bit byte offsets into one batch volume, with 0x80000000 as the out-of-range sentinel)
+  DF_REQUIRE(D * H * W * (Cin > Cout ? Cin : Cout) <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
+             "df_wino_conv_fwd: one batch volume must stay below 2 GiB (use df_conv_fwd)");
   DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_BIAS without bias");
   DF_REQUIRE(!(flags & DF_CONV_RESIDUAL) || residual, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_RESIDUAL without residual");
   DF_REQUIRE(!(flags & DF_CONV_MASK) || mask_src, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_MASK without mask_src");

@@ -185,7 +185,7 @@ int df_add_up2x(const float* a, const float* bc, float* y, int64_t B, int64_t D,
 
 /* ---- Winograd F(2x2x2, 3x3x3) form of the 3-D stride-1 convolution (conv_wino.hip) ------------------------------------
  * Same result as df_conv_fwd with kz = 3 up to fp32 rounding order (all arithmetic fp32, 3.4x fewer matrix-core FLOPs);
- * same epilogue flags.  Needs Cin % 32 == 0 and Cout % 32 == 0.  Weights: TF layout [3,3,3,Cin,Cout], transformed and
+ * same epilogue flags.  Needs Cin % 32 == 0, Cout % 32 == 0 and D*H*W*max(Cin,Cout) <= 2^29 (one batch volume below 2 GiB).  Weights: TF layout [3,3,3,Cin,Cout], transformed and
  * packed once per update by df_wino_pack_weights (mode 0: forward operand, mode 1: dgrad operand). */
 int64_t df_wino_packed_elems(int64_t cin, int64_t cout, int mode);
 int df_wino_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, int mode, df_stream_t stream);
