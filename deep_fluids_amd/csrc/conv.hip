@@ -103,16 +103,19 @@ inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 // S = stride (1 | 2).  Stride 2 follows TF 'SAME' on even extents: pad 0 before / 1 after, i.e.
 // out[o] = sum_k in[2o + k] w[k]; the LDS tile is the (2T+1)-wide input footprint of the output tile.
 // KT = taps per in-plane axis (3; 2 for the parity-class convs of an up-sampled input), KZ = taps along z.
-template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, bool VEC, int S, int KT>
+// CKT = input channels per LDS chunk (16; 32 for the 8-tap parity-class convs, whose 16-channel chunks are only 16 steps long)
+template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, bool VEC, int S, int KT, int CKT = CK>
 __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in) {
   static_assert(TZ * TY * TX == 128 && WM * MB * 32 == 128 && WM * WN == 4, "tile shape");
   constexpr int HZ = (TZ - 1) * S + KZ, HY = (TY - 1) * S + KT, HX = (TX - 1) * S + KT, HV = HZ * HY * HX;
-  constexpr int NPIECE = HV * (CK / 4);
+  constexpr int LSTR = CKT + 4;             // LDS row stride (floats): (CKT+4)/4 odd -> conflict-free ds_read_b128
+  constexpr int QPV = CKT / 4;              // float4 pieces per staged voxel
+  constexpr int NPIECE = HV * QPV;
   constexpr int NLOAD = (NPIECE + kThreads - 1) / kThreads;
   constexpr int LBATCH = NLOAD < 8 ? NLOAD : 8;        // staging loads in flight per thread (bounds the registers)
   constexpr int NTAP = KZ * KT * KT;
   constexpr int NTILE = WN * NB * 32;
-  __shared__ __attribute__((aligned(16))) float sA[HV * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sA[HV * LSTR];
 
   ConvArgs a = a_in;
   if (a.nclass > 1) {          // parity class of the up-sampling-aware conv (wave-uniform)
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in
   // per-lane LDS index (16-byte units: 5 per staged voxel) of this lane's voxel row in each M block,
   // at tap (0,0,0), channel quad `half`
   const f32x4* sA4 = reinterpret_cast<const f32x4*>(sA);
-  constexpr int S4 = LDS_STRIDE / 4;
+  constexpr int S4 = LSTR / 4;
   int aidx[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
@@ -172,15 +175,15 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.f;
 
-  const int nchunk = a.Kpad / CK;
+  const int nchunk = a.Kpad / CKT;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     // ---- stage the halo'd input block of this 16-channel chunk ------------------------------------
     auto stage_load = [&](int it) -> float4 {
       const int p = it * kThreads + tid;
-      const int hv = p >> 2, q = p & 3;
+      const int hv = p / QPV, q = p % QPV;
       const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
       const int gz = tz0 * S + hz - a.pz, gy = ty0 * S + hy - a.py, gx = tx0 * S + hx - a.px;
-      const int ch = chunk * CK + q * 4;
+      const int ch = chunk * CKT + q * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const bool inb = p < NPIECE && gz >= 0 && gz < a.Di && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
       if (inb) {
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in
     };
     auto stage_store = [&](int it, const float4& v) {
       const int p = it * kThreads + tid;
-      if (p < NPIECE) *reinterpret_cast<float4*>(&sA[(p >> 2) * LDS_STRIDE + (p & 3) * 4]) = v;
+      if (p < NPIECE) *reinterpret_cast<float4*>(&sA[(p / QPV) * LSTR + (p % QPV) * 4]) = v;
     };
     if (NLOAD <= LBATCH) {
       float4 stg[LBATCH];
@@ -222,20 +225,21 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in
     __syncthreads();
 
     // ---- 9 / 27 taps x 2 channel-octets, software-pipelined by one step ---------------------------
-    const f32x4* bchunk = wbase + static_cast<int64_t>(chunk * 2) * bstep;      // wave-uniform
+    constexpr int C8 = CKT / 8;             // channel octets per chunk
+    const f32x4* bchunk = wbase + static_cast<int64_t>(chunk * C8) * bstep;      // wave-uniform
     const int64_t tapstride = static_cast<int64_t>(K8) * bstep;
 
     // A fragments: one step ahead (LDS);  B fragments: two steps ahead (L2), ring of three
     f32x4 af[2][MB], bf[3][NB];
     auto lds_a = [&](int step, f32x4 (&dst)[MB]) {
-      const int tap = step >> 1, c8 = step & 1;
+      const int tap = step / C8, c8 = step % C8;
       const int dz = tap / (KT * KT), dy = (tap / KT) % KT, dx = tap % KT;
       const int toff = ((dz * HY + dy) * HX + dx) * S4 + c8 * 2;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) dst[mb] = sA4[aidx[mb] + toff];
     };
     auto glb_b = [&](int step, f32x4 (&dst)[NB]) {
-      const int tap = step >> 1, c8 = step & 1;
+      const int tap = step / C8, c8 = step % C8;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) dst[nb] = (bchunk + (tap * tapstride + c8 * bstep))[boff[nb]];
     };
@@ -244,10 +248,10 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in
     lds_a(0, af[0]);
 
 #pragma unroll
-    for (int step = 0; step < NTAP * 2; ++step) {
+    for (int step = 0; step < NTAP * C8; ++step) {
       const int ca = step & 1, cb = step % 3;
-      if (step + 2 < NTAP * 2) glb_b(step + 2, bf[(step + 2) % 3]);
-      if (step + 1 < NTAP * 2) lds_a(step + 1, af[ca ^ 1]);
+      if (step + 2 < NTAP * C8) glb_b(step + 2, bf[(step + 2) % 3]);
+      if (step + 1 < NTAP * C8) lds_a(step + 1, af[ca ^ 1]);
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetches at the head of the step
 #pragma unroll
       for (int s = 0; s < 4; ++s)
@@ -295,7 +299,9 @@ int launch(const ConvArgs& a_in, hipStream_t s) {
   a.ntiles = (int)nt;
   dim3 grid((unsigned)nt, (unsigned)(a.Npad / (WN * NB * 32)), (unsigned)(a.nclass > 1 ? a.nclass : 1));
   const bool vec = (a.Cin % 4 == 0) && df::aligned16(a.x);
-  if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, true, S, KT>), grid, dim3(kThreads), 0, s, a);
+  if (KT == 2 && KZ == 2 && vec && a.Kpad % 32 == 0)     // 8-tap parity-class convs: 32-channel chunks (half the barriers per MFMA)
+    hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, true, S, KT, (KT == 2 && KZ == 2 ? 32 : CK)>), grid, dim3(kThreads), 0, s, a);
+  else if (vec) hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, true, S, KT>), grid, dim3(kThreads), 0, s, a);
   else hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, WM, WN, MB, NB, false, S, KT>), grid, dim3(kThreads), 0, s, a);
   return df::launched("df_conv_fwd");
 }
