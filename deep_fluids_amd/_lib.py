@@ -39,6 +39,8 @@ SIGNATURES = {
     "df_concat2_fwd": (I32, [P, P, P, I64, I64, I64, P]),
     "df_concat2_bwd": (I32, [P, P, P, I64, I64, I64, P]),
     "df_dilate2_odd": (I32, [P, P, I64, I64, I64, I64, I64, I32, P]),
+    "df_kl_bernoulli_fwd": (I32, [P, I64, I64, I64, F32, P, P]),
+    "df_kl_bernoulli_bwd": (I32, [P, P, F32, P, I64, I64, I64, F32, P]),
     "df_sigmoid_fwd": (I32, [P, P, I64, P]),
     "df_sigmoid_bwd": (I32, [P, P, P, I64, P]),
     "df_mse_mean_fwd": (I32, [P, P, I64, P, P, I64, P]),

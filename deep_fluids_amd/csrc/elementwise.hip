@@ -171,6 +171,38 @@ __global__ __launch_bounds__(kThreads) void dilate2_kernel(const float4* __restr
   }
 }
 
+// ---- Bernoulli-KL sparsity of the AE latent code (trainer3.py:272-277 / trainer.py:389-394) ---------------------------------------
+// loss = sum_j KL(Bern(rho) || Bern(rhat_j)),  rhat_j = mean_b z[b][j],  j < n  (the code's first n of ncol columns)
+//      = sum_j rho log(rho / rhat_j) + (1 - rho) log((1 - rho) / (1 - rhat_j))            (tf.distributions.kl_divergence)
+// One workgroup: the code is [B, 16] in the reference's runs.
+__global__ __launch_bounds__(kThreads) void kl_bernoulli_kernel(const float* __restrict__ z, const float* __restrict__ gout,
+                                                                float* __restrict__ out, float* __restrict__ gz, int B, int ncol,
+                                                                int n, float rho, float scale, int bwd) {
+  __shared__ double sacc[kThreads];
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < ncol; j += kThreads) {
+    double m = 0.0;
+    if (j < n) {
+      for (int b = 0; b < B; ++b) m += static_cast<double>(z[static_cast<int64_t>(b) * ncol + j]);
+      m /= B;
+      acc += rho * log(rho / m) + (1.0 - rho) * log((1.0 - rho) / (1.0 - m));
+    }
+    if (bwd) {
+      const float g = j < n ? static_cast<float>((-rho / m + (1.0 - rho) / (1.0 - m)) / B) * gout[0] * scale : 0.f;
+      for (int b = 0; b < B; ++b) gz[static_cast<int64_t>(b) * ncol + j] = g;
+    }
+  }
+  if (!bwd) {
+    sacc[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int i = 0; i < kThreads; ++i) t += sacc[i];      // fixed order
+      out[0] = static_cast<float>(t);
+    }
+  }
+}
+
 // ---- sigmoid (AE latent code when use_sparse, model.py:210) -------------------------------------------------------------
 template <int DIR>
 __global__ __launch_bounds__(kThreads) void sigmoid_kernel(const float* __restrict__ a, const float* __restrict__ yv,
@@ -655,6 +687,25 @@ int df_dilate2_odd(const float* g, float* out, int64_t B, int64_t D, int64_t H, 
   else hipLaunchKernelGGL((dilate2_kernel<false>), dim3(grid_for(n4)), dim3(kThreads), 0, df::as_stream(stream), g4, o4, n4,
                           (int)D, (int)H, (int)W, (int)(C / 4));
   return df::launched("df_dilate2_odd");
+}
+
+int df_kl_bernoulli_fwd(const float* z, int64_t B, int64_t ncol, int64_t n, float rho, float* out, df_stream_t stream) {
+  DF_REQUIRE(z && out, DF_EINVAL, "df_kl_bernoulli_fwd: null pointer");
+  DF_REQUIRE(B > 0 && ncol > 0 && n >= 0 && n <= ncol && B < (1 << 24) && ncol < (1 << 24), DF_ESHAPE, "df_kl_bernoulli_fwd: bad shape");
+  DF_REQUIRE(rho > 0.f && rho < 1.f, DF_EINVAL, "df_kl_bernoulli_fwd: rho must be in (0, 1)");
+  hipLaunchKernelGGL(kl_bernoulli_kernel, dim3(1), dim3(kThreads), 0, df::as_stream(stream), z, nullptr, out, nullptr, (int)B, (int)ncol,
+                     (int)n, rho, 1.f, 0);
+  return df::launched("df_kl_bernoulli_fwd");
+}
+
+int df_kl_bernoulli_bwd(const float* z, const float* gout, float scale, float* gz, int64_t B, int64_t ncol, int64_t n, float rho,
+                        df_stream_t stream) {
+  DF_REQUIRE(z && gout && gz, DF_EINVAL, "df_kl_bernoulli_bwd: null pointer");
+  DF_REQUIRE(B > 0 && ncol > 0 && n >= 0 && n <= ncol && B < (1 << 24) && ncol < (1 << 24), DF_ESHAPE, "df_kl_bernoulli_bwd: bad shape");
+  DF_REQUIRE(rho > 0.f && rho < 1.f, DF_EINVAL, "df_kl_bernoulli_bwd: rho must be in (0, 1)");
+  hipLaunchKernelGGL(kl_bernoulli_kernel, dim3(1), dim3(kThreads), 0, df::as_stream(stream), z, gout, nullptr, gz, (int)B, (int)ncol,
+                     (int)n, rho, scale, 1);
+  return df::launched("df_kl_bernoulli_bwd");
 }
 
 int df_sigmoid_fwd(const float* x, float* y, int64_t n, df_stream_t stream) {

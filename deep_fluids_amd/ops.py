@@ -526,6 +526,28 @@ class _Sigmoid(torch.autograd.Function):
         return gx
 
 
+class _KlBernoulli(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, n, rho):
+        z = _prep(z, "z")
+        if z.dim() != 2 or not 0 <= n <= z.shape[1]:
+            raise ValueError("kl_bernoulli: z must be [B, ncol] with n <= ncol")
+        out = torch.empty((), dtype=torch.float32, device=z.device)
+        call("df_kl_bernoulli_fwd", _ptr(z), z.shape[0], z.shape[1], int(n), float(rho), _ptr(out), _stream())
+        ctx.save_for_backward(z)
+        ctx.geom = (int(n), float(rho))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (z,) = ctx.saved_tensors
+        n, rho = ctx.geom
+        gout = _prep(gout, "grad")
+        gz = torch.empty_like(z)
+        call("df_kl_bernoulli_bwd", _ptr(z), _ptr(gout), 1.0, _ptr(gz), z.shape[0], z.shape[1], n, rho, _stream())
+        return gz, None, None
+
+
 class _MseMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -736,6 +758,12 @@ def concat(values, axis=-1):
 def sigmoid(x):
     """``tf.sigmoid`` (model.py:196,210)."""
     return _Sigmoid.apply(x)
+
+
+def kl_bernoulli(z, n, rho):
+    """``tf.reduce_sum(ds.kl_divergence(ds.Bernoulli(probs=rho), ds.Bernoulli(probs=tf.reduce_mean(z[:, :n], axis=0))))``
+    (trainer3.py:272-277)."""
+    return _KlBernoulli.apply(z, n, rho)
 
 
 def mse_mean(a, b):

@@ -22,7 +22,7 @@ import torch
 from . import ops
 from .ops import curl, curl3, jacobian, jacobian3, l1_mean, mse_mean, get_conv_shape, _ptr, _stream, call
 from .model import GeneratorBE, GeneratorBE3, AE, AE3, DiscriminatorPatch, DiscriminatorPatch3
-from .ops import concat
+from .ops import concat, kl_bernoulli
 from .dist import GradSync
 
 
@@ -227,9 +227,8 @@ class AETrainer(Trainer):
         self.z_num = config.z_num
         self.p_num = config.p_num
         self.use_sparse = config.use_sparse
-        if self.use_sparse:
-            raise NotImplementedError("use_sparse=True (Bernoulli-KL sparsity, trainer3.py:272-277) is not built; "
-                                      "the reference's documented runs never enable it (run.bat:56,73)")
+        self.sparsity = config.sparsity
+        self.w5 = config.w5
         self.w4 = config.w4
         super(AETrainer, self).__init__(config, device, name)
 
@@ -260,8 +259,12 @@ class AETrainer(Trainer):
         y_last = y[:, :, -1] if y.dim() == 3 else y                # trainer3.py:268
         loss_p = mse_mean(y_last.contiguous(), z[:, -self.p_num:].contiguous())   # trainer3.py:269-270
         loss = loss_l1 * self.w1 + loss_j_l1 * self.w2 + loss_p * self.w4
+        loss_kl = None
+        if self.use_sparse:                                        # trainer3.py:272-277 (z is sigmoid(enc) then, model.py:210)
+            loss_kl = kl_bernoulli(z, self.z_num - self.p_num, self.sparsity)
+            loss = loss + loss_kl * self.w5
         return SimpleNamespace(s=out, G_=x_, x_=x_, z=z, G_jaco_=x_jaco_, G_vort_=x_vort_, x_jaco=x_jaco,
-                               g_loss_l1=loss_l1, g_loss_j_l1=loss_j_l1, loss_p=loss_p, g_loss=loss, loss=loss)
+                               g_loss_l1=loss_l1, g_loss_j_l1=loss_j_l1, loss_p=loss_p, loss_kl=loss_kl, g_loss=loss, loss=loss)
 
 
 class _Slab(object):

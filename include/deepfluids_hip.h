@@ -123,6 +123,11 @@ int df_dilate2_odd(const float* g, float* out, int64_t B, int64_t D, int64_t H, 
                    df_stream_t stream);
 
 /* tf.sigmoid (AE latent code with use_sparse, model.py:196,210) and its backward from the saved output. */
+/* Bernoulli-KL sparsity of the auto-encoder code (trainer3.py:272-277): out = sum_{j<n} KL(Bern(rho) || Bern(mean_b z[b][j]));
+ * z is [B, ncol] (sigmoid outputs), the first n columns take part.  bwd: gz[B, ncol] = gout * scale * dloss/dz (0 for j >= n). */
+int df_kl_bernoulli_fwd(const float* z, int64_t B, int64_t ncol, int64_t n, float rho, float* out, df_stream_t stream);
+int df_kl_bernoulli_bwd(const float* z, const float* gout, float scale, float* gz, int64_t B, int64_t ncol, int64_t n, float rho,
+                        df_stream_t stream);
 int df_sigmoid_fwd(const float* x, float* y, int64_t n, df_stream_t stream);
 int df_sigmoid_bwd(const float* gy, const float* y, float* gx, int64_t n, df_stream_t stream);
 

@@ -465,12 +465,29 @@ def ae_init(rng, x_shape, filters, z_num, name="AE", num_conv=4, repeat=0):
     return p
 
 
+def kl_bernoulli(z, n, rho):
+    """trainer3.py:272-277 / trainer.py:389-394: sum_j KL(Bernoulli(rho) || Bernoulli(mean_b z[b, j])), j < n.
+    (tf.distributions.kl_divergence for two Bernoullis -- TensorFlow 1.15 is absent here, so this line is a restatement of its
+    documented closed form p log(p/q) + (1-p) log((1-p)/(1-q)): parity unpinned for this one term.)"""
+    q = z[:, :n].mean(axis=0)
+    return float((rho * np.log(rho / q) + (1 - rho) * np.log((1 - rho) / (1 - q))).sum())
+
+
+def kl_bernoulli_bwd(z, n, rho, scale=1.0):
+    q = z[:, :n].mean(axis=0)
+    g = np.zeros_like(z)
+    g[:, :n] = scale * (-rho / q + (1 - rho) / (1 - q)) / z.shape[0]
+    return g
+
+
 def ae_train_step(x, y_last, p, opt, filters, z_num, p_num, is_3d, num_conv=4, repeat=0, use_curl=True, w1=1.0, w2=1.0,
-                  w4=1.0, name="AE"):
-    """build_model_ae + one optimizer step (trainer.py:357-423 / trainer3.py:240-279), use_sparse=False.
-    ``y_last`` = y[:, :, -1]  [B, p_num];  loss = w1*L1 + w2*J-L1 + w4*mean((y_last - z[:, -p_num:])^2)."""
+                  w4=1.0, name="AE", use_sparse=False, sparsity=0.01, w5=1.0):
+    """build_model_ae + one optimizer step (trainer.py:357-423 / trainer3.py:240-279).
+    ``y_last`` = y[:, :, -1]  [B, p_num];  loss = w1*L1 + w2*J-L1 + w4*mean((y_last - z[:, -p_num:])^2)
+    (+ w5 * Bernoulli-KL of the sigmoid code's first z_num - p_num columns when use_sparse, model.py:196,210)."""
     oshape = list(x.shape[1:])                           # model.py:197,211: the decoder emits x's own shape
-    z, ecache = encoder_fwd(x, p, filters, z_num, name + "/enc", num_conv - 1, repeat, keep=True)
+    zpre, ecache = encoder_fwd(x, p, filters, z_num, name + "/enc", num_conv - 1, repeat, keep=True)
+    z = 1.0 / (1.0 + np.exp(-zpre)) if use_sparse else zpre
     s, dcache = generator_fwd(z, p, oshape, filters, name + "/dec", num_conv, repeat, keep=True)
     if use_curl:
         if is_3d:
@@ -487,13 +504,18 @@ def ae_train_step(x, y_last, p, opt, filters, z_num, p_num, is_3d, num_conv=4, r
     grads = generator_bwd(ds, dcache, p, name + "/dec")
     dz = _generator_dz(ds, dcache, p, name + "/dec").copy()      # dL/dz through the decoder (z is the encoder's output)
     dz[:, -p_num:] += dzp
+    loss_kl = 0.0
+    if use_sparse:
+        loss_kl = kl_bernoulli(z, z_num - p_num, sparsity)
+        dz = dz + kl_bernoulli_bwd(z, z_num - p_num, sparsity, w5)
+        dz = dz * z * (1.0 - z)                                   # through the sigmoid
     grads.update(encoder_bwd(dz, ecache, p, name + "/enc"))
     t = opt["t"] + 1
     new_p, new_m, new_v = {}, {}, {}
     for k in p:
         new_p[k], new_m[k], new_v[k] = adam_tf1(p[k], grads[k], opt["m"][k], opt["v"][k], t, opt["lr"])
-    info = {"loss": res["loss"] + w4 * loss_p, "l1": res["l1"], "j_l1": res["j_l1"], "loss_p": loss_p, "u": res["u"],
-            "z": z, "grads": grads}
+    info = {"loss": res["loss"] + w4 * loss_p + w5 * loss_kl, "l1": res["l1"], "j_l1": res["j_l1"], "loss_p": loss_p,
+            "loss_kl": loss_kl, "u": res["u"], "z": z, "grads": grads}
     return new_p, {"m": new_m, "v": new_v, "t": t, "lr": opt["lr"]}, info
 
 

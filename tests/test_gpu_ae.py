@@ -97,6 +97,17 @@ def test_ae_vs_reference_model_py(tag):
 
 @pytest.mark.parametrize("is_3d,spatial,filters", [(True, (8, 16, 8), 16), (False, (16, 16), 16)])
 def test_ae_train_step_vs_oracle(is_3d, spatial, filters):
+    _ae_step_case(is_3d, spatial, filters, False)
+
+
+@pytest.mark.parametrize("is_3d,spatial,filters", [(True, (8, 16, 8), 8), (False, (16, 16), 16)])
+def test_ae_train_step_use_sparse_vs_oracle(is_3d, spatial, filters):
+    """use_sparse=True (trainer3.py:272-277): sigmoid on the code (model.py:196,210) + w5 * Bernoulli-KL on its first
+    z_num - p_num columns."""
+    _ae_step_case(is_3d, spatial, filters, True)
+
+
+def _ae_step_case(is_3d, spatial, filters, use_sparse):
     from deep_fluids_amd import ops
     from deep_fluids_amd.trainer import AETrainer, default_config
     ops.reset_variables()
@@ -111,7 +122,8 @@ def test_ae_train_step_vs_oracle(is_3d, spatial, filters):
     x, _ = orc.synthetic_batch(rng, batch, spatial)
     y = rng.uniform(-1, 1, (batch, p_num, 5)).astype(np.float32)
     cfg = default_config(is_3d=is_3d, res_x=spatial[-1], res_y=spatial[-2], res_z=spatial[0] if is_3d else 1,
-                         filters=filters, batch_size=batch, num_samples=1000, z_num=z_num, p_num=p_num)
+                         filters=filters, batch_size=batch, num_samples=1000, z_num=z_num, p_num=p_num,
+                         use_sparse=use_sparse, sparsity=0.05, w5=0.7)
     tr = AETrainer(cfg)
     assert sorted(tr.var_names) == sorted(p)
     tr.load_variables(p)
@@ -119,7 +131,10 @@ def test_ae_train_step_vs_oracle(is_3d, spatial, filters):
     opt = {"m": {k: np.zeros_like(v) for k, v in p64.items()}, "v": {k: np.zeros_like(v) for k, v in p64.items()},
            "t": 0, "lr": cfg.lr_max}
     m = tr.train_step(dev(x), dev(y))
-    _, _, info = orc.ae_train_step(x.astype(np.float64), y[:, :, -1].astype(np.float64), p64, opt, filters, z_num, p_num, is_3d)
+    _, _, info = orc.ae_train_step(x.astype(np.float64), y[:, :, -1].astype(np.float64), p64, opt, filters, z_num, p_num, is_3d,
+                                   use_sparse=use_sparse, sparsity=0.05, w5=0.7)
+    if use_sparse:
+        assert abs(float(m.loss_kl.detach()) - info["loss_kl"]) < 1e-5 * abs(info["loss_kl"])
     assert rel_l1(host(m.G_), info["u"]) <= 1e-4
     assert abs(float(m.g_loss.detach()) - info["loss"]) < 1e-5 * abs(info["loss"])
     assert abs(float(m.loss_p.detach()) - info["loss_p"]) < 1e-5 * abs(info["loss_p"]) + 1e-8

@@ -41,3 +41,19 @@ def test_stencils_numpy_vs_torch():
     np.testing.assert_array_equal(j, jt.numpy()); np.testing.assert_array_equal(c, ct.numpy())
     s = rng.randn(2, 5, 6, 1)
     np.testing.assert_array_equal(orc.curl(s), ort.curl(torch.tensor(s)).numpy())
+
+
+def test_kl_bernoulli_gradient_numeric():
+    """oracle kl_bernoulli / kl_bernoulli_bwd (trainer3.py:272-277): closed form vs a central difference."""
+    rng = np.random.RandomState(4)
+    z = rng.uniform(0.05, 0.95, (5, 8))
+    n, rho = 6, 0.07
+    q = z[:, :n].mean(0)
+    brute = sum(rho * np.log(rho / qq) + (1 - rho) * np.log((1 - rho) / (1 - qq)) for qq in q)
+    assert abs(orc.kl_bernoulli(z, n, rho) - brute) < 1e-12
+    g = orc.kl_bernoulli_bwd(z, n, rho)
+    for (b, j) in [(0, 0), (3, 5), (4, 7)]:
+        zp = z.copy(); zp[b, j] += 1e-6
+        zm = z.copy(); zm[b, j] -= 1e-6
+        num = (orc.kl_bernoulli(zp, n, rho) - orc.kl_bernoulli(zm, n, rho)) / 2e-6
+        assert abs(num - g[b, j]) < 1e-6 * max(1.0, abs(num))
