@@ -297,7 +297,7 @@ def main():
         torch.cuda.synchronize(); el3 = (time.perf_counter() - t2) / 10
         out["extra_2d_128x96"] = {"ms_per_step": el3 * 1e3, "value": 64 * 128 * 96 / el3, "unit": "pixels/s", "batch": 64,
                                   "conv_tflops_reference_equivalent": 3.71e12 / el3 / 1e12, "dtype": "f32",
-                                  "note": "2-D 128x96 train step (GeneratorBE filters=128), direct fp32 MFMA convs + Winograd-(x,y) weight gradient; not the reported metric"}
+                                  "note": "2-D 128x96 train step (GeneratorBE filters=128), Winograd F(2x2,3x3) forward/dgrad + Winograd-(x,y) weight gradient at the top levels; not the reported metric"}
         ops.reset_variables()
     out["cpu_baseline"] = None
     if world == 1 and not a.no_cpu_baseline:

@@ -199,25 +199,29 @@ def _sfx(cin, cout):
 
 
 # Algorithm of the wide 3-D stride-1 convs (forward and dgrad), fp32 mode only:
-#   "auto"     Winograd F(2x2x2,3x3x3) (conv_wino.hip: same fp32 arithmetic, 3.4x fewer matrix FLOPs) where it applies
-#              (3-D, Cin and Cout multiples of 32, extents >= 8) and the direct implicit-GEMM kernel everywhere else;
+#   "auto"     Winograd F(2x2x2,3x3x3) / F(2x2,3x3) (conv_wino.hip / conv_wino2d.hip: same fp32 arithmetic, 3.4x / 2.25x fewer
+#              matrix FLOPs) where it applies (Cin and Cout multiples of 32; 3-D extents >= 8, 2-D extents >= 16 x 24) and the direct
+#              implicit-GEMM kernel everywhere else;
 #   "direct"   always the direct kernel;   "winograd"  Winograd wherever the channel counts allow (tests).
 CONV_ALGO = "auto"
 
 
 def _use_wino(cin, cout, dims, kz):
-    if kz != 3 or CONV_ALGO == "direct" or CONV_PRECISION != "fp32" or cin % 32 or cout % 32:
-        return False
-    if CONV_ALGO == "winograd":
-        return True
-    return min(dims[1], dims[2], dims[3]) >= 8
+    """0: direct kernel; 3: 3-D Winograd F(2x2x2,3x3x3) (conv_wino.hip); 2: 2-D Winograd F(2x2,3x3) (conv_wino2d.hip)."""
+    if CONV_ALGO == "direct" or CONV_PRECISION != "fp32" or cin % 32 or cout % 32:
+        return 0
+    if kz == 3:
+        return 3 if (CONV_ALGO == "winograd" or min(dims[1], dims[2], dims[3]) >= 8) else 0
+    return 2 if (CONV_ALGO == "winograd" or (dims[2] >= 16 and dims[3] >= 24)) else 0
 
 
 def _pack(w, taps, cin, cout, mode, dims=None):
     """Packed MFMA operand of w for the stride-1 conv on `dims` (mode 0: forward, mode 1: dgrad)."""
-    if dims is not None and _use_wino(cin, cout, dims, 3 if taps == 27 else 1):
-        wp = torch.empty(query("df_wino_packed_elems", cin, cout, mode), dtype=torch.float32, device=w.device)
-        call("df_wino_pack_weights", _ptr(w), _ptr(wp), cin, cout, mode, _stream())
+    algo = _use_wino(cin, cout, dims, 3 if taps == 27 else 1) if dims is not None else 0
+    if algo:
+        fn = "df_wino" if algo == 3 else "df_wino2d"
+        wp = torch.empty(query(fn + "_packed_elems", cin, cout, mode), dtype=torch.float32, device=w.device)
+        call(fn + "_pack_weights", _ptr(w), _ptr(wp), cin, cout, mode, _stream())
         return wp
     sfx = _sfx(cin, cout)
     n = query("df_conv_packed_elems" + sfx, taps, cin, cout, mode)
@@ -230,8 +234,13 @@ def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak)
     """`wp` must come from ``_pack(..., dims)`` with the same dims (the two agree on the algorithm)."""
     B, D, H, W = dims
     y = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
-    if _use_wino(cin, cout, dims, kz):
+    algo = _use_wino(cin, cout, dims, kz)
+    if algo == 3:
         call("df_wino_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, D, H, W, cin, cout,
+             flags, float(leak), _stream())
+        return y
+    if algo == 2:
+        call("df_wino2d_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, H, W, cin, cout,
              flags, float(leak), _stream())
         return y
     call("df_conv_fwd" + _sfx(cin, cout), _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, D, H, W,

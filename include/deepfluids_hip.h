@@ -198,6 +198,14 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
                      float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak,
                      df_stream_t stream);
 
+/* 2-D twin: Winograd F(2x2, 3x3) form of the stride-1 3x3 convolution (conv_wino2d.hip): 2.25x fewer matrix-core FLOPs than df_conv_fwd
+ * with kz = 1, fp32 throughout, same epilogue flags.  Needs Cin % 32 == 0, Cout % 32 == 0, H*W*max(Cin,Cout) <= 2^29. */
+int64_t df_wino2d_packed_elems(int64_t cin, int64_t cout, int mode);
+int df_wino2d_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, int mode, df_stream_t stream);
+int df_wino2d_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
+                       float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak,
+                       df_stream_t stream);
+
 /* ---- opt-in "bf16x3" precision mode (conv_bf16.hip) ---------------------------------------------------------------------
  * fp32 operands are split a = hi + lo into two bf16 words and a*b ~= hi*hi + hi*lo + lo*hi runs on the bf16 matrix pipe
  * (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate): 16 significand bits per operand, ~5x the fp32 MFMA rate.  Same arguments

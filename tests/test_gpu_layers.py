@@ -101,6 +101,28 @@ WINO_CASES = [
 ]
 
 
+WINO2D_CASES = [
+    ((1, 16, 32), 32, 32, 0.2),         # exactly one tile block
+    ((2, 32, 48), 64, 32, 0.2),         # Cin != Cout; half-filled block column
+    ((3, 33, 47), 32, 64, None),        # ragged in both axes (odd extents), no activation
+    ((1, 10, 12), 32, 32, 0.2),         # smaller than a block
+    ((2, 16, 64), 128, 128, 0.2),       # the hot layer's channel counts (8 chunks, 4 cout slices)
+    ((2, 24, 32), 96, 96, 0.2),         # 3 cout slices: generic worker mapping; 6 chunks
+]
+
+
+@pytest.mark.parametrize("shape,cin,cout,leak", WINO2D_CASES)
+def test_conv2d_winograd_fwd_bwd(ops, shape, cin, cout, leak):
+    """conv_wino2d.hip (forward and dgrad through _ConvSame3) against the fp64 oracle, same tolerance as the direct kernel."""
+    old = ops.CONV_ALGO
+    ops.CONV_ALGO = "winograd"
+    try:
+        errs = _conv_case(ops, shape, cin, cout, leak, seed=cin * 3 + cout + sum(shape), mask_from_gpu=True)
+    finally:
+        ops.CONV_ALGO = old
+    assert max(errs.values()) < TOL, errs
+
+
 @pytest.mark.parametrize("shape,cin,cout,leak", WINO_CASES)
 def test_conv3d_winograd_fwd_bwd(ops, shape, cin, cout, leak):
     """conv_wino.hip (forward and dgrad through _ConvSame3; the wgrad stays direct) against the fp64 oracle, same tolerance
