@@ -30,6 +30,9 @@ __global__ __launch_bounds__(kThreads) void conv_small_n_kernel(const ConvArgs a
   constexpr int NTAP = KZ * 9;
   constexpr int S4 = LDS_STRIDE / 4;
   __shared__ __attribute__((aligned(16))) float sA[HV * LDS_STRIDE];
+  // the chunk's weights [tap][channel quad][n < 4][4]: 6.9 KB.  (They used to be SGPR operands fetched by 108 scattered scalar
+  //  loads per chunk -- a 55 KB footprint that thrashes the 16 KB scalar cache; an LDS broadcast read has no such cliff.)
+  __shared__ __attribute__((aligned(16))) f32x4 sWt[NTAP * 4 * 4];
   const f32x4* sA4 = reinterpret_cast<const f32x4*>(sA);
 
   const int tid = threadIdx.x;
@@ -43,7 +46,6 @@ __global__ __launch_bounds__(kThreads) void conv_small_n_kernel(const ConvArgs a
   const int lx = tid % TX, ly = (tid / TX) % TY, lz = tid / (TX * TY);
   const int aidx = ((lz * HY + ly) * HX + lx) * S4;
   const int K8 = a.Kpad >> 3;
-  const float* __restrict__ wflat = reinterpret_cast<const float*>(a.wp);
 
   // two partial sums per output channel (even / odd input channel of a pair): the inner product runs as packed fp32 FMAs
   f32x2 acc2[CO];
@@ -76,12 +78,25 @@ __global__ __launch_bounds__(kThreads) void conv_small_n_kernel(const ConvArgs a
       }
       stg[it] = v;
     }
+    f32x4 wst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = i * kThreads + tid;            // record (tap, q, n): r = (tap*4 + q)*4 + n
+      if (r < NTAP * 16) {
+        const int n = r & 3, q = (r >> 2) & 3, tap = r >> 4;
+        const int k8 = chunk * 2 + (q >> 1), half = q & 1;
+        wst[i] = a.wp[((static_cast<int64_t>(tap) * K8 + k8) * 2 + half) * a.Npad + n];
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
       const int p = it * kThreads + tid;
       if (p < NPIECE) *reinterpret_cast<float4*>(&sA[(p >> 2) * LDS_STRIDE + (p & 3) * 4]) = stg[it];
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (i * kThreads + tid < NTAP * 16) sWt[i * kThreads + tid] = wst[i];
     __syncthreads();
 
 #pragma unroll
@@ -91,13 +106,11 @@ __global__ __launch_bounds__(kThreads) void conv_small_n_kernel(const ConvArgs a
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 xv = sA4[aidx + toff + q];
-        // packed record [tap][k8][half][n][s]: for n < 4 the 16 floats (n-major, s-minor) are contiguous
-        const int k8 = chunk * 2 + (q >> 1), half = q & 1;
-        const float* wr = wflat + ((static_cast<int64_t>(tap) * K8 + k8) * 2 + half) * a.Npad * 4;   // wave-uniform
         const f32x2 x01 = {xv[0], xv[1]}, x23 = {xv[2], xv[3]};
 #pragma unroll
         for (int n = 0; n < CO; ++n) {
-          const f32x2 w01 = {wr[n * 4 + 0], wr[n * 4 + 1]}, w23 = {wr[n * 4 + 2], wr[n * 4 + 3]};
+          const f32x4 wn = sWt[(tap * 4 + q) * 4 + n];                 // same address in every lane: LDS broadcast
+          const f32x2 w01 = {wn[0], wn[1]}, w23 = {wn[2], wn[3]};
           acc2[n] = __builtin_elementwise_fma(x01, w01, acc2[n]);
           acc2[n] = __builtin_elementwise_fma(x23, w23, acc2[n]);
         }
