@@ -629,7 +629,9 @@ struct WxyArgs {
   int Ht, ntrows;      // tile rows per (b,z) = H/2; B*D*Ht
 };
 
-template <int WP8, int CS>
+// GB: the workgroup's xi_y needs the second gradient row (xi_y = 1, 2); xi_y = 0, 3 use one row and skip those loads.
+// The two kinds are launched separately (6 | 2 workgroup types each), `a.ndzdy` = types per launch.
+template <int WP8, int CS, bool GB>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_wxy_kernel(const WxyArgs aa) {
   const WgradArgs& a = aa.w;
   const int tid = threadIdx.x;
@@ -647,9 +649,11 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxy_kernel(const WxyArgs aa
     const int xcd = bid & 7, idx = bid >> 3;
     wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
-  const int range = wg / a.ndzdy, dzxy = wg % a.ndzdy;
-  const int dz = a.ndzdy == 12 ? dzxy / 4 - 1 : 0;
-  const int xiy = dzxy & 3;
+  const int range = wg / a.ndzdy, dzsel = wg % a.ndzdy;
+  const int dzi = dzsel >> 1;                          // 0..2 (3-D) | 0 (2-D)
+  const int dz = a.ndzdy == 6 ? dzi - 1 : 0;
+  const int xiy = GB ? 1 + (dzsel & 1) : 3 * (dzsel & 1);
+  const int dzxy = dzi * 4 + xiy;                      // partial slot group
   const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
   if (ci0 >= a.Cin || co0 >= a.Cout) return;
 
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxy_kernel(const WxyArgs aa
     rw.xa = (zv && ya >= 0 && ya < a.H && ci_ok0) ? a.x + (xbase + ya) * a.W * a.Cin + cia : zb;
     rw.xb = (zv && yb >= 0 && yb < a.H && ci_ok0) ? a.x + (xbase + yb) * a.W * a.Cin + cia : zb;
     rw.ga = (ok && co_ok0) ? a.g + (gbase + y0 + goa) * a.W * a.Cout + coa : zb;
-    rw.gb = (ok && co_ok0 && sgf != 0.f) ? a.g + (gbase + y0 + 1) * a.W * a.Cout + coa : zb;
+    rw.gb = (GB && ok && co_ok0) ? a.g + (gbase + y0 + 1) * a.W * a.Cout + coa : zb;
     return rw;
   };
   const int xs = CS ? CS : a.Cin, gs = CS ? CS : a.Cout;
@@ -719,7 +723,8 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxy_kernel(const WxyArgs aa
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     xra[i] = ld(cur.xa, i, xs); xrb[i] = ld(cur.xb, i, xs);
-    gra[i] = ld(cur.ga, i, gs); grb[i] = ld(cur.gb, i, gs);
+    gra[i] = ld(cur.ga, i, gs);
+    if (GB) grb[i] = ld(cur.gb, i, gs);
   }
   xc[0] = pkfma(xrb[0], sx2, xra[0]);
 
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxy_kernel(const WxyArgs aa
     // y-combination of the two positions this tile is the first to need, and of its two gradient positions
     xc[(u + 1) & 7] = pkfma(xrb[(u + 1) & 7], sx2, xra[(u + 1) & 7]);
     xc[(u + 2) & 7] = pkfma(xrb[(u + 2) & 7], sx2, xra[(u + 2) & 7]);
-    const f32x2 g0 = pkfma(grb[u], sg2, gra[u]), g1 = pkfma(grb[(u + 1) & 7], sg2, gra[(u + 1) & 7]);
+    const f32x2 g0 = GB ? pkfma(grb[u], sg2, gra[u]) : gra[u], g1 = GB ? pkfma(grb[(u + 1) & 7], sg2, gra[(u + 1) & 7]) : gra[(u + 1) & 7];
     f32x2 dm = xc[(u + 7) & 7], d0 = xc[u], d1 = xc[(u + 1) & 7], d2 = xc[(u + 2) & 7];
     if (x == 0) dm = f32x2{0.f, 0.f};
     if (x == Wc - 2) d2 = f32x2{0.f, 0.f};
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxy_kernel(const WxyArgs aa
     xra[(u + 6) & 7] = ld(lr.xa, lpos, xs); xra[(u + 7) & 7] = ld(lr.xa, lpos + 1, xs);
     xrb[(u + 6) & 7] = ld(lr.xb, lpos, xs); xrb[(u + 7) & 7] = ld(lr.xb, lpos + 1, xs);
     gra[(u + 6) & 7] = ld(lr.ga, lpos, gs); gra[(u + 7) & 7] = ld(lr.ga, lpos + 1, gs);
-    grb[(u + 6) & 7] = ld(lr.gb, lpos, gs); grb[(u + 7) & 7] = ld(lr.gb, lpos + 1, gs);
+    if (GB) { grb[(u + 6) & 7] = ld(lr.gb, lpos, gs); grb[(u + 7) & 7] = ld(lr.gb, lpos + 1, gs); }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -769,7 +774,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxy_kernel(const WxyArgs aa
   }
 
   // ---- partial: slot = (dz, xi_y) * 4 + xi_x ------------------------------------------------------------------------------------
-  float* P = a.partial + static_cast<int64_t>(erange) * a.ndzdy * 4 * a.Cinp * a.Coutp;
+  float* P = a.partial + static_cast<int64_t>(erange) * (a.ndzdy * 2) * 4 * a.Cinp * a.Coutp;      // 2 launches x ndzdy groups
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     const int slot = dzxy * 4 + d;
@@ -1447,14 +1452,22 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     WxyArgs aa;
     aa.w = a; aa.Ht = (int)(H / 2); aa.ntrows = p.nrows;
     const bool c128 = Cin == 128 && Cout == 128;
-    if (W == 64 && c128) hipLaunchKernelGGL((wgrad_wxy_kernel<8, 128>), grid, dim3(kThreads), 0, s, aa);
-    else if (W == 64) hipLaunchKernelGGL((wgrad_wxy_kernel<8, 0>), grid, dim3(kThreads), 0, s, aa);
-    else if (W == 112) hipLaunchKernelGGL((wgrad_wxy_kernel<14, 0>), grid, dim3(kThreads), 0, s, aa);      // cfg4 row lengths
-    else if (W == 56) hipLaunchKernelGGL((wgrad_wxy_kernel<7, 0>), grid, dim3(kThreads), 0, s, aa);
-    else if (W == 32 && c128) hipLaunchKernelGGL((wgrad_wxy_kernel<4, 128>), grid, dim3(kThreads), 0, s, aa);
-    else if (W == 32) hipLaunchKernelGGL((wgrad_wxy_kernel<4, 0>), grid, dim3(kThreads), 0, s, aa);
-    else if (c128) hipLaunchKernelGGL((wgrad_wxy_kernel<2, 128>), grid, dim3(kThreads), 0, s, aa);
-    else hipLaunchKernelGGL((wgrad_wxy_kernel<2, 0>), grid, dim3(kThreads), 0, s, aa);
+    aa.w.ndzdy = p.ndzdy / 2;                         // workgroup types per launch: (dz) x 2 xi_y
+    const dim3 gridh((unsigned)(p.nranges * aa.w.ndzdy), grid.y, grid.z);
+#define DF_WXY(WP, CSV)                                                                                  \
+  do {                                                                                                   \
+    hipLaunchKernelGGL((wgrad_wxy_kernel<WP, CSV, true>), gridh, dim3(kThreads), 0, s, aa);              \
+    hipLaunchKernelGGL((wgrad_wxy_kernel<WP, CSV, false>), gridh, dim3(kThreads), 0, s, aa);             \
+  } while (0)
+    if (W == 64 && c128) DF_WXY(8, 128);
+    else if (W == 64) DF_WXY(8, 0);
+    else if (W == 112) DF_WXY(14, 0);      // cfg4 row lengths
+    else if (W == 56) DF_WXY(7, 0);
+    else if (W == 32 && c128) DF_WXY(4, 128);
+    else if (W == 32) DF_WXY(4, 0);
+    else if (c128) DF_WXY(2, 128);
+    else DF_WXY(2, 0);
+#undef DF_WXY
     const int ndz = kz == 3 ? 3 : 1;
     const int64_t tot = static_cast<int64_t>(ndz) * Cin * Cout;
     const int64_t rgx = ceil_div(tot, 32);
