@@ -275,7 +275,10 @@ __device__ __forceinline__ f32x2 wpk_sub(f32x2 a, f32x2 b) {
 // two fine-gradient rings (fine positions 2x and 2x+1), and exactly the four useful products per position
 //   X[x-1] g0 -> (px=0, slot 0)   X[x] g0 -> (px=0, slot 1)   X[x] g1 -> (px=1, slot 1)   X[x+1] g1 -> (px=1, slot 2)
 // = 16 MFMAs for 3 loads (instead of 2 x 12 MFMAs for 2 x 2 loads, a third of them wasted).  Partial layout and reduce unchanged.
-template <int WP8>
+// CS > 0: Cin == Cout == CS at compile time (position offsets become load immediates; with run-time strides the fully unrolled
+// W = 32 body needs more scalar registers than exist and hipcc's SGPR spilling produced wrong sums -- those shapes keep the
+// generic kernel)
+template <int WP8, int CS>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_up2_kernel(const WgradArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -331,14 +334,18 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_up2_kernel(const WgradArgs 
     rw.xb = (xv && ci_ok0) ? a.x + xvox * a.Cin + cia : zb;
     return rw;
   };
-  auto load_x = [&](const Row& rw, int pos) -> f32x2 { return *reinterpret_cast<const f32x2*>(rw.xb + static_cast<int64_t>(pos) * a.Cin); };
+  const int xs = CS ? CS : a.Cin, gs_ = CS ? CS : a.Cout;
+  auto load_x = [&](const Row& rw, int pos) -> f32x2 { return *reinterpret_cast<const f32x2*>(rw.xb + static_cast<int64_t>(pos) * xs); };
   auto load_g = [&](const Row& rw, int pos, int px) -> f32x2 {
-    return *reinterpret_cast<const f32x2*>(rw.gb + static_cast<int64_t>(2 * pos + px) * a.Cout);
+    return *reinterpret_cast<const f32x2*>(rw.gb + static_cast<int64_t>(2 * pos + px) * gs_);
   };
 
-  f32x16 acc[4][2][2];
+  // Three products instead of four per position (the reduce kernel only ever needs their sums k0 = X[x-1] g0 + X[x] g1,
+  // k1 = X[x] (g0 + g1), k2 = X[x] g0 + X[x+1] g1):  m1 = X[x] (g0 + g1),  m2 = (X[x-1] - X[x]) g0,  m3 = (X[x+1] - X[x]) g1,
+  // k0 = m1 + m2, k1 = m1, k2 = m1 + m3.
+  f32x16 acc[3][2][2];
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < 3; ++d)
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -364,14 +371,14 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_up2_kernel(const WgradArgs 
     if (x == 0) am = f32x2{0.f, 0.f};
     if (x == Wc - 1) ap = f32x2{0.f, 0.f};
     bsum0 = wpk_add(bsum0, g0); bsum1 = wpk_add(bsum1, g1);
+    const f32x2 gs = wpk_add(g0, g1), dm = wpk_sub(am, a0), dp = wpk_sub(ap, a0);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        acc[0][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(am[s], g0[t], acc[0][s][t], 0, 0, 0);
-        acc[1][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], g0[t], acc[1][s][t], 0, 0, 0);
-        acc[2][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], g1[t], acc[2][s][t], 0, 0, 0);
-        acc[3][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s], g1[t], acc[3][s][t], 0, 0, 0);
+        acc[0][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], gs[t], acc[0][s][t], 0, 0, 0);
+        acc[1][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dm[s], g0[t], acc[1][s][t], 0, 0, 0);
+        acc[2][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[s], g1[t], acc[2][s][t], 0, 0, 0);
       }
   };
 
@@ -400,7 +407,9 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_up2_kernel(const WgradArgs 
     cur = nxt;
   }
 
-  // partial slot = (class * nd2 + dd) * 3 + (coarse offset + 1): (cls0: 0, 1), (cls1: 1, 2)
+  // partial slot = (class * nd2 + dd) * 3 + (coarse offset + 1): (cls0: 0, 1), (cls1: 1, 2).  The reduce kernel forms
+  // k0 = s(cls0,0) + s(cls1,1), k1 = s(cls0,1) + s(cls1,1), k2 = s(cls0,1) + s(cls1,2); so write s(cls0,0) = m2, s(cls0,1) = 0,
+  // s(cls1,1) = m1, s(cls1,2) = m1 + m3.
   float* P = a.partial + static_cast<int64_t>(erange) * a.ndzdy * 3 * a.Cinp * a.Coutp;
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
@@ -413,7 +422,8 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_up2_kernel(const WgradArgs 
         for (int e = 0; e < 16; ++e) {
           const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
           const int ci = ci0 + 2 * i + s, co = co0 + 2 * r + t;
-          P[(static_cast<int64_t>(slot) * a.Cinp + ci) * a.Coutp + co] = acc[d][s][t][e];
+          const float v = d == 0 ? acc[1][s][t][e] : d == 1 ? 0.f : d == 2 ? acc[0][s][t][e] : acc[0][s][t][e] + acc[2][s][t][e];
+          P[(static_cast<int64_t>(slot) * a.Cinp + ci) * a.Coutp + co] = v;
         }
   }
   if (do_bias) {
@@ -1576,9 +1586,9 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   const bool aligned8 = ((reinterpret_cast<uintptr_t>(xc) | reinterpret_cast<uintptr_t>(gy)) & 7u) == 0;
   const dim3 grid2((unsigned)(p.nranges * (p.ndzdy / 2)), grid.y, grid.z);     // one workgroup per x-parity class PAIR
   if (prec == 1 && wgrad_bf16x3_ok(Wc, Cin, Cout)) launch_wgrad_bf16x3(Wc, grid, s, a);
-  else if (prec == 0 && aligned8 && exact && wp8 == 4 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<4>), grid2, dim3(kThreads), 0, s, a);
-  else if (prec == 0 && aligned8 && exact && wp8 == 2 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<2>), grid2, dim3(kThreads), 0, s, a);
-  else if (prec == 0 && aligned8 && exact && wp8 == 1 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<1>), grid2, dim3(kThreads), 0, s, a);
+  else if (prec == 0 && aligned8 && exact && wp8 == 4 && Cin == 128 && Cout == 128 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<4, 128>), grid2, dim3(kThreads), 0, s, a);
+  else if (prec == 0 && aligned8 && exact && wp8 == 2 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<2, 0>), grid2, dim3(kThreads), 0, s, a);
+  else if (prec == 0 && aligned8 && exact && wp8 == 1 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<1, 0>), grid2, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 4) hipLaunchKernelGGL((wgrad_kernel<true, true, 4>), grid, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 2) hipLaunchKernelGGL((wgrad_kernel<true, true, 2>), grid, dim3(kThreads), 0, s, a);

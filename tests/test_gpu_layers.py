@@ -255,7 +255,7 @@ def test_colsum(ops):
 
 
 @pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 16), ((2, 4, 6, 8), 32), ((1, 3, 5, 7), 128), ((2, 8, 16), 16),
-                                      ((1, 5, 9), 128), ((1, 2, 2, 32), 64)])
+                                      ((1, 5, 9), 128), ((1, 2, 2, 32), 64), ((1, 2, 2, 32), 128), ((2, 1, 3, 16), 64)])
 def test_upconv_block_vs_materialised_upsample(ops, cshape, C):
     """The up-sampling-aware fused block (parity-class convs on the coarse grid) == upscale + conv + ... + add of the
     oracle, forward and every gradient (input, 27-tap weights, biases)."""
