@@ -145,6 +145,7 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 template <int DBG, int FL = -1>
 __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   __shared__ __attribute__((aligned(16))) float sIn[2 * BUF];
+  __shared__ float sM[16 * kT];      // lrelu-mask operands of a tile block's outputs, fetched by LDS-DMA loads (no registers)
 
   const int eflags = FL >= 0 ? FL : a.flags;
   const int tid = threadIdx.x;
@@ -391,19 +392,26 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       const int64_t sW = a.Cout, sH = static_cast<int64_t>(a.W) * a.Cout, sD = sH * a.H;
       const int64_t obase = (((static_cast<int64_t>(cur.b) * a.D + oz0) * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl;
       const bool full = cur.z0 + 4 <= a.D && cur.y0 + 8 <= a.H && cur.x0 + 8 <= a.W;
+      // The 16 lrelu-mask operands of this lane's outputs go global -> LDS by DMA loads issued now and are read back after the
+      // first combine: in registers hipcc spills each one to scratch behind its own vmcnt(0) (14 serial HBM round trips).
+      if (full && (eflags & DF_CONV_MASK)) {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        const __amdgpu_buffer_rsrc_t msrd = make_srd(a.mask_src + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout,
+                                                     static_cast<unsigned>(a.D) * a.H * a.W * a.Cout * 4u);
+        const unsigned mv = static_cast<unsigned>(((oz0 * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl) * 4u;
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const unsigned so_ = static_cast<unsigned>(n2 * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) * 4u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(msrd, (lds_ptr)(sM + (n2 * 8 + s) * kT + wave * 64), 4, mv, so_, 0, 0);
+          }
+      }
+      float rres[2][8];
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         const int col = n0 + nb * 16 + tl;
         const float bv = (eflags & DF_CONV_BIAS) ? a.bias[col] : 0.f;
-        float rres[8], rmask[8];
-        if (full) {
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const int64_t o = obase + nb * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW;
-            rres[s] = (eflags & DF_CONV_RESIDUAL) ? a.residual[o] : 0.f;
-            rmask[s] = (eflags & DF_CONV_MASK) ? a.mask_src[o] : 1.f;
-          }
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           f32x2 px[4];
@@ -415,18 +423,26 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           const f32x2 o01 = px[0] + px[1] + px[2], o23 = px[1] - px[2] - px[3];
           sO[((xz * 2 + th) * 4 + e) * 64 + lane] = f32x4{o01[0], o01[1], o23[0], o23[1]};
         }
+        if (nb == 0 && full && (eflags & DF_CONV_RESIDUAL)) {
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+              rres[n2][s] = a.residual[obase + n2 * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW];
+        }
         __syncthreads();
         const f32x4 m0 = sO[((0 * 2 + th) * 4 + xz) * 64 + lane], m1 = sO[((1 * 2 + th) * 4 + xz) * 64 + lane];
         const f32x4 m2 = sO[((2 * 2 + th) * 4 + xz) * 64 + lane], m3 = sO[((3 * 2 + th) * 4 + xz) * 64 + lane];
         const f32x4 lo = m0 + m1 + m2, hi = m1 - m2 - m3;
+        if (nb == 0 && full && (eflags & DF_CONV_MASK)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // mask DMA landed
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           float v = (s < 4 ? lo[s & 3] : hi[s & 3]) + bv;
           if (eflags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
           const int64_t o = obase + nb * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW;
           if (full) {
-            if (eflags & DF_CONV_RESIDUAL) v += rres[s];
-            if (eflags & DF_CONV_MASK) v = rmask[s] > 0.f ? v : a.leak * v;
+            if (eflags & DF_CONV_RESIDUAL) v += rres[nb][s];
+            if (eflags & DF_CONV_MASK) v = sM[(nb * 8 + s) * kT + tid] > 0.f ? v : a.leak * v;
             a.y[o] = v;
           } else if (oz0 + (s >> 2) < a.D && oy0 + ((s >> 1) & 1) < a.H && ox0 + (s & 1) < a.W) {
             if (eflags & DF_CONV_RESIDUAL) v += a.residual[o];

@@ -28,7 +28,7 @@ def run(B, D, H, W, C, N, flags=8 | 1, iters=5):
         call("df_wino_pack_weights", _ptr(w), _ptr(ww), C, N, mode, s)
         b_ = bias if mode == 0 else torch.rand(NN, device="cuda") * 0.1
         r_ = res if mode == 0 else torch.rand((B, D, H, W, NN), device="cuda")
-        fl = flags if mode == 0 else (8 | 2 | 4)
+        fl = flags if mode == 0 else 4
         y0 = torch.empty((B, D, H, W, NN), device="cuda"); y1 = torch.full_like(y0, float("nan"))
         call("df_conv_fwd", _ptr(xin), _ptr(wd), _ptr(b_), _ptr(r_), _ptr(r_), _ptr(y0), B, D, H, W, K, NN, 3, fl, 0.2, s)
         call("df_wino_conv_fwd", _ptr(xin), _ptr(ww), _ptr(b_), _ptr(r_), _ptr(r_), _ptr(y1), B, D, H, W, K, NN, fl, 0.2, s)
