@@ -392,6 +392,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       const int64_t sW = a.Cout, sH = static_cast<int64_t>(a.W) * a.Cout, sD = sH * a.H;
       const int64_t obase = (((static_cast<int64_t>(cur.b) * a.D + oz0) * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl;
       const bool full = cur.z0 + 4 <= a.D && cur.y0 + 8 <= a.H && cur.x0 + 8 <= a.W;
+      const unsigned lane_off = static_cast<unsigned>(((oz0 * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl) * 4u;      // bytes within the batch volume
       // The 16 lrelu-mask operands of this lane's outputs go global -> LDS by DMA loads issued now and are read back after the
       // first combine: in registers hipcc spills each one to scratch behind its own vmcnt(0) (14 serial HBM round trips).
       if (full && (eflags & DF_CONV_MASK)) {
@@ -443,7 +444,10 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           if (full) {
             if (eflags & DF_CONV_RESIDUAL) v += rres[nb][s];
             if (eflags & DF_CONV_MASK) v = sM[(nb * 8 + s) * kT + tid] > 0.f ? v : a.leak * v;
-            a.y[o] = v;
+            // wave-uniform base (batch volume + this output's scalar offset) + 32-bit lane offset: no 64-bit address per output
+            char* yb = reinterpret_cast<char*>(a.y + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
+                                               ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
+            *reinterpret_cast<float*>(yb + lane_off) = v;
           } else if (oz0 + (s >> 2) < a.D && oy0 + ((s >> 1) & 1) < a.H && ox0 + (s & 1) < a.W) {
             if (eflags & DF_CONV_RESIDUAL) v += a.residual[o];
             if (eflags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
