@@ -264,44 +264,54 @@ def main():
                        "wino3d_kernel": out["roofline_wino"]}.get(dom)
     # extra, clearly separate from `value`: the same step in the opt-in bf16x3 conv mode (NOT the reported metric)
     out["alt_bf16x3_mode"] = None
-    if world == 1 and a.precision == "fp32" and not a.no_alt:
-        rel_alt = l1_vs_oracle(a.filters, "bf16x3")
-        ops.CONV_PRECISION = "bf16x3"
-        ops.reset_variables()
-        tr2 = Trainer(cfg)
-        for _ in range(2):
-            tr2.train_step(x, y)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        for _ in range(3):
-            tr2.train_step(x, y)
-        torch.cuda.synchronize(); el2 = (time.perf_counter() - t1) / 3
-        ops.CONV_PRECISION = "fp32"
-        out["alt_bf16x3_mode"] = {"ms_per_step": el2 * 1e3, "value": vox_per_step / el2, "unit": "voxels/s",
-                                  "l1_vs_ref": rel_alt, "note": "opt-in precision mode, not the BASELINE cfg3 dtype: conv operands "
-                                  "split into bf16 hi/lo words, 3 bf16 MFMAs per product, fp32 accumulation"}
+    try:
+        if world == 1 and a.precision == "fp32" and not a.no_alt:
+            rel_alt = l1_vs_oracle(a.filters, "bf16x3")
+            ops.CONV_PRECISION = "bf16x3"
+            ops.reset_variables()
+            tr2 = Trainer(cfg)
+            for _ in range(2):
+                tr2.train_step(x, y)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(3):
+                tr2.train_step(x, y)
+            torch.cuda.synchronize(); el2 = (time.perf_counter() - t1) / 3
+            ops.CONV_PRECISION = "fp32"
+            out["alt_bf16x3_mode"] = {"ms_per_step": el2 * 1e3, "value": vox_per_step / el2, "unit": "voxels/s",
+                                      "l1_vs_ref": rel_alt, "note": "opt-in precision mode, not the BASELINE cfg3 dtype: conv operands "
+                                      "split into bf16 hi/lo words, 3 bf16 MFMAs per product, fp32 accumulation"}
+    except Exception as e:      # an extra must never take the metric line down with it
+        out["alt_bf16x3_mode"] = {"error": repr(e)[:300]}
+    ops.CONV_PRECISION = "fp32"
     # the north star also asks for the 2-D grid: same train step on 128x96, batch 64 (BASELINE cfg2's shape; fp32 here)
     out["extra_2d_128x96"] = None
-    if world == 1 and not a.no_alt:
-        ops.reset_variables()
-        cfg2 = default_config(is_3d=False, res_x=96, res_y=128, filters=a.filters, batch_size=64, num_samples=21000)
-        tr3 = Trainer(cfg2)
-        g2 = torch.Generator(device="cuda").manual_seed(1)
-        y2 = torch.rand((64, 3), device="cuda", generator=g2) * 2 - 1
-        x2 = ops.curl(torch.rand((64, 128, 96, 1), device="cuda", generator=g2) * 2 - 1)
-        x2 = (x2 / x2.abs().max()).contiguous()
-        for _ in range(3):
-            tr3.train_step(x2, y2)
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        for _ in range(10):
-            tr3.train_step(x2, y2)
-        torch.cuda.synchronize(); el3 = (time.perf_counter() - t2) / 10
-        out["extra_2d_128x96"] = {"ms_per_step": el3 * 1e3, "value": 64 * 128 * 96 / el3, "unit": "pixels/s", "batch": 64,
-                                  "conv_tflops_reference_equivalent": 3.71e12 / el3 / 1e12, "dtype": "f32",
-                                  "note": "2-D 128x96 train step (GeneratorBE filters=128), Winograd F(2x2,3x3) forward/dgrad + Winograd-(x,y) weight gradient at the top levels; not the reported metric"}
-        ops.reset_variables()
+    try:
+        if world == 1 and not a.no_alt:
+            ops.reset_variables()
+            cfg2 = default_config(is_3d=False, res_x=96, res_y=128, filters=a.filters, batch_size=64, num_samples=21000)
+            tr3 = Trainer(cfg2)
+            g2 = torch.Generator(device="cuda").manual_seed(1)
+            y2 = torch.rand((64, 3), device="cuda", generator=g2) * 2 - 1
+            x2 = ops.curl(torch.rand((64, 128, 96, 1), device="cuda", generator=g2) * 2 - 1)
+            x2 = (x2 / x2.abs().max()).contiguous()
+            for _ in range(3):
+                tr3.train_step(x2, y2)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            for _ in range(10):
+                tr3.train_step(x2, y2)
+            torch.cuda.synchronize(); el3 = (time.perf_counter() - t2) / 10
+            out["extra_2d_128x96"] = {"ms_per_step": el3 * 1e3, "value": 64 * 128 * 96 / el3, "unit": "pixels/s", "batch": 64,
+                                      "conv_tflops_reference_equivalent": 3.71e12 / el3 / 1e12, "dtype": "f32",
+                                      "note": "2-D 128x96 train step (GeneratorBE filters=128), Winograd F(2x2,3x3) forward/dgrad + Winograd-(x,y) weight gradient at the top levels; not the reported metric"}
+            ops.reset_variables()
+    except Exception as e:      # an extra must never take the metric line down with it
+        out["extra_2d_128x96"] = {"error": repr(e)[:300]}
     out["cpu_baseline"] = None
-    if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.res, a.filters, a.cpu_seconds)
+    try:
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.res, a.filters, a.cpu_seconds)
+    except Exception as e:      # an extra must never take the metric line down with it
+        out["cpu_baseline"] = {"error": repr(e)[:300]}
     print(json.dumps(out))
 
 
