@@ -387,3 +387,55 @@ def test_full_size_conv_algorithms_agree_cfg3(ops):
     # the bias gradient is a plain column sum: check it against torch in fp64
     ref = g.double().sum(dim=(0, 1, 2, 3))
     assert ((res[0][1].double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
+def test_full_size_upconv_agrees_with_materialised_upsample_cfg3(ops):
+    """The up-sampling-aware first conv of the top generator block at BASELINE cfg3 size (coarse 32x48x32 -> 64x96x64, C = 128, one
+    batch element): df_upconv_{fwd,dgrad,wgrad} (8-tap parity convs with 32-channel chunks, wgrad_up2_kernel<4,128>) must agree with
+    nearest_up2x materialised + the plain direct kernels (which the small cases above pin against the oracle)."""
+    from deep_fluids_amd._lib import call, query, lib
+    from deep_fluids_amd.ops import _ptr, _stream
+    torch.manual_seed(5)
+    B, D, H, W, C = 1, 32, 48, 32, 128
+    s = _stream()
+    xc = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    g = torch.rand((B, 2 * D, 2 * H, 2 * W, C), device="cuda") * 2 - 1
+    w = (torch.rand((3, 3, 3, C, C), device="cuda") * 2 - 1) * (1.0 / (27 * C)) ** 0.5
+    bias = torch.rand(C, device="cuda") - 0.5
+    xf = torch.empty((B, 2 * D, 2 * H, 2 * W, C), device="cuda")
+    call("df_upsample2x_fwd", _ptr(xc), _ptr(xf), B, D, H, W, C, 1, s)
+    lib().df_debug_set_wgrad_algo(ctypes.c_int(1))           # references: direct kernels only
+    try:
+        wd = torch.empty(query("df_conv_packed_elems", 27, C, C, 0), device="cuda")
+        call("df_conv_pack_weights", _ptr(w), _ptr(wd), 27, C, C, 0, s)
+        y0 = torch.empty_like(xf)
+        call("df_conv_fwd", _ptr(xf), _ptr(wd), _ptr(bias), None, None, _ptr(y0), B, 2 * D, 2 * H, 2 * W, C, C, 3, 8, 0.0, s)
+        wdd = torch.empty(query("df_conv_packed_elems", 27, C, C, 1), device="cuda")
+        call("df_conv_pack_weights", _ptr(w), _ptr(wdd), 27, C, C, 1, s)
+        gxf = torch.empty_like(xf)
+        call("df_conv_fwd", _ptr(g), _ptr(wdd), None, None, None, _ptr(gxf), B, 2 * D, 2 * H, 2 * W, C, C, 3, 0, 0.0, s)
+        gxc0 = torch.empty_like(xc)
+        call("df_upsample2x_bwd", _ptr(gxf), _ptr(gxc0), B, D, H, W, C, 1, s)
+        nb0 = query("df_conv_wgrad_workspace_bytes", B, 2 * D, 2 * H, 2 * W, C, C, 3)
+        ws0 = torch.empty((nb0 + 3) // 4, device="cuda")
+        gw0 = torch.empty_like(w); gb0 = torch.empty(C, device="cuda")
+        call("df_conv_wgrad", _ptr(xf), _ptr(g), _ptr(gw0), _ptr(gb0), B, 2 * D, 2 * H, 2 * W, C, C, 3, _ptr(ws0), nb0, s)
+    finally:
+        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+    del xf, gxf, ws0
+    wu = torch.empty(query("df_upconv_packed_elems", C, C, 3, 0), device="cuda")
+    call("df_upconv_pack_weights", _ptr(w), _ptr(wu), C, C, 3, 0, s)
+    y1 = torch.full_like(y0, float("nan"))
+    call("df_upconv_fwd", _ptr(xc), _ptr(wu), _ptr(bias), _ptr(y1), B, D, H, W, C, C, 3, 8, 0.0, s)
+    assert ((y0 - y1).abs().max() / y0.abs().max()).item() < 2e-5
+    wud = torch.empty(query("df_upconv_packed_elems", C, C, 3, 1), device="cuda")
+    call("df_upconv_pack_weights", _ptr(w), _ptr(wud), C, C, 3, 1, s)
+    gxc1 = torch.zeros_like(xc)
+    call("df_upconv_dgrad", _ptr(g), _ptr(wud), _ptr(gxc1), B, D, H, W, C, C, 3, s)
+    assert ((gxc0 - gxc1).abs().max() / gxc0.abs().max()).item() < 2e-5
+    nb1 = query("df_upconv_wgrad_workspace_bytes", B, D, H, W, C, C, 3)
+    ws1 = torch.empty((nb1 + 3) // 4, device="cuda")
+    gw1 = torch.full_like(w, float("nan")); gb1 = torch.full((C,), float("nan"), device="cuda")
+    call("df_upconv_wgrad", _ptr(xc), _ptr(g), _ptr(gw1), _ptr(gb1), B, D, H, W, C, C, 3, _ptr(ws1), nb1, s)
+    assert ((gw0 - gw1).abs().max() / gw0.abs().max()).item() < 2e-5
+    assert ((gb0 - gb1).abs().max() / gb0.abs().max()).item() < 2e-5
