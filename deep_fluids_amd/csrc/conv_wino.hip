@@ -142,7 +142,11 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 }
 
 // FL >= 0: the epilogue flags are the compile-time constant FL (no per-element flag tests); FL < 0: run-time a.flags
-template <int DBG, int FL = -1>
+// UP: the input is the COARSE tensor of an up-sampling-aware conv (x = nearest_up2x(xc) is never materialised): the staging reads
+// xc[g >> 1] for fine halo coordinate g, and because every 2x2x2 tile then sees each coarse value twice, the transform points with
+// index 2 in any axis are identically zero (B^T d = (c-1 - c0, 2 c0, 0, c0 - c1)): only 27 of the 64 points are multiplied
+// (the xi_z = 2 waves and the xi_y|xi_x = 2 MFMAs are skipped) -- the 27-product form of the parity-class convolution.
+template <int DBG, int FL = -1, bool UP = false>
 __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   __shared__ __attribute__((aligned(16))) float sIn[2 * BUF];
   __shared__ float sM[16 * kT];      // lrelu-mask operands of a tile block's outputs, fetched by LDS-DMA loads (no registers)
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const int bz = t2 % a.nbz;
     bi.b = t2 / a.nbz;
     bi.z0 = bz * 4; bi.y0 = by * 8; bi.x0 = bx * 8;
-    bi.xb = a.x + static_cast<int64_t>(bi.b) * a.D * a.H * a.W * a.Cin;
+    bi.xb = a.x + static_cast<int64_t>(bi.b) * (UP ? (a.D >> 1) * (a.H >> 1) * (a.W >> 1) : a.D * a.H * a.W) * a.Cin;
     bi.hoff = (((bi.z0 - 1) * a.H + (bi.y0 - 1)) * a.W + (bi.x0 - 1)) * a.Cin;
     return bi;
   };
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
     ldst[it] = ((q4 * 4) * CP + hz * PZ + hy * PY + hx) * 4;          // bytes, buffer 0
   }
-  const unsigned vol_bytes = static_cast<unsigned>(a.D) * a.H * a.W * a.Cin * 4u;
+  const unsigned vol_bytes = static_cast<unsigned>(UP ? (a.D >> 1) * (a.H >> 1) * (a.W >> 1) : a.D * a.H * a.W) * a.Cin * 4u;
   auto set_offs = [&](const BlockInfo& bi) {
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
@@ -226,7 +230,12 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       bool ok = static_cast<unsigned>(gz) < static_cast<unsigned>(a.D) && static_cast<unsigned>(gy) < static_cast<unsigned>(a.H) &&
                 static_cast<unsigned>(gx) < static_cast<unsigned>(a.W);
       if ((DBG & 4) || (a.dbg & 2)) ok = false;
-      so[it] = ok ? static_cast<unsigned>(bi.hoff + roff) * 4u : 0x80000000u;
+      if (UP) {
+        const int Hc = a.H >> 1, Wc = a.W >> 1;
+        so[it] = ok ? static_cast<unsigned>((((gz >> 1) * Hc + (gy >> 1)) * Wc + (gx >> 1)) * a.Cin + q4 * 4) * 4u : 0x80000000u;
+      } else {
+        so[it] = ok ? static_cast<unsigned>(bi.hoff + roff) * 4u : 0x80000000u;
+      }
     }
   };
   auto stage_load = [&](int it, __amdgpu_buffer_rsrc_t srd, unsigned chunkbytes) -> f32x4 {
@@ -326,6 +335,23 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
     const unsigned long long tp1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
     unsigned long long ph[4] = {0, 0, 0, 0};
+    if (UP && xz == 2) {
+      // the xi_z = 2 transform points of an up-sampled input are identically zero: these two waves only do their share of the
+      // staging and meet the others at the barriers (their accumulators stay zero for the epilogue's combine)
+      for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const int bn = BUF * 4 - ((chunk + pb) & 1) * BUF * 4;
+        const bool lastc = chunk + 1 == nchunk;
+        if (lastc) set_offs(nxt);
+        const __amdgpu_buffer_rsrc_t ssrd = make_srd(lastc ? nxt.xb : cur.xb, vol_bytes);
+        const unsigned schunk = lastc ? 0u : static_cast<unsigned>(chunk + 1) * (CKW * 4u);
+        f32x4 stg[NLOAD];
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, ssrd, schunk);
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) stage_store(it, bn, stg[it]);
+        __syncthreads();
+      }
+    } else
     for (int chunk = 0; chunk < nchunk; ++chunk) {
       const int bo = ((chunk + pb) & 1) * BUF * 4, bn = BUF * 4 - bo;        // byte offsets of this / the other buffer
       const bool lastc = chunk + 1 == nchunk;
@@ -358,13 +384,15 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         if (DBG & 32) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
+          if (!UP || ((i >> 2) != 2 && (i & 3) != 2))
+            acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (!(DBG & 8)) issue_b(0, chunk * 4 + ks + 1);       // weights of the next k-step, as each register block frees up
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
+          if (!UP || ((i >> 2) != 2 && (i & 3) != 2))
+            acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (DBG & 32) __builtin_amdgcn_s_setprio(0);
         if (!(DBG & 8)) issue_b(1, chunk * 4 + ks + 1);
@@ -496,6 +524,24 @@ int df_wino_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, i
   return df::launched("df_wino_pack_weights");
 }
 
+static int64_t wino_grid(WinoArgs& a, int64_t ntb) {
+  // persistent workers: one workgroup per CU (a workgroup owns a CU's whole register file and most of its LDS)
+  int64_t grid = df::kCUs;
+  a.spx = 1;
+  if (8 % a.ncs == 0) {
+    a.spx = (g_wino_spx > 0 && a.ncs % g_wino_spx == 0) ? g_wino_spx : (a.ncs % 2 == 0 ? 2 : 1);
+    const int xpg = a.ncs / a.spx, ngroups = 8 / xpg;
+    const int64_t need = ceil_div(ntb, ngroups) * a.spx * 8;      // workers that get at least one tile block
+    if (need < grid) grid = need;
+    if ((grid >> 3) % a.spx) grid = ((grid >> 3) / a.spx + 1) * a.spx * 8;
+    if (grid > df::kCUs) grid = df::kCUs;
+  } else {
+    grid = (grid / a.ncs) * a.ncs;
+    if (ntb * a.ncs < grid) grid = ntb * a.ncs;
+  }
+  return grid;
+}
+
 int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
                      float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak,
                      df_stream_t stream) {
@@ -520,20 +566,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
   DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_conv_fwd: too many workgroups");
   a.ntb = (int)ntb;
   a.flags = flags; a.leak = leak; a.dbg = g_wino_dbg;
-  // persistent workers: one workgroup per CU (a workgroup owns a CU's whole register file and 111 KB of its LDS)
-  int64_t grid = df::kCUs;
-  a.spx = 1;
-  if (8 % a.ncs == 0) {
-    a.spx = (g_wino_spx > 0 && a.ncs % g_wino_spx == 0) ? g_wino_spx : (a.ncs % 2 == 0 ? 2 : 1);
-    const int xpg = a.ncs / a.spx, ngroups = 8 / xpg;
-    const int64_t need = ceil_div(ceil_div(ntb, ngroups) * a.spx, 1) * 8;      // workers that get at least one tile block
-    if (need < grid) grid = need;
-    if ((grid >> 3) % a.spx) grid = ((grid >> 3) / a.spx + 1) * a.spx * 8;
-    if (grid > df::kCUs) grid = df::kCUs;
-  } else {
-    grid = (grid / a.ncs) * a.ncs;
-    if (ntb * a.ncs < grid) grid = ntb * a.ncs;
-  }
+  const int64_t grid = wino_grid(a, ntb);
   switch (g_wino_dbg >> 2) {
     case 0:
       if (flags == (DF_CONV_BIAS | DF_CONV_LRELU)) hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
@@ -565,6 +598,31 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     default: return df::fail(DF_EINVAL, "df_wino_conv_fwd: unknown debug variant");
   }
   return df::launched("df_wino_conv_fwd");
+}
+
+int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
+                       int64_t Wc, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream) {
+  DF_REQUIRE(xc && wp && y, DF_EINVAL, "df_wino_upconv_fwd: null pointer");
+  DF_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0, DF_EINVAL, "df_wino_upconv_fwd: non-positive extent");
+  DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE,
+             "df_wino_upconv_fwd: Cin, Cout must be multiples of 32 (use df_upconv_fwd otherwise)");
+  DF_REQUIRE(flags == (DF_CONV_BIAS | DF_CONV_LRELU) && bias, DF_EINVAL, "df_wino_upconv_fwd: flags must be DF_CONV_BIAS | DF_CONV_LRELU");
+  DF_REQUIRE(8 * Dc * Hc * Wc * Cout <= (1LL << 29) && Dc * Hc * Wc * Cin <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
+             "df_wino_upconv_fwd: one batch volume must stay below 2 GiB (use df_upconv_fwd)");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(xc), DF_EALIGN, "df_wino_upconv_fwd: xc and packed weights must be 16-byte aligned");
+  WinoArgs a;
+  a.x = xc; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
+  a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y;
+  a.B = (int)B; a.D = (int)(2 * Dc); a.H = (int)(2 * Hc); a.W = (int)(2 * Wc); a.Cin = (int)Cin; a.Cout = (int)Cout;      // OUTPUT (fine) extents
+  a.nbz = (int)ceil_div(a.D, 4); a.nby = (int)ceil_div(a.H, 8); a.nbx = (int)ceil_div(a.W, 8);
+  const int64_t ntb = B * a.nbz * a.nby * a.nbx;
+  a.ncs = (int)(Cout / 32);
+  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_upconv_fwd: too many workgroups");
+  a.ntb = (int)ntb;
+  a.flags = flags; a.leak = leak; a.dbg = 0;
+  const int64_t grid = wino_grid(a, ntb);
+  hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU, true>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+  return df::launched("df_wino_upconv_fwd");
 }
 
 }  // extern "C"

@@ -381,7 +381,13 @@ class _UpGenBlock(torch.autograd.Function):
             cin, cout = w.shape[-2], w.shape[-1]
             if tuple(w.shape[:-2]) != (3,) * nd or cin != C or cout != C:
                 raise ValueError("up_gen_block: weights %s do not match %d channels" % (tuple(w.shape), C))
-            if i == 0:
+            if i == 0 and is3d and _use_wino(cin, cout, fdims, kz) == 3:
+                # 27-point up-sampling-aware Winograd form (conv_wino.hip, UP variant): same packed operand as a plain conv
+                wp = _pack(w, taps, cin, cout, 0, fdims)
+                x = torch.empty(fshape, dtype=torch.float32, device=xc.device)
+                call("df_wino_upconv_fwd", _ptr(xc), _ptr(wp), _ptr(b), _ptr(x), cdims[0], cdims[1], cdims[2], cdims[3], cin, cout,
+                     DF_CONV_BIAS | DF_CONV_LRELU, float(leak), _stream())
+            elif i == 0:
                 sfx = _sfx(cin, cout)
                 wp = torch.empty(query("df_upconv_packed_elems" + sfx, cin, cout, kz, 0), dtype=torch.float32,
                                  device=xc.device)

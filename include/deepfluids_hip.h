@@ -198,6 +198,12 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
                      float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak,
                      df_stream_t stream);
 
+/* Up-sampling-aware variant: y[B,2Dc,2Hc,2Wc,Cout] = lrelu(conv_same(nearest_up2x(xc), w) + bias) without materialising the up-sampled
+ * tensor and with only 27 of the 64 Winograd products (the others are identically zero for a duplicated input).  `wp` is the mode-0
+ * pack of df_wino_pack_weights; flags must be DF_CONV_BIAS | DF_CONV_LRELU. */
+int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
+                       int64_t Wc, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream);
+
 /* 2-D twin: Winograd F(2x2, 3x3) form of the stride-1 3x3 convolution (conv_wino2d.hip): 2.25x fewer matrix-core FLOPs than df_conv_fwd
  * with kz = 1, fp32 throughout, same epilogue flags.  Needs Cin % 32 == 0, Cout % 32 == 0, H*W*max(Cin,Cout) <= 2^29. */
 int64_t df_wino2d_packed_elems(int64_t cin, int64_t cout, int mode);

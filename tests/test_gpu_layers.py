@@ -294,6 +294,39 @@ def test_upconv_block_vs_materialised_upsample(ops, cshape, C):
     assert rel_linf(host(xt.grad), dxc) < TOL
 
 
+@pytest.mark.parametrize("cshape,cin,cout", [((1, 2, 4, 16), 32, 32), ((2, 4, 6, 8), 32, 64), ((1, 3, 5, 7), 128, 128),
+                                             ((1, 1, 1, 1), 64, 32), ((1, 5, 2, 3), 96, 160)])
+def test_wino_upconv_fwd_vs_oracle(ops, cshape, cin, cout):
+    """df_wino_upconv_fwd (the 27-point up-sampling-aware Winograd form, conv_wino.hip UP variant) == lrelu(conv_same(upscale(xc)) + b)
+    of the oracle, including ragged tile blocks (fine extents that are not multiples of 4/8/8) and Cin != Cout."""
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream
+    rng = np.random.RandomState(cin + cout + sum(cshape))
+    xc = rng.uniform(-1, 1, cshape + (cin,)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (3, 3, 3, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
+    b = rng.uniform(-0.3, 0.3, cout).astype(np.float32)
+    s = _stream()
+    xt, wt, bt = dev(xc), dev(w), dev(b)
+    wp = torch.empty(query("df_wino_packed_elems", cin, cout, 0), device="cuda")
+    call("df_wino_pack_weights", _ptr(wt), _ptr(wp), cin, cout, 0, s)
+    B, D, H, W = cshape
+    y = torch.full((B, 2 * D, 2 * H, 2 * W, cout), float("nan"), device="cuda")
+    call("df_wino_upconv_fwd", _ptr(xt), _ptr(wp), _ptr(bt), _ptr(y), B, D, H, W, cin, cout, 9, 0.2, s)
+    ref = orc.lrelu(orc.conv_same(orc.upscale_nn(xc.astype(np.float64)), w.astype(np.float64), b.astype(np.float64)))
+    assert rel_linf(host(y), ref) < TOL
+
+
+@pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 32), ((1, 3, 5, 7), 128), ((1, 2, 2, 32), 64)])
+def test_upconv_block_winograd_forced(ops, cshape, C):
+    """The fused up-sampling block with the Winograd kernels forced on small/ragged grids (forward through df_wino_upconv_fwd)."""
+    old = ops.CONV_ALGO
+    ops.CONV_ALGO = "winograd"
+    try:
+        test_upconv_block_vs_materialised_upsample(ops, cshape, C)
+    finally:
+        ops.CONV_ALGO = old
+
+
 @pytest.fixture
 def bf16x3(ops):
     ops.CONV_PRECISION = "bf16x3"
@@ -428,6 +461,12 @@ def test_full_size_upconv_agrees_with_materialised_upsample_cfg3(ops):
     y1 = torch.full_like(y0, float("nan"))
     call("df_upconv_fwd", _ptr(xc), _ptr(wu), _ptr(bias), _ptr(y1), B, D, H, W, C, C, 3, 8, 0.0, s)
     assert ((y0 - y1).abs().max() / y0.abs().max()).item() < 2e-5
+    ww = torch.empty(query("df_wino_packed_elems", C, C, 0), device="cuda")
+    call("df_wino_pack_weights", _ptr(w), _ptr(ww), C, C, 0, s)
+    y2 = torch.full_like(y0, float("nan"))
+    call("df_wino_upconv_fwd", _ptr(xc), _ptr(ww), _ptr(bias), _ptr(y2), B, D, H, W, C, C, 9, 1.0, s)      # leak 1: lrelu is the identity
+    assert ((y0 - y2).abs().max() / y0.abs().max()).item() < 2e-5
+    del y2, ww
     wud = torch.empty(query("df_upconv_packed_elems", C, C, 3, 1), device="cuda")
     call("df_upconv_pack_weights", _ptr(w), _ptr(wud), C, C, 3, 1, s)
     gxc1 = torch.zeros_like(xc)
