@@ -146,8 +146,12 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 // xc[g >> 1] for fine halo coordinate g, and because every 2x2x2 tile then sees each coarse value twice, the transform points with
 // index 2 in any axis are identically zero (B^T d = (c-1 - c0, 2 c0, 0, c0 - c1)): only 27 of the 64 points are multiplied
 // (the xi_z = 2 waves and the xi_y|xi_x = 2 MFMAs are skipped) -- the 27-product form of the parity-class convolution.
-template <int DBG, int FL = -1, bool UP = false>
+// POOL (MODE 2): the adjoint case -- the output is the 2x2x2 sum-pool of the convolution (d/d(xc) of the up-sampling-aware conv: x is
+// the fine gradient, y the COARSE tensor [B, D/2, H/2, W/2, Cout], accumulated into).  The pooled inverse transform is
+// (A^T row 0 + row 1) = (1, 2, 0, -1) per axis, so the same 27 points are the only ones needed and a tile block writes 32 voxels, not 256.
+template <int DBG, int FL = -1, int MODE = 0>
 __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
+  constexpr bool UP = MODE == 1, POOL = MODE == 2, P27 = MODE != 0;
   __shared__ __attribute__((aligned(16))) float sIn[2 * BUF];
   __shared__ float sM[16 * kT];      // lrelu-mask operands of a tile block's outputs, fetched by LDS-DMA loads (no registers)
 
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
     const unsigned long long tp1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
     unsigned long long ph[4] = {0, 0, 0, 0};
-    if (UP && xz == 2) {
+    if (P27 && xz == 2) {
       // the xi_z = 2 transform points of an up-sampled input are identically zero: these two waves only do their share of the
       // staging and meet the others at the barriers (their accumulators stay zero for the epilogue's combine)
       for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -384,14 +388,14 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         if (DBG & 32) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (!UP || ((i >> 2) != 2 && (i & 3) != 2))
+          if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
             acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (!(DBG & 8)) issue_b(0, chunk * 4 + ks + 1);       // weights of the next k-step, as each register block frees up
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (!UP || ((i >> 2) != 2 && (i & 3) != 2))
+          if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
             acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (DBG & 32) __builtin_amdgcn_s_setprio(0);
@@ -412,7 +416,33 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const unsigned long long tp2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
     // ---- epilogue: inverse transform in x, y per accumulator element; z across the waves through the idle LDS buffer ---------
     // (the buffer of the last chunk is free since that chunk's barrier; the other one holds the next block's chunk 0)
-    {
+    if constexpr (POOL) {
+      const int lb = ((nchunk - 1 + pb) & 1) * BUF;
+      float* sP = sIn + lb;      // [xi_z][tz][e][lane]: the (y, x)-pooled value of accumulator element e
+      const int Dc = a.D >> 1, Hc = a.H >> 1, Wc = a.W >> 1;
+      const int cz = (cur.z0 >> 1) + th, cy = (cur.y0 >> 1) + kq, cx = (cur.x0 >> 1) + xz;      // this wave combines e = xz of its z-row
+      const bool inb = cz < Dc && cy < Hc && cx < Wc;
+      float* yo = a.y + (((static_cast<int64_t>(cur.b) * Dc + cz) * Hc + cy) * Wc + cx) * a.Cout + n0 + tl;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float prev = inb ? yo[nb * 16] : 0.f;
+        if (xz != 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float py[4];
+#pragma unroll
+            for (int yy = 0; yy < 4; ++yy)
+              py[yy] = yy == 2 ? 0.f : acc[nb][yy * 4 + 0][e] + 2.f * acc[nb][yy * 4 + 1][e] - acc[nb][yy * 4 + 3][e];
+            sP[((xz * 2 + th) * 4 + e) * 64 + lane] = py[0] + 2.f * py[1] - py[3];
+          }
+        }
+        __syncthreads();
+        const float m0 = sP[((0 * 2 + th) * 4 + xz) * 64 + lane], m1 = sP[((1 * 2 + th) * 4 + xz) * 64 + lane];
+        const float m3 = sP[((3 * 2 + th) * 4 + xz) * 64 + lane];
+        if (inb) yo[nb * 16] = prev + (m0 + 2.f * m1 - m3);
+        __syncthreads();
+      }
+    } else {
       const int lb = ((nchunk - 1 + pb) & 1) * BUF;
       f32x4* sO = reinterpret_cast<f32x4*>(sIn + lb);      // [xi_z][tz][e][lane] float4 = (oy0ox0, oy0ox1, oy1ox0, oy1ox1)
       // this wave combines accumulator element e = xi_z of its own z-row:  tile (ty = lane>>4, tx = e), cout = lane & 15
@@ -621,8 +651,32 @@ int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, floa
   a.ntb = (int)ntb;
   a.flags = flags; a.leak = leak; a.dbg = 0;
   const int64_t grid = wino_grid(a, ntb);
-  hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU, true>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+  hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
   return df::launched("df_wino_upconv_fwd");
+}
+
+int df_wino_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin,
+                         int64_t Cout, df_stream_t stream) {
+  DF_REQUIRE(g && wp && acc, DF_EINVAL, "df_wino_upconv_dgrad: null pointer");
+  DF_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0, DF_EINVAL, "df_wino_upconv_dgrad: non-positive extent");
+  DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE,
+             "df_wino_upconv_dgrad: Cin, Cout must be multiples of 32 (use df_upconv_dgrad otherwise)");
+  DF_REQUIRE(8 * Dc * Hc * Wc * (Cin > Cout ? Cin : Cout) <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
+             "df_wino_upconv_dgrad: one batch volume must stay below 2 GiB (use df_upconv_dgrad)");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(g), DF_EALIGN, "df_wino_upconv_dgrad: g and packed weights must be 16-byte aligned");
+  WinoArgs a;      // the adjoint conv reads g (Cout channels, fine grid) and produces Cin channels
+  a.x = g; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
+  a.bias = nullptr; a.residual = nullptr; a.mask_src = nullptr; a.y = acc;
+  a.B = (int)B; a.D = (int)(2 * Dc); a.H = (int)(2 * Hc); a.W = (int)(2 * Wc); a.Cin = (int)Cout; a.Cout = (int)Cin;
+  a.nbz = (int)ceil_div(a.D, 4); a.nby = (int)ceil_div(a.H, 8); a.nbx = (int)ceil_div(a.W, 8);
+  const int64_t ntb = B * a.nbz * a.nby * a.nbx;
+  a.ncs = (int)(Cin / 32);
+  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_upconv_dgrad: too many workgroups");
+  a.ntb = (int)ntb;
+  a.flags = 0; a.leak = 0.f; a.dbg = 0;
+  const int64_t grid = wino_grid(a, ntb);
+  hipLaunchKernelGGL((wino3d_kernel<0, 0, 2>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+  return df::launched("df_wino_upconv_dgrad");
 }
 
 }  // extern "C"

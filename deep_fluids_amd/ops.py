@@ -436,12 +436,18 @@ class _UpGenBlock(torch.autograd.Function):
                     dxc = torch.empty_like(xc)          # skip path: sum-pool of dy, then += the conv path per parity class
                     call("df_upsample2x_bwd", _ptr(dy), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, int(is3d),
                          _stream())
-                    sfx = _sfx(C, C)
-                    wpd = torch.empty(query("df_upconv_packed_elems" + sfx, C, C, kz, 1), dtype=torch.float32,
-                                      device=dy.device)
-                    call("df_upconv_pack_weights" + sfx, _ptr(w), _ptr(wpd), C, C, kz, 1, _stream())
-                    call("df_upconv_dgrad" + sfx, _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, C, kz,
-                         _stream())
+                    if is3d and _use_wino(C, C, fdims, kz) == 3:
+                        # pooled-output Winograd form (conv_wino.hip, POOL variant): 27 of the 64 products, coarse stores
+                        wpd = _pack(w, taps, C, C, 1, fdims)
+                        call("df_wino_upconv_dgrad", _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, C,
+                             _stream())
+                    else:
+                        sfx = _sfx(C, C)
+                        wpd = torch.empty(query("df_upconv_packed_elems" + sfx, C, C, kz, 1), dtype=torch.float32,
+                                          device=dy.device)
+                        call("df_upconv_pack_weights" + sfx, _ptr(w), _ptr(wpd), C, C, kz, 1, _stream())
+                        call("df_upconv_dgrad" + sfx, _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, C,
+                             kz, _stream())
             grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
         return (dxc, None) + tuple(grads)
 

@@ -204,6 +204,12 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
 int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
                        int64_t Wc, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream);
 
+/* Its adjoint w.r.t. xc: acc[B,Dc,Hc,Wc,Cin] += sum-pool2x(conv_same^T(g, w)) for g = d(loss)/d(y) on the fine grid
+ * [B,2Dc,2Hc,2Wc,Cout]; the pooled inverse transform needs the same 27 points.  `wp` is the mode-1 pack of
+ * df_wino_pack_weights(w, wp, Cin, Cout, 1).  Drop-in for df_upconv_dgrad (kz = 3, channels multiples of 32). */
+int df_wino_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin,
+                         int64_t Cout, df_stream_t stream);
+
 /* 2-D twin: Winograd F(2x2, 3x3) form of the stride-1 3x3 convolution (conv_wino2d.hip): 2.25x fewer matrix-core FLOPs than df_conv_fwd
  * with kz = 1, fp32 throughout, same epilogue flags.  Needs Cin % 32 == 0, Cout % 32 == 0, H*W*max(Cin,Cout) <= 2^29. */
 int64_t df_wino2d_packed_elems(int64_t cin, int64_t cout, int mode);

@@ -316,6 +316,29 @@ def test_wino_upconv_fwd_vs_oracle(ops, cshape, cin, cout):
     assert rel_linf(host(y), ref) < TOL
 
 
+@pytest.mark.parametrize("cshape,cin,cout", [((1, 2, 4, 16), 32, 32), ((2, 4, 6, 8), 32, 64), ((1, 3, 5, 7), 128, 128),
+                                             ((1, 1, 1, 1), 64, 32), ((1, 5, 2, 3), 96, 160)])
+def test_wino_upconv_dgrad_vs_oracle(ops, cshape, cin, cout):
+    """df_wino_upconv_dgrad (pooled-output Winograd form) accumulates d/d(xc) of conv_same(upscale(xc), w) into acc: oracle =
+    upscale_nn_bwd(conv_same_bwd(...).dx) on top of the previous contents of acc."""
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream
+    rng = np.random.RandomState(cin + 2 * cout + sum(cshape))
+    B, D, H, W = cshape
+    g = rng.uniform(-1, 1, (B, 2 * D, 2 * H, 2 * W, cout)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (3, 3, 3, cin, cout)) / np.sqrt(cout * 27)).astype(np.float32)
+    acc0 = rng.uniform(-1, 1, cshape + (cin,)).astype(np.float32)
+    s = _stream()
+    gt, wt, acc = dev(g), dev(w), dev(acc0)
+    wp = torch.empty(query("df_wino_packed_elems", cin, cout, 1), device="cuda")
+    call("df_wino_pack_weights", _ptr(wt), _ptr(wp), cin, cout, 1, s)
+    call("df_wino_upconv_dgrad", _ptr(gt), _ptr(wp), _ptr(acc), B, D, H, W, cin, cout, s)
+    xf = np.zeros((B, 2 * D, 2 * H, 2 * W, cin))
+    dx, _, _ = orc.conv_same_bwd(xf, w.astype(np.float64), g.astype(np.float64))
+    ref = acc0.astype(np.float64) + orc.upscale_nn_bwd(dx)
+    assert rel_linf(host(acc), ref) < TOL
+
+
 @pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 32), ((1, 3, 5, 7), 128), ((1, 2, 2, 32), 64)])
 def test_upconv_block_winograd_forced(ops, cshape, C):
     """The fused up-sampling block with the Winograd kernels forced on small/ragged grids (forward through df_wino_upconv_fwd)."""
@@ -472,6 +495,12 @@ def test_full_size_upconv_agrees_with_materialised_upsample_cfg3(ops):
     gxc1 = torch.zeros_like(xc)
     call("df_upconv_dgrad", _ptr(g), _ptr(wud), _ptr(gxc1), B, D, H, W, C, C, 3, s)
     assert ((gxc0 - gxc1).abs().max() / gxc0.abs().max()).item() < 2e-5
+    wwd = torch.empty(query("df_wino_packed_elems", C, C, 1), device="cuda")
+    call("df_wino_pack_weights", _ptr(w), _ptr(wwd), C, C, 1, s)
+    gxc2 = torch.zeros_like(xc)
+    call("df_wino_upconv_dgrad", _ptr(g), _ptr(wwd), _ptr(gxc2), B, D, H, W, C, C, s)
+    assert ((gxc0 - gxc2).abs().max() / gxc0.abs().max()).item() < 2e-5
+    del gxc2, wwd
     nb1 = query("df_upconv_wgrad_workspace_bytes", B, D, H, W, C, C, 3)
     ws1 = torch.empty((nb1 + 3) // 4, device="cuda")
     gw1 = torch.full_like(w, float("nan")); gb1 = torch.full((C,), float("nan"), device="cuda")

@@ -31,6 +31,20 @@ def run(B, Dc, Hc, Wc, C, N, iters=5):
     l1 = (y0 - y1).abs().sum().item() / y0.abs().sum().item()
     t0 = timeit(f0, iters, 2)
     t1 = timeit(f1, iters, 2)
+    g = torch.rand((B, 2 * Dc, 2 * Hc, 2 * Wc, N), device="cuda") * 2 - 1
+    wdd = torch.empty(query("df_upconv_packed_elems", C, N, 3, 1), device="cuda")
+    call("df_upconv_pack_weights", _ptr(w), _ptr(wdd), C, N, 3, 1, s)
+    wwd = torch.empty(query("df_wino_packed_elems", C, N, 1), device="cuda")
+    call("df_wino_pack_weights", _ptr(w), _ptr(wwd), C, N, 1, s)
+    a0 = torch.zeros_like(xc); a1 = torch.zeros_like(xc)
+    d0 = lambda: call("df_upconv_dgrad", _ptr(g), _ptr(wdd), _ptr(a0), B, Dc, Hc, Wc, C, N, 3, s)
+    d1 = lambda: call("df_wino_upconv_dgrad", _ptr(g), _ptr(wwd), _ptr(a1), B, Dc, Hc, Wc, C, N, s)
+    d0(); d1()
+    torch.cuda.synchronize()
+    derr = (a0 - a1).abs().max().item() / a0.abs().max().item()
+    td0 = timeit(d0, iters, 2)
+    td1 = timeit(d1, iters, 2)
+    print("   dgrad: rel-linf %.2e | direct %.3f ms  wino-pool %.3f ms" % (derr, td0 * 1e3, td1 * 1e3), flush=True)
     print("B%d coarse %dx%dx%d C%d N%d: rel-linf %.2e rel-l1 %.2e | direct %.3f ms  wino-up %.3f ms" % (
         B, Dc, Hc, Wc, C, N, err, l1, t0 * 1e3, t1 * 1e3), flush=True)
 
