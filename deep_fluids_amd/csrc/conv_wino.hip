@@ -21,6 +21,7 @@
 //     a lane needs 8 coalesced 16-byte global loads per k-step (L2 / L1 hits: the two tz waves read the same words).
 //   * epilogue: inverse transform in y,x in registers, the four xi_z partial planes are combined through the idle LDS
 //     buffer, then bias / lrelu / residual / lrelu-mask as in conv.hip.  The dgrad is the same kernel on mode-1 weights.
+#include <type_traits>
 #include "df_common.hpp"
 #include "conv_args.hpp"
 
@@ -145,7 +146,7 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 // UP: the input is the COARSE tensor of an up-sampling-aware conv (x = nearest_up2x(xc) is never materialised): the staging reads
 // xc[g >> 1] for fine halo coordinate g, and because every 2x2x2 tile then sees each coarse value twice, the transform points with
 // index 2 in any axis are identically zero (B^T d = (c-1 - c0, 2 c0, 0, c0 - c1)): only 27 of the 64 points are multiplied
-// (the xi_z = 2 waves and the xi_y|xi_x = 2 MFMAs are skipped) -- the 27-product form of the parity-class convolution.
+// (no wave takes xi_z = 2 and the xi_y|xi_x = 2 MFMAs are skipped) -- the 27-product form of the parity-class convolution.
 // POOL (MODE 2): the adjoint case -- the output is the 2x2x2 sum-pool of the convolution (d/d(xc) of the up-sampling-aware conv: x is
 // the fine gradient, y the COARSE tensor [B, D/2, H/2, W/2, Cout], accumulated into).  The pooled inverse transform is
 // (A^T row 0 + row 1) = (1, 2, 0, -1) per axis, so the same 27 points are the only ones needed and a tile block writes 32 voxels, not 256.
@@ -254,11 +255,18 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
   // ---- A operand: this lane's tile, planes (za, zb) of xi_z ---------------------------------------------------------------
   const int tx = tl & 3, ty = tl >> 2;
-  const int za = xz == 0 ? 0 : xz == 2 ? 2 : 1;
-  const int zb = xz == 0 ? 2 : xz == 1 ? 2 : xz == 2 ? 1 : 3;
-  const float qs = xz == 1 ? 1.f : -1.f;
+  // main-loop role (mz = xi_z, mth = tile z-row).  Plain conv: the wave's (xz, th).  27-point modes: only xi_z in {0, 1, 3} is
+  // multiplied, 6 (xi_z, z-row) roles of 2 x 9 MFMAs per k-step: waves 0-3 take (xi_z in {0, 1}) x (z-row) with both 16-cout blocks,
+  // waves 4-7 split the two xi_z = 3 roles by cout block (hnb) -- every SIMD (wave & 3) then issues 27 MFMAs per k-step.
+  const bool half = P27 && wave >= 4;
+  const int mz = !P27 ? xz : (wave < 4 ? (wave >> 1) : 3);
+  const int mth = !P27 ? th : (wave < 4 ? (wave & 1) : ((wave >> 1) & 1));
+  const int hnb = half ? (wave & 1) : 0;
+  const int za = mz == 0 ? 0 : mz == 2 ? 2 : 1;
+  const int zb = mz == 0 ? 2 : mz == 1 ? 2 : mz == 2 ? 1 : 3;
+  const float qs = mz == 1 ? 1.f : -1.f;
   const f32x2 qs2 = {qs, qs};
-  const int abase = kq * CP + (2 * th) * PZ + (2 * ty) * PY + 2 * tx;
+  const int abase = kq * CP + (2 * mth) * PZ + (2 * ty) * PY + 2 * tx;
   const int offA = abase + za * PZ, offB = abase + zb * PZ;
 
   f32x2 ra[8], rb[8];      // raw inputs [y][x pair] of planes za / zb
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   f32x4 bq[2][4];          // [cout 16-block][xi_y] = (xi_x 0..3)
   const unsigned laneb = static_cast<unsigned>(lane) * 16u;
   const __amdgpu_buffer_rsrc_t wsrd = make_srd(a.wp, static_cast<unsigned>(a.Cin) * a.Cout * 256u);
-  const unsigned wbase_b = static_cast<unsigned>((cs * 4 + xz) * nk4) * 8192u;
+  const unsigned wbase_b = static_cast<unsigned>((cs * 4 + mz) * nk4) * 8192u + static_cast<unsigned>(hnb) * 4096u;
   auto issue_b = [&](int nb, int k4) {
     const int k2 = k4 < nk4 ? k4 : 0;        // wraps to the first k-step of the next tile block
     const unsigned sb = wbase_b + static_cast<unsigned>(k2) * 8192u + nb * 4096u;      // wave-uniform
@@ -335,27 +343,12 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     // nothing is prefetched across the epilogue (registers): first raw inputs / weights of this block
     raw_read(pb * BUF * 4);
     issue_b(0, 0);
-    issue_b(1, 0);
+    if (!half) issue_b(1, 0);
 
     const unsigned long long tp1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
     unsigned long long ph[4] = {0, 0, 0, 0};
-    if (P27 && xz == 2) {
-      // the xi_z = 2 transform points of an up-sampled input are identically zero: these two waves only do their share of the
-      // staging and meet the others at the barriers (their accumulators stay zero for the epilogue's combine)
-      for (int chunk = 0; chunk < nchunk; ++chunk) {
-        const int bn = BUF * 4 - ((chunk + pb) & 1) * BUF * 4;
-        const bool lastc = chunk + 1 == nchunk;
-        if (lastc) set_offs(nxt);
-        const __amdgpu_buffer_rsrc_t ssrd = make_srd(lastc ? nxt.xb : cur.xb, vol_bytes);
-        const unsigned schunk = lastc ? 0u : static_cast<unsigned>(chunk + 1) * (CKW * 4u);
-        f32x4 stg[NLOAD];
-#pragma unroll
-        for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, ssrd, schunk);
-#pragma unroll
-        for (int it = 0; it < NLOAD; ++it) stage_store(it, bn, stg[it]);
-        __syncthreads();
-      }
-    } else
+    auto main_loop = [&](auto half_c) {
+    constexpr bool HALF = decltype(half_c)::value;      // this wave owns one 16-cout block only (acc[0], weights of block hnb)
     for (int chunk = 0; chunk < nchunk; ++chunk) {
       const int bo = ((chunk + pb) & 1) * BUF * 4, bn = BUF * 4 - bo;        // byte offsets of this / the other buffer
       const bool lastc = chunk + 1 == nchunk;
@@ -393,13 +386,15 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (!(DBG & 8)) issue_b(0, chunk * 4 + ks + 1);       // weights of the next k-step, as each register block frees up
         __builtin_amdgcn_sched_barrier(0);
+        if (!HALF) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
-            acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int i = 0; i < 16; ++i)
+            if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
+              acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (DBG & 32) __builtin_amdgcn_s_setprio(0);
-        if (!(DBG & 8)) issue_b(1, chunk * 4 + ks + 1);
+        if (!HALF && !(DBG & 8)) issue_b(1, chunk * 4 + ks + 1);
         if (ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
                                          // the first wait that covers them is the one for the NEXT weight batch (1.5 k-steps away)
 #pragma unroll
@@ -412,6 +407,8 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         }
       }
     }
+    };
+    if (half) main_loop(std::true_type{}); else main_loop(std::false_type{});
 
     const unsigned long long tp2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
     // ---- epilogue: inverse transform in x, y per accumulator element; z across the waves through the idle LDS buffer ---------
@@ -426,16 +423,18 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         const float prev = inb ? yo[nb * 16] : 0.f;
-        if (xz != 2) {
+        auto emit = [&](const f32x4 (&c)[16]) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float py[4];
 #pragma unroll
             for (int yy = 0; yy < 4; ++yy)
-              py[yy] = yy == 2 ? 0.f : acc[nb][yy * 4 + 0][e] + 2.f * acc[nb][yy * 4 + 1][e] - acc[nb][yy * 4 + 3][e];
-            sP[((xz * 2 + th) * 4 + e) * 64 + lane] = py[0] + 2.f * py[1] - py[3];
+              py[yy] = yy == 2 ? 0.f : c[yy * 4 + 0][e] + 2.f * c[yy * 4 + 1][e] - c[yy * 4 + 3][e];
+            sP[((mz * 2 + mth) * 4 + e) * 64 + lane] = py[0] + 2.f * py[1] - py[3];
           }
-        }
+        };
+        if (!half) emit(acc[nb]);
+        else if (nb == hnb) emit(acc[0]);
         __syncthreads();
         const float m0 = sP[((0 * 2 + th) * 4 + xz) * 64 + lane], m1 = sP[((1 * 2 + th) * 4 + xz) * 64 + lane];
         const float m3 = sP[((3 * 2 + th) * 4 + xz) * 64 + lane];
@@ -471,17 +470,26 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       for (int nb = 0; nb < 2; ++nb) {
         const int col = n0 + nb * 16 + tl;
         const float bv = (eflags & DF_CONV_BIAS) ? a.bias[col] : 0.f;
+        auto emit = [&](const f32x4 (&c)[16]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f32x2 px[4];
+          for (int e = 0; e < 4; ++e) {
+            f32x2 px[4];
 #pragma unroll
-          for (int yy = 0; yy < 4; ++yy) {
-            px[yy][0] = acc[nb][yy * 4 + 0][e] + acc[nb][yy * 4 + 1][e] + acc[nb][yy * 4 + 2][e];
-            px[yy][1] = acc[nb][yy * 4 + 1][e] - acc[nb][yy * 4 + 2][e] - acc[nb][yy * 4 + 3][e];
+            for (int yy = 0; yy < 4; ++yy) {
+              if (P27) {      // the xi = 2 points were never multiplied
+                px[yy][0] = c[yy * 4 + 0][e] + c[yy * 4 + 1][e];
+                px[yy][1] = c[yy * 4 + 1][e] - c[yy * 4 + 3][e];
+              } else {
+                px[yy][0] = c[yy * 4 + 0][e] + c[yy * 4 + 1][e] + c[yy * 4 + 2][e];
+                px[yy][1] = c[yy * 4 + 1][e] - c[yy * 4 + 2][e] - c[yy * 4 + 3][e];
+              }
+            }
+            const f32x2 o01 = P27 ? px[0] + px[1] : px[0] + px[1] + px[2], o23 = P27 ? px[1] - px[3] : px[1] - px[2] - px[3];
+            sO[((mz * 2 + mth) * 4 + e) * 64 + lane] = f32x4{o01[0], o01[1], o23[0], o23[1]};
           }
-          const f32x2 o01 = px[0] + px[1] + px[2], o23 = px[1] - px[2] - px[3];
-          sO[((xz * 2 + th) * 4 + e) * 64 + lane] = f32x4{o01[0], o01[1], o23[0], o23[1]};
-        }
+        };
+        if (!half) emit(acc[nb]);
+        else if (nb == hnb) emit(acc[0]);
         if (nb == 0 && full && (eflags & DF_CONV_RESIDUAL)) {
 #pragma unroll
           for (int n2 = 0; n2 < 2; ++n2)
@@ -491,8 +499,12 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         }
         __syncthreads();
         const f32x4 m0 = sO[((0 * 2 + th) * 4 + xz) * 64 + lane], m1 = sO[((1 * 2 + th) * 4 + xz) * 64 + lane];
-        const f32x4 m2 = sO[((2 * 2 + th) * 4 + xz) * 64 + lane], m3 = sO[((3 * 2 + th) * 4 + xz) * 64 + lane];
-        const f32x4 lo = m0 + m1 + m2, hi = m1 - m2 - m3;
+        const f32x4 m3 = sO[((3 * 2 + th) * 4 + xz) * 64 + lane];
+        f32x4 lo = m0 + m1, hi = m1 - m3;
+        if (!P27) {
+          const f32x4 m2 = sO[((2 * 2 + th) * 4 + xz) * 64 + lane];
+          lo += m2; hi -= m2;
+        }
         if (nb == 0 && full && (eflags & DF_CONV_MASK)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // mask DMA landed
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
