@@ -1277,6 +1277,199 @@ __global__ __launch_bounds__(kThreads) void wgrad_small_reduce_kernel(const floa
   }
 }
 
+// ---- small-N weight gradient on the matrix cores (3-D, Cin = 128, Cout <= 4: the generator's last layer) -----------------------
+// The 27 taps are folded into the M side of ONE GEMM:  P[(tap, co), ci] = sum_v G'[v, (tap, co)] * x[v, ci]  with
+// G'[v, (tap, co)] = g[v - (tap - 1), co]  (zero outside the image) -- M = 27*Cout <= 96|128 rows, N = 128 input channels, K = voxels.
+// x is then a plain LINEAR stream (no halo, read exactly once: one 1 KB buffer load per wave feeds 12|16 v_mfma_f32_32x32x2), and
+// the shifted copies of the 3|4-channel gradient are gathered from a 9-row LDS tile private to the wave (x-halo of zeros, zero rows
+// for SAME padding, double-buffered per image row: no workgroup barriers at all).  B operand columns are permuted (lane l's float4
+// = channels 4*(l%32)..+3 feed the four N blocks), which makes the partial-sum stores float4-contiguous.
+// One wave per SIMD (192|256 accumulator registers); latency is covered by an 8-step ring of x loads.
+struct ThinWgradArgs {
+  const float* x;
+  const float* g;
+  float* partial;      // [nstreams][27*CO][128]
+  float* bpartial;     // [nstreams][CO]
+  int B, D, H, W;
+  int nrows, nstreams, rows_per, RS;      // RS: LDS row stride in floats = W*CO + 8
+  unsigned x_bytes_lo, x_bytes_hi;        // size of x in bytes
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t thin_srd(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+template <int CO>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_thin_mfma_kernel(const ThinWgradArgs a) {
+  constexpr int NM = 27 * CO, MB = (NM + 31) / 32, MBC = (13 * CO) / 32;      // MBC: the M block that holds the centre tap
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smem_thin[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stream = blockIdx.x * 4 + wave;
+  const int RS = a.RS, W = a.W, WC = W * CO;
+  float* sG = smem_thin + wave * 19 * RS;          // [2 buffers][9 (tz, ty) rows][RS] + one zero row
+  const int r0 = stream * a.rows_per;
+  int r1 = r0 + a.rows_per;
+  if (r1 > a.nrows) r1 = a.nrows;
+  for (int i = lane; i < 19 * RS; i += 64) sG[i] = 0.f;
+  if (r0 >= r1) {      // (only when nrows is not a multiple of the stream count) -- still publish zero partials
+    for (int i = lane; i < NM * 128; i += 64) a.partial[static_cast<int64_t>(stream) * NM * 128 + i] = 0.f;
+    if (lane < CO) a.bpartial[stream * CO + lane] = 0.f;
+    return;
+  }
+
+  // ---- gradient rows of image row `row` -> registers -> LDS buffer -------------------------------------------------------------
+  const int nl4 = WC / 4;      // float4 pieces per gradient row (<= 48)
+  f32x4 gq[9];
+  auto load_g = [&](int row) {
+    const int y = row % a.H;
+    const int t = row / a.H;
+    const int z = t % a.D;
+    const int b = t / a.D;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int zs = z - (k / 3 - 1), ys = y - (k % 3 - 1);
+      const bool ok = zs >= 0 && zs < a.D && ys >= 0 && ys < a.H;      // wave-uniform
+      const int zc = ok ? zs : z, yc = ok ? ys : y;
+      const float* src = a.g + ((static_cast<int64_t>(b) * a.D + zc) * a.H + yc) * WC;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (lane < nl4) v = *reinterpret_cast<const f32x4*>(src + lane * 4);
+      gq[k] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_g = [&](int buf) {
+    if (lane < nl4) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) *reinterpret_cast<f32x4*>(sG + (buf * 9 + k) * RS + 4 + lane * 4) = gq[k];
+    }
+  };
+
+  // ---- A operand gather: lane (m = l % 32 of block mb, voxel kk = l / 32 of the pair) --------------------------------------------
+  const int kk = lane >> 5;
+  int aoff[MB], adb[MB];      // byte offset inside buffer 0; byte distance to buffer 1 (0 for the zero row)
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = mb * 32 + (lane & 31);
+    if (m < NM) {
+      const int tap = m / CO, co = m % CO;
+      const int t9 = tap / 3, tx = tap % 3;
+      aoff[mb] = (t9 * RS + 4 + (kk - (tx - 1)) * CO + co) * 4;
+      adb[mb] = 9 * RS * 4;
+    } else {
+      aoff[mb] = (18 * RS + 4) * 4;
+      adb[mb] = 0;
+    }
+  }
+  const char* sGb = reinterpret_cast<const char*>(sG);
+  auto gather = [&](int buf, int pair, float (&out)[MB]) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      out[mb] = *reinterpret_cast<const float*>(sGb + aoff[mb] + buf * adb[mb] + pair * (2 * CO * 4));
+  };
+
+  // ---- x stream ----------------------------------------------------------------------------------------------------------------------
+  const int64_t xoff0 = static_cast<int64_t>(r0) * W * 128;      // floats
+  const uint64_t xbytes = (static_cast<uint64_t>(a.x_bytes_hi) << 32) | a.x_bytes_lo;
+  const uint64_t remain = xbytes - static_cast<uint64_t>(xoff0) * 4u;
+  const __amdgpu_buffer_rsrc_t xsrd = thin_srd(a.x + xoff0, remain > 0xffffffffull ? 0xffffffffu : static_cast<unsigned>(remain));
+  const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
+  auto load_x = [&](unsigned step) -> f32x4 {       // step = voxel pair index within the stream; past the tensor's end reads zeros
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrd, lane16, step * 1024u, 0));
+  };
+
+  f32x16 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][j][r] = 0.f;
+  float bs = 0.f;
+
+  f32x4 xr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xr[i] = load_x(i);
+  load_g(r0);
+  store_g(0);
+  float an[MB];
+  gather(0, 0, an);
+
+  const int ngrp = W >> 4;      // groups of 8 voxel pairs per image row
+  unsigned step = 0;
+  int buf = 0;
+  for (int row = r0; row < r1; ++row) {
+    const bool more = row + 1 < r1;
+    if (more) load_g(row + 1);
+    for (int grp = 0; grp < ngrp; ++grp) {
+      const bool lastg = grp + 1 == ngrp;
+      if (lastg && more) store_g(buf ^ 1);      // the row's last pair prefetches the first gather of the next row
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float ac[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) ac[mb] = an[mb];
+        if (i < 7) gather(buf, grp * 8 + i + 1, an);
+        else if (!lastg) gather(buf, grp * 8 + 8, an);
+        else gather(buf ^ 1, 0, an);
+        const f32x4 xv = xr[i];
+        xr[i] = load_x(step + 8);
+        ++step;
+        bs += ac[MBC];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mb], xv[j], acc[mb][j], 0, 0, 0);
+      }
+    }
+    buf ^= 1;
+  }
+
+  // ---- partial sums: row m of block mb lives in register r of lanes with l / 32 == ((m % 8) / 4) --------------------------------------
+  float* P = a.partial + static_cast<int64_t>(stream) * NM * 128 + (lane & 31) * 4;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mb * 32 + (r >> 2) * 8 + kk * 4 + (r & 3);
+      if (m < NM) *reinterpret_cast<f32x4*>(P + m * 128) = f32x4{acc[mb][0][r], acc[mb][1][r], acc[mb][2][r], acc[mb][3][r]};
+    }
+  // bias gradient: lanes (13*CO + co) % 32 of both halves hold the two voxel-parity sums of g[., co]
+  const float other = __shfl_xor(bs, 32);
+  const int l0 = (13 * CO) & 31;
+  if (lane >= l0 && lane < l0 + CO) a.bpartial[stream * CO + (lane - l0)] = bs + other;
+}
+
+// gw[tap][ci][co] = sum_stream partial[stream][tap*CO + co][ci]  (fixed order: 8 interleaved stream groups, combined in order)
+__global__ __launch_bounds__(kThreads) void wgrad_thin_reduce_kernel(const float* __restrict__ partial,
+                                                                     const float* __restrict__ bpartial,
+                                                                     float* __restrict__ gw, float* __restrict__ gb,
+                                                                     int nstreams, int NM, int CO) {
+  __shared__ float sP[8][32];
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int m = blockIdx.x >> 2, ci = (blockIdx.x & 3) * 32 + el;
+  float acc = 0.f;
+  for (int sidx = grp; sidx < nstreams; sidx += 8) acc += partial[(static_cast<int64_t>(sidx) * NM + m) * 128 + ci];
+  sP[grp][el] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    float t = sP[0][el];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += sP[k][el];
+    gw[(static_cast<int64_t>(m / CO) * 128 + ci) * CO + (m % CO)] = t;
+  }
+  if (gb && blockIdx.x == 0 && threadIdx.x < CO) {
+    float t = 0.f;
+    for (int sidx = 0; sidx < nstreams; ++sidx) t += bpartial[sidx * CO + threadIdx.x];
+    gb[threadIdx.x] = t;
+  }
+}
+
+// (LDS: 4 waves x 19 rows x (W*Cout + 8) floats must stay under the 64 KB a launch gets without opting in)
+inline bool thin_mfma_ok(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
+  return kz == 3 && Cin == 128 && Cout <= 4 && W % 16 == 0 && W * Cout <= 192 && B * D * H >= 4 &&
+         B * D * H * W * 128 * 4 < (1LL << 44);
+}
 inline bool small_n_ok(int64_t Cin, int64_t Cout) { return Cout <= 4 && Cin % 64 == 0; }
 
 struct SmallPlan { int nrows, ncib, nstreams, rows_per, taps, CO; int64_t partial_elems; };
@@ -1413,6 +1606,34 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   DF_REQUIRE(df::aligned16(workspace), DF_EALIGN, "df_conv_wgrad: workspace must be 16-byte aligned");
   DF_REQUIRE(workspace_bytes >= df_conv_wgrad_workspace_bytes(B, D, H, W, Cin, Cout, kz), DF_EWORKSPACE,
              "df_conv_wgrad: workspace too small");
+  if (small_n_ok(Cin, Cout) && g_wgrad_algo != 1 && prec == 0 && thin_mfma_ok(B, D, H, W, Cin, Cout, kz) && df::aligned16(x) &&
+      df::aligned16(gy)) {
+    // matrix-core form; shares the workspace layout budget of the vector-ALU plan (never more streams than that plan has)
+    const SmallPlan sp = make_small_plan(B, D, H, Cin, Cout, kz);
+    ThinWgradArgs ta;
+    int ns = 4 * df::kCUs;
+    if (ns > sp.nstreams) ns = sp.nstreams / 4 * 4;
+    const int nrows = (int)(B * D * H);
+    if (ns > nrows) ns = nrows / 4 * 4;
+    ta.x = x; ta.g = gy; ta.partial = static_cast<float*>(workspace);
+    ta.bpartial = ta.partial + static_cast<int64_t>(ns) * 27 * Cout * 128;
+    ta.B = (int)B; ta.D = (int)D; ta.H = (int)H; ta.W = (int)W;
+    ta.nrows = nrows; ta.nstreams = ns; ta.rows_per = (nrows + ns - 1) / ns;
+    ta.RS = (int)(W * Cout + 8);
+    const uint64_t xb = static_cast<uint64_t>(B * D * H * W) * 128u * 4u;
+    ta.x_bytes_lo = static_cast<unsigned>(xb & 0xffffffffu); ta.x_bytes_hi = static_cast<unsigned>(xb >> 32);
+    if (static_cast<int64_t>(ta.rows_per) * W * 512 < (1LL << 32) && ns >= 4) {
+      hipStream_t s = df::as_stream(stream);
+      const size_t lds = static_cast<size_t>(4) * 19 * ta.RS * sizeof(float);
+      dim3 grid((unsigned)(ns / 4));
+#define DF_WT(CO) hipLaunchKernelGGL((wgrad_thin_mfma_kernel<CO>), grid, dim3(kThreads), lds, s, ta)
+      if (Cout == 1) DF_WT(1); else if (Cout == 2) DF_WT(2); else if (Cout == 3) DF_WT(3); else DF_WT(4);
+#undef DF_WT
+      hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)(27 * Cout * 4)), dim3(kThreads), 0, s, ta.partial, ta.bpartial, gw, gb,
+                         ns, (int)(27 * Cout), (int)Cout);
+      return df::launched("df_conv_wgrad(thin-N mfma)");
+    }
+  }
   if (small_n_ok(Cin, Cout)) {
     const SmallPlan sp = make_small_plan(B, D, H, Cin, Cout, kz);
     SmallWgradArgs sa;

@@ -142,6 +142,10 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// Barrier that orders LDS traffic only.  __syncthreads() is a full fence: its s_waitcnt vmcnt(0) also waits for the acknowledgement of
+// every global STORE issued before it -- in the epilogue that exposed two HBM write round trips per tile block.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // FL >= 0: the epilogue flags are the compile-time constant FL (no per-element flag tests); FL < 0: run-time a.flags
 // UP: the input is the COARSE tensor of an up-sampling-aware conv (x = nearest_up2x(xc) is never materialised): the staging reads
 // xc[g >> 1] for fine halo coordinate g, and because every 2x2x2 tile then sees each coarse value twice, the transform points with
@@ -154,6 +158,7 @@ template <int DBG, int FL = -1, int MODE = 0>
 __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   constexpr bool UP = MODE == 1, POOL = MODE == 2, P27 = MODE != 0;
   __shared__ __attribute__((aligned(16))) float sIn[2 * BUF];
+  __shared__ float sBias[32];        // this worker's cout slice of the bias (the slice is fixed for the worker's whole life)
   __shared__ float sM[16 * kT];      // lrelu-mask operands of a tile block's outputs, fetched by LDS-DMA loads (no registers)
 
   const int eflags = FL >= 0 ? FL : a.flags;
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   }
   if (tb >= a.ntb) return;
   const int n0 = cs * 32;
+  if (tid < 32) sBias[tid] = (eflags & DF_CONV_BIAS) ? a.bias[n0 + tid] : 0.f;      // visible after the prologue's barrier
   const int tb0 = tb;
   const int niter = (a.ntb - tb0 + tstride - 1) / tstride;
   auto seq = [&](int k) -> int { return tb0 + k * tstride; };
@@ -346,7 +352,25 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     if (!half) issue_b(1, 0);
 
     const unsigned long long tp1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
-    unsigned long long ph[4] = {0, 0, 0, 0};
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // The 16 lrelu-mask operands of this lane's outputs go global -> LDS by DMA loads (in registers hipcc spills each one to scratch
+    // behind its own vmcnt(0): 14 serial HBM round trips).  Issued at the top of the epilogue and read back after the first combine
+    // (issuing them inside the last chunk costs more than it hides: +20 % kernel time); every thread reads only what it requested.
+    auto mask_dma = [&]() {
+      typedef __attribute__((address_space(3))) void* lds_ptr;
+      const int oz0 = cur.z0 + 2 * th, oy0 = cur.y0 + 2 * kq, ox0 = cur.x0 + 2 * xz;
+      const int sW = a.Cout, sH = a.W * a.Cout, sD = sH * a.H;
+      const __amdgpu_buffer_rsrc_t msrd = make_srd(a.mask_src + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout,
+                                                   static_cast<unsigned>(a.D) * a.H * a.W * a.Cout * 4u);
+      const unsigned mv = static_cast<unsigned>(((oz0 * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl) * 4u;
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const unsigned so_ = static_cast<unsigned>(n2 * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) * 4u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(msrd, (lds_ptr)(sM + (n2 * 8 + s) * kT + wave * 64), 4, mv, so_, 0, 0);
+        }
+    };
     auto main_loop = [&](auto half_c) {
     constexpr bool HALF = decltype(half_c)::value;      // this wave owns one 16-cout block only (acc[0], weights of block hnb)
     for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -450,26 +474,12 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       const int64_t obase = (((static_cast<int64_t>(cur.b) * a.D + oz0) * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl;
       const bool full = cur.z0 + 4 <= a.D && cur.y0 + 8 <= a.H && cur.x0 + 8 <= a.W;
       const unsigned lane_off = static_cast<unsigned>(((oz0 * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl) * 4u;      // bytes within the batch volume
-      // The 16 lrelu-mask operands of this lane's outputs go global -> LDS by DMA loads issued now and are read back after the
-      // first combine: in registers hipcc spills each one to scratch behind its own vmcnt(0) (14 serial HBM round trips).
-      if (full && (eflags & DF_CONV_MASK)) {
-        typedef __attribute__((address_space(3))) void* lds_ptr;
-        const __amdgpu_buffer_rsrc_t msrd = make_srd(a.mask_src + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout,
-                                                     static_cast<unsigned>(a.D) * a.H * a.W * a.Cout * 4u);
-        const unsigned mv = static_cast<unsigned>(((oz0 * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl) * 4u;
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const unsigned so_ = static_cast<unsigned>(n2 * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) * 4u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(msrd, (lds_ptr)(sM + (n2 * 8 + s) * kT + wave * 64), 4, mv, so_, 0, 0);
-          }
-      }
+      if (full && (eflags & DF_CONV_MASK)) mask_dma();
       float rres[2][8];
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         const int col = n0 + nb * 16 + tl;
-        const float bv = (eflags & DF_CONV_BIAS) ? a.bias[col] : 0.f;
+        const float bv = sBias[nb * 16 + tl];
         auto emit = [&](const f32x4 (&c)[16]) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -488,8 +498,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
             sO[((mz * 2 + mth) * 4 + e) * 64 + lane] = f32x4{o01[0], o01[1], o23[0], o23[1]};
           }
         };
+        const unsigned long long e0 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (!half) emit(acc[nb]);
         else if (nb == hnb) emit(acc[0]);
+        if (DBG & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long e1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (nb == 0 && full && (eflags & DF_CONV_RESIDUAL)) {
 #pragma unroll
           for (int n2 = 0; n2 < 2; ++n2)
@@ -498,6 +511,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
               rres[n2][s] = a.residual[obase + n2 * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW];
         }
         __syncthreads();
+        const unsigned long long e2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         const f32x4 m0 = sO[((0 * 2 + th) * 4 + xz) * 64 + lane], m1 = sO[((1 * 2 + th) * 4 + xz) * 64 + lane];
         const f32x4 m3 = sO[((3 * 2 + th) * 4 + xz) * 64 + lane];
         f32x4 lo = m0 + m1, hi = m1 - m3;
@@ -517,6 +531,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
             // wave-uniform base (batch volume + this output's scalar offset) + 32-bit lane offset: no 64-bit address per output
             char* yb = reinterpret_cast<char*>(a.y + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
                                                ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
+            if (DBG & 512) asm volatile("" :: "v"(v)); else      // (experiment: no stores)
             *reinterpret_cast<float*>(yb + lane_off) = v;
           } else if (oz0 + (s >> 2) < a.D && oy0 + ((s >> 1) & 1) < a.H && ox0 + (s & 1) < a.W) {
             if (eflags & DF_CONV_RESIDUAL) v += a.residual[o];
@@ -524,13 +539,18 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
             a.y[o] = v;
           }
         }
+        const unsigned long long e3 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         __syncthreads();
+        if (DBG & 16) {
+          const unsigned long long e4 = __builtin_readcyclecounter();
+          ph[4 + 0] += e1 - e0; ph[4 + 1] += e2 - e1; ph[4 + 2] += e3 - e2; ph[4 + 3] += e4 - e3;
+        }
       }
     }
     if ((DBG & 16) && blockIdx.x == 8 && tid == 0) {
       const unsigned long long tp3 = __builtin_readcyclecounter();
       g_wino_prof[0] += tp1 - tp0; g_wino_prof[1] += tp2 - tp1; g_wino_prof[2] += tp3 - tp2; g_wino_prof[3] += 1;
-      for (int i = 0; i < 4; ++i) g_wino_prof[4 + i] += ph[i];
+      for (int i = 0; i < 8; ++i) g_wino_prof[4 + i] += ph[i];
     }
     pb = (pb + nchunk) & 1;
     cur = nxt;
@@ -636,6 +656,8 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 272: hipLaunchKernelGGL((wino3d_kernel<272, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 16: hipLaunchKernelGGL((wino3d_kernel<16, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 20: hipLaunchKernelGGL((wino3d_kernel<20, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 1024: hipLaunchKernelGGL((wino3d_kernel<1024, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 1536: hipLaunchKernelGGL((wino3d_kernel<1536, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 15: hipLaunchKernelGGL((wino3d_kernel<15, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     default: return df::fail(DF_EINVAL, "df_wino_conv_fwd: unknown debug variant");
   }

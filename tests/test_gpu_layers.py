@@ -350,6 +350,36 @@ def test_upconv_block_winograd_forced(ops, cshape, C):
         ops.CONV_ALGO = old
 
 
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("shape,cout", [((1, 3, 5, 32), 1), ((1, 3, 5, 32), 2), ((2, 4, 6, 16), 3), ((1, 3, 5, 32), 4), ((2, 2, 3, 64), 3),
+                                        ((1, 1, 7, 16), 3), ((1, 5, 3, 48), 4)])
+def test_thin_wgrad_mfma_and_valu_vs_oracle(ops, shape, cout, algo):
+    """Weight gradient of the 128 -> Cout <= 4 conv (the generator's last layer): algo 0 = matrix-core form with the taps folded into the
+    GEMM's M side (wgrad_thin_mfma_kernel), algo 1 = the vector-ALU kernel; both against the fp64 oracle, incl. row counts that leave
+    streams empty or ragged."""
+    from deep_fluids_amd._lib import call, query, lib
+    from deep_fluids_amd.ops import _ptr, _stream
+    rng = np.random.RandomState(cout + sum(shape))
+    cin = 128
+    x = rng.uniform(-1, 1, shape + (cin,)).astype(np.float32)
+    g = rng.uniform(-1, 1, shape + (cout,)).astype(np.float32)
+    B, D, H, W = shape
+    s = _stream()
+    xt, gt = dev(x), dev(g)
+    gw = torch.full((3, 3, 3, cin, cout), float("nan"), device="cuda"); gb = torch.full((cout,), float("nan"), device="cuda")
+    lib().df_debug_set_wgrad_algo(ctypes.c_int(algo))
+    try:
+        nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, 3)
+        ws = torch.empty((nb + 3) // 4, device="cuda")
+        call("df_conv_wgrad", _ptr(xt), _ptr(gt), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, 3, _ptr(ws), nb, s)
+    finally:
+        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+    w0 = np.zeros((3, 3, 3, cin, cout))
+    _, dw, db = orc.conv_same_bwd(x.astype(np.float64), w0, g.astype(np.float64))
+    assert rel_linf(host(gw), dw) < TOL
+    assert rel_linf(host(gb), db) < TOL
+
+
 @pytest.fixture
 def bf16x3(ops):
     ops.CONV_PRECISION = "bf16x3"

@@ -26,3 +26,11 @@ nb = query("df_conv_wgrad_workspace_bytes", B, Z, Y, X, F, 3, 3)
 ws = torch.empty(nb // 4 + 1, device="cuda")
 t = timeit(lambda: call("df_conv_wgrad", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, Z, Y, X, F, 3, 3, _ptr(ws), nb, s), 5, 2)
 print("wgrad 128x3       : %.3f ms" % (t * 1e3))
+import ctypes
+from deep_fluids_amd._lib import lib
+lib().df_debug_set_wgrad_algo(ctypes.c_int(1))
+gw1 = torch.empty_like(w); gb1 = torch.empty(3, device="cuda")
+t = timeit(lambda: call("df_conv_wgrad", _ptr(x), _ptr(g), _ptr(gw1), _ptr(gb1), B, Z, Y, X, F, 3, 3, _ptr(ws), nb, s), 5, 2)
+lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+print("wgrad 128x3 (VALU): %.3f ms   mfma-vs-valu rel diff gw %.2e gb %.2e" % (
+    t * 1e3, ((gw - gw1).abs().max() / gw1.abs().max()).item(), ((gb - gb1).abs().max() / gb1.abs().max()).item()))

@@ -58,6 +58,7 @@ if __name__ == "__main__":
             lib().df_debug_wino_prof(buf, 0)
             n = max(buf[3], 1)
             print("  per block cycles: setup %.0f  main %.0f  epilogue %.0f  (n=%d)" % (buf[0] / n, buf[1] / n, buf[2] / n, n))
+            print("  epilogue split (both cout blocks): emit %.0f  barrier %.0f  combine+stores %.0f  barrier(+store acks) %.0f" % tuple(buf[8 + i] / n for i in range(4)))
             print("  main split: wait-raw %.0f  transform+stage+rawissue %.0f  wait-B %.0f  mfma+Bissue %.0f" % tuple(buf[4 + i] / n for i in range(4)))
     if len(sys.argv) > 1:
         run(16, 64, 96, 64, 128, 128, iters=3)
