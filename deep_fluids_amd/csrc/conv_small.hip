@@ -18,6 +18,7 @@ namespace {
 
 using df::ceil_div;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+int g_thin_valu = 0;      // debug: 1 = keep the thin-K conv on the vector-ALU kernel (df_debug_set_thin_valu)
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int KZ, int TZ, int TY, int TX, int CO, bool VEC>
@@ -229,6 +230,183 @@ __global__ __launch_bounds__(kThreads) void conv_small_k_kernel(const ConvArgs a
   }
 }
 
+// ---- thin-K conv on the matrix cores (3-D, Cin <= 4 -> 128 channels: the dgrad of the generator's last layer) ------------------------
+// im2col GEMM with the taps on the K side:  y[v, n] = sum_{(tap, c)} A[v, (tap, c)] * W[(tap, c), n],  A[v, (tap, c)] = x[v + tap - 1, c],
+// K = 27*Cin (81 | 108) in steps of 2 for v_mfma_f32_32x32x2.  The whole filter bank lives in registers (K/2 x 2 values per lane), a
+// wave walks image rows in 32-voxel chunks, and the shifted 3|4-channel input records are gathered from a 9-row LDS tile private to the
+// wave (zero x-halo, zero rows for SAME padding, double-buffered per image row: no workgroup barriers).  Two waves share a row stream,
+// 64 output channels each; N-block j of lane l holds channel 2*(l%32)+j of the wave's half, so every output / residual / mask access is
+// a float2 and a wave instruction covers two voxels' 256-byte half rows.
+struct ThinKArgs {
+  const float* x;
+  const f32x4* wp;
+  const float* bias;
+  const float* residual;
+  const float* mask_src;
+  float* y;
+  int D, H, W;
+  int tapstride;       // float4 records between taps of the packed filter bank
+  int nrows, rows_per, RS;
+  int flags;
+  float leak;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CI>
+__global__ __launch_bounds__(kThreads, 1) void conv_thin_k_mfma_kernel(const ThinKArgs a) {
+  constexpr int NK = 27 * CI, KS = (NK + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float smem_thin_k[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gwave = blockIdx.x * 4 + wave;
+  const int stream = gwave >> 1, half = gwave & 1;      // two waves per row stream: 64 output channels each (the filter bank fits the registers)
+  const int RS = a.RS, W = a.W, WC = W * CI;
+  float* sG = smem_thin_k + wave * 19 * RS;          // [2 buffers][9 (dz, dy) rows][RS] + one zero row
+  const int r0 = stream * a.rows_per;
+  int r1 = r0 + a.rows_per;
+  if (r1 > a.nrows) r1 = a.nrows;
+  for (int i = lane; i < 19 * RS; i += 64) sG[i] = 0.f;
+  if (r0 >= r1) return;
+  const int kk = lane >> 5, n4 = half * 64 + (lane & 31) * 2;      // this lane's channel pair
+
+  // ---- filter bank -> registers: wr[s][j] = W[k = 2s + kk][channel n4 + j] -----------------------------------------------------------
+  float wr[KS][2];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 2 * s + kk;
+    const bool ok = k < NK;
+    const int tap = ok ? k / CI : 0, c = ok ? k % CI : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 rec = a.wp[static_cast<int64_t>(tap) * a.tapstride + n4 + j];
+      const float v = c == 0 ? rec[0] : c == 1 ? rec[1] : c == 2 ? rec[2] : rec[3];
+      wr[s][j] = ok ? v : 0.f;
+    }
+  }
+  f32x2 bias2 = {0.f, 0.f};
+  if (a.flags & DF_CONV_BIAS) bias2 = *reinterpret_cast<const f32x2*>(a.bias + n4);
+
+  // ---- input rows of image row `row` -> registers -> LDS buffer ----------------------------------------------------------------------
+  const int nl4 = WC / 4;
+  f32x4 gq[9];
+  auto load_g = [&](int row) {
+    const int y = row % a.H;
+    const int t = row / a.H;
+    const int z = t % a.D;
+    const int b = t / a.D;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int zs = z + (k / 3 - 1), ys = y + (k % 3 - 1);
+      const bool ok = zs >= 0 && zs < a.D && ys >= 0 && ys < a.H;      // wave-uniform
+      const int zc = ok ? zs : z, yc = ok ? ys : y;
+      const float* src = a.x + ((static_cast<int64_t>(b) * a.D + zc) * a.H + yc) * WC;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (lane < nl4) v = *reinterpret_cast<const f32x4*>(src + lane * 4);
+      gq[k] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_g = [&](int buf) {
+    if (lane < nl4) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) *reinterpret_cast<f32x4*>(sG + (buf * 9 + k) * RS + 4 + lane * 4) = gq[k];
+    }
+  };
+
+  // ---- A operand gather: lane (voxel m = l % 32 of the chunk, k = 2s + l / 32) ---------------------------------------------------------
+  const char* sGb = reinterpret_cast<const char*>(sG);
+  const int lanebase = (lane & 31) * CI * 4;
+  auto gather = [&](int buf, int chunk, float (&av)[KS]) {
+    const int cb = lanebase + chunk * (32 * CI * 4);
+    const int bb = buf * (9 * RS * 4);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k0 = 2 * s, k1 = 2 * s + 1;
+      const int o0 = ((k0 / CI / 3) * RS + 4 + ((k0 / CI) % 3 - 1) * CI + k0 % CI) * 4 + bb;
+      const int o1 = k1 < NK ? ((k1 / CI / 3) * RS + 4 + ((k1 / CI) % 3 - 1) * CI + k1 % CI) * 4 + bb : (18 * RS + 4) * 4;
+      av[s] = *reinterpret_cast<const float*>(sGb + cb + (kk ? o1 : o0));
+    }
+  };
+
+  load_g(r0);
+  store_g(0);
+  const int nchunk = W >> 5;
+  int buf = 0;
+  for (int row = r0; row < r1; ++row) {
+    const bool more = row + 1 < r1;
+    if (more) load_g(row + 1);
+    const int64_t obase = static_cast<int64_t>(row) * W * 128 + n4;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      float av[KS];
+      gather(buf, chunk, av);
+      const int64_t oc = obase + static_cast<int64_t>(chunk) * 32 * 128;
+      f32x2 mk[16];
+      if (a.flags & DF_CONV_MASK) {      // requested now, used after the chunk's 2*KS MFMAs
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mk[r] = *reinterpret_cast<const f32x2*>(a.mask_src + oc + ((r >> 2) * 8 + kk * 4 + (r & 3)) * 128);
+      }
+      f32x16 acc[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wr[s][j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t o = oc + ((r >> 2) * 8 + kk * 4 + (r & 3)) * 128;
+        f32x2 v = f32x2{acc[0][r], acc[1][r]} + bias2;
+        if (a.flags & DF_CONV_LRELU) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) v[j] = fmaxf(v[j], a.leak * v[j]);
+        }
+        if (a.flags & DF_CONV_RESIDUAL) v += *reinterpret_cast<const f32x2*>(a.residual + o);
+        if (a.flags & DF_CONV_MASK) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) v[j] = mk[r][j] > 0.f ? v[j] : a.leak * v[j];
+        }
+        *reinterpret_cast<f32x2*>(a.y + o) = v;
+      }
+      if (chunk == 0 && more) store_g(buf ^ 1);
+    }
+    buf ^= 1;
+  }
+}
+
+// (LDS: 4 waves x 19 rows x (W*Cin + 8) floats under the 64 KB a launch gets without opting in)
+inline bool thin_k_mfma_ok(const ConvArgs& a, int kz) {
+  return kz == 3 && a.Cin <= 4 && a.Cout == 128 && a.W % 32 == 0 && a.W * a.Cin <= 192 && (a.W * a.Cin) % 16 == 0 &&
+         static_cast<int64_t>(a.B) * a.D * a.H >= 4 && a.nclass == 1 && df::aligned16(a.x) && df::aligned16(a.y) &&
+         (!(a.flags & DF_CONV_BIAS) || df::aligned16(a.bias)) && (!(a.flags & DF_CONV_RESIDUAL) || df::aligned16(a.residual)) &&
+         (!(a.flags & DF_CONV_MASK) || df::aligned16(a.mask_src));
+}
+
+int launch_thin_k_mfma(const ConvArgs& a, hipStream_t s) {
+  ThinKArgs t;
+  t.x = a.x; t.wp = a.wp; t.bias = a.bias; t.residual = a.residual; t.mask_src = a.mask_src; t.y = a.y;
+  t.D = a.D; t.H = a.H; t.W = a.W;
+  t.tapstride = (a.Kpad >> 3) * 2 * a.Npad;
+  t.nrows = a.B * a.D * a.H;
+  int ns = 2 * df::kCUs;      // row streams (two waves each)
+  if (ns > t.nrows) ns = t.nrows / 2 * 2;
+  t.rows_per = (t.nrows + ns - 1) / ns;
+  t.RS = a.W * a.Cin + 8;
+  t.flags = a.flags; t.leak = a.leak;
+  const size_t lds = static_cast<size_t>(4) * 19 * t.RS * sizeof(float);
+  dim3 grid((unsigned)ceil_div(ceil_div(t.nrows, t.rows_per), 2));
+#define DF_TK(CI) hipLaunchKernelGGL((conv_thin_k_mfma_kernel<CI>), grid, dim3(kThreads), lds, s, t)
+  switch (a.Cin) {
+    case 1: DF_TK(1); break;
+    case 2: DF_TK(2); break;
+    case 3: DF_TK(3); break;
+    default: DF_TK(4); break;
+  }
+#undef DF_TK
+  return df::launched("df_conv_fwd(thin-K mfma)");
+}
+
 template <int KZ, int TZ, int TY, int TX>
 int launch_small_k_t(ConvArgs a, hipStream_t s) {
   a.nz = (int)ceil_div(a.D, TZ); a.ny = (int)ceil_div(a.H, TY); a.nx = (int)ceil_div(a.W, TX);
@@ -249,8 +427,11 @@ int launch_small_n(const ConvArgs& a, int kz, hipStream_t s) {
 }
 
 int launch_small_k(const ConvArgs& a, int kz, hipStream_t s) {
+  if (thin_k_mfma_ok(a, kz) && !g_thin_valu) return launch_thin_k_mfma(a, s);
   if (kz == 3) return a.W >= 12 ? launch_small_k_t<3, 2, 4, 16>(a, s) : launch_small_k_t<3, 4, 4, 8>(a, s);
   return a.W >= 12 ? launch_small_k_t<1, 1, 8, 16>(a, s) : launch_small_k_t<1, 1, 16, 8>(a, s);
 }
 
 }  // namespace dfconv
+
+extern "C" void df_debug_set_thin_valu(int v) { dfconv::g_thin_valu = v; }

@@ -380,6 +380,43 @@ def test_thin_wgrad_mfma_and_valu_vs_oracle(ops, shape, cout, algo):
     assert rel_linf(host(gb), db) < TOL
 
 
+@pytest.mark.parametrize("shape,cin,leak", [((1, 3, 5, 32), 3, 0.2), ((2, 2, 3, 64), 3, None), ((1, 4, 2, 32), 1, 0.2), ((1, 2, 3, 32), 4, 0.2),
+                                            ((1, 1, 5, 32), 2, 0.2), ((1, 5, 1, 64), 3, 0.2)])
+def test_thin_k_conv_mfma_vs_oracle(ops, shape, cin, leak):
+    """Cin <= 4 -> 128 conv on the matrix cores (conv_thin_k_mfma_kernel: taps on the GEMM's K side, rows of 32-voxel chunks), forward and
+    all gradients against the fp64 oracle."""
+    errs = _conv_case(ops, shape, cin, 128, leak, seed=cin + sum(shape), mask_from_gpu=True)
+    assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize("flags", [0, 9, 4, 2, 15])
+def test_thin_k_conv_mfma_epilogues_match_valu_kernel(ops, flags):
+    """Every fused epilogue of the thin-K matrix-core kernel (bias, lrelu, residual, lrelu-mask of another tensor: the dgrad of the
+    generator's last layer uses the mask) against the vector-ALU kernel it replaces."""
+    from deep_fluids_amd._lib import call, query, lib
+    from deep_fluids_amd.ops import _ptr, _stream
+    torch.manual_seed(flags)
+    B, D, H, W, C, N = 2, 3, 5, 64, 3, 128
+    s = _stream()
+    x = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    w = (torch.rand((3, 3, 3, N, C), device="cuda") * 2 - 1) * 0.2      # weights of the 128 -> 3 layer whose dgrad this is
+    bias = torch.rand(N, device="cuda") - 0.5
+    res = torch.rand((B, D, H, W, N), device="cuda") * 2 - 1
+    msk = torch.rand((B, D, H, W, N), device="cuda") * 2 - 1
+    wp = torch.empty(query("df_conv_packed_elems", 27, N, C, 1), device="cuda")
+    call("df_conv_pack_weights", _ptr(w), _ptr(wp), 27, N, C, 1, s)
+    ys = []
+    for valu in (0, 1):
+        lib().df_debug_set_thin_valu(ctypes.c_int(valu))
+        try:
+            y = torch.full((B, D, H, W, N), float("nan"), device="cuda")
+            call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(res), _ptr(msk), _ptr(y), B, D, H, W, C, N, 3, flags, 0.2, s)
+            ys.append(y)
+        finally:
+            lib().df_debug_set_thin_valu(ctypes.c_int(0))
+    assert ((ys[0] - ys[1]).abs().max() / ys[1].abs().max()).item() < 2e-6
+
+
 @pytest.fixture
 def bf16x3(ops):
     ops.CONV_PRECISION = "bf16x3"

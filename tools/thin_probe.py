@@ -34,3 +34,8 @@ t = timeit(lambda: call("df_conv_wgrad", _ptr(x), _ptr(g), _ptr(gw1), _ptr(gb1),
 lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
 print("wgrad 128x3 (VALU): %.3f ms   mfma-vs-valu rel diff gw %.2e gb %.2e" % (
     t * 1e3, ((gw - gw1).abs().max() / gw1.abs().max()).item(), ((gb - gb1).abs().max() / gb1.abs().max()).item()))
+lib().df_debug_set_thin_valu(ctypes.c_int(1))
+dx1 = torch.empty_like(x)
+t = timeit(lambda: call("df_conv_fwd", _ptr(g), _ptr(wpd), None, None, _ptr(x), _ptr(dx1), B, Z, Y, X, 3, F, 3, 4, 0.2, s), 5, 2)
+lib().df_debug_set_thin_valu(ctypes.c_int(0))
+print("conv 3->128 dgrad (VALU): %.3f ms   mfma-vs-valu rel diff %.2e" % (t * 1e3, ((dx - dx1).abs().max() / dx1.abs().max()).item()))
