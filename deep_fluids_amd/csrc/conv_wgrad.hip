@@ -1561,7 +1561,9 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   (void)W;
   // (the (x,y) Winograd kernel has 12 | 4 workgroup types and 16 partial slots per dz: 128 ranges = 6 | 2 whole rounds and half
   //  the partial traffic of 256)
-  const int maxr = g_wgrad_ranges > 0 ? g_wgrad_ranges : (algo == 2 ? 128 : kMaxRanges);
+  // (small problems: the fixed-order reduce of the partial sums costs as much as the products -- 64 ranges measured best below
+  //  4096 row pairs: 0.45 -> 0.22 ms at 16 x 8x12x8, 0.84 -> 0.67 ms at 16 x 16x24x16)
+  const int maxr = g_wgrad_ranges > 0 ? g_wgrad_ranges : (p.npairs < 4096 ? 64 : (algo == 2 ? 128 : kMaxRanges));
   int nr = p.npairs >= maxr ? maxr : p.npairs;
   p.ppr = (p.npairs + nr - 1) / nr;
   p.nranges = (p.npairs + p.ppr - 1) / p.ppr;

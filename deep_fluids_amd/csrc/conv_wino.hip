@@ -63,38 +63,52 @@ struct WinoArgs {
 // mode 0: g[tap][k][n] = w[tap][k][n]          (K = cin,  N = cout)
 // mode 1: g[tap][k][n] = w[26 - tap][n][k]     (K = cout, N = cin; taps mirrored)  -> dgrad operand
 // Up[cs][xz][k4][nb][xy][kq][j][xx] = sum_taps G[xz][tz] G[xy][ty] G[xx][tx] g[tap][4 k4 + kq][32 cs + 16 nb + j]
-__device__ __forceinline__ double gmat(int xi, int t) {
-  return xi == 0 ? (t == 0 ? 1.0 : 0.0) : xi == 3 ? (t == 2 ? 1.0 : 0.0) : (xi == 2 && t == 1 ? -0.5 : 0.5);
-}
+// thread = one (k, n) filter: its 27 taps are read once and all 64 transform points come out of the separable G transform in fp64
+// (3 -> 4 points per axis), written as 16 float4 (the four xi_x of a (xi_z, xi_y)); the float4 of consecutive n are contiguous.
 __global__ __launch_bounds__(kPackT) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout,
                                                            int mode, int64_t total) {
-  const int K = mode == 0 ? cin : cout;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kPackT + threadIdx.x; i < total + kZeroFloats;
-       i += static_cast<int64_t>(gridDim.x) * kPackT) {
-    if (i >= total) { wp[i] = 0.f; continue; }
-    int64_t r = i;
-    const int xx = static_cast<int>(r & 3); r >>= 2;
-    const int j = static_cast<int>(r & 15); r >>= 4;
-    const int kq = static_cast<int>(r & 3); r >>= 2;
-    const int xy = static_cast<int>(r & 3); r >>= 2;
-    const int nb = static_cast<int>(r & 1); r >>= 1;
-    const int k4 = static_cast<int>(r % (K / 4)); r /= (K / 4);
-    const int xz = static_cast<int>(r & 3); r >>= 2;
-    const int cs = static_cast<int>(r);
-    const int k = 4 * k4 + kq, n = cs * 32 + nb * 16 + j;
-    double acc = 0.0;
-    for (int tz = 0; tz < 3; ++tz)
+  const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  const int64_t nfil = static_cast<int64_t>(K) * N;
+  for (int64_t f = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; f < nfil; f += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int n = static_cast<int>(f % N), k = static_cast<int>(f / N);
+    double g[27];
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap)
+      g[tap] = static_cast<double>(mode == 0 ? w[(static_cast<int64_t>(tap) * cin + k) * cout + n]
+                                             : w[(static_cast<int64_t>(26 - tap) * cin + n) * cout + k]);
+    // x: [tz][ty][3] -> [tz][ty][4]
+    double gx[9][4];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const double a = g[r * 3], b = g[r * 3 + 1], c = g[r * 3 + 2];
+      gx[r][0] = a; gx[r][1] = 0.5 * (a + b + c); gx[r][2] = 0.5 * (a - b + c); gx[r][3] = c;
+    }
+    const int cs = n >> 5, nb = (n >> 4) & 1, j = n & 15, k4 = k >> 2, kq = k & 3;
+#pragma unroll
+    for (int xz = 0; xz < 4; ++xz) {
+      double gz[3][4];      // z combined: [ty][xx]
+#pragma unroll
       for (int ty = 0; ty < 3; ++ty)
-        for (int tx = 0; tx < 3; ++tx) {
-          const double c = gmat(xz, tz) * gmat(xy, ty) * gmat(xx, tx);
-          if (c == 0.0) continue;
-          const int tap = (tz * 3 + ty) * 3 + tx;
-          const float v = mode == 0 ? w[(static_cast<int64_t>(tap) * cin + k) * cout + n]
-                                    : w[(static_cast<int64_t>(26 - tap) * cin + n) * cout + k];
-          acc += c * static_cast<double>(v);
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx) {
+          const double a = gx[ty][xx], b = gx[3 + ty][xx], c = gx[6 + ty][xx];
+          gz[ty][xx] = xz == 0 ? a : xz == 3 ? c : xz == 1 ? 0.5 * (a + b + c) : 0.5 * (a - b + c);
         }
-    wp[i] = static_cast<float>(acc);
+#pragma unroll
+      for (int xy = 0; xy < 4; ++xy) {
+        f32x4 o;
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx) {
+          const double a = gz[0][xx], b = gz[1][xx], c = gz[2][xx];
+          o[xx] = static_cast<float>(xy == 0 ? a : xy == 3 ? c : xy == 1 ? 0.5 * (a + b + c) : 0.5 * (a - b + c));
+        }
+        const int64_t idx = ((((((static_cast<int64_t>(cs) * 4 + xz) * (K / 4) + k4) * 2 + nb) * 4 + xy) * 4 + kq) * 16 + j) * 4;
+        *reinterpret_cast<f32x4*>(wp + idx) = o;
+      }
+    }
   }
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < kZeroFloats; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    wp[total + i] = 0.f;
 }
 
 // ---- packed-fp32 helpers (VOP3P): one instruction = two lanes of the separable B^T transform --------------------------------
@@ -478,7 +492,6 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       float rres[2][8];
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
-        const int col = n0 + nb * 16 + tl;
         const float bv = sBias[nb * 16 + tl];
         auto emit = [&](const f32x4 (&c)[16]) {
 #pragma unroll
@@ -579,9 +592,9 @@ int df_wino_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, i
   DF_REQUIRE(cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 && (mode == 0 || mode == 1), DF_ESHAPE,
              "df_wino_pack_weights: cin, cout must be multiples of 32; mode 0|1");
   const int64_t total = 64 * cin * cout;
-  int64_t g = ceil_div(total + kZeroFloats, kPackT);
+  int64_t g = ceil_div(cin * cout, 64);      // one wave per workgroup: 16 K filters still cover all 256 CUs
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)g), dim3(kPackT), 0, df::as_stream(stream), w, wp, (int)cin, (int)cout, mode,
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)g), dim3(64), 0, df::as_stream(stream), w, wp, (int)cin, (int)cout, mode,
                      total);
   return df::launched("df_wino_pack_weights");
 }

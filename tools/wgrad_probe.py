@@ -47,7 +47,9 @@ if __name__ == "__main__":
             pass
         _set = lambda v: orig(ctypes.c_int(v.value | (R << 2)))
         lib().df_debug_set_wgrad_algo = _set
+    run(16, 8, 12, 8, 128, 128)
     run(16, 16, 24, 16, 128, 128)
     run(16, 32, 48, 32, 128, 128)
-    run(4, 64, 96, 64, 128, 128)
-    run(16, 64, 96, 64, 128, 128, iters=2)
+    if not os.environ.get("WGRAD_SMALL"):
+        run(4, 64, 96, 64, 128, 128)
+        run(16, 64, 96, 64, 128, 128, iters=2)
