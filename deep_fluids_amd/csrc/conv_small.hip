@@ -407,6 +407,176 @@ int launch_thin_k_mfma(const ConvArgs& a, hipStream_t s) {
   return df::launched("df_conv_fwd(thin-K mfma)");
 }
 
+// ---- thin-N conv on the matrix cores (3-D, 128 -> Cout <= 3: the generator's last layer, forward) ---------------------------------
+// The in-plane taps go to the N side and the z taps to the K side of one GEMM per input row:
+//   T[(y', x'), (dy, dx, co)] = sum_{dz, c} x[z + dz - 1, y', x', c] * W[dz, dy, dx][c][co]        (N = 9*Cout <= 27 of 32, K = 3*128)
+//   y[z, y, x, co] = b[co] + sum_{dy, dx} T[(y + dy - 1, x + dx - 1), (dy, dx, co)]
+// A wave owns a range of rows of ONE (b, z) plane and walks it row by row in 32-voxel chunks: 48 float4 loads per lane (each 128-byte
+// line of x is consumed by four back-to-back loads) feed 192 v_mfma_f32_32x32x2 whose filter operands all stay in registers; the
+// 9-way (dy, dx) shift-add of the product tile goes through a three-row LDS ring private to the wave (ds_add_f32 in program order:
+// deterministic), and a finished output row leaves as 3*W contiguous floats.  x is read by the three waves of neighbouring planes
+// at about the same time (L2 / Infinity Cache), 16 loads in flight per lane.
+struct ThinNArgs {
+  const float* x;
+  const f32x4* wp;
+  const float* bias;
+  float* y;
+  int B, D, H, W;
+  int K8, Npad;            // packed filter bank geometry: record index ((tap*K8 + c/8)*2 + (c/4)%2)*Npad + n, element c%4
+  int nsplit, rows_per;    // y ranges per plane
+  int flags;
+  float leak;
+};
+
+template <int CO>
+__global__ __launch_bounds__(kThreads, 1) void conv_thin_n_mfma_kernel(const ThinNArgs a) {
+  constexpr int NC = 9 * CO;
+  extern __shared__ __attribute__((aligned(16))) float smem_thin_n[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // workgroup g runs on XCD g % 8: give every XCD a contiguous run of planes, so the three readers of a plane share one L2
+  const int stream = xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
+  const int W = a.W, H = a.H, RS = W * CO + 8;
+  float* ring = smem_thin_n + wave * 3 * RS;       // [3 output rows][4 + W*CO + 4]: position of (x, co) = 4 + x*CO + co
+  const int plane = stream / a.nsplit, part = stream % a.nsplit;
+  if (plane >= a.B * a.D) return;
+  const int y0 = part * a.rows_per;
+  int y1 = y0 + a.rows_per;
+  if (y1 > H) y1 = H;
+  if (y0 >= y1) return;
+  const int z = plane % a.D, b = plane / a.D;
+  for (int i = lane; i < 3 * RS; i += 64) ring[i] = 0.f;
+  const int n = lane & 31, kk = lane >> 5;
+
+  // ---- filter bank -> registers: item (dz, q) holds W[dz, dy(n), dx(n)][c = 8q + 4kk + t][co(n)], t = 0..3 ------------------------
+  f32x4 wr[48];
+#pragma unroll
+  for (int it = 0; it < 48; ++it) {
+    const int dz = it >> 4, q = it & 15;
+    const int tap = dz * 9 + (n < NC ? n / CO : 0);
+    const f32x4 rec = a.wp[((static_cast<int64_t>(tap) * a.K8 + q) * 2 + kk) * a.Npad + (n < NC ? n % CO : 0)];
+    wr[it] = n < NC ? rec : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // output-side constants of this lane's column
+  const int dy = n / (3 * CO), dx = (n / CO) % 3, co = n % CO;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.flags & DF_CONV_BIAS) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = a.bias[(lane * 4 + j) % CO];
+  }
+
+  // ---- x loads: batch volume as a buffer; lane (voxel m = n, half kk) reads channels 8q + 4kk .. +3 ----------------------------------
+  const int64_t vol = static_cast<int64_t>(a.D) * H * W * 128;
+  const __amdgpu_buffer_rsrc_t xsrd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + static_cast<int64_t>(b) * vol), 0, static_cast<unsigned>(vol * 4), 0x00020000);
+  const unsigned lanev = static_cast<unsigned>(n) * 512u + static_cast<unsigned>(kk) * 16u;
+  unsigned vplane[3];      // per z tap: lane offset, or an out-of-range offset (reads zeros) when the plane is outside the volume
+#pragma unroll
+  for (int dz = 0; dz < 3; ++dz) vplane[dz] = (z + dz - 1 >= 0 && z + dz - 1 < a.D) ? lanev : 0x80000000u;
+  auto soff_of = [&](int dz, int row, int chunk) -> unsigned {      // wave-uniform byte offset of (plane, row, chunk); clamped plane
+    int zz = z + dz - 1;
+    zz = zz < 0 ? 0 : (zz >= a.D ? a.D - 1 : zz);
+    return static_cast<unsigned>(((zz * H + row) * W + chunk * 32) * 512);
+  };
+  auto load_x = [&](unsigned voff, unsigned soff, int q) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrd, voff + static_cast<unsigned>(q) * 32u, soff, 0));
+  };
+
+  const int nchunk = W >> 5;
+  const int ra = y0 > 0 ? y0 - 1 : 0, rb = y1 < H ? y1 + 1 : H;      // input rows [ra, rb)
+  f32x4 xr[16];
+  {
+    const unsigned s0 = soff_of(0, ra, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xr[i] = load_x(vplane[0], s0, i);
+  }
+
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  for (int row = ra; row < rb; ++row) {
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      // where the loads issued during this chunk go: planes 1, 2 of this chunk, then plane 0 of the next chunk / row
+      const bool lastc = chunk + 1 == nchunk;
+      const int nrow = lastc ? row + 1 : row, nchk = lastc ? 0 : chunk + 1;
+      const bool more = nrow < rb;
+      const unsigned s1 = soff_of(1, row, chunk), s2 = soff_of(2, row, chunk);
+      const unsigned sn = soff_of(0, more ? nrow : row, more ? nchk : chunk);
+      const unsigned vn = more ? vplane[0] : 0x80000000u;
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+      for (int it = 0; it < 48; ++it) {
+        const f32x4 xv = xr[it & 15];
+        const int nit = it + 16;      // the item this slot is refilled for
+        if (nit < 32) xr[it & 15] = load_x(vplane[1], s1, nit & 15);
+        else if (nit < 48) xr[it & 15] = load_x(vplane[2], s2, nit & 15);
+        else xr[it & 15] = load_x(vn, sn, nit & 15);
+        __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks every load to just before its use: vmcnt(0) per item)
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[0], wr[it][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[1], wr[it][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[2], wr[it][2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[3], wr[it][3], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- shift-add: column (dy, dx, co) of input row `row` belongs to output row row - (dy - 1), position x' - (dx - 1) --------
+      const int orow = row + 1 - dy;
+      if (n < NC && orow >= y0 && orow < y1) {
+        float* dst = ring + (orow % 3) * RS + 4 + (chunk * 32 + kk * 4 + 1 - dx) * CO + co;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __hip_atomic_fetch_add(dst + ((r >> 2) * 8 + (r & 3)) * CO, acc0[r] + acc1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+    // ---- output rows completed by this input row: row - 1, and row itself when it is the last one of the plane --------------------
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int fr = k == 0 ? row - 1 : row;
+      const bool go = k == 0 ? (fr >= y0 && fr < y1) : (row == H - 1 && fr >= y0 && fr < y1);
+      if (!go) continue;
+      float* src = ring + (fr % 3) * RS + 4;
+      if (lane * 4 < W * CO) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + lane * 4) + bias4;
+        if (a.flags & DF_CONV_LRELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], a.leak * v[j]);
+        }
+        *reinterpret_cast<f32x4*>(a.y + ((static_cast<int64_t>(plane) * H + fr) * W) * CO + lane * 4) = v;
+        *reinterpret_cast<f32x4*>(src + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+}
+
+inline bool thin_n_mfma_ok(const ConvArgs& a, int kz) {
+  return kz == 3 && a.Cin == 128 && a.Cout <= 3 && a.W % 32 == 0 && a.W * a.Cout <= 256 && a.nclass == 1 &&
+         !(a.flags & (DF_CONV_RESIDUAL | DF_CONV_MASK)) && df::aligned16(a.x) && df::aligned16(a.y) &&
+         static_cast<int64_t>(a.D) * a.H * a.W * 512 < (1LL << 31);
+}
+
+int launch_thin_n_mfma(const ConvArgs& a, hipStream_t s) {
+  ThinNArgs t;
+  t.x = a.x; t.wp = a.wp; t.bias = a.bias; t.y = a.y;
+  t.B = a.B; t.D = a.D; t.H = a.H; t.W = a.W;
+  t.K8 = a.Kpad >> 3; t.Npad = a.Npad;
+  const int64_t planes = static_cast<int64_t>(a.B) * a.D;
+  int nsplit = (int)ceil_div(4 * df::kCUs, planes);      // y ranges per plane: fill the chip when there are few planes
+  if (nsplit > a.H / 4) nsplit = a.H / 4;               // (each range re-reads two halo rows)
+  if (nsplit < 1) nsplit = 1;
+  t.rows_per = (int)ceil_div(a.H, nsplit);
+  t.nsplit = (int)ceil_div(a.H, t.rows_per);
+  t.flags = a.flags; t.leak = a.leak;
+  const size_t lds = static_cast<size_t>(4) * 3 * (a.W * a.Cout + 8) * sizeof(float);
+  dim3 grid((unsigned)ceil_div(planes * t.nsplit, 4));
+#define DF_TN(CO) hipLaunchKernelGGL((conv_thin_n_mfma_kernel<CO>), grid, dim3(kThreads), lds, s, t)
+  switch (a.Cout) {
+    case 1: DF_TN(1); break;
+    case 2: DF_TN(2); break;
+    default: DF_TN(3); break;
+  }
+#undef DF_TN
+  return df::launched("df_conv_fwd(thin-N mfma)");
+}
+
 template <int KZ, int TZ, int TY, int TX>
 int launch_small_k_t(ConvArgs a, hipStream_t s) {
   a.nz = (int)ceil_div(a.D, TZ); a.ny = (int)ceil_div(a.H, TY); a.nx = (int)ceil_div(a.W, TX);
@@ -422,6 +592,7 @@ int launch_small_k_t(ConvArgs a, hipStream_t s) {
 }  // namespace
 
 int launch_small_n(const ConvArgs& a, int kz, hipStream_t s) {
+  if (thin_n_mfma_ok(a, kz) && !g_thin_valu) return launch_thin_n_mfma(a, s);
   if (kz == 3) return a.W >= 12 ? launch_small_n_t<3, 4, 4, 16>(a, s) : launch_small_n_t<3, 4, 8, 8>(a, s);
   return a.W >= 12 ? launch_small_n_t<1, 1, 16, 16>(a, s) : launch_small_n_t<1, 1, 32, 8>(a, s);
 }

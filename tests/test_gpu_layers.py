@@ -389,6 +389,15 @@ def test_thin_k_conv_mfma_vs_oracle(ops, shape, cin, leak):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("shape,cout,leak", [((1, 3, 5, 32), 3, None), ((2, 2, 4, 64), 3, 0.2), ((1, 4, 9, 32), 1, None), ((1, 2, 3, 32), 2, None),
+                                             ((1, 1, 6, 32), 3, None), ((1, 2, 16, 32), 3, None), ((1, 1, 13, 64), 3, 0.2)])
+def test_thin_n_conv_mfma_vs_oracle(ops, shape, cout, leak):
+    """128 -> Cout <= 3 conv forward on the matrix cores (conv_thin_n_mfma_kernel: z taps on the GEMM's K side, in-plane taps on its N
+    side, LDS shift-add ring), incl. single-plane volumes, y ranges with halo rows (few planes) and the gradients of the same layer."""
+    errs = _conv_case(ops, shape, 128, cout, leak, seed=cout + sum(shape), mask_from_gpu=True)
+    assert max(errs.values()) < TOL, errs
+
+
 @pytest.mark.parametrize("flags", [0, 9, 4, 2, 15])
 def test_thin_k_conv_mfma_epilogues_match_valu_kernel(ops, flags):
     """Every fused epilogue of the thin-K matrix-core kernel (bias, lrelu, residual, lrelu-mask of another tensor: the dgrad of the

@@ -39,3 +39,9 @@ dx1 = torch.empty_like(x)
 t = timeit(lambda: call("df_conv_fwd", _ptr(g), _ptr(wpd), None, None, _ptr(x), _ptr(dx1), B, Z, Y, X, 3, F, 3, 4, 0.2, s), 5, 2)
 lib().df_debug_set_thin_valu(ctypes.c_int(0))
 print("conv 3->128 dgrad (VALU): %.3f ms   mfma-vs-valu rel diff %.2e" % (t * 1e3, ((dx - dx1).abs().max() / dx1.abs().max()).item()))
+lib().df_debug_set_thin_valu(ctypes.c_int(1))
+y1 = torch.empty_like(y)
+t = timeit(lambda: call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(b), None, None, _ptr(y1), B, Z, Y, X, F, 3, 3, 8, 0.0, s), 5, 2)
+lib().df_debug_set_thin_valu(ctypes.c_int(0))
+call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(b), None, None, _ptr(y), B, Z, Y, X, F, 3, 3, 8, 0.0, s)
+print("conv 128->3 fwd (VALU): %.3f ms   mfma-vs-valu rel diff %.2e" % (t * 1e3, ((y - y1).abs().max() / y1.abs().max()).item()))
