@@ -243,12 +243,12 @@ def main():
         "kernels": {k: {"launches": v["launches"], "ms_total": v["seconds"] * 1e3} for k, v in sorted(ks.items())},
     }
     if out["roofline_wgrad"]:
-        # same convention for the weight gradient: Winograd in (x,y) (F(2x2,3x3), direct in z) executes 12/27 of the algorithmic
-        # flops at the top levels (conv_wgrad.hip picks direct / x / (x,y) by size; the dominant instance is an (x,y) one)
+        # same convention for the weight gradient: Winograd in (x,y,z) (F(2x2x2,3x3x3)) executes 8/27 of the algorithmic flops at the
+        # top levels (conv_wgrad.hip picks direct / x / (x,y) / (x,y,z) by size; the dominant instance is an (x,y,z) one)
         rg = out["roofline_wgrad"]
-        rg["mfma_executed_tflops"] = rg["achieved"] * 12.0 / 27.0
-        rg["mfma_executed_frac"] = rg["frac"] * 12.0 / 27.0
-        rg["note"] = "achieved = direct-convolution flops / time (can exceed the fp32 MFMA peak); mfma_executed_* = flops the Winograd-(x,y) kernel issues"
+        rg["mfma_executed_tflops"] = rg["achieved"] * 8.0 / 27.0
+        rg["mfma_executed_frac"] = rg["frac"] * 8.0 / 27.0
+        rg["note"] = "achieved = direct-convolution flops / time (can exceed the fp32 MFMA peak); mfma_executed_* = flops the Winograd-(x,y,z) kernel issues"
     if out["roofline_wino"]:
         # `achieved` above counts the convolution's algorithmic flops; Winograd F(2x2x2,3x3x3) executes 8/27 of
         # them on the matrix pipe, so the matrix-pipe utilisation is frac * 8/27 -- both are reported

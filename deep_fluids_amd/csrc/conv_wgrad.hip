@@ -876,18 +876,300 @@ __global__ __launch_bounds__(kThreads) void wgrad_wxy_reduce_kernel(const float*
   }
 }
 
+// ---- Winograd-in-(x,y,z) weight gradient ------------------------------------------------------------------------------------------
+// F(2x2x2, 3x3x3): the z axis gets the same two-term combination as y in wgrad_wxy_kernel, so a workgroup owns ONE (xi_z, xi_y) and
+// the four xi_x, and both operands are combinations of 2 planes x 2 rows with workgroup-uniform coefficients
+//   X_c = (X[za][ya] + sy X[za][yb]) + sz (X[zb][ya] + sy X[zb][yb]),   G_c likewise over (1 | 2 planes) x (1 | 2 rows).
+// 64 transform-domain products per 2x2x2 positions instead of 96 in the (x,y) form (216 direct): 1.5x fewer matrix FLOPs for twice the
+// operand loads per x-tile (16 8-byte loads, 17 packed-fp32 ops, 16 MFMAs).  Tile rows are (b, z pair, y pair); D, H, W even.
+// GZ / GY: xi_z / xi_y in {1, 2} (the gradient combination needs the second plane / row); {0, 3} use one.  Four launches of 4
+// workgroup types.
+struct WxyzArgs {
+  WgradArgs w;
+  int Ht, Dt, ntrows;      // tile rows per plane pair = H/2; plane pairs per batch = D/2; B*Dt*Ht
+};
+
+template <int WP8, int CS, bool GZ, bool GY>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs aa) {
+  const WgradArgs& a = aa.w;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nq = a.nqi * a.nqj;
+  const int qi = (wave % nq) / a.nqj, qj = (wave % nq) % a.nqj, sub = wave / nq;
+  constexpr int Wc = WP8 * 8;
+  const int half = lane >> 5, r = lane & 31;
+
+  const int nwg = a.nranges * 4;
+  int wg;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, rem = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int range = wg >> 2, sel = wg & 3;
+  const int xiz = GZ ? 1 + (sel >> 1) : 3 * (sel >> 1);
+  const int xiy = GY ? 1 + (sel & 1) : 3 * (sel & 1);
+  const int zy = xiz * 4 + xiy;                        // partial slot group
+  const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
+  if (ci0 >= a.Cin || co0 >= a.Cout) return;
+
+  const int ppe = (a.pairs_per_range + a.nsub - 1) / a.nsub;
+  const int p0 = range * a.pairs_per_range + sub * ppe;
+  int p1 = p0 + ppe;
+  if (p1 > (range + 1) * a.pairs_per_range) p1 = (range + 1) * a.pairs_per_range;
+  if (p1 > a.npairs) p1 = a.npairs;
+  const int erange = range * a.nsub + sub;
+
+  const int cia = ci0 + 2 * r, coa = co0 + 2 * r;
+  const bool ci_ok0 = cia < a.Cin, co_ok0 = coa < a.Cout;
+  const float* zb = a.zeros;
+  // offsets (relative to 2t) and coefficients of this workgroup's xi_y / xi_z (same table for both axes)
+  const int yoa = xiy == 0 ? -1 : xiy == 2 ? 1 : 0, yob = xiy == 0 ? 1 : xiy == 1 ? 1 : xiy == 2 ? 0 : 2;
+  const int zoa = xiz == 0 ? -1 : xiz == 2 ? 1 : 0, zob = xiz == 0 ? 1 : xiz == 1 ? 1 : xiz == 2 ? 0 : 2;
+  const float syf = xiy == 1 ? 1.f : -1.f, szf = xiz == 1 ? 1.f : -1.f;
+  const int gya = xiy == 3 ? 1 : 0, gza = xiz == 3 ? 1 : 0;
+  const float sgyf = xiy == 1 ? 1.f : -1.f, sgzf = xiz == 1 ? 1.f : -1.f;      // (used only for xi in {1, 2})
+  const f32x2 sy2 = {syf, syf}, sz2 = {szf, szf}, sgy2 = {sgyf, sgyf}, sgz2 = {sgzf, sgzf};
+  struct Row { const float* x[2][2]; const float* g[2][2]; };      // [plane a|b][row a|b]
+  auto row_setup = [&](int pair) -> Row {
+    Row rw;
+    const int trow = 2 * pair + half;
+    const bool ok = pair < p1 && trow < aa.ntrows;
+    const int yt = trow % aa.Ht;
+    const int t = trow / aa.Ht;
+    const int zt = t % aa.Dt;
+    const int b = t / aa.Dt;
+    const int z0 = 2 * zt, y0 = 2 * yt;
+    const int64_t bbase = static_cast<int64_t>(b) * a.D;
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+      const int zs = z0 + (pz ? zob : zoa);
+      const bool zv = ok && zs >= 0 && zs < a.D && ci_ok0;
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        const int ys = y0 + (py ? yob : yoa);
+        rw.x[pz][py] = (zv && ys >= 0 && ys < a.H) ? a.x + ((bbase + zs) * a.H + ys) * a.W * a.Cin + cia : zb;
+      }
+      const int gz = z0 + (pz ? 1 : gza);
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        const int gy = y0 + (py ? 1 : gya);
+        const bool need = (pz == 0 || GZ) && (py == 0 || GY);
+        rw.g[pz][py] = (need && ok && co_ok0) ? a.g + ((bbase + gz) * a.H + gy) * a.W * a.Cout + coa : zb;
+      }
+    }
+    return rw;
+  };
+  const int xs = CS ? CS : a.Cin, gs = CS ? CS : a.Cout;
+  auto ld = [&](const float* base, int pos, int stride) -> f32x2 {
+    return *reinterpret_cast<const f32x2*>(base + static_cast<int64_t>(pos) * stride);
+  };
+  auto pkfma = [&](f32x2 x, f32x2 y, f32x2 z) -> f32x2 {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+  };
+
+  f32x16 acc[4][2][2];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][s][t][e] = 0.f;
+  f32x2 bsum = {0.f, 0.f};
+  const bool do_bias = a.want_bias && GZ && GY && sel == 0 && blockIdx.y == 0 && qi == 0;     // G_c = sum of the 2x2 (z, y) rows
+
+  // raw rings by (position in row) % 8 and the ring of combined X values
+  f32x2 xr[2][2][8], gr[2][2][8], xc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { xr[q >> 1][q & 1][i] = f32x2{0.f, 0.f}; gr[q >> 1][q & 1][i] = f32x2{0.f, 0.f}; }
+    xc[i] = f32x2{0.f, 0.f};
+  }
+  auto load_pos = [&](const Row& lr, int slot, int pos) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xr[q >> 1][q & 1][slot] = ld(lr.x[q >> 1][q & 1], pos, xs);
+    gr[0][0][slot] = ld(lr.g[0][0], pos, gs);
+    if (GY) gr[0][1][slot] = ld(lr.g[0][1], pos, gs);
+    if (GZ) gr[1][0][slot] = ld(lr.g[1][0], pos, gs);
+    if (GZ && GY) gr[1][1][slot] = ld(lr.g[1][1], pos, gs);
+  };
+  auto xcomb = [&](int slot) -> f32x2 {
+    const f32x2 ta = pkfma(xr[0][1][slot], sy2, xr[0][0][slot]), tb = pkfma(xr[1][1][slot], sy2, xr[1][0][slot]);
+    return pkfma(tb, sz2, ta);
+  };
+  auto gcomb = [&](int slot) -> f32x2 {
+    if (GZ && GY) {
+      const f32x2 ta = pkfma(gr[0][1][slot], sgy2, gr[0][0][slot]), tb = pkfma(gr[1][1][slot], sgy2, gr[1][0][slot]);
+      return pkfma(tb, sgz2, ta);
+    }
+    if (GY) return pkfma(gr[0][1][slot], sgy2, gr[0][0][slot]);
+    if (GZ) return pkfma(gr[1][0][slot], sgz2, gr[0][0][slot]);
+    return gr[0][0][slot];
+  };
+  Row cur = row_setup(p0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) load_pos(cur, i, i);
+  xc[0] = xcomb(0);
+
+  auto tile = [&](int u, int x, const Row& lr, int lpos) {
+    __builtin_amdgcn_sched_barrier(0);
+    xc[(u + 1) & 7] = xcomb((u + 1) & 7);
+    xc[(u + 2) & 7] = xcomb((u + 2) & 7);
+    const f32x2 g0 = gcomb(u), g1 = gcomb((u + 1) & 7);
+    f32x2 dm = xc[(u + 7) & 7], d0 = xc[u], d1 = xc[(u + 1) & 7], d2 = xc[(u + 2) & 7];
+    if (x == 0) dm = f32x2{0.f, 0.f};
+    if (x == Wc - 2) d2 = f32x2{0.f, 0.f};
+    const f32x2 v0 = wpk_sub(dm, d1), v1 = wpk_add(d0, d1), v2 = wpk_sub(d1, d0), v3 = wpk_sub(d0, d2);
+    const f32x2 m1 = wpk_add(g0, g1), m2 = wpk_sub(g0, g1);
+    bsum = wpk_add(bsum, m1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_pos(lr, (u + 6) & 7, lpos);
+    load_pos(lr, (u + 7) & 7, lpos + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[0][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[s], g0[t], acc[0][s][t], 0, 0, 0);
+        acc[1][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[s], m1[t], acc[1][s][t], 0, 0, 0);
+        acc[2][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[s], m2[t], acc[2][s][t], 0, 0, 0);
+        acc[3][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3[s], g1[t], acc[3][s][t], 0, 0, 0);
+      }
+  };
+
+  for (int pair = p0; pair < p1; ++pair) {
+    const Row nxt = row_setup(pair + 1);
+#pragma unroll
+    for (int x0 = 0; x0 < Wc - 8; x0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) tile(u, x0 + u, cur, x0 + u + 6);
+    }
+    {
+      constexpr int x0 = Wc - 8;
+      tile(0, x0, cur, x0 + 6);
+#pragma unroll
+      for (int u = 2; u < 8; u += 2) tile(u, x0 + u, nxt, u - 2);
+    }
+    cur = nxt;
+  }
+
+  // ---- partial: slot = (xi_z, xi_y) * 4 + xi_x -----------------------------------------------------------------------------------
+  float* P = a.partial + static_cast<int64_t>(erange) * 64 * a.Cinp * a.Coutp;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int slot = zy * 4 + d;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int ci = ci0 + 2 * i + s, co = co0 + 2 * r + t;
+          P[(static_cast<int64_t>(slot) * a.Cinp + ci) * a.Coutp + co] = acc[d][s][t][e];
+        }
+  }
+  if (do_bias) {
+    bsum[0] += __shfl_xor(bsum[0], 32, 64);
+    bsum[1] += __shfl_xor(bsum[1], 32, 64);
+    if (half == 0) {
+      float* pb = a.bpartial + static_cast<int64_t>(erange) * a.Coutp + co0 + 2 * r;
+      pb[0] = bsum[0]; pb[1] = bsum[1];
+    }
+  }
+}
+
+// gw[dz][dy][dx][ci][co] = G^T_z G^T_y G^T_x of the summed (fixed order) partials U[xi_z][xi_y][xi_x]; index 3 of every axis carries a
+// flipped sign.  Workgroup = 32 consecutive (ci, co) elements x 8 range groups; every group applies the (linear) transform to its own
+// sums, the 8 x 27 results are combined in a fixed order through LDS.
+__global__ __launch_bounds__(kThreads) void wgrad_wxyz_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
+                                                                     float* __restrict__ gw, float* __restrict__ gb, int nranges, int Cin,
+                                                                     int Cout, int Cinp, int Coutp) {
+  __shared__ float sV[8][27][32];
+  const int64_t total = static_cast<int64_t>(Cin) * Cout;
+  const int64_t slot = static_cast<int64_t>(Cinp) * Coutp;
+  const int64_t pstride = 64 * slot;
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 32 + el;
+  const bool ok = i < total;
+  const int co = ok ? static_cast<int>(i % Cout) : 0;
+  const int ci = ok ? static_cast<int>(i / Cout) : 0;
+  const float* p = partial + static_cast<int64_t>(ci) * Coutp + co;
+  float u[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) u[k] = 0.f;
+  if (ok) {
+    for (int rg = grp; rg < nranges; rg += 8) {
+      const float* q = p + rg * pstride;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) u[k] += q[k * slot];
+    }
+  }
+  // x, then y, then z:  (u0 + h, (u1 - u2)/2, h - u3) with h = (u1 + u2)/2
+  float a1[16][3];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float h = 0.5f * (u[k * 4 + 1] + u[k * 4 + 2]);
+    a1[k][0] = u[k * 4] + h; a1[k][1] = 0.5f * (u[k * 4 + 1] - u[k * 4 + 2]); a1[k][2] = h - u[k * 4 + 3];
+  }
+  float a2[4][3][3];      // [xi_z][dy][dx]
+#pragma unroll
+  for (int z = 0; z < 4; ++z)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const float h = 0.5f * (a1[z * 4 + 1][dx] + a1[z * 4 + 2][dx]);
+      a2[z][0][dx] = a1[z * 4][dx] + h; a2[z][1][dx] = 0.5f * (a1[z * 4 + 1][dx] - a1[z * 4 + 2][dx]); a2[z][2][dx] = h - a1[z * 4 + 3][dx];
+    }
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const float h = 0.5f * (a2[1][dy][dx] + a2[2][dy][dx]);
+      sV[grp][0 * 9 + dy * 3 + dx][el] = a2[0][dy][dx] + h;
+      sV[grp][1 * 9 + dy * 3 + dx][el] = 0.5f * (a2[1][dy][dx] - a2[2][dy][dx]);
+      sV[grp][2 * 9 + dy * 3 + dx][el] = h - a2[3][dy][dx];
+    }
+  __syncthreads();
+  for (int k = grp; k < 27; k += 8) {
+    if (!ok) break;
+    float t = sV[0][k][el];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += sV[g][k][el];
+    gw[(static_cast<int64_t>(k) * Cin + ci) * Cout + co] = t;
+  }
+  if (gb && blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < Cout; c += kThreads) {
+      float acc = 0.f;
+      for (int rg = 0; rg < nranges; ++rg) acc += bpartial[static_cast<int64_t>(rg) * Coutp + c];
+      gb[c] = acc;
+    }
+  }
+}
+
 // the Winograd-in-x variant exists for the fully unrolled row lengths below (even channel counts: float2 operand loads)
 inline bool wx_ok(int64_t W, int64_t Cin, int64_t Cout) {
   return (W == 16 || W == 32 || W == 64 || W == 56 || W == 112) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
 }
 inline bool wxy_ok(int64_t H, int64_t W, int64_t Cin, int64_t Cout) { return wx_ok(W, Cin, Cout) && H % 2 == 0 && H >= 4; }
+// (x,y,z): instantiated for the 128 -> 128 layers at W = 64 | 32
+inline bool wxyz_ok(int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
+  return kz == 3 && wxy_ok(H, W, Cin, Cout) && D % 2 == 0 && D >= 4 && Cin == 128 && Cout == 128 && (W == 64 || W == 32);
+}
 int g_wgrad_ranges = 0;   // debug: override the number of voxel ranges (0 = default)
-int g_wgrad_algo = 0;     // 0: best available, 1: always the direct kernel, 2: at most Winograd-in-x (df_debug_set_wgrad_algo)
-// 0 direct | 1 Winograd in x | 2 Winograd in (x,y)
-inline int wgrad_algo(int64_t rows, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
+int g_wgrad_algo = 0;     // 0: best available, 1: always the direct kernel, 2: at most Winograd-in-x, 3: (x,y) wherever it exists, 4: (x,y,z) wherever it exists (df_debug_set_wgrad_algo)
+// 0 direct | 1 Winograd in x | 2 Winograd in (x,y) | 3 Winograd in (x,y,z)
+inline int wgrad_algo(int64_t rows, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
   if (g_wgrad_algo == 1) return 0;
-  // (x,y) pays a larger partial buffer: worth it from ~4096 tile rows (measured: 16x24x16x16 ties, 32x48x32x16 wins 1.2x)
-  if (g_wgrad_algo != 2 && wxy_ok(H, W, Cin, Cout) && (rows >= 8192 || g_wgrad_algo == 3)) return 2;
+  if ((g_wgrad_algo == 0 || g_wgrad_algo == 4) && wxyz_ok(D, H, W, Cin, Cout, kz) && (rows >= 4096 || g_wgrad_algo == 4)) return 3;
+  // (x,y) and (x,y,z) pay a larger partial buffer: worth it from ~4096 image rows (measured at batch 16, 128 -> 128:
+  //  16x24x16: x 0.68, xy 0.52, xyz 0.51 ms; 32x48x32: 3.72, 2.54, 2.00 ms; 64x96x64: 26.7, 18.9, 15.1 ms)
+  if (g_wgrad_algo != 2 && wxy_ok(H, W, Cin, Cout) && (rows >= 4096 || g_wgrad_algo >= 3)) return 2;
   return wx_ok(W, Cin, Cout) ? 1 : 0;
 }
 
@@ -1551,9 +1833,9 @@ struct Plan {
 
 Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int algo = 0) {
   Plan p;
-  p.nrows = (int)(algo == 2 ? B * D * (H / 2) : B * D * H);       // image rows, or 2-row tile rows
+  p.nrows = (int)(algo == 3 ? B * (D / 2) * (H / 2) : algo == 2 ? B * D * (H / 2) : B * D * H);       // image rows, or tile rows
   p.npairs = (p.nrows + 1) / 2;
-  p.ndzdy = algo == 2 ? (kz == 3 ? 12 : 4) : (kz == 3 ? 9 : 3);  // workgroup types: (dz,dy) or (dz,xi_y)
+  p.ndzdy = algo == 3 ? 16 : algo == 2 ? (kz == 3 ? 12 : 4) : (kz == 3 ? 9 : 3);  // workgroup types: (dz,dy), (dz,xi_y) or (xi_z,xi_y)
   p.taps = kz == 3 ? 27 : 9;
   // The kernel runs ONE workgroup per CU (192-256 accumulator registers per lane): a grid that is not a multiple
   // of 256 leaves most of the chip idle in its last round.  256 equal voxel ranges x (9 | 3 | 12 | 4) groups is
@@ -1563,7 +1845,7 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   //  the partial traffic of 256)
   // (small problems: the fixed-order reduce of the partial sums costs as much as the products -- 64 ranges measured best below
   //  4096 row pairs: 0.45 -> 0.22 ms at 16 x 8x12x8, 0.84 -> 0.67 ms at 16 x 16x24x16)
-  const int maxr = g_wgrad_ranges > 0 ? g_wgrad_ranges : (p.npairs < 4096 ? 64 : (algo == 2 ? 128 : kMaxRanges));
+  const int maxr = g_wgrad_ranges > 0 ? g_wgrad_ranges : (p.npairs < 4096 ? 64 : (algo >= 2 ? 128 : kMaxRanges));
   int nr = p.npairs >= maxr ? maxr : p.npairs;
   p.ppr = (p.npairs + nr - 1) / nr;
   p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
@@ -1588,8 +1870,8 @@ int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W
     return sp.partial_elems * static_cast<int64_t>(sizeof(float)) + kZeroBytes;
   }
   int64_t best = 0;
-  for (int algo = 0; algo <= 2; ++algo) {       // the launch may fall back (operand alignment), so size for the largest
-    if ((algo == 1 && !wx_ok(W, Cin, Cout)) || (algo == 2 && !wxy_ok(H, W, Cin, Cout))) continue;
+  for (int algo = 0; algo <= 3; ++algo) {       // the launch may fall back (operand alignment), so size for the largest
+    if ((algo == 1 && !wx_ok(W, Cin, Cout)) || (algo == 2 && !wxy_ok(H, W, Cin, Cout)) || (algo == 3 && !wxyz_ok(D, H, W, Cin, Cout, kz))) continue;
     const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, algo);
     const int64_t n = (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float));
     if (n > best) best = n;
@@ -1661,7 +1943,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   }
   const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
-  const int algo = (prec == 0 && xvec && gvec) ? wgrad_algo(B * D * H, H, W, Cin, Cout) : 0;
+  const int algo = (prec == 0 && xvec && gvec) ? wgrad_algo(B * D * H, D, H, W, Cin, Cout, kz) : 0;
   const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, algo);
   WgradArgs a;
   a.x = x; a.g = gy;
@@ -1681,6 +1963,23 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)ceil_div(Cin, 128), (unsigned)ceil_div(Cout, 128));
   if (prec == 1 && xvec && gvec && wgrad_bf16x3_ok(W, Cin, Cout)) {
     launch_wgrad_bf16x3(W, grid, s, a);
+  } else if (algo == 3) {
+    WxyzArgs aa;
+    aa.w = a; aa.Ht = (int)(H / 2); aa.Dt = (int)(D / 2); aa.ntrows = p.nrows;
+    const dim3 gridq((unsigned)(p.nranges * 4), grid.y, grid.z);      // 4 workgroup types per launch
+#define DF_WXYZ(WP)                                                                                         \
+  do {                                                                                                      \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, true, true>), gridq, dim3(kThreads), 0, s, aa);          \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, true, false>), gridq, dim3(kThreads), 0, s, aa);         \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, true>), gridq, dim3(kThreads), 0, s, aa);         \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, false>), gridq, dim3(kThreads), 0, s, aa);        \
+  } while (0)
+    if (W == 64) DF_WXYZ(8); else DF_WXYZ(4);
+#undef DF_WXYZ
+    const int64_t rgx = ceil_div(Cin * Cout, 32);
+    hipLaunchKernelGGL(wgrad_wxyz_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
+                       p.nranges * p.nsub, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
+    return df::launched("df_conv_wgrad(winograd-xyz)");
   } else if (algo == 2) {
     WxyArgs aa;
     aa.w = a; aa.Ht = (int)(H / 2); aa.ntrows = p.nrows;
@@ -1745,7 +2044,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   return df::launched("df_conv_wgrad");
 }
 
-void df_debug_set_wgrad_algo(int v) { g_wgrad_algo = v & 3; g_wgrad_ranges = v >> 2; }
+void df_debug_set_wgrad_algo(int v) { g_wgrad_algo = v & 7; g_wgrad_ranges = v >> 3; }
 
 int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
                   int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {

@@ -91,6 +91,19 @@ def test_conv_wgrad_algorithms(ops, shape, cin, cout, leak, algo):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("shape,leak", [((1, 4, 4, 32), 0.2), ((2, 6, 4, 64), None), ((3, 4, 6, 32), 0.2), ((1, 8, 4, 64), 0.2)])
+def test_conv_wgrad_winograd_xyz(ops, shape, leak):
+    """df_conv_wgrad forced to the Winograd F(2x2x2,3x3x3) form (algo 4: 64 transform-domain products per 2x2x2 positions, four launches of
+    (xi_z, xi_y) workgroup types, z/y/x G^T in the reduce) against the fp64 oracle; odd tile-row counts, several batches."""
+    from deep_fluids_amd._lib import lib
+    lib().df_debug_set_wgrad_algo(ctypes.c_int(4))
+    try:
+        errs = _conv_case(ops, shape, 128, 128, leak, seed=sum(shape), mask_from_gpu=True)
+    finally:
+        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+    assert max(errs.values()) < TOL, errs
+
+
 WINO_CASES = [
     ((1, 4, 8, 8), 32, 32, 0.2),        # exactly one tile block
     ((2, 8, 16, 8), 64, 32, 0.2),       # Cin != Cout (forward and dgrad swap them)

@@ -22,31 +22,27 @@ def run(B, D, H, W, C, N, kz=3, iters=3):
     nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, N, kz)
     ws = torch.empty((nb + 3) // 4, device="cuda")
     out = []
-    for algo in (1, 2, 0):
-        lib().df_debug_set_wgrad_algo(ctypes.c_int(algo))
+    for algo in (1, 2, 3, 4, 0):
+        lib().df_debug_set_wgrad_algo(ctypes.c_int(algo | (RANGES << 3)))
         gw = torch.empty((taps, C, N), device="cuda"); gb = torch.empty(N, device="cuda")
         f = lambda: call("df_conv_wgrad", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, N, kz, _ptr(ws), nb, s)
         f(); torch.cuda.synchronize()
         t = timeit(f, iters, 1)
         out.append((gw.clone(), gb.clone(), t))
     lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
-    (w0, b0, t0), (w1, b1, t1), (w2, b2, t2) = out
+    w0, b0, t0 = out[0]
     fl = 2.0 * taps * C * N * B * D * H * W
-    print("B%d %dx%dx%d C%d N%d: x: gw %.2e gb %.2e  xy: gw %.2e gb %.2e | direct %.3f ms (%.0f TF)  wino-x %.3f ms (%.0f TF-eq)  wino-xy %.3f ms (%.0f TF-eq)" % (
-        B, D, H, W, C, N, ((w0 - w1).abs().max() / w0.abs().max()).item(), ((b0 - b1).abs().max() / b0.abs().max()).item(),
-        ((w0 - w2).abs().max() / w0.abs().max()).item(), ((b0 - b2).abs().max() / b0.abs().max()).item(),
-        t0 * 1e3, fl / t0 / 1e12, t1 * 1e3, fl / t1 / 1e12, t2 * 1e3, fl / t2 / 1e12), flush=True)
+    msg = "B%d %dx%dx%d C%d N%d: direct %.3f ms (%.0f TF)" % (B, D, H, W, C, N, t0 * 1e3, fl / t0 / 1e12)
+    for name, (w1, b1, t1) in zip(("x", "xy", "xyz", "default"), out[1:]):
+        msg += " | %s %.3f ms (%.0f TF-eq) gw %.1e gb %.1e" % (name, t1 * 1e3, fl / t1 / 1e12, ((w0 - w1).abs().max() / w0.abs().max()).item(),
+                                                             ((b0 - b1).abs().max() / b0.abs().max()).item())
+    print(msg, flush=True)
 
 
+RANGES = 0
 if __name__ == "__main__":
     if len(sys.argv) > 1:
-        R = int(sys.argv[1])
-        import deep_fluids_amd._lib as L
-        orig = lib().df_debug_set_wgrad_algo
-        class _W:  # route the algo setter through a range override
-            pass
-        _set = lambda v: orig(ctypes.c_int(v.value | (R << 2)))
-        lib().df_debug_set_wgrad_algo = _set
+        RANGES = int(sys.argv[1])
     run(16, 8, 12, 8, 128, 128)
     run(16, 16, 24, 16, 128, 128)
     run(16, 32, 48, 32, 128, 128)
