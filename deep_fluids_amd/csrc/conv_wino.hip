@@ -667,7 +667,11 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 80: hipLaunchKernelGGL((wino3d_kernel<80, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 144: hipLaunchKernelGGL((wino3d_kernel<144, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 272: hipLaunchKernelGGL((wino3d_kernel<272, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 16: hipLaunchKernelGGL((wino3d_kernel<16, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 16:      // cycle profile (df_debug_wino_prof) of the SPECIALISED epilogues where they exist
+      if (flags == (DF_CONV_BIAS | DF_CONV_LRELU)) hipLaunchKernelGGL((wino3d_kernel<16, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+      else if (flags == DF_CONV_MASK) hipLaunchKernelGGL((wino3d_kernel<16, DF_CONV_MASK>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+      else hipLaunchKernelGGL((wino3d_kernel<16, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+      break;
     case 20: hipLaunchKernelGGL((wino3d_kernel<20, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 1024: hipLaunchKernelGGL((wino3d_kernel<1024, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 1536: hipLaunchKernelGGL((wino3d_kernel<1536, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;

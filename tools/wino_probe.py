@@ -42,6 +42,21 @@ def run(B, D, H, W, C, N, flags=8 | 1, iters=5):
             B, D, H, W, C, N, mode, err, l1, t0 * 1e3, fl_ / t0 / 1e12, t1 * 1e3, fl_ / t1 / 1e12, fl_ * 8 / 27 / t1 / 1e12), flush=True)
 
 
+def run_one(B, D, H, W, C, N, mode, fl, iters=3):
+    torch.manual_seed(0)
+    s = _stream()
+    K, NN = (C, N) if mode == 0 else (N, C)
+    x = torch.rand((B, D, H, W, K), device="cuda") * 2 - 1
+    w = (torch.rand((3, 3, 3, C, N), device="cuda") * 2 - 1) * (2.0 / (27 * C)) ** 0.5
+    ww = torch.empty(query("df_wino_packed_elems", C, N, mode), device="cuda")
+    call("df_wino_pack_weights", _ptr(w), _ptr(ww), C, N, mode, s)
+    b_ = torch.rand(NN, device="cuda") * 0.1
+    r_ = torch.rand((B, D, H, W, NN), device="cuda")
+    y1 = torch.empty((B, D, H, W, NN), device="cuda")
+    t1 = timeit(lambda: call("df_wino_conv_fwd", _ptr(x), _ptr(ww), _ptr(b_), _ptr(r_), _ptr(r_), _ptr(y1), B, D, H, W, K, NN, fl, 0.2, s), iters, 2)
+    print("  mode %d flags %d: %.3f ms" % (mode, fl, t1 * 1e3), flush=True)
+
+
 if __name__ == "__main__":
     import ctypes
     from deep_fluids_amd._lib import lib
@@ -51,7 +66,16 @@ if __name__ == "__main__":
         lib().df_debug_set_wino(ctypes.c_int(dbg))
         print("dbg", dbg)
         if (dbg >> 2) & 16:
-            lib().df_debug_wino_prof(None, 1)
+            for mode_flags in ((0, 9), (1, 4)):      # forward (bias+lrelu) and dgrad (mask) profiled separately
+                lib().df_debug_wino_prof(None, 1)
+                run_one(4, 64, 96, 64, 128, 128, *mode_flags)
+                buf = (ctypes.c_ulonglong * 32)()
+                lib().df_debug_wino_prof(buf, 0)
+                n = max(buf[3], 1)
+                print("  mode %d flags %d per block cycles: setup %.0f  main %.0f  epilogue %.0f  (n=%d)" % (mode_flags + (buf[0] / n, buf[1] / n, buf[2] / n, n)))
+                print("    epilogue split (both cout blocks): emit %.0f  barrier %.0f  combine+stores %.0f  barrier(+store acks) %.0f" % tuple(buf[8 + i] / n for i in range(4)))
+                print("    main split: wait-raw %.0f  transform+stage+rawissue %.0f  wait-B %.0f  mfma+Bissue %.0f" % tuple(buf[4 + i] / n for i in range(4)))
+            continue
         run(4, 64, 96, 64, 128, 128, iters=3)
         if (dbg >> 2) & 16:
             buf = (ctypes.c_ulonglong * 32)()
