@@ -889,7 +889,10 @@ struct WxyzArgs {
   int Ht, Dt, ntrows;      // tile rows per plane pair = H/2; plane pairs per batch = D/2; B*Dt*Ht
 };
 
-template <int WP8, int CS, bool GZ, bool GY>
+// UP: x is the COARSE tensor of an up-sampling-aware conv (fine position p reads xc[p >> 1] on every axis; a.D/H/W are the fine extents):
+// the transform points with index 2 vanish for the duplicated input, so only xi_z, xi_y in {0, 1, 3} workgroup types exist and the
+// xi_x = 2 products are skipped -- 27 of the 64 products (wgrad_up2_kernel's parity-class form needs 48 per coarse voxel).
+template <int WP8, int CS, bool GZ, bool GY, bool UP = false>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs aa) {
   const WgradArgs& a = aa.w;
   const int tid = threadIdx.x;
@@ -900,16 +903,17 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
   constexpr int Wc = WP8 * 8;
   const int half = lane >> 5, r = lane & 31;
 
-  const int nwg = a.nranges * 4;
+  constexpr int NTZ = (UP && GZ) ? 1 : 2, NTY = (UP && GY) ? 1 : 2, NT = NTZ * NTY;      // workgroup types of this launch
+  const int nwg = a.nranges * NT;
   int wg;
   {
     const int bid = blockIdx.x, q = nwg >> 3, rem = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
-  const int range = wg >> 2, sel = wg & 3;
-  const int xiz = GZ ? 1 + (sel >> 1) : 3 * (sel >> 1);
-  const int xiy = GY ? 1 + (sel & 1) : 3 * (sel & 1);
+  const int range = wg / NT, sel = wg % NT;
+  const int xiz = GZ ? 1 + sel / NTY : 3 * (sel / NTY);
+  const int xiy = GY ? 1 + sel % NTY : 3 * (sel % NTY);
   const int zy = xiz * 4 + xiy;                        // partial slot group
   const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
   if (ci0 >= a.Cin || co0 >= a.Cout) return;
@@ -949,7 +953,9 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
 #pragma unroll
       for (int py = 0; py < 2; ++py) {
         const int ys = y0 + (py ? yob : yoa);
-        rw.x[pz][py] = (zv && ys >= 0 && ys < a.H) ? a.x + ((bbase + zs) * a.H + ys) * a.W * a.Cin + cia : zb;
+        if (UP) rw.x[pz][py] = (zv && ys >= 0 && ys < a.H)
+                                   ? a.x + ((static_cast<int64_t>(b) * (a.D >> 1) + (zs >> 1)) * (a.H >> 1) + (ys >> 1)) * (a.W >> 1) * a.Cin + cia : zb;
+        else rw.x[pz][py] = (zv && ys >= 0 && ys < a.H) ? a.x + ((bbase + zs) * a.H + ys) * a.W * a.Cin + cia : zb;
       }
       const int gz = z0 + (pz ? 1 : gza);
 #pragma unroll
@@ -993,7 +999,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
   }
   auto load_pos = [&](const Row& lr, int slot, int pos) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xr[q >> 1][q & 1][slot] = ld(lr.x[q >> 1][q & 1], pos, xs);
+    for (int q = 0; q < 4; ++q) xr[q >> 1][q & 1][slot] = ld(lr.x[q >> 1][q & 1], UP ? pos >> 1 : pos, xs);
     gr[0][0][slot] = ld(lr.g[0][0], pos, gs);
     if (GY) gr[0][1][slot] = ld(lr.g[0][1], pos, gs);
     if (GZ) gr[1][0][slot] = ld(lr.g[1][0], pos, gs);
@@ -1031,6 +1037,10 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
     __builtin_amdgcn_sched_barrier(0);
     load_pos(lr, (u + 6) & 7, lpos);
     load_pos(lr, (u + 7) & 7, lpos + 1);
+    if (UP) {      // lpos is even: both fine positions read the same coarse voxel -- keep one load
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xr[q >> 1][q & 1][(u + 7) & 7] = xr[q >> 1][q & 1][(u + 6) & 7];
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -1038,7 +1048,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
       for (int t = 0; t < 2; ++t) {
         acc[0][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[s], g0[t], acc[0][s][t], 0, 0, 0);
         acc[1][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[s], m1[t], acc[1][s][t], 0, 0, 0);
-        acc[2][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[s], m2[t], acc[2][s][t], 0, 0, 0);
+        if (!UP) acc[2][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[s], m2[t], acc[2][s][t], 0, 0, 0);
         acc[3][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3[s], g1[t], acc[3][s][t], 0, 0, 0);
       }
   };
@@ -1063,6 +1073,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
   float* P = a.partial + static_cast<int64_t>(erange) * 64 * a.Cinp * a.Coutp;
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
+    if (UP && d == 2) continue;
     const int slot = zy * 4 + d;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -1090,7 +1101,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
 // sums, the 8 x 27 results are combined in a fixed order through LDS.
 __global__ __launch_bounds__(kThreads) void wgrad_wxyz_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
                                                                      float* __restrict__ gw, float* __restrict__ gb, int nranges, int Cin,
-                                                                     int Cout, int Cinp, int Coutp) {
+                                                                     int Cout, int Cinp, int Coutp, int up) {
   __shared__ float sV[8][27][32];
   const int64_t total = static_cast<int64_t>(Cin) * Cout;
   const int64_t slot = static_cast<int64_t>(Cinp) * Coutp;
@@ -1108,7 +1119,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_wxyz_reduce_kernel(const float
     for (int rg = grp; rg < nranges; rg += 8) {
       const float* q = p + rg * pstride;
 #pragma unroll
-      for (int k = 0; k < 64; ++k) u[k] += q[k * slot];
+      for (int k = 0; k < 64; ++k)
+        if (!(up && ((k >> 4) == 2 || ((k >> 2) & 3) == 2 || (k & 3) == 2))) u[k] += q[k * slot];      // (never written in up mode)
     }
   }
   // x, then y, then z:  (u0 + h, (u1 - u2)/2, h - u3) with h = (u1 + u2)/2
@@ -1978,7 +1990,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
 #undef DF_WXYZ
     const int64_t rgx = ceil_div(Cin * Cout, 32);
     hipLaunchKernelGGL(wgrad_wxyz_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
-                       p.nranges * p.nsub, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
+                       p.nranges * p.nsub, (int)Cin, (int)Cout, p.Cinp, p.Coutp, 0);
     return df::launched("df_conv_wgrad(winograd-xyz)");
   } else if (algo == 2) {
     WxyArgs aa;
@@ -2069,8 +2081,21 @@ static Plan make_up_plan(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t 
   return p;
 }
 
+// the 27-point Winograd-(x,y,z) form of the up-sampling-aware weight gradient (fine extents 2Dc x 2Hc x 2Wc)
+static bool up_wxyz_ok(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
+  return wxyz_ok(2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz) && (B * Dc * Hc >= 2048 || g_wgrad_algo == 4) && g_wgrad_algo != 1 &&
+         g_wgrad_algo != 2 && g_wgrad_algo != 3;
+}
+
 int64_t df_upconv_wgrad_workspace_bytes(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
   if (B <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  if (wxyz_ok(2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz)) {      // sized for either form (the choice depends on a debug switch)
+    const Plan q = make_plan(B, 2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz, 3);
+    const Plan p = make_up_plan(B, Dc, Hc, Wc, Cin, Cout, kz);
+    const int64_t nq = (q.partial_elems + q.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(2 * Wc, Cin, Cout);
+    const int64_t np = (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(Wc, Cin, Cout);
+    return nq > np ? nq : np;
+  }
   const Plan p = make_up_plan(B, Dc, Hc, Wc, Cin, Cout, kz);
   return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(Wc, Cin, Cout);
 }
@@ -2086,6 +2111,42 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   DF_REQUIRE(df::aligned16(workspace), DF_EALIGN, "df_upconv_wgrad: workspace must be 16-byte aligned");
   DF_REQUIRE(workspace_bytes >= df_upconv_wgrad_workspace_bytes(B, Dc, Hc, Wc, Cin, Cout, kz), DF_EWORKSPACE,
              "df_upconv_wgrad: workspace too small");
+  if (prec == 0 && up_wxyz_ok(B, Dc, Hc, Wc, Cin, Cout, kz) && df::aligned16(xc) && df::aligned16(gy)) {
+    const int64_t D = 2 * Dc, H = 2 * Hc, W = 2 * Wc;
+    const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, 3);
+    WxyzArgs aa;
+    WgradArgs& a = aa.w;
+    a.x = xc; a.g = gy;
+    a.partial = static_cast<float*>(workspace);
+    a.bpartial = a.partial + p.partial_elems;
+    float* zeros = a.bpartial + p.bpartial_elems;
+    a.zeros = zeros;
+    a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
+    a.Cinp = p.Cinp; a.Coutp = p.Coutp;
+    a.Wp = (int)W;
+    a.nrows = p.nrows; a.npairs = p.npairs; a.nranges = p.nranges; a.pairs_per_range = p.ppr;
+    a.ndzdy = p.ndzdy; a.want_bias = gb != nullptr;
+    a.nqi = p.nqi; a.nqj = p.nqj; a.nsub = p.nsub;
+    a.up = 0; a.gD = a.D; a.gH = a.H; a.gW = a.W;
+    aa.Ht = (int)Hc; aa.Dt = (int)Dc; aa.ntrows = p.nrows;
+    hipStream_t s = df::as_stream(stream);
+    if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(W, Cin, Cout), s)) return df::fail((int)e, "df_upconv_wgrad: memset: %s", hipGetErrorString(e));
+    const unsigned gy_ = (unsigned)ceil_div(Cin, 128), gz_ = (unsigned)ceil_div(Cout, 128);
+    // largest launch first: 4 | 2 | 2 | 1 workgroup types
+#define DF_UWXYZ(WP)                                                                                                                \
+  do {                                                                                                                              \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, false, true>), dim3((unsigned)(p.nranges * 4), gy_, gz_), dim3(kThreads), 0, s, aa);  \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, true, false, true>), dim3((unsigned)(p.nranges * 2), gy_, gz_), dim3(kThreads), 0, s, aa);   \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, true, true>), dim3((unsigned)(p.nranges * 2), gy_, gz_), dim3(kThreads), 0, s, aa);   \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, true, true, true>), dim3((unsigned)(p.nranges * 1), gy_, gz_), dim3(kThreads), 0, s, aa);    \
+  } while (0)
+    if (W == 64) DF_UWXYZ(8); else DF_UWXYZ(4);
+#undef DF_UWXYZ
+    const int64_t rgx = ceil_div(Cin * Cout, 32);
+    hipLaunchKernelGGL(wgrad_wxyz_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
+                       p.nranges * p.nsub, (int)Cin, (int)Cout, p.Cinp, p.Coutp, 1);
+    return df::launched("df_upconv_wgrad(winograd-xyz, 27-point)");
+  }
   const Plan p = make_up_plan(B, Dc, Hc, Wc, Cin, Cout, kz);
   WgradArgs a;
   a.x = xc; a.g = gy;

@@ -352,6 +352,18 @@ def test_wino_upconv_dgrad_vs_oracle(ops, cshape, cin, cout):
     assert rel_linf(host(acc), ref) < TOL
 
 
+@pytest.mark.parametrize("cshape", [(1, 2, 2, 32), (1, 2, 3, 16), (2, 3, 2, 32), (1, 4, 5, 16)])
+def test_upconv_block_wgrad_winograd_xyz_27point(ops, cshape):
+    """The up-sampling-aware weight gradient in its 27-point Winograd-(x,y,z) form (wgrad_wxyz_kernel<.., UP>: coarse operand reads,
+    9 workgroup types, xi_x = 2 skipped), forced on small grids; whole fused block against the oracle."""
+    from deep_fluids_amd._lib import lib
+    lib().df_debug_set_wgrad_algo(ctypes.c_int(4))
+    try:
+        test_upconv_block_vs_materialised_upsample(ops, cshape, 128)
+    finally:
+        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+
+
 @pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 32), ((1, 3, 5, 7), 128), ((1, 2, 2, 32), 64)])
 def test_upconv_block_winograd_forced(ops, cshape, C):
     """The fused up-sampling block with the Winograd kernels forced on small/ragged grids (forward through df_wino_upconv_fwd)."""
@@ -596,3 +608,11 @@ def test_full_size_upconv_agrees_with_materialised_upsample_cfg3(ops):
     call("df_upconv_wgrad", _ptr(xc), _ptr(g), _ptr(gw1), _ptr(gb1), B, D, H, W, C, C, 3, _ptr(ws1), nb1, s)
     assert ((gw0 - gw1).abs().max() / gw0.abs().max()).item() < 2e-5
     assert ((gb0 - gb1).abs().max() / gb0.abs().max()).item() < 2e-5
+    lib().df_debug_set_wgrad_algo(ctypes.c_int(4))           # the 27-point Winograd-(x,y,z) form (default from 2048 coarse rows)
+    try:
+        gw2 = torch.full_like(w, float("nan")); gb2 = torch.full((C,), float("nan"), device="cuda")
+        call("df_upconv_wgrad", _ptr(xc), _ptr(g), _ptr(gw2), _ptr(gb2), B, D, H, W, C, C, 3, _ptr(ws1), nb1, s)
+    finally:
+        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+    assert ((gw0 - gw2).abs().max() / gw0.abs().max()).item() < 2e-5
+    assert ((gb0 - gb2).abs().max() / gb0.abs().max()).item() < 2e-5
