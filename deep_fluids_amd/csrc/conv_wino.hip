@@ -51,6 +51,7 @@ struct WinoArgs {
   const float* residual;
   const float* mask_src;
   float* y;
+  float* y2;           // DF_CONV_ADDUP: second output  y2 = y + nearest_up2x(residual)  (residual = the COARSE tensor)
   int B, D, H, W, Cin, Cout;
   int nbz, nby, nbx, ntb, ncs;
   int flags;
@@ -533,6 +534,10 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           lo += m2; hi -= m2;
         }
         if (nb == 0 && full && (eflags & DF_CONV_MASK)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // mask DMA landed
+        float rup = 0.f;      // DF_CONV_ADDUP: the 2x2x2 outputs of this lane's tile share ONE coarse voxel of the skip tensor
+        if ((eflags & DF_CONV_ADDUP) && oz0 < a.D && oy0 < a.H && ox0 < a.W)
+          rup = a.residual[(((static_cast<int64_t>(cur.b) * (a.D >> 1) + (oz0 >> 1)) * (a.H >> 1) + (oy0 >> 1)) * (a.W >> 1) + (ox0 >> 1)) * a.Cout +
+                           n0 + nb * 16 + tl];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           float v = (s < 4 ? lo[s & 3] : hi[s & 3]) + bv;
@@ -546,10 +551,16 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
                                                ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
             if (DBG & 512) asm volatile("" :: "v"(v)); else      // (experiment: no stores)
             *reinterpret_cast<float*>(yb + lane_off) = v;
+            if (eflags & DF_CONV_ADDUP) {
+              char* yb2 = reinterpret_cast<char*>(a.y2 + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
+                                                  ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
+              *reinterpret_cast<float*>(yb2 + lane_off) = v + rup;
+            }
           } else if (oz0 + (s >> 2) < a.D && oy0 + ((s >> 1) & 1) < a.H && ox0 + (s & 1) < a.W) {
             if (eflags & DF_CONV_RESIDUAL) v += a.residual[o];
             if (eflags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
             a.y[o] = v;
+            if (eflags & DF_CONV_ADDUP) a.y2[o] = v + rup;
           }
         }
         const unsigned long long e3 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
@@ -627,13 +638,14 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
   // (staging goes through 32-bit byte offsets into one batch volume, with 0x80000000 as the out-of-range sentinel)
   DF_REQUIRE(D * H * W * (Cin > Cout ? Cin : Cout) <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
              "df_wino_conv_fwd: one batch volume must stay below 2 GiB (use df_conv_fwd)");
+  DF_REQUIRE(!(flags & DF_CONV_ADDUP), DF_EINVAL, "df_wino_conv_fwd: DF_CONV_ADDUP needs df_wino_conv_fwd_addup");
   DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_BIAS without bias");
   DF_REQUIRE(!(flags & DF_CONV_RESIDUAL) || residual, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_RESIDUAL without residual");
   DF_REQUIRE(!(flags & DF_CONV_MASK) || mask_src, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_MASK without mask_src");
   DF_REQUIRE(df::aligned16(wp) && df::aligned16(x), DF_EALIGN, "df_wino_conv_fwd: x and packed weights must be 16-byte aligned");
   WinoArgs a;
   a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
-  a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y;
+  a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y; a.y2 = nullptr;
   a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
   a.nbz = (int)ceil_div(D, 4); a.nby = (int)ceil_div(H, 8); a.nbx = (int)ceil_div(W, 8);
   const int64_t ntb = B * a.nbz * a.nby * a.nbx;
@@ -693,7 +705,7 @@ int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, floa
   DF_REQUIRE(df::aligned16(wp) && df::aligned16(xc), DF_EALIGN, "df_wino_upconv_fwd: xc and packed weights must be 16-byte aligned");
   WinoArgs a;
   a.x = xc; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
-  a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y;
+  a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y; a.y2 = nullptr;
   a.B = (int)B; a.D = (int)(2 * Dc); a.H = (int)(2 * Hc); a.W = (int)(2 * Wc); a.Cin = (int)Cin; a.Cout = (int)Cout;      // OUTPUT (fine) extents
   a.nbz = (int)ceil_div(a.D, 4); a.nby = (int)ceil_div(a.H, 8); a.nbx = (int)ceil_div(a.W, 8);
   const int64_t ntb = B * a.nbz * a.nby * a.nbx;
@@ -717,7 +729,7 @@ int df_wino_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B,
   DF_REQUIRE(df::aligned16(wp) && df::aligned16(g), DF_EALIGN, "df_wino_upconv_dgrad: g and packed weights must be 16-byte aligned");
   WinoArgs a;      // the adjoint conv reads g (Cout channels, fine grid) and produces Cin channels
   a.x = g; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
-  a.bias = nullptr; a.residual = nullptr; a.mask_src = nullptr; a.y = acc;
+  a.bias = nullptr; a.residual = nullptr; a.mask_src = nullptr; a.y = acc; a.y2 = nullptr;
   a.B = (int)B; a.D = (int)(2 * Dc); a.H = (int)(2 * Hc); a.W = (int)(2 * Wc); a.Cin = (int)Cout; a.Cout = (int)Cin;
   a.nbz = (int)ceil_div(a.D, 4); a.nby = (int)ceil_div(a.H, 8); a.nbx = (int)ceil_div(a.W, 8);
   const int64_t ntb = B * a.nbz * a.nby * a.nbx;
@@ -728,6 +740,30 @@ int df_wino_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B,
   const int64_t grid = wino_grid(a, ntb);
   hipLaunchKernelGGL((wino3d_kernel<0, 0, 2>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
   return df::launched("df_wino_upconv_dgrad");
+}
+
+int df_wino_conv_fwd_addup(const float* x, const float* wp, const float* bias, const float* xc, float* y, float* y2, int64_t B,
+                           int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, float leak, df_stream_t stream) {
+  DF_REQUIRE(x && wp && bias && xc && y && y2, DF_EINVAL, "df_wino_conv_fwd_addup: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, DF_EINVAL,
+             "df_wino_conv_fwd_addup: extents must be positive and even (the output of a 2x up-sampling block)");
+  DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE, "df_wino_conv_fwd_addup: Cin, Cout must be multiples of 32");
+  DF_REQUIRE(D * H * W * (Cin > Cout ? Cin : Cout) <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
+             "df_wino_conv_fwd_addup: one batch volume must stay below 2 GiB");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x), DF_EALIGN, "df_wino_conv_fwd_addup: x and packed weights must be 16-byte aligned");
+  WinoArgs a;
+  a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
+  a.bias = bias; a.residual = xc; a.mask_src = nullptr; a.y = y; a.y2 = y2;
+  a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.nbz = (int)ceil_div(D, 4); a.nby = (int)ceil_div(H, 8); a.nbx = (int)ceil_div(W, 8);
+  const int64_t ntb = B * a.nbz * a.nby * a.nbx;
+  a.ncs = (int)(Cout / 32);
+  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_conv_fwd_addup: too many workgroups");
+  a.ntb = (int)ntb;
+  a.flags = DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_ADDUP; a.leak = leak; a.dbg = 0;
+  const int64_t grid = wino_grid(a, ntb);
+  hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_ADDUP>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+  return df::launched("df_wino_conv_fwd_addup");
 }
 
 }  // extern "C"

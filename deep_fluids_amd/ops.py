@@ -376,6 +376,7 @@ class _UpGenBlock(torch.autograd.Function):
         C = int(xc.shape[-1])
         fshape = (xc.shape[0],) + tuple(2 * int(d) for d in xc.shape[1:-1]) + (C,)
         xs = []
+        y = None
         for i in range(n):
             w = _prep(wb[2 * i], "weights"); b = _prep(wb[2 * i + 1], "biases")
             cin, cout = w.shape[-2], w.shape[-1]
@@ -397,10 +398,18 @@ class _UpGenBlock(torch.autograd.Function):
                      kz, DF_CONV_BIAS | DF_CONV_LRELU, float(leak), _stream())
             else:
                 wp = _pack(w, taps, cin, cout, 0, fdims)
-                x = _conv_raw(x, wp, b, None, None, fdims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak).view(fshape)
+                if i == n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3:
+                    # block-end skip add fused into the last conv's epilogue: second output y = x + upscale(xc)
+                    x_in, x = x, torch.empty(fshape, dtype=torch.float32, device=xc.device)
+                    y = torch.empty(fshape, dtype=torch.float32, device=xc.device)
+                    call("df_wino_conv_fwd_addup", _ptr(x_in), _ptr(wp), _ptr(b), _ptr(xc), _ptr(x), _ptr(y), fdims[0], fdims[1],
+                         fdims[2], fdims[3], cin, cout, float(leak), _stream())
+                else:
+                    x = _conv_raw(x, wp, b, None, None, fdims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak).view(fshape)
             xs.append(x)
-        y = torch.empty_like(x)
-        call("df_add_up2x", _ptr(x), _ptr(xc), _ptr(y), cdims[0], cdims[1], cdims[2], cdims[3], C, int(is3d), _stream())
+        if y is None:
+            y = torch.empty_like(x)
+            call("df_add_up2x", _ptr(x), _ptr(xc), _ptr(y), cdims[0], cdims[1], cdims[2], cdims[3], C, int(is3d), _stream())
         ctx.save_for_backward(*([xc] + xs + [wb[2 * i] for i in range(n)]))
         ctx.geom = (n, cdims, fdims, kz, taps, float(leak), C, is3d)
         return y

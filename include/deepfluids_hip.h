@@ -42,7 +42,8 @@ enum {
   DF_CONV_LRELU = 1,      /* y = max(v, leak*v)            ops.py:9-10 fused into the conv epilogue   */
   DF_CONV_RESIDUAL = 2,   /* y += residual (after act)      model.py:35,40,77,82                       */
   DF_CONV_MASK = 4,       /* y *= (mask_src > 0 ? 1 : leak) lrelu backward fused into the dgrad epilogue */
-  DF_CONV_BIAS = 8        /* v += bias[cout]                slim.conv* biases                          */
+  DF_CONV_BIAS = 8,       /* v += bias[cout]                slim.conv* biases                          */
+  DF_CONV_ADDUP = 16      /* second output y2 = y + nearest_up2x(xc)  (df_wino_conv_fwd_addup only)     */
 };
 
 typedef void* df_stream_t; /* hipStream_t */
@@ -209,6 +210,12 @@ int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, floa
  * df_wino_pack_weights(w, wp, Cin, Cout, 1).  Drop-in for df_upconv_dgrad (kz = 3, channels multiples of 32). */
 int df_wino_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin,
                          int64_t Cout, df_stream_t stream);
+
+/* Last conv of an up-sampling generator block with the block-end skip add fused in (model.py:35,40,77,82 `x += x0`, x0 = upscale(xc)):
+ *   y = lrelu(conv_same(x, w) + bias)  (kept for the backward pass),   y2 = y + nearest_up2x(xc),  xc [B,D/2,H/2,W/2,Cout].
+ * Same packed weights and shape limits as df_wino_conv_fwd; D, H, W even. */
+int df_wino_conv_fwd_addup(const float* x, const float* wp, const float* bias, const float* xc, float* y, float* y2, int64_t B,
+                           int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, float leak, df_stream_t stream);
 
 /* 2-D twin: Winograd F(2x2, 3x3) form of the stride-1 3x3 convolution (conv_wino2d.hip): 2.25x fewer matrix-core FLOPs than df_conv_fwd
  * with kz = 1, fp32 throughout, same epilogue flags.  Needs Cin % 32 == 0, Cout % 32 == 0, H*W*max(Cin,Cout) <= 2^29. */
