@@ -1169,9 +1169,9 @@ inline bool wx_ok(int64_t W, int64_t Cin, int64_t Cout) {
   return (W == 16 || W == 32 || W == 64 || W == 56 || W == 112) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
 }
 inline bool wxy_ok(int64_t H, int64_t W, int64_t Cin, int64_t Cout) { return wx_ok(W, Cin, Cout) && H % 2 == 0 && H >= 4; }
-// (x,y,z): instantiated for the 128 -> 128 layers at W = 64 | 32 | 16
+// (x,y,z): instantiated for the 128 -> 128 layers at W = 64 | 32 | 16 (cfg3) and 112 | 56 (cfg4)
 inline bool wxyz_ok(int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
-  return kz == 3 && wxy_ok(H, W, Cin, Cout) && D % 2 == 0 && D >= 4 && Cin == 128 && Cout == 128 && (W == 64 || W == 32 || W == 16);
+  return kz == 3 && wxy_ok(H, W, Cin, Cout) && D % 2 == 0 && D >= 4 && Cin == 128 && Cout == 128 && (W == 64 || W == 32 || W == 16 || W == 112 || W == 56);
 }
 int g_wgrad_ranges = 0;   // debug: override the number of voxel ranges (0 = default)
 int g_wgrad_algo = 0;     // 0: best available, 1: always the direct kernel, 2: at most Winograd-in-x, 3: (x,y) wherever it exists, 4: (x,y,z) wherever it exists (df_debug_set_wgrad_algo)
@@ -1986,7 +1986,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, true>), gridq, dim3(kThreads), 0, s, aa);         \
     hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, false>), gridq, dim3(kThreads), 0, s, aa);        \
   } while (0)
-    if (W == 64) DF_WXYZ(8); else if (W == 32) DF_WXYZ(4); else DF_WXYZ(2);
+    if (W == 64) DF_WXYZ(8); else if (W == 32) DF_WXYZ(4); else if (W == 16) DF_WXYZ(2); else if (W == 112) DF_WXYZ(14); else DF_WXYZ(7);
 #undef DF_WXYZ
     const int64_t rgx = ceil_div(Cin * Cout, 32);
     hipLaunchKernelGGL(wgrad_wxyz_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
@@ -2140,7 +2140,7 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
     hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, true, true>), dim3((unsigned)(p.nranges * 2), gy_, gz_), dim3(kThreads), 0, s, aa);   \
     hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, true, true, true>), dim3((unsigned)(p.nranges * 1), gy_, gz_), dim3(kThreads), 0, s, aa);    \
   } while (0)
-    if (W == 64) DF_UWXYZ(8); else if (W == 32) DF_UWXYZ(4); else DF_UWXYZ(2);
+    if (W == 64) DF_UWXYZ(8); else if (W == 32) DF_UWXYZ(4); else if (W == 16) DF_UWXYZ(2); else if (W == 112) DF_UWXYZ(14); else DF_UWXYZ(7);
 #undef DF_UWXYZ
     const int64_t rgx = ceil_div(Cin * Cout, 32);
     hipLaunchKernelGGL(wgrad_wxyz_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,

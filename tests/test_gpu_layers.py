@@ -91,7 +91,7 @@ def test_conv_wgrad_algorithms(ops, shape, cin, cout, leak, algo):
     assert max(errs.values()) < TOL, errs
 
 
-@pytest.mark.parametrize("shape,leak", [((1, 4, 4, 32), 0.2), ((2, 6, 4, 64), None), ((3, 4, 6, 32), 0.2), ((1, 8, 4, 64), 0.2), ((2, 4, 6, 16), 0.2)])
+@pytest.mark.parametrize("shape,leak", [((1, 4, 4, 32), 0.2), ((2, 6, 4, 64), None), ((3, 4, 6, 32), 0.2), ((1, 8, 4, 64), 0.2), ((2, 4, 6, 16), 0.2), ((1, 4, 4, 56), 0.2), ((1, 4, 4, 112), None)])
 def test_conv_wgrad_winograd_xyz(ops, shape, leak):
     """df_conv_wgrad forced to the Winograd F(2x2x2,3x3x3) form (algo 4: 64 transform-domain products per 2x2x2 positions, four launches of
     (xi_z, xi_y) workgroup types, z/y/x G^T in the reduce) against the fp64 oracle; odd tile-row counts, several batches."""
@@ -352,7 +352,7 @@ def test_wino_upconv_dgrad_vs_oracle(ops, cshape, cin, cout):
     assert rel_linf(host(acc), ref) < TOL
 
 
-@pytest.mark.parametrize("cshape", [(1, 2, 2, 32), (1, 2, 3, 16), (2, 3, 2, 32), (1, 4, 5, 16), (1, 3, 2, 8)])
+@pytest.mark.parametrize("cshape", [(1, 2, 2, 32), (1, 2, 3, 16), (2, 3, 2, 32), (1, 4, 5, 16), (1, 3, 2, 8), (1, 2, 2, 28), (1, 2, 2, 56)])
 def test_upconv_block_wgrad_winograd_xyz_27point(ops, cshape):
     """The up-sampling-aware weight gradient in its 27-point Winograd-(x,y,z) form (wgrad_wxyz_kernel<.., UP>: coarse operand reads,
     9 workgroup types, xi_x = 2 skipped), forced on small grids; whole fused block against the oracle."""
