@@ -1166,12 +1166,12 @@ __global__ __launch_bounds__(kThreads) void wgrad_wxyz_reduce_kernel(const float
 
 // the Winograd-in-x variant exists for the fully unrolled row lengths below (even channel counts: float2 operand loads)
 inline bool wx_ok(int64_t W, int64_t Cin, int64_t Cout) {
-  return (W == 16 || W == 32 || W == 64 || W == 56 || W == 112) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
+  return (W == 16 || W == 32 || W == 64 || W == 56 || W == 112 || W == 128) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
 }
 inline bool wxy_ok(int64_t H, int64_t W, int64_t Cin, int64_t Cout) { return wx_ok(W, Cin, Cout) && H % 2 == 0 && H >= 4; }
 // (x,y,z): instantiated for the 128 -> 128 layers at W = 64 | 32 | 16 (cfg3) and 112 | 56 (cfg4)
 inline bool wxyz_ok(int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
-  return kz == 3 && wxy_ok(H, W, Cin, Cout) && D % 2 == 0 && D >= 4 && Cin == 128 && Cout == 128 && (W == 64 || W == 32 || W == 16 || W == 112 || W == 56);
+  return kz == 3 && wxy_ok(H, W, Cin, Cout) && D % 2 == 0 && D >= 4 && Cin == 128 && Cout == 128 && (W == 64 || W == 32 || W == 16 || W == 112 || W == 56 || W == 128);
 }
 int g_wgrad_ranges = 0;   // debug: override the number of voxel ranges (0 = default)
 int g_wgrad_algo = 0;     // 0: best available, 1: always the direct kernel, 2: at most Winograd-in-x, 3: (x,y) wherever it exists, 4: (x,y,z) wherever it exists (df_debug_set_wgrad_algo)
@@ -1986,7 +1986,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, true>), gridq, dim3(kThreads), 0, s, aa);         \
     hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, false>), gridq, dim3(kThreads), 0, s, aa);        \
   } while (0)
-    if (W == 64) DF_WXYZ(8); else if (W == 32) DF_WXYZ(4); else if (W == 16) DF_WXYZ(2); else if (W == 112) DF_WXYZ(14); else DF_WXYZ(7);
+    if (W == 64) DF_WXYZ(8); else if (W == 32) DF_WXYZ(4); else if (W == 16) DF_WXYZ(2); else if (W == 112) DF_WXYZ(14); else if (W == 128) DF_WXYZ(16); else DF_WXYZ(7);
 #undef DF_WXYZ
     const int64_t rgx = ceil_div(Cin * Cout, 32);
     hipLaunchKernelGGL(wgrad_wxyz_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
@@ -2005,6 +2005,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   } while (0)
     if (W == 64 && c128) DF_WXY(8, 128);
     else if (W == 64) DF_WXY(8, 0);
+    else if (W == 128) DF_WXY(16, 0);      // AE3 128^3 (cfg5)
     else if (W == 112) DF_WXY(14, 0);      // cfg4 row lengths
     else if (W == 56) DF_WXY(7, 0);
     else if (W == 32 && c128) DF_WXY(4, 128);
@@ -2022,6 +2023,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     const bool c128 = Cin == 128 && Cout == 128;
     if (W == 64 && c128) hipLaunchKernelGGL((wgrad_wx_kernel<8, 128>), grid, dim3(kThreads), 0, s, a);
     else if (W == 64) hipLaunchKernelGGL((wgrad_wx_kernel<8, 0>), grid, dim3(kThreads), 0, s, a);
+    else if (W == 128) hipLaunchKernelGGL((wgrad_wx_kernel<16, 0>), grid, dim3(kThreads), 0, s, a);
     else if (W == 112) hipLaunchKernelGGL((wgrad_wx_kernel<14, 0>), grid, dim3(kThreads), 0, s, a);
     else if (W == 56) hipLaunchKernelGGL((wgrad_wx_kernel<7, 0>), grid, dim3(kThreads), 0, s, a);
     else if (W == 32 && c128) hipLaunchKernelGGL((wgrad_wx_kernel<4, 128>), grid, dim3(kThreads), 0, s, a);
@@ -2038,6 +2040,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   const int wp8 = a.Wp / 8;
   const bool exact = (W % 8) == 0;
   if (xvec && gvec && exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);
+  else if (xvec && gvec && exact && wp8 == 16) hipLaunchKernelGGL((wgrad_kernel<true, true, 16>), grid, dim3(kThreads), 0, s, a);
   else if (xvec && gvec && exact && wp8 == 4) hipLaunchKernelGGL((wgrad_kernel<true, true, 4>), grid, dim3(kThreads), 0, s, a);
   else if (xvec && gvec && exact && wp8 == 14) hipLaunchKernelGGL((wgrad_kernel<true, true, 14>), grid, dim3(kThreads), 0, s, a);
   else if (xvec && gvec && exact && wp8 == 12) hipLaunchKernelGGL((wgrad_kernel<true, true, 12>), grid, dim3(kThreads), 0, s, a);
@@ -2140,7 +2143,7 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
     hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, true, true>), dim3((unsigned)(p.nranges * 2), gy_, gz_), dim3(kThreads), 0, s, aa);   \
     hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, true, true, true>), dim3((unsigned)(p.nranges * 1), gy_, gz_), dim3(kThreads), 0, s, aa);    \
   } while (0)
-    if (W == 64) DF_UWXYZ(8); else if (W == 32) DF_UWXYZ(4); else if (W == 16) DF_UWXYZ(2); else if (W == 112) DF_UWXYZ(14); else DF_UWXYZ(7);
+    if (W == 64) DF_UWXYZ(8); else if (W == 32) DF_UWXYZ(4); else if (W == 16) DF_UWXYZ(2); else if (W == 112) DF_UWXYZ(14); else if (W == 128) DF_UWXYZ(16); else DF_UWXYZ(7);
 #undef DF_UWXYZ
     const int64_t rgx = ceil_div(Cin * Cout, 32);
     hipLaunchKernelGGL(wgrad_wxyz_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,

@@ -78,7 +78,7 @@ CASES_2D = [
 
 @pytest.mark.parametrize("algo", [1, 2, 3])
 @pytest.mark.parametrize("shape,cin,cout,leak", [((3, 2, 2, 64), 128, 128, 0.2), ((1, 2, 6, 32), 32, 64, 0.2), ((2, 3, 4, 16), 32, 96, None),
-                                                 ((2, 8, 32), 64, 64, 0.2), ((1, 2, 4, 56), 32, 32, 0.2), ((1, 1, 2, 112), 32, 32, None)])
+                                                 ((2, 8, 32), 64, 64, 0.2), ((1, 2, 4, 56), 32, 32, 0.2), ((1, 1, 2, 112), 32, 32, None), ((1, 2, 2, 128), 64, 64, 0.2)])
 def test_conv_wgrad_algorithms(ops, shape, cin, cout, leak, algo):
     """df_conv_wgrad forced to the direct kernel (1), Winograd in x (2) and Winograd in (x,y) (3) -- the default picks by size --
     against the fp64 oracle; the last case is 2-D (kz = 1)."""
@@ -91,7 +91,7 @@ def test_conv_wgrad_algorithms(ops, shape, cin, cout, leak, algo):
     assert max(errs.values()) < TOL, errs
 
 
-@pytest.mark.parametrize("shape,leak", [((1, 4, 4, 32), 0.2), ((2, 6, 4, 64), None), ((3, 4, 6, 32), 0.2), ((1, 8, 4, 64), 0.2), ((2, 4, 6, 16), 0.2), ((1, 4, 4, 56), 0.2), ((1, 4, 4, 112), None)])
+@pytest.mark.parametrize("shape,leak", [((1, 4, 4, 32), 0.2), ((2, 6, 4, 64), None), ((3, 4, 6, 32), 0.2), ((1, 8, 4, 64), 0.2), ((2, 4, 6, 16), 0.2), ((1, 4, 4, 56), 0.2), ((1, 4, 4, 112), None), ((1, 4, 4, 128), 0.2)])
 def test_conv_wgrad_winograd_xyz(ops, shape, leak):
     """df_conv_wgrad forced to the Winograd F(2x2x2,3x3x3) form (algo 4: 64 transform-domain products per 2x2x2 positions, four launches of
     (xi_z, xi_y) workgroup types, z/y/x G^T in the reduce) against the fp64 oracle; odd tile-row counts, several batches."""
