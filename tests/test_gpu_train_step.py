@@ -114,6 +114,32 @@ def test_train_step_cfg3_geometry_filters128(algo):
     assert r["grad_rel_linf"] < (1e-3 if algo == "direct" else 3e-2), r
 
 
+def test_train_step_is_run_to_run_deterministic():
+    """Two trainers started from the same variables, fed the same batch, must end two steps with bit-identical parameters and loss: every
+    reduction in the path is fixed-order (range partials + fixed-order combines, per-wave LDS accumulation in program order, no global
+    atomics).  F = 128 at 16x24x16 exercises the Winograd forward / dgrad, the Winograd weight gradients, the up-sampling-aware kernels
+    and the matrix-core thin layer."""
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import Trainer, default_config
+    spatial, filters, batch = (16, 24, 16), 128, 2
+    rng = np.random.RandomState(7)
+    p = orc.generator_init(rng, 3, list(spatial) + [3], filters)
+    x, y = orc.synthetic_batch(rng, batch, spatial)
+    cfg = default_config(is_3d=True, res_x=spatial[2], res_y=spatial[1], res_z=spatial[0], filters=filters, batch_size=batch, num_samples=1000)
+    results = []
+    for _ in range(2):
+        ops.reset_variables()
+        tr = Trainer(cfg)
+        tr.load_variables(p)
+        for _ in range(2):
+            m = tr.train_step(dev(x), dev(y))
+        results.append((float(m.g_loss), tr.variables_numpy()))
+    ops.reset_variables()
+    assert results[0][0] == results[1][0]
+    for k in results[0][1]:
+        assert np.array_equal(results[0][1][k], results[1][1][k]), k
+
+
 def test_checkpoint_resume_and_dataset_reader(tmp_path):
     """read a dataset in the reference's on-disk format, train, save, restore into a fresh trainer
     (slim variable names + Adam slots + step + g_lr) and continue: the next step must be bit-identical."""
