@@ -666,28 +666,15 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 2: hipLaunchKernelGGL((wino3d_kernel<2, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 3: hipLaunchKernelGGL((wino3d_kernel<3, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 7: hipLaunchKernelGGL((wino3d_kernel<7, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 17: hipLaunchKernelGGL((wino3d_kernel<17, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 19: hipLaunchKernelGGL((wino3d_kernel<19, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 23: hipLaunchKernelGGL((wino3d_kernel<23, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 31: hipLaunchKernelGGL((wino3d_kernel<31, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 18: hipLaunchKernelGGL((wino3d_kernel<18, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 24: hipLaunchKernelGGL((wino3d_kernel<24, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 25: hipLaunchKernelGGL((wino3d_kernel<25, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 27: hipLaunchKernelGGL((wino3d_kernel<27, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 32: hipLaunchKernelGGL((wino3d_kernel<32, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 48: hipLaunchKernelGGL((wino3d_kernel<48, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 80: hipLaunchKernelGGL((wino3d_kernel<80, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 144: hipLaunchKernelGGL((wino3d_kernel<144, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 272: hipLaunchKernelGGL((wino3d_kernel<272, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 16:      // cycle profile (df_debug_wino_prof) of the SPECIALISED epilogues where they exist
       if (flags == (DF_CONV_BIAS | DF_CONV_LRELU)) hipLaunchKernelGGL((wino3d_kernel<16, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
       else if (flags == DF_CONV_MASK) hipLaunchKernelGGL((wino3d_kernel<16, DF_CONV_MASK>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
       else hipLaunchKernelGGL((wino3d_kernel<16, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
       break;
-    case 20: hipLaunchKernelGGL((wino3d_kernel<20, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 1024: hipLaunchKernelGGL((wino3d_kernel<1024, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 1536: hipLaunchKernelGGL((wino3d_kernel<1536, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 15: hipLaunchKernelGGL((wino3d_kernel<15, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     default: return df::fail(DF_EINVAL, "df_wino_conv_fwd: unknown debug variant");
   }
   return df::launched("df_wino_conv_fwd");
