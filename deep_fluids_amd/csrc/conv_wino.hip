@@ -533,7 +533,9 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           const f32x4 m2 = sO[((2 * 2 + th) * 4 + xz) * 64 + lane];
           lo += m2; hi -= m2;
         }
-        if (nb == 0 && full && (eflags & DF_CONV_MASK)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // mask DMA landed
+        // mask DMA of THIS cout block landed: the 16 loads were issued block 0 first and vmcnt retires in order, so "at most 8
+        // outstanding" covers block 0 while block 1's eight are still in flight, and block 1 while block 0's eight stores are
+        if (full && (eflags & DF_CONV_MASK)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         float rup = 0.f;      // DF_CONV_ADDUP: the 2x2x2 outputs of this lane's tile share ONE coarse voxel of the skip tensor
         if ((eflags & DF_CONV_ADDUP) && oz0 < a.D && oy0 < a.H && ox0 < a.W)
           rup = a.residual[(((static_cast<int64_t>(cur.b) * (a.D >> 1) + (oz0 >> 1)) * (a.H >> 1) + (oy0 >> 1)) * (a.W >> 1) + (ox0 >> 1)) * a.Cout +
