@@ -1580,42 +1580,49 @@ __global__ __launch_bounds__(kThreads) void wgrad_small_reduce_kernel(const floa
 // = channels 4*(l%32)..+3 feed the four N blocks), which makes the partial-sum stores float4-contiguous.
 // One wave per SIMD (192|256 accumulator registers); latency is covered by an 8-step ring of x loads.
 struct ThinWgradArgs {
-  const float* x;
-  const float* g;
-  float* partial;      // [nstreams][27*CO][128]
-  float* bpartial;     // [nstreams][CO]
+  const float* x;      // the WIDE tensor (NJ*32 channels), streamed linearly
+  const float* g;      // the THIN tensor (CT <= 4 channels), gathered from the per-wave LDS tile
+  float* partial;      // [nstreams][27*CT][NJ*32]
+  float* bpartial;     // [nstreams][CT]  (SWAP: [nstreams][NJ*32])
   int B, D, H, W;
-  int nrows, nstreams, rows_per, RS;      // RS: LDS row stride in floats = W*CO + 8
-  unsigned x_bytes_lo, x_bytes_hi;        // size of x in bytes
+  int nrows, nstreams, rows_per, RS;      // RS: LDS row stride in floats = W*CT + 8
+  unsigned x_bytes_lo, x_bytes_hi;        // size of the wide tensor in bytes
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t thin_srd(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
-template <int CO>
+// CT: channels of the thin tensor; NJ: the wide tensor has NJ*32 channels (lane l holds channels NJ*(l%32)..+NJ-1 of voxel l/32);
+// NP: 64-lane passes per thin row (W*CT/4 float4 pieces).  SWAP = false: wide = x (Cin), thin = g (Cout <= 4), the gradient of a
+// F -> 1..4 layer; SWAP = true: wide = g (Cout), thin = x (Cin <= 4), the gradient of a 1..4 -> F layer (gather offsets mirrored,
+// bias gradient = column sums of the wide stream).
+template <int CT, int NJ, bool SWAP, int NP>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_thin_mfma_kernel(const ThinWgradArgs a) {
-  constexpr int NM = 27 * CO, MB = (NM + 31) / 32, MBC = (13 * CO) / 32;      // MBC: the M block that holds the centre tap
+  constexpr int NM = 27 * CT, MB = (NM + 31) / 32, MBC = (13 * CT) / 32;      // MBC: the M block that holds the centre tap
+  constexpr int NCH = NJ * 32;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float vt __attribute__((ext_vector_type(NJ)));
   extern __shared__ __attribute__((aligned(16))) float smem_thin[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int stream = blockIdx.x * 4 + wave;
-  const int RS = a.RS, W = a.W, WC = W * CO;
+  const int RS = a.RS, W = a.W, WC = W * CT;
   float* sG = smem_thin + wave * 19 * RS;          // [2 buffers][9 (tz, ty) rows][RS] + one zero row
   const int r0 = stream * a.rows_per;
   int r1 = r0 + a.rows_per;
   if (r1 > a.nrows) r1 = a.nrows;
   for (int i = lane; i < 19 * RS; i += 64) sG[i] = 0.f;
+  constexpr int NBIAS = SWAP ? NCH : CT;
   if (r0 >= r1) {      // (only when nrows is not a multiple of the stream count) -- still publish zero partials
-    for (int i = lane; i < NM * 128; i += 64) a.partial[static_cast<int64_t>(stream) * NM * 128 + i] = 0.f;
-    if (lane < CO) a.bpartial[stream * CO + lane] = 0.f;
+    for (int i = lane; i < NM * NCH; i += 64) a.partial[static_cast<int64_t>(stream) * NM * NCH + i] = 0.f;
+    for (int i = lane; i < NBIAS; i += 64) a.bpartial[stream * NBIAS + i] = 0.f;
     return;
   }
 
-  // ---- gradient rows of image row `row` -> registers -> LDS buffer -------------------------------------------------------------
-  const int nl4 = WC / 4;      // float4 pieces per gradient row (<= 48)
-  f32x4 gq[9];
+  // ---- thin rows of image row `row` -> registers -> LDS buffer ----------------------------------------------------------------------
+  const int nl4 = WC / 4;      // float4 pieces per thin row (<= 64 * NP)
+  f32x4 gq[9][NP];
   auto load_g = [&](int row) {
     const int y = row % a.H;
     const int t = row / a.H;
@@ -1623,20 +1630,25 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_thin_mfma_kernel(const Thin
     const int b = t / a.D;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const int zs = z - (k / 3 - 1), ys = y - (k % 3 - 1);
+      const int zs = SWAP ? z + (k / 3 - 1) : z - (k / 3 - 1), ys = SWAP ? y + (k % 3 - 1) : y - (k % 3 - 1);
       const bool ok = zs >= 0 && zs < a.D && ys >= 0 && ys < a.H;      // wave-uniform
       const int zc = ok ? zs : z, yc = ok ? ys : y;
       const float* src = a.g + ((static_cast<int64_t>(b) * a.D + zc) * a.H + yc) * WC;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (lane < nl4) v = *reinterpret_cast<const f32x4*>(src + lane * 4);
-      gq[k] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (lane + pp * 64 < nl4) v = *reinterpret_cast<const f32x4*>(src + (lane + pp * 64) * 4);
+        gq[k][pp] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
   auto store_g = [&](int buf) {
-    if (lane < nl4) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) *reinterpret_cast<f32x4*>(sG + (buf * 9 + k) * RS + 4 + lane * 4) = gq[k];
-    }
+    for (int pp = 0; pp < NP; ++pp)
+      if (lane + pp * 64 < nl4) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) *reinterpret_cast<f32x4*>(sG + (buf * 9 + k) * RS + 4 + (lane + pp * 64) * 4) = gq[k][pp];
+      }
   };
 
   // ---- A operand gather: lane (m = l % 32 of block mb, voxel kk = l / 32 of the pair) --------------------------------------------
@@ -1646,9 +1658,9 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_thin_mfma_kernel(const Thin
   for (int mb = 0; mb < MB; ++mb) {
     const int m = mb * 32 + (lane & 31);
     if (m < NM) {
-      const int tap = m / CO, co = m % CO;
+      const int tap = m / CT, co = m % CT;
       const int t9 = tap / 3, tx = tap % 3;
-      aoff[mb] = (t9 * RS + 4 + (kk - (tx - 1)) * CO + co) * 4;
+      aoff[mb] = (t9 * RS + 4 + (SWAP ? kk + (tx - 1) : kk - (tx - 1)) * CT + co) * 4;
       adb[mb] = 9 * RS * 4;
     } else {
       aoff[mb] = (18 * RS + 4) * 4;
@@ -1659,29 +1671,33 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_thin_mfma_kernel(const Thin
   auto gather = [&](int buf, int pair, float (&out)[MB]) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
-      out[mb] = *reinterpret_cast<const float*>(sGb + aoff[mb] + buf * adb[mb] + pair * (2 * CO * 4));
+      out[mb] = *reinterpret_cast<const float*>(sGb + aoff[mb] + buf * adb[mb] + pair * (2 * CT * 4));
   };
 
-  // ---- x stream ----------------------------------------------------------------------------------------------------------------------
-  const int64_t xoff0 = static_cast<int64_t>(r0) * W * 128;      // floats
+  // ---- wide stream -------------------------------------------------------------------------------------------------------------------
+  const int64_t xoff0 = static_cast<int64_t>(r0) * W * NCH;      // floats
   const uint64_t xbytes = (static_cast<uint64_t>(a.x_bytes_hi) << 32) | a.x_bytes_lo;
   const uint64_t remain = xbytes - static_cast<uint64_t>(xoff0) * 4u;
   const __amdgpu_buffer_rsrc_t xsrd = thin_srd(a.x + xoff0, remain > 0xffffffffull ? 0xffffffffu : static_cast<unsigned>(remain));
-  const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
-  auto load_x = [&](unsigned step) -> f32x4 {       // step = voxel pair index within the stream; past the tensor's end reads zeros
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrd, lane16, step * 1024u, 0));
+  const unsigned lanev = static_cast<unsigned>(lane) * (NJ * 4u);
+  auto load_x = [&](unsigned step) -> vt {       // step = voxel pair index within the stream; past the tensor's end reads zeros
+    if constexpr (NJ == 4) return __builtin_bit_cast(vt, __builtin_amdgcn_raw_buffer_load_b128(xsrd, lanev, step * (2u * NCH * 4u), 0));
+    else return __builtin_bit_cast(vt, __builtin_amdgcn_raw_buffer_load_b64(xsrd, lanev, step * (2u * NCH * 4u), 0));
   };
 
-  f32x16 acc[MB][4];
+  f32x16 acc[MB][NJ];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][j][r] = 0.f;
   float bs = 0.f;
+  vt bsw;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) bsw[j] = 0.f;
 
-  f32x4 xr[8];
+  vt xr[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) xr[i] = load_x(i);
   load_g(r0);
@@ -1706,64 +1722,98 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_thin_mfma_kernel(const Thin
         if (i < 7) gather(buf, grp * 8 + i + 1, an);
         else if (!lastg) gather(buf, grp * 8 + 8, an);
         else gather(buf ^ 1, 0, an);
-        const f32x4 xv = xr[i];
+        const vt xv = xr[i];
         xr[i] = load_x(step + 8);
         ++step;
-        bs += ac[MBC];
+        if (SWAP) bsw += xv; else bs += ac[MBC];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mb], xv[j], acc[mb][j], 0, 0, 0);
+          for (int j = 0; j < NJ; ++j) acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mb], xv[j], acc[mb][j], 0, 0, 0);
       }
     }
     buf ^= 1;
   }
 
   // ---- partial sums: row m of block mb lives in register r of lanes with l / 32 == ((m % 8) / 4) --------------------------------------
-  float* P = a.partial + static_cast<int64_t>(stream) * NM * 128 + (lane & 31) * 4;
+  float* P = a.partial + static_cast<int64_t>(stream) * NM * NCH + (lane & 31) * NJ;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = mb * 32 + (r >> 2) * 8 + kk * 4 + (r & 3);
-      if (m < NM) *reinterpret_cast<f32x4*>(P + m * 128) = f32x4{acc[mb][0][r], acc[mb][1][r], acc[mb][2][r], acc[mb][3][r]};
+      if (m < NM) {
+        vt o;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) o[j] = acc[mb][j][r];
+        *reinterpret_cast<vt*>(P + m * NCH) = o;
+      }
     }
-  // bias gradient: lanes (13*CO + co) % 32 of both halves hold the two voxel-parity sums of g[., co]
-  const float other = __shfl_xor(bs, 32);
-  const int l0 = (13 * CO) & 31;
-  if (lane >= l0 && lane < l0 + CO) a.bpartial[stream * CO + (lane - l0)] = bs + other;
+  if (SWAP) {      // bias gradient = column sums of the wide stream (two voxel parities per lane pair)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float t = bsw[j] + __shfl_xor(bsw[j], 32);
+      if (lane < 32) a.bpartial[stream * NCH + lane * NJ + j] = t;
+    }
+  } else {         // lanes (13*CT + c) % 32 of both halves hold the two voxel-parity sums of thin[., c]
+    const float other = __shfl_xor(bs, 32);
+    const int l0 = (13 * CT) & 31;
+    if (lane >= l0 && lane < l0 + CT) a.bpartial[stream * CT + (lane - l0)] = bs + other;
+  }
 }
 
-// gw[tap][ci][co] = sum_stream partial[stream][tap*CO + co][ci]  (fixed order: 8 interleaved stream groups, combined in order)
+// gw[tap][ci][co] = sum_stream partial[stream][tap*CT + c][ch]  (fixed order: 8 interleaved stream groups, combined in order);
+// SWAP = 0: (ci, co) = (ch, c);  SWAP = 1: (ci, co) = (c, ch)
 __global__ __launch_bounds__(kThreads) void wgrad_thin_reduce_kernel(const float* __restrict__ partial,
                                                                      const float* __restrict__ bpartial,
                                                                      float* __restrict__ gw, float* __restrict__ gb,
-                                                                     int nstreams, int NM, int CO) {
+                                                                     int nstreams, int NM, int CT, int NCH, int swap) {
   __shared__ float sP[8][32];
   const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int m = blockIdx.x >> 2, ci = (blockIdx.x & 3) * 32 + el;
+  const int nq = NCH >> 5;
+  const int m = blockIdx.x / nq, ch = (blockIdx.x % nq) * 32 + el;
   float acc = 0.f;
-  for (int sidx = grp; sidx < nstreams; sidx += 8) acc += partial[(static_cast<int64_t>(sidx) * NM + m) * 128 + ci];
+  for (int sidx = grp; sidx < nstreams; sidx += 8) acc += partial[(static_cast<int64_t>(sidx) * NM + m) * NCH + ch];
   sP[grp][el] = acc;
   __syncthreads();
   if (grp == 0) {
     float t = sP[0][el];
 #pragma unroll
     for (int k = 1; k < 8; ++k) t += sP[k][el];
-    gw[(static_cast<int64_t>(m / CO) * 128 + ci) * CO + (m % CO)] = t;
+    if (swap) gw[static_cast<int64_t>(m) * NCH + ch] = t;
+    else gw[(static_cast<int64_t>(m / CT) * NCH + ch) * CT + (m % CT)] = t;
   }
-  if (gb && blockIdx.x == 0 && threadIdx.x < CO) {
+  const int nbias = swap ? NCH : CT;
+  if (gb && blockIdx.x == 0 && threadIdx.x < nbias) {
     float t = 0.f;
-    for (int sidx = 0; sidx < nstreams; ++sidx) t += bpartial[sidx * CO + threadIdx.x];
+    for (int sidx = 0; sidx < nstreams; ++sidx) t += bpartial[sidx * nbias + threadIdx.x];
     gb[threadIdx.x] = t;
   }
 }
 
-// (LDS: 4 waves x 19 rows x (W*Cout + 8) floats must stay under the 64 KB a launch gets without opting in)
-inline bool thin_mfma_ok(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
-  return kz == 3 && Cin == 128 && Cout <= 4 && W % 16 == 0 && W * Cout <= 192 && B * D * H >= 4 &&
-         B * D * H * W * 128 * 4 < (1LL << 44);
+// wide channels 64 | 128, thin <= 4, rows of 16-voxel groups, at most two 64-lane passes per thin row, LDS 4 waves x 19 rows x
+// (W*CT + 8) floats <= 150 KB (above 64 KB the launch opts in)
+inline bool thin_mfma_ok(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cwide, int64_t Cthin, int kz) {
+  return kz == 3 && (Cwide == 128 || Cwide == 64) && Cthin >= 1 && Cthin <= 4 && W % 16 == 0 && (W * Cthin) % 16 == 0 && W * Cthin <= 480 &&
+         B * D * H >= 4 && B * D * H * W * Cwide * 4 < (1LL << 44);
 }
+// instantiated combinations (others fall back to the generic kernels)
+inline bool thin_mfma_inst(int64_t W, int64_t Cwide, int64_t Cthin, bool swap) {
+  const bool two = W * Cthin > 256;
+  if (!swap && Cwide == 128 && !two) return true;                 // CT 1..4
+  return Cthin == 3;                                              // every (NJ, SWAP, NP) for three thin channels
+}
+// streams (waves) of the matrix-core thin weight gradient and its workspace floats
+static int thin_wgrad_streams(int64_t B, int64_t D, int64_t H) {
+  int64_t ns = 4 * df::kCUs;
+  const int64_t nrows = B * D * H;
+  if (ns > nrows) ns = nrows / 4 * 4;
+  return (int)ns;
+}
+static int64_t thin_wgrad_ws_floats(int64_t B, int64_t D, int64_t H, int64_t Cw, int64_t Ct, bool swap) {
+  return static_cast<int64_t>(thin_wgrad_streams(B, D, H)) * (27 * Ct * Cw + (swap ? Cw : Ct));
+}
+
 inline bool small_n_ok(int64_t Cin, int64_t Cout) { return Cout <= 4 && Cin % 64 == 0; }
 
 struct SmallPlan { int nrows, ncib, nstreams, rows_per, taps, CO; int64_t partial_elems; };
@@ -1879,9 +1929,16 @@ int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W
   if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
   if (small_n_ok(Cin, Cout)) {
     const SmallPlan sp = make_small_plan(B, D, H, Cin, Cout, kz);
-    return sp.partial_elems * static_cast<int64_t>(sizeof(float)) + kZeroBytes;
+    int64_t fl = sp.partial_elems;
+    if (thin_mfma_ok(B, D, H, W, Cin, Cout, kz)) {
+      const int64_t t = thin_wgrad_ws_floats(B, D, H, Cin, Cout, false);
+      if (t > fl) fl = t;
+    }
+    return fl * static_cast<int64_t>(sizeof(float)) + kZeroBytes;
   }
   int64_t best = 0;
+  if (Cin <= 4 && Cout >= 64 && thin_mfma_ok(B, D, H, W, Cout, Cin, kz))
+    best = thin_wgrad_ws_floats(B, D, H, Cout, Cin, true) * static_cast<int64_t>(sizeof(float));
   for (int algo = 0; algo <= 3; ++algo) {       // the launch may fall back (operand alignment), so size for the largest
     if ((algo == 1 && !wx_ok(W, Cin, Cout)) || (algo == 2 && !wxy_ok(H, W, Cin, Cout)) || (algo == 3 && !wxyz_ok(D, H, W, Cin, Cout, kz))) continue;
     const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, algo);
@@ -1889,6 +1946,47 @@ int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W
     if (n > best) best = n;
   }
   return best + zero_row_bytes(W, Cin, Cout);
+}
+
+static int launch_thin_wgrad(const float* wide, const float* thin, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
+                             int64_t Cw, int64_t Ct, bool swap, void* workspace, df_stream_t stream) {
+  ThinWgradArgs ta;
+  const int ns = thin_wgrad_streams(B, D, H);
+  const int nrows = (int)(B * D * H);
+  ta.x = wide; ta.g = thin; ta.partial = static_cast<float*>(workspace);
+  ta.bpartial = ta.partial + static_cast<int64_t>(ns) * 27 * Ct * Cw;
+  ta.B = (int)B; ta.D = (int)D; ta.H = (int)H; ta.W = (int)W;
+  ta.nrows = nrows; ta.nstreams = ns; ta.rows_per = (nrows + ns - 1) / ns;
+  ta.RS = (int)(W * Ct + 8);
+  const uint64_t xb = static_cast<uint64_t>(B * D * H * W) * static_cast<uint64_t>(Cw) * 4u;
+  ta.x_bytes_lo = static_cast<unsigned>(xb & 0xffffffffu); ta.x_bytes_hi = static_cast<unsigned>(xb >> 32);
+  if (!(static_cast<int64_t>(ta.rows_per) * W * Cw * 4 < (1LL << 32) && ns >= 4)) return 1;
+  hipStream_t s = df::as_stream(stream);
+  const size_t lds = static_cast<size_t>(4) * 19 * ta.RS * sizeof(float);
+  const dim3 grid((unsigned)(ns / 4));
+  const bool two = W * Ct > 256;
+#define DF_WT(CT, NJ, SW, NP)                                                                                                         \
+  do {                                                                                                                                \
+    if (lds > 65536) {                                                                                                                \
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_thin_mfma_kernel<CT, NJ, SW, NP>),                  \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))                                   \
+        return df::fail((int)e, "df_conv_wgrad: LDS opt-in: %s", hipGetErrorString(e));                                               \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((wgrad_thin_mfma_kernel<CT, NJ, SW, NP>), grid, dim3(kThreads), lds, s, ta);                                   \
+  } while (0)
+  if (!swap && Cw == 128 && !two) {
+    if (Ct == 1) DF_WT(1, 4, false, 1); else if (Ct == 2) DF_WT(2, 4, false, 1); else if (Ct == 3) DF_WT(3, 4, false, 1); else DF_WT(4, 4, false, 1);
+  } else if (!swap && Cw == 128) DF_WT(3, 4, false, 2);
+  else if (!swap && !two) DF_WT(3, 2, false, 1);
+  else if (!swap) DF_WT(3, 2, false, 2);
+  else if (Cw == 128 && !two) DF_WT(3, 4, true, 1);
+  else if (Cw == 128) DF_WT(3, 4, true, 2);
+  else if (!two) DF_WT(3, 2, true, 1);
+  else DF_WT(3, 2, true, 2);
+#undef DF_WT
+  hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)(27 * Ct * (Cw / 32))), dim3(kThreads), 0, s, ta.partial, ta.bpartial, gw, gb,
+                     ns, (int)(27 * Ct), (int)Ct, (int)Cw, swap ? 1 : 0);
+  return df::launched("df_conv_wgrad(thin mfma)");
 }
 
 static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
@@ -1902,32 +2000,14 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   DF_REQUIRE(df::aligned16(workspace), DF_EALIGN, "df_conv_wgrad: workspace must be 16-byte aligned");
   DF_REQUIRE(workspace_bytes >= df_conv_wgrad_workspace_bytes(B, D, H, W, Cin, Cout, kz), DF_EWORKSPACE,
              "df_conv_wgrad: workspace too small");
-  if (small_n_ok(Cin, Cout) && g_wgrad_algo != 1 && prec == 0 && thin_mfma_ok(B, D, H, W, Cin, Cout, kz) && df::aligned16(x) &&
-      df::aligned16(gy)) {
-    // matrix-core form; shares the workspace layout budget of the vector-ALU plan (never more streams than that plan has)
-    const SmallPlan sp = make_small_plan(B, D, H, Cin, Cout, kz);
-    ThinWgradArgs ta;
-    int ns = 4 * df::kCUs;
-    if (ns > sp.nstreams) ns = sp.nstreams / 4 * 4;
-    const int nrows = (int)(B * D * H);
-    if (ns > nrows) ns = nrows / 4 * 4;
-    ta.x = x; ta.g = gy; ta.partial = static_cast<float*>(workspace);
-    ta.bpartial = ta.partial + static_cast<int64_t>(ns) * 27 * Cout * 128;
-    ta.B = (int)B; ta.D = (int)D; ta.H = (int)H; ta.W = (int)W;
-    ta.nrows = nrows; ta.nstreams = ns; ta.rows_per = (nrows + ns - 1) / ns;
-    ta.RS = (int)(W * Cout + 8);
-    const uint64_t xb = static_cast<uint64_t>(B * D * H * W) * 128u * 4u;
-    ta.x_bytes_lo = static_cast<unsigned>(xb & 0xffffffffu); ta.x_bytes_hi = static_cast<unsigned>(xb >> 32);
-    if (static_cast<int64_t>(ta.rows_per) * W * 512 < (1LL << 32) && ns >= 4) {
-      hipStream_t s = df::as_stream(stream);
-      const size_t lds = static_cast<size_t>(4) * 19 * ta.RS * sizeof(float);
-      dim3 grid((unsigned)(ns / 4));
-#define DF_WT(CO) hipLaunchKernelGGL((wgrad_thin_mfma_kernel<CO>), grid, dim3(kThreads), lds, s, ta)
-      if (Cout == 1) DF_WT(1); else if (Cout == 2) DF_WT(2); else if (Cout == 3) DF_WT(3); else DF_WT(4);
-#undef DF_WT
-      hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)(27 * Cout * 4)), dim3(kThreads), 0, s, ta.partial, ta.bpartial, gw, gb,
-                         ns, (int)(27 * Cout), (int)Cout);
-      return df::launched("df_conv_wgrad(thin-N mfma)");
+  {
+    // matrix-core form of the thin layers: F -> 1..4 (wide = x, thin = gy) or 1..4 -> F (SWAP: wide = gy, thin = x)
+    const bool swap = Cin <= 4 && Cout >= 64;
+    const int64_t Cw = swap ? Cout : Cin, Ct = swap ? Cin : Cout;
+    if ((swap || small_n_ok(Cin, Cout)) && g_wgrad_algo != 1 && prec == 0 && thin_mfma_ok(B, D, H, W, Cw, Ct, kz) &&
+        thin_mfma_inst(W, Cw, Ct, swap) && df::aligned16(x) && df::aligned16(gy)) {
+      const int rc = launch_thin_wgrad(swap ? gy : x, swap ? x : gy, gw, gb, B, D, H, W, Cw, Ct, swap, workspace, stream);
+      if (rc != 1) return rc;      // 1: shape outside the kernel's 32-bit stream offsets -> generic path below
     }
   }
   if (small_n_ok(Cin, Cout)) {

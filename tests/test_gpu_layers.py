@@ -451,6 +451,31 @@ def test_thin_k_conv_mfma_epilogues_match_valu_kernel(ops, flags):
     assert ((ys[0] - ys[1]).abs().max() / ys[1].abs().max()).item() < 2e-6
 
 
+@pytest.mark.parametrize("shape,cin,cout", [((1, 3, 5, 32), 64, 3), ((1, 2, 2, 128), 64, 3), ((1, 2, 3, 112), 128, 3),      # F -> 3, 64 channels / two passes
+                                            ((1, 3, 5, 32), 3, 64), ((2, 2, 3, 64), 3, 128), ((1, 2, 2, 128), 3, 64),          # 3 -> F (SWAP)
+                                            ((1, 2, 3, 112), 3, 128), ((1, 1, 7, 16), 3, 64)])
+def test_thin_wgrad_mfma_orientations_vs_oracle(ops, shape, cin, cout):
+    """The matrix-core thin weight gradient in its other instantiations: 64-channel wide side, rows that need two 64-lane passes (LDS
+    opt-in above 64 KB), and the mirrored orientation 3 -> F (thin = x gathered with +offsets, wide = the gradient stream, bias gradient
+    = its column sums) -- the first layer of the auto-encoder."""
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream
+    rng = np.random.RandomState(cin + 2 * cout + sum(shape))
+    x = rng.uniform(-1, 1, shape + (cin,)).astype(np.float32)
+    g = rng.uniform(-1, 1, shape + (cout,)).astype(np.float32)
+    B, D, H, W = shape
+    s = _stream()
+    xt, gt = dev(x), dev(g)
+    gw = torch.full((3, 3, 3, cin, cout), float("nan"), device="cuda"); gb = torch.full((cout,), float("nan"), device="cuda")
+    nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, 3)
+    ws = torch.empty((nb + 3) // 4, device="cuda")
+    call("df_conv_wgrad", _ptr(xt), _ptr(gt), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, 3, _ptr(ws), nb, s)
+    w0 = np.zeros((3, 3, 3, cin, cout))
+    _, dw, db = orc.conv_same_bwd(x.astype(np.float64), w0, g.astype(np.float64))
+    assert rel_linf(host(gw), dw) < TOL
+    assert rel_linf(host(gb), db) < TOL
+
+
 @pytest.fixture
 def bf16x3(ops):
     ops.CONV_PRECISION = "bf16x3"
