@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_wxyz_reduce_kernel(const float
 
 // the Winograd-in-x variant exists for the fully unrolled row lengths below (even channel counts: float2 operand loads)
 inline bool wx_ok(int64_t W, int64_t Cin, int64_t Cout) {
-  return (W == 16 || W == 32 || W == 64 || W == 56 || W == 112 || W == 128) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
+  return (W == 16 || W == 32 || W == 64 || W == 56 || W == 112 || W == 128 || W == 96 || W == 48) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
 }
 inline bool wxy_ok(int64_t H, int64_t W, int64_t Cin, int64_t Cout) { return wx_ok(W, Cin, Cout) && H % 2 == 0 && H >= 4; }
 // (x,y,z): instantiated for the 128 -> 128 layers at W = 64 | 32 | 16 (cfg3) and 112 | 56 (cfg4)
@@ -2086,6 +2086,10 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     if (W == 64 && c128) DF_WXY(8, 128);
     else if (W == 64) DF_WXY(8, 0);
     else if (W == 128) DF_WXY(16, 0);      // AE3 128^3 (cfg5)
+    else if (W == 96 && c128) DF_WXY(12, 128);      // 2-D 128x96 (cfg1/cfg2) and its 64x48 level
+    else if (W == 96) DF_WXY(12, 0);
+    else if (W == 48 && c128) DF_WXY(6, 128);
+    else if (W == 48) DF_WXY(6, 0);
     else if (W == 112) DF_WXY(14, 0);      // cfg4 row lengths
     else if (W == 56) DF_WXY(7, 0);
     else if (W == 32 && c128) DF_WXY(4, 128);
@@ -2104,6 +2108,8 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     if (W == 64 && c128) hipLaunchKernelGGL((wgrad_wx_kernel<8, 128>), grid, dim3(kThreads), 0, s, a);
     else if (W == 64) hipLaunchKernelGGL((wgrad_wx_kernel<8, 0>), grid, dim3(kThreads), 0, s, a);
     else if (W == 128) hipLaunchKernelGGL((wgrad_wx_kernel<16, 0>), grid, dim3(kThreads), 0, s, a);
+    else if (W == 96) hipLaunchKernelGGL((wgrad_wx_kernel<12, 0>), grid, dim3(kThreads), 0, s, a);
+    else if (W == 48) hipLaunchKernelGGL((wgrad_wx_kernel<6, 0>), grid, dim3(kThreads), 0, s, a);
     else if (W == 112) hipLaunchKernelGGL((wgrad_wx_kernel<14, 0>), grid, dim3(kThreads), 0, s, a);
     else if (W == 56) hipLaunchKernelGGL((wgrad_wx_kernel<7, 0>), grid, dim3(kThreads), 0, s, a);
     else if (W == 32 && c128) hipLaunchKernelGGL((wgrad_wx_kernel<4, 128>), grid, dim3(kThreads), 0, s, a);
