@@ -1551,23 +1551,32 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_small_n_kernel(const SmallW
   }
 }
 
-// gw[tap][ci][co] = sum_stream partial[stream][tap][ci][co]  (fixed order)
+// gw[tap][ci][co] = sum_stream partial[stream][tap][ci][co]  (fixed order: workgroup = 32 consecutive elements x 8 interleaved stream
+// groups, the 8 group sums combined in order through LDS)
 __global__ __launch_bounds__(kThreads) void wgrad_small_reduce_kernel(const float* __restrict__ partial,
                                                                       const float* __restrict__ bpartial,
                                                                       float* __restrict__ gw, float* __restrict__ gb,
                                                                       int nstreams, int64_t per_stream, int CO,
                                                                       int Cout) {
+  __shared__ float sP[8][32];
   if (gb && blockIdx.x == 0 && threadIdx.x < Cout) {
     float acc = 0.f;
     for (int sidx = 0; sidx < nstreams; ++sidx) acc += bpartial[sidx * CO + threadIdx.x];
     gb[threadIdx.x] = acc;
   }
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < per_stream;
-       i += static_cast<int64_t>(gridDim.x) * kThreads) {
-    float acc = 0.f;
-    for (int sidx = 0; sidx < nstreams; ++sidx) acc += partial[sidx * per_stream + i];
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 32 + el;
+  float acc = 0.f;
+  if (i < per_stream)
+    for (int sidx = grp; sidx < nstreams; sidx += 8) acc += partial[sidx * per_stream + i];
+  sP[grp][el] = acc;
+  __syncthreads();
+  if (grp == 0 && i < per_stream) {
+    float t = sP[0][el];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += sP[k][el];
     const int co = static_cast<int>(i % CO);
-    if (co < Cout) gw[(i / CO) * Cout + co] = acc;
+    if (co < Cout) gw[(i / CO) * Cout + co] = t;
   }
 }
 
@@ -2028,7 +2037,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     else { if (Cout == 1) DF_WS(1, 1); else if (Cout == 2) DF_WS(1, 2); else if (Cout == 3) DF_WS(1, 3); else DF_WS(1, 4); }
 #undef DF_WS
     const int64_t per = static_cast<int64_t>(sp.taps) * Cin * sp.CO;
-    int64_t rg = ceil_div(per, kThreads);
+    int64_t rg = ceil_div(per, 32);
     hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, sa.partial, sa.bpartial, gw,
                        gb, sp.nstreams, per, sp.CO, (int)Cout);
     return df::launched("df_conv_wgrad(small-N)");
@@ -2132,6 +2141,8 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   else if (xvec && gvec && exact && wp8 == 12) hipLaunchKernelGGL((wgrad_kernel<true, true, 12>), grid, dim3(kThreads), 0, s, a);
   else if (xvec && gvec && exact && wp8 == 7) hipLaunchKernelGGL((wgrad_kernel<true, true, 7>), grid, dim3(kThreads), 0, s, a);
   else if (xvec && gvec && exact && wp8 == 2) hipLaunchKernelGGL((wgrad_kernel<true, true, 2>), grid, dim3(kThreads), 0, s, a);
+  else if (xvec && gvec && exact && wp8 == 3) hipLaunchKernelGGL((wgrad_kernel<true, true, 3>), grid, dim3(kThreads), 0, s, a);
+  else if (xvec && gvec && exact && wp8 == 6) hipLaunchKernelGGL((wgrad_kernel<true, true, 6>), grid, dim3(kThreads), 0, s, a);
   else if (xvec && gvec) hipLaunchKernelGGL((wgrad_kernel<true, true, 0>), grid, dim3(kThreads), 0, s, a);
   else if (xvec) hipLaunchKernelGGL((wgrad_kernel<true, false, 0>), grid, dim3(kThreads), 0, s, a);
   else if (gvec) hipLaunchKernelGGL((wgrad_kernel<false, true, 0>), grid, dim3(kThreads), 0, s, a);
@@ -2259,6 +2270,8 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   const dim3 grid2((unsigned)(p.nranges * (p.ndzdy / 2)), grid.y, grid.z);     // one workgroup per x-parity class PAIR
   if (prec == 1 && wgrad_bf16x3_ok(Wc, Cin, Cout)) launch_wgrad_bf16x3(Wc, grid, s, a);
   else if (prec == 0 && aligned8 && exact && wp8 == 4 && Cin == 128 && Cout == 128 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<4, 128>), grid2, dim3(kThreads), 0, s, a);
+  else if (prec == 0 && aligned8 && exact && wp8 == 6 && Cin == 128 && Cout == 128 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<6, 128>), grid2, dim3(kThreads), 0, s, a);      // 2-D 128x96: coarse W = 48 | 24
+  else if (prec == 0 && aligned8 && exact && wp8 == 3 && Cin == 128 && Cout == 128 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<3, 128>), grid2, dim3(kThreads), 0, s, a);
   else if (prec == 0 && aligned8 && exact && wp8 == 2 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<2, 0>), grid2, dim3(kThreads), 0, s, a);
   else if (prec == 0 && aligned8 && exact && wp8 == 1 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<1, 0>), grid2, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);

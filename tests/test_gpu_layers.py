@@ -79,7 +79,7 @@ CASES_2D = [
 @pytest.mark.parametrize("algo", [1, 2, 3])
 @pytest.mark.parametrize("shape,cin,cout,leak", [((3, 2, 2, 64), 128, 128, 0.2), ((1, 2, 6, 32), 32, 64, 0.2), ((2, 3, 4, 16), 32, 96, None),
                                                  ((2, 8, 32), 64, 64, 0.2), ((1, 2, 4, 56), 32, 32, 0.2), ((1, 1, 2, 112), 32, 32, None), ((1, 2, 2, 128), 64, 64, 0.2), ((2, 8, 96), 128, 128, 0.2), ((1, 4, 48), 32, 64, None),
-                                                 ((1, 2, 4, 96), 32, 32, 0.2)])
+                                                 ((1, 2, 4, 96), 32, 32, 0.2), ((1, 6, 24), 64, 64, 0.2)])
 def test_conv_wgrad_algorithms(ops, shape, cin, cout, leak, algo):
     """df_conv_wgrad forced to the direct kernel (1), Winograd in x (2) and Winograd in (x,y) (3) -- the default picks by size --
     against the fp64 oracle; the last case is 2-D (kz = 1)."""
@@ -269,7 +269,8 @@ def test_colsum(ops):
 
 
 @pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 16), ((2, 4, 6, 8), 32), ((1, 3, 5, 7), 128), ((2, 8, 16), 16),
-                                      ((1, 5, 9), 128), ((1, 2, 2, 32), 64), ((1, 2, 2, 32), 128), ((2, 1, 3, 16), 64)])
+                                      ((1, 5, 9), 128), ((1, 2, 2, 32), 64), ((1, 2, 2, 32), 128), ((2, 1, 3, 16), 64),
+                                      ((1, 3, 24), 128), ((1, 2, 48), 128)])
 def test_upconv_block_vs_materialised_upsample(ops, cshape, C):
     """The up-sampling-aware fused block (parity-class convs on the coarse grid) == upscale + conv + ... + add of the
     oracle, forward and every gradient (input, 27-tap weights, biases)."""
