@@ -68,6 +68,8 @@ SIGNATURES = {
     "df_wino2d_packed_elems": (I64, [I64, I64, I32]),
     "df_wino2d_pack_weights": (I32, [P, P, I64, I64, I32, P]),
     "df_wino2d_conv_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, F32, P]),
+    "df_wino2d_upconv_fwd": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I32, F32, P]),
+    "df_wino2d_upconv_dgrad": (I32, [P, P, P, I64, I64, I64, I64, I64, P]),
     "df_conv_packed_elems_bf16x3": (I64, [I64, I64, I64, I32]),
     "df_conv_pack_weights_bf16x3": (I32, [P, P, I64, I64, I64, I32, P]),
     "df_conv_fwd_bf16x3": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),

@@ -112,8 +112,12 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 
 struct Blk { const float* xb; int hoff, b, y0, x0; };
 
-template <int FL>
+// MODE 1 (UP): x is the COARSE image of an up-sampling-aware conv (fine pixel p reads xc[p >> 1]; a.H, a.W are the fine extents): the
+// transform points with index 2 vanish for the duplicated input, 9 of the 16 products remain.  MODE 2 (POOL): the adjoint -- the output
+// is the 2x2 sum-pool of the convolution, accumulated into the coarse image y; the pooled inverse transform is (1, 2, 0, -1) per axis.
+template <int FL, int MODE = 0>
 __global__ __launch_bounds__(kT, 1) void wino2d_kernel(const Wino2dArgs a) {
+  constexpr bool UP = MODE == 1, POOL = MODE == 2, P9 = MODE != 0;
   __shared__ __attribute__((aligned(16))) float sIn[2 * BUF];
   __shared__ __attribute__((aligned(16))) float sW[2 * WBUF];
   const int eflags = FL >= 0 ? FL : a.flags;
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(kT, 1) void wino2d_kernel(const Wino2dArgs a) {
     const int by = t2 % a.nby;
     bi.b = t2 / a.nby;
     bi.y0 = by * 16; bi.x0 = bx * 32;
-    bi.xb = a.x + static_cast<int64_t>(bi.b) * a.H * a.W * a.Cin;
+    bi.xb = a.x + static_cast<int64_t>(bi.b) * (UP ? (a.H >> 1) * (a.W >> 1) : a.H * a.W) * a.Cin;
     bi.hoff = ((bi.y0 - 1) * a.W + (bi.x0 - 1)) * a.Cin;
     return bi;
   };
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(kT, 1) void wino2d_kernel(const Wino2dArgs a) {
     const int hv = p >> 2, q4 = p & 3;
     ldst[it] = ((q4 * 4) * CP + (hv / HX) * PY + hv % HX) * 4;
   }
-  const unsigned img_bytes = static_cast<unsigned>(a.H) * a.W * a.Cin * 4u;
+  const unsigned img_bytes = static_cast<unsigned>(UP ? (a.H >> 1) * (a.W >> 1) : a.H * a.W) * a.Cin * 4u;
   auto set_offs = [&](const Blk& bi) {
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
@@ -178,7 +182,8 @@ __global__ __launch_bounds__(kT, 1) void wino2d_kernel(const Wino2dArgs a) {
       const int hx = hv % HX, hy = hv / HX;
       const int gy = bi.y0 - 1 + hy, gx = bi.x0 - 1 + hx;
       const bool ok = static_cast<unsigned>(gy) < static_cast<unsigned>(a.H) && static_cast<unsigned>(gx) < static_cast<unsigned>(a.W);
-      so[it] = ok ? static_cast<unsigned>(bi.hoff + (hy * a.W + hx) * a.Cin + q4 * 4) * 4u : 0x80000000u;
+      if (UP) so[it] = ok ? static_cast<unsigned>(((gy >> 1) * (a.W >> 1) + (gx >> 1)) * a.Cin + q4 * 4) * 4u : 0x80000000u;
+      else so[it] = ok ? static_cast<unsigned>(bi.hoff + (hy * a.W + hx) * a.Cin + q4 * 4) * 4u : 0x80000000u;
     }
   };
   char* sInB = reinterpret_cast<char*>(sIn);
@@ -296,13 +301,31 @@ __global__ __launch_bounds__(kT, 1) void wino2d_kernel(const Wino2dArgs a) {
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
           for (int i = 0; i < 16; ++i)
-            acc[nb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[nb][i >> 2][i & 3], acc[nb][i], 0, 0, 0);
+            if (!P9 || ((i >> 2) != 2 && (i & 3) != 2))
+              acc[nb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[nb][i >> 2][i & 3], acc[nb][i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
 
     // ---- epilogue: inverse transform in registers; accumulator element e of lane (kq, tl) = tile 4 kq + e, cout = tl (+16 nb) ---
-    {
+    if constexpr (POOL) {
+      const int Hc = a.H >> 1, Wc = a.W >> 1;
+      const int cy = (cur.y0 >> 1) + wave;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cx = (cur.x0 >> 1) + 4 * kq + e;
+          float py[4];
+#pragma unroll
+          for (int yy = 0; yy < 4; ++yy)
+            py[yy] = yy == 2 ? 0.f : acc[nb][yy * 4 + 0][e] + 2.f * acc[nb][yy * 4 + 1][e] - acc[nb][yy * 4 + 3][e];
+          if (cy < Hc && cx < Wc) {
+            float* yo = a.y + ((static_cast<int64_t>(cur.b) * Hc + cy) * Wc + cx) * a.Cout + n0 + nb * 16 + tl;
+            *yo += py[0] + 2.f * py[1] - py[3];
+          }
+        }
+    } else {
       const int oy0 = cur.y0 + 2 * wave;
       const int64_t sW_ = a.Cout, sH_ = static_cast<int64_t>(a.W) * a.Cout;
       const bool full = cur.y0 + 16 <= a.H && cur.x0 + 32 <= a.W;      // workgroup-uniform
@@ -327,10 +350,15 @@ __global__ __launch_bounds__(kT, 1) void wino2d_kernel(const Wino2dArgs a) {
           f32x2 px[4];
 #pragma unroll
           for (int yy = 0; yy < 4; ++yy) {
-            px[yy][0] = acc[nb][yy * 4 + 0][e] + acc[nb][yy * 4 + 1][e] + acc[nb][yy * 4 + 2][e];
-            px[yy][1] = acc[nb][yy * 4 + 1][e] - acc[nb][yy * 4 + 2][e] - acc[nb][yy * 4 + 3][e];
+            if (P9) {      // the xi = 2 points were never multiplied
+              px[yy][0] = acc[nb][yy * 4 + 0][e] + acc[nb][yy * 4 + 1][e];
+              px[yy][1] = acc[nb][yy * 4 + 1][e] - acc[nb][yy * 4 + 3][e];
+            } else {
+              px[yy][0] = acc[nb][yy * 4 + 0][e] + acc[nb][yy * 4 + 1][e] + acc[nb][yy * 4 + 2][e];
+              px[yy][1] = acc[nb][yy * 4 + 1][e] - acc[nb][yy * 4 + 2][e] - acc[nb][yy * 4 + 3][e];
+            }
           }
-          const f32x2 o01 = px[0] + px[1] + px[2], o23 = px[1] - px[2] - px[3];
+          const f32x2 o01 = P9 ? px[0] + px[1] : px[0] + px[1] + px[2], o23 = P9 ? px[1] - px[3] : px[1] - px[2] - px[3];
           const float ov[4] = {o01[0], o01[1], o23[0], o23[1]};
           const int ox0 = cur.x0 + 2 * (4 * kq + e);
 #pragma unroll
@@ -379,6 +407,23 @@ int df_wino2d_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout,
   return df::launched("df_wino2d_pack_weights");
 }
 
+static int64_t wino2d_grid(Wino2dArgs& a, int64_t ntb) {
+  int64_t grid = df::kCUs;
+  a.spx = 1;
+  if (8 % a.ncs == 0) {
+    a.spx = (g_wino2d_spx > 0 && a.ncs % g_wino2d_spx == 0) ? g_wino2d_spx : (a.ncs % 2 == 0 ? 2 : 1);
+    const int xpg = a.ncs / a.spx, ngroups = 8 / xpg;
+    const int64_t need = ceil_div(ntb, ngroups) * a.spx * 8;
+    if (need < grid) grid = need;
+    if ((grid >> 3) % a.spx) grid = ((grid >> 3) / a.spx + 1) * a.spx * 8;
+    if (grid > df::kCUs) grid = df::kCUs;
+  } else {
+    grid = (grid / a.ncs) * a.ncs;
+    if (ntb * a.ncs < grid) grid = ntb * a.ncs;
+  }
+  return grid;
+}
+
 int df_wino2d_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
                        float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak,
                        df_stream_t stream) {
@@ -402,19 +447,7 @@ int df_wino2d_conv_fwd(const float* x, const float* wp, const float* bias, const
   DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino2d_conv_fwd: too many workgroups");
   a.ntb = (int)ntb;
   a.flags = flags; a.leak = leak;
-  int64_t grid = df::kCUs;
-  a.spx = 1;
-  if (8 % a.ncs == 0) {
-    a.spx = (g_wino2d_spx > 0 && a.ncs % g_wino2d_spx == 0) ? g_wino2d_spx : (a.ncs % 2 == 0 ? 2 : 1);
-    const int xpg = a.ncs / a.spx, ngroups = 8 / xpg;
-    const int64_t need = ceil_div(ntb, ngroups) * a.spx * 8;
-    if (need < grid) grid = need;
-    if ((grid >> 3) % a.spx) grid = ((grid >> 3) / a.spx + 1) * a.spx * 8;
-    if (grid > df::kCUs) grid = df::kCUs;
-  } else {
-    grid = (grid / a.ncs) * a.ncs;
-    if (ntb * a.ncs < grid) grid = ntb * a.ncs;
-  }
+  const int64_t grid = wino2d_grid(a, ntb);
   const dim3 g((unsigned)grid), b(kT);
   hipStream_t s = df::as_stream(stream);
   if (flags == (DF_CONV_BIAS | DF_CONV_LRELU)) hipLaunchKernelGGL((wino2d_kernel<DF_CONV_BIAS | DF_CONV_LRELU>), g, b, 0, s, a);
@@ -422,6 +455,48 @@ int df_wino2d_conv_fwd(const float* x, const float* wp, const float* bias, const
   else if (flags == DF_CONV_RESIDUAL) hipLaunchKernelGGL((wino2d_kernel<DF_CONV_RESIDUAL>), g, b, 0, s, a);
   else hipLaunchKernelGGL((wino2d_kernel<-1>), g, b, 0, s, a);
   return df::launched("df_wino2d_conv_fwd");
+}
+
+static int wino2d_up_common(const char* fn, Wino2dArgs& a, const float* wp, int64_t B, int64_t Hc, int64_t Wc, int64_t K, int64_t N) {
+  DF_REQUIRE(B > 0 && Hc > 0 && Wc > 0, DF_EINVAL, "%s: non-positive extent", fn);
+  DF_REQUIRE(K > 0 && N > 0 && K % 32 == 0 && N % 32 == 0, DF_ESHAPE, "%s: channel counts must be multiples of 32", fn);
+  DF_REQUIRE(4 * Hc * Wc * (K > N ? K : N) <= (1LL << 29) && K * N <= (1LL << 24), DF_ESHAPE, "%s: one image must stay below 2 GiB", fn);
+  DF_REQUIRE(df::aligned16(wp), DF_EALIGN, "%s: packed weights must be 16-byte aligned", fn);
+  a.wp = reinterpret_cast<const f32x4*>(wp);
+  a.B = (int)B; a.H = (int)(2 * Hc); a.W = (int)(2 * Wc); a.Cin = (int)K; a.Cout = (int)N;      // fine extents
+  a.nby = (int)ceil_div(a.H, 16); a.nbx = (int)ceil_div(a.W, 32);
+  const int64_t ntb = B * a.nby * a.nbx;
+  a.ncs = (int)(N / 32);
+  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "%s: too many workgroups", fn);
+  a.ntb = (int)ntb;
+  return DF_OK;
+}
+
+int df_wino2d_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Hc, int64_t Wc, int64_t Cin,
+                         int64_t Cout, int flags, float leak, df_stream_t stream) {
+  DF_REQUIRE(xc && wp && y && bias, DF_EINVAL, "df_wino2d_upconv_fwd: null pointer");
+  DF_REQUIRE(flags == (DF_CONV_BIAS | DF_CONV_LRELU), DF_EINVAL, "df_wino2d_upconv_fwd: flags must be DF_CONV_BIAS | DF_CONV_LRELU");
+  DF_REQUIRE(df::aligned16(xc), DF_EALIGN, "df_wino2d_upconv_fwd: xc must be 16-byte aligned");
+  Wino2dArgs a;
+  if (int rc = wino2d_up_common("df_wino2d_upconv_fwd", a, wp, B, Hc, Wc, Cin, Cout)) return rc;
+  a.x = xc; a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y;
+  a.flags = flags; a.leak = leak;
+  const int64_t grid = wino2d_grid(a, a.ntb);
+  hipLaunchKernelGGL((wino2d_kernel<DF_CONV_BIAS | DF_CONV_LRELU, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+  return df::launched("df_wino2d_upconv_fwd");
+}
+
+int df_wino2d_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout,
+                           df_stream_t stream) {
+  DF_REQUIRE(g && wp && acc, DF_EINVAL, "df_wino2d_upconv_dgrad: null pointer");
+  DF_REQUIRE(df::aligned16(g), DF_EALIGN, "df_wino2d_upconv_dgrad: g must be 16-byte aligned");
+  Wino2dArgs a;      // the adjoint conv reads g (Cout channels, fine grid) and produces Cin channels on the coarse grid
+  if (int rc = wino2d_up_common("df_wino2d_upconv_dgrad", a, wp, B, Hc, Wc, Cout, Cin)) return rc;
+  a.x = g; a.bias = nullptr; a.residual = nullptr; a.mask_src = nullptr; a.y = acc;
+  a.flags = 0; a.leak = 0.f;
+  const int64_t grid = wino2d_grid(a, a.ntb);
+  hipLaunchKernelGGL((wino2d_kernel<0, 2>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+  return df::launched("df_wino2d_upconv_dgrad");
 }
 
 }  // extern "C"

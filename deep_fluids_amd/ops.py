@@ -388,6 +388,12 @@ class _UpGenBlock(torch.autograd.Function):
                 x = torch.empty(fshape, dtype=torch.float32, device=xc.device)
                 call("df_wino_upconv_fwd", _ptr(xc), _ptr(wp), _ptr(b), _ptr(x), cdims[0], cdims[1], cdims[2], cdims[3], cin, cout,
                      DF_CONV_BIAS | DF_CONV_LRELU, float(leak), _stream())
+            elif i == 0 and not is3d and _use_wino(cin, cout, fdims, kz) == 2:
+                # 2-D twin: 9 of the 16 Winograd products (conv_wino2d.hip, UP variant)
+                wp = _pack(w, taps, cin, cout, 0, fdims)
+                x = torch.empty(fshape, dtype=torch.float32, device=xc.device)
+                call("df_wino2d_upconv_fwd", _ptr(xc), _ptr(wp), _ptr(b), _ptr(x), cdims[0], cdims[2], cdims[3], cin, cout,
+                     DF_CONV_BIAS | DF_CONV_LRELU, float(leak), _stream())
             elif i == 0:
                 sfx = _sfx(cin, cout)
                 wp = torch.empty(query("df_upconv_packed_elems" + sfx, cin, cout, kz, 0), dtype=torch.float32,
@@ -450,6 +456,9 @@ class _UpGenBlock(torch.autograd.Function):
                         wpd = _pack(w, taps, C, C, 1, fdims)
                         call("df_wino_upconv_dgrad", _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, C,
                              _stream())
+                    elif not is3d and _use_wino(C, C, fdims, kz) == 2:
+                        wpd = _pack(w, taps, C, C, 1, fdims)
+                        call("df_wino2d_upconv_dgrad", _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[2], cdims[3], C, C, _stream())
                     else:
                         sfx = _sfx(C, C)
                         wpd = torch.empty(query("df_upconv_packed_elems" + sfx, C, C, kz, 1), dtype=torch.float32,

@@ -224,6 +224,14 @@ int df_wino2d_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout,
 int df_wino2d_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,
                        float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak,
                        df_stream_t stream);
+/* 2-D up-sampling-aware forms (9 of the 16 Winograd products): forward y[B,2Hc,2Wc,Cout] = lrelu(conv_same(nearest_up2x(xc), w) + bias)
+ * (mode-0 pack of df_wino2d_pack_weights; flags = DF_CONV_BIAS | DF_CONV_LRELU) and its adjoint acc[B,Hc,Wc,Cin] += sum-pool2x(conv_same^T(g, w))
+ * (mode-1 pack).  Drop-ins for df_upconv_fwd / df_upconv_dgrad with kz = 1, channels multiples of 32. */
+int df_wino2d_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Hc, int64_t Wc, int64_t Cin,
+                         int64_t Cout, int flags, float leak, df_stream_t stream);
+int df_wino2d_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout,
+                           df_stream_t stream);
+
 
 /* ---- opt-in "bf16x3" precision mode (conv_bf16.hip) ---------------------------------------------------------------------
  * fp32 operands are split a = hi + lo into two bf16 words and a*b ~= hi*hi + hi*lo + lo*hi runs on the bf16 matrix pipe

@@ -270,7 +270,7 @@ def test_colsum(ops):
 
 @pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 16), ((2, 4, 6, 8), 32), ((1, 3, 5, 7), 128), ((2, 8, 16), 16),
                                       ((1, 5, 9), 128), ((1, 2, 2, 32), 64), ((1, 2, 2, 32), 128), ((2, 1, 3, 16), 64),
-                                      ((1, 3, 24), 128), ((1, 2, 48), 128)])
+                                      ((1, 3, 24), 128), ((1, 2, 48), 128), ((1, 8, 12), 32), ((2, 9, 20), 64)])
 def test_upconv_block_vs_materialised_upsample(ops, cshape, C):
     """The up-sampling-aware fused block (parity-class convs on the coarse grid) == upscale + conv + ... + add of the
     oracle, forward and every gradient (input, 27-tap weights, biases)."""
@@ -366,9 +366,11 @@ def test_upconv_block_wgrad_winograd_xyz_27point(ops, cshape):
         lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
 
 
-@pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 32), ((1, 3, 5, 7), 128), ((1, 2, 2, 32), 64)])
+@pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 32), ((1, 3, 5, 7), 128), ((1, 2, 2, 32), 64), ((1, 5, 9), 128), ((2, 8, 16), 32),
+                                      ((1, 3, 24), 128), ((1, 1, 1), 32)])
 def test_upconv_block_winograd_forced(ops, cshape, C):
-    """The fused up-sampling block with the Winograd kernels forced on small/ragged grids (forward through df_wino_upconv_fwd)."""
+    """The fused up-sampling block with the Winograd kernels forced on small/ragged grids (forward through df_wino_upconv_fwd, adjoint
+    through df_wino_upconv_dgrad; 2-D: df_wino2d_upconv_fwd / _dgrad, 9 of 16 products)."""
     old = ops.CONV_ALGO
     ops.CONV_ALGO = "winograd"
     try:
