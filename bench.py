@@ -1,29 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- the Deep Fluids velocity-field train step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+
+N > 1: one rank per GPU over RCCL.  Either launch it under ``python -m torch.distributed.run --nproc-per-node N ...`` (the
+ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or run it as plain ``python bench.py --gpus N``:
+without WORLD_SIZE in the environment the script re-executes itself under torch.distributed.run on 127.0.0.1.
 
 Workload (config.workload): BASELINE cfg3 = 3-D 64x96x64 grid (Z,Y,X), 3-channel stream function / velocity,
-GeneratorBE3 with filters=128, num_conv=4 (18 layers, 7,483,523 parameters), fp32 end to end, per-GPU batch 16,
-one full step = generator fwd -> curl3 -> jacobian3 -> L1 + Jacobian-L1 -> backward -> (grad all-reduce) -> TF1 Adam
--> cosine LR.  Synthetic inputs resident in HBM, random-init (Xavier) weights.  Weak scaling: the global batch is
-16 * N.  Prints ONE JSON line on rank 0.
+GeneratorBE3 with filters=128, num_conv=4 (18 layers, 7,483,523 parameters), fp32 end to end, one full step = generator
+fwd -> curl3 -> jacobian3 -> L1 + Jacobian-L1 -> backward -> (bucketed grad all-reduce, overlapped) -> TF1 Adam ->
+cosine LR.  Synthetic inputs resident in HBM, random-init (Xavier) weights.
+  --scaling weak   (default) per-GPU batch 16, global batch 16 N;
+  --scaling strong global batch 16 split N ways (16 -> 2 per GPU at N = 8).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 peak
 PEAK_HBM_GBS = 8000.0
+# fraction of the convolution's algorithmic (direct-form) multiply-adds the Winograd kernels execute on the matrix pipe
+EXEC_RATIO = {"wino3d_kernel": 8.0 / 27.0, "wino2d_kernel": 4.0 / 9.0, "conv_mfma_kernel": 1.0, "wgrad_kernel": None}
 
 
 def parse():
@@ -31,22 +37,33 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=16, help="weak: per-GPU batch; strong: GLOBAL batch (split over the GPUs)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--res", type=int, nargs=3, default=[64, 96, 64], metavar=("Z", "Y", "X"))
     ap.add_argument("--filters", type=int, default=128)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"],
-                    help="cfg3 = the BASELINE metric (3-D); cfg2 = 2-D 128x96 per-GPU batch 64 (diagnostic only)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="conv arithmetic: fp32 = exact fp32 MFMA (the BASELINE cfg3 dtype, default); bf16x3 = opt-in split-bf16 "
                          "MFMA mode (16-bit operand significands, fp32 accumulate)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3-mode measurement appended at N=1")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra measurements appended at N=1 (bf16x3 mode, 2-D, cfg4, AE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
+def self_launch(a):
+    """``python bench.py --gpus N`` without a launcher: re-execute under torch.distributed.run (one rank per GPU, rendezvous
+    on 127.0.0.1 -- the container hostname may not resolve) and hand its exit code back."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def make_inputs(batch, res, seed, ops):
     """y ~ U(-1,1) [B,3]; x = curl3(psi_gt) rescaled to max|x| = 1 (divergence-free, in [-1,1])."""
+    import torch
     g = torch.Generator(device="cuda").manual_seed(seed)
     y = torch.rand((batch, 3), device="cuda", generator=g) * 2 - 1
     psi = torch.rand((batch, res[0], res[1], res[2], 3), device="cuda", generator=g) * 2 - 1
@@ -56,28 +73,48 @@ def make_inputs(batch, res, seed, ops):
 
 
 def select_kernel(name, args):
-    """KernelTimer filter: the three kernels whose rooflines are reported."""
+    """KernelTimer filter: the kernels whose rooflines are reported.  work = ALGORITHMIC flops (direct form) / bytes."""
     if name == "df_conv_fwd":
-        B, D, H, W, cin, cout = args[6:12]
+        B, D, H, W, cin, cout, kz = args[6:13]
         if cin >= 64 and cout >= 64:
-            return ("conv_mfma_kernel fwd/dgrad %dx%dx%d C%d->%d" % (D, H, W, cin, cout), 2.0 * 27 * cin * cout * B * D * H * W)
-    if name == "df_wino_conv_fwd":
+            return ("conv_mfma_kernel fwd/dgrad %dx%dx%d C%d->%d" % (D, H, W, cin, cout), 2.0 * (27 if kz == 3 else 9) * cin * cout * B * D * H * W)
+    if name in ("df_wino_conv_fwd", "df_wino_conv_fwd_addup"):
         B, D, H, W, cin, cout = args[6:12]
-        # work = ALGORITHMIC flops of the convolution (what the direct kernel executes); the Winograd kernel executes 8/27 of it
         return ("wino3d_kernel fwd/dgrad %dx%dx%d C%d->%d" % (D, H, W, cin, cout), 2.0 * 27 * cin * cout * B * D * H * W)
-    if name == "df_conv_wgrad":
-        B, D, H, W, cin, cout = args[4:10]
+    if name == "df_wino2d_conv_fwd":
+        B, H, W, cin, cout = args[6:11]
+        return ("wino2d_kernel fwd/dgrad %dx%d C%d->%d" % (H, W, cin, cout), 2.0 * 9 * cin * cout * B * H * W)
+    if name == "df_conv_wgrad_algo":
+        B, D, H, W, cin, cout, kz = args[4:11]
         if cin >= 64 and cout >= 64:
-            return ("wgrad_kernel %dx%dx%d C%dx%d" % (D, H, W, cin, cout), 2.0 * 27 * cin * cout * B * D * H * W)
+            return ("wgrad_kernel %dx%dx%d C%dx%d" % (D, H, W, cin, cout), 2.0 * (27 if kz == 3 else 9) * cin * cout * B * D * H * W)
     if name == "df_jacobian3d_fwd" and args[1] is not None and args[2] is not None:
         B, Z, Y, X = args[3:7]
         return ("jacobian3d_fwd_kernel<j,c>", 60.0 * B * Z * Y * X)
+    if name == "df_jacobian3d_bwd":
+        B, Z, Y, X = args[3:7]
+        nb = (36.0 if args[0] is not None else 0.0) + (12.0 if args[1] is not None else 0.0) + 12.0
+        return ("jacobian3d_bwd_kernel<%s>" % ("j" if args[0] is not None else "c"), nb * B * Z * Y * X)
+    if name == "df_jacobian2d_fwd":
+        B, Y, X = args[3:6]
+        return ("jacobian2d_fwd_kernel", 28.0 * B * Y * X)
     return None
 
 
+def wgrad_exec_ratio(D, H, W):
+    """Executed / algorithmic multiply-adds of the default weight-gradient form at 128 -> 128 (conv_wgrad.hip::wgrad_algo):
+    Winograd-(x,y,z) 8/27 from 4096 image rows at the W the kernel is instantiated for, (x,y) 4/9 in 2-D."""
+    if D > 1:
+        return 8.0 / 27.0 if (W in (16, 32, 64, 56, 112, 128) and D % 2 == 0 and H % 2 == 0) else 1.0
+    return 4.0 / 9.0 if (W in (16, 32, 64, 56, 112, 128, 96, 48) and H % 2 == 0) else 1.0
+
+
 def cpu_baseline(res, filters, budget_s):
-    """The oracle's PyTorch-CPU restatement of the SAME train step, timed on this node's host cores on a bounded
-    sample (batch 1, grid halved per axis).  A reported baseline, not the optimisation target."""
+    """The oracle's PyTorch-CPU restatement of the SAME train step, timed on this node's host cores at the FULL grid of the
+    workload, batch 1 (a bounded sample: one warm-up step + as many timed steps as fit the budget, at least one).  A reported
+    baseline, not the optimisation target."""
+    import numpy as np
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import df_oracle as orc
     import df_oracle_torch as ort
@@ -85,9 +122,9 @@ def cpu_baseline(res, filters, budget_s):
         cores = len(os.sched_getaffinity(0))          # cores this process may actually use (cgroup / affinity)
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))                     # beyond one socket the small per-level convs only thrash
+    cores = max(1, min(cores, 64))                     # beyond one socket the per-level convs only thrash
     torch.set_num_threads(cores)
-    sres = [max(r // 4, 8) for r in res]
+    sres = list(res)
     rng = np.random.RandomState(123)
     oshape = sres + [3]
     p = ort.to_torch(orc.generator_init(rng, 3, oshape, filters))
@@ -95,18 +132,15 @@ def cpu_baseline(res, filters, budget_s):
     x, y = orc.synthetic_batch(rng, 1, sres)
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
     t0 = time.time()
-    ort.train_step(yt, xt, p, opt, oshape, filters, True)           # warm-up (thread pools, oneDNN primitives)
+    ort.train_step(yt, xt, p, opt, oshape, filters, True)           # warm-up (thread pools, oneDNN primitives, page faults)
     warm = time.time() - t0
     n, t0, el = 0, time.time(), 0.0
-    if warm < budget_s:
-        while True:
-            ort.train_step(yt, xt, p, opt, oshape, filters, True)
-            n += 1
-            el = time.time() - t0
-            if el >= budget_s or n >= 50:
-                break
-    else:                                                            # pathologically slow host: keep the one step
-        n, el = 1, warm
+    while True:
+        ort.train_step(yt, xt, p, opt, oshape, filters, True)
+        n += 1
+        el = time.time() - t0
+        if el + el / n > budget_s - warm or n >= 50:
+            break
     vox = float(np.prod(sres))
     model = ""
     try:
@@ -117,14 +151,16 @@ def cpu_baseline(res, filters, budget_s):
     except OSError:
         pass
     return {"value": vox * n / el, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": "PyTorch-CPU fp32 restatement of the reference graph (TF 1.15 unavailable): %d full train steps, "
-                      "batch 1, grid %dx%dx%d, filters %d, %d threads, %.1f s" % (n, sres[0], sres[1], sres[2], filters,
-                                                                                  cores, el),
-            "cpu": model}
+            "sample": "PyTorch-CPU fp32 restatement of the reference graph (TF 1.15 unavailable): %d full train step(s) after one "
+                      "warm-up step (%.1f s), batch 1, FULL grid %dx%dx%d, filters %d, %d threads, %.1f s timed" % (
+                          n, warm, sres[0], sres[1], sres[2], filters, cores, el),
+            "ms_per_step": el / n * 1e3, "cpu": model}
 
 
-def l1_vs_oracle(filters, precision="fp32"):
-    """Relative L1 of the velocity field vs the fp64 oracle on identical inputs/weights (reduced grid 16x24x16)."""
+def l1_vs_oracle(filters, precision="fp32", is_3d=True):
+    """Relative L1 of the velocity field vs the fp64 oracle on identical inputs/weights (reduced grid 16x24x16 | 32x24)."""
+    import numpy as np
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import df_oracle as orc
     from deep_fluids_amd import ops
@@ -132,43 +168,203 @@ def l1_vs_oracle(filters, precision="fp32"):
     ops.CONV_PRECISION = precision
     ops.reset_variables()
     rng = np.random.RandomState(123)
-    spatial = (16, 24, 16)
-    oshape = list(spatial) + [3]
+    spatial = (16, 24, 16) if is_3d else (32, 24)
+    oshape = list(spatial) + [3 if is_3d else 1]
     p = orc.generator_init(rng, 3, oshape, filters)
     x, y = orc.synthetic_batch(rng, 1, spatial)
-    cfg = default_config(is_3d=True, res_x=16, res_y=24, res_z=16, filters=filters, batch_size=1, num_samples=100)
+    cfg = default_config(is_3d=is_3d, res_x=spatial[-1], res_y=spatial[-2], res_z=spatial[0] if is_3d else 1, filters=filters,
+                         batch_size=1, num_samples=100)
     tr = Trainer(cfg)
     tr.load_variables(p)
     u = tr.generate(torch.from_numpy(y).cuda()).cpu().numpy().astype(np.float64)
     psi = orc.generator_fwd(y.astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()}, oshape, filters)
-    ref = orc.curl3(psi)
+    ref = orc.curl3(psi) if is_3d else orc.curl(psi)
     ops.reset_variables()
+    ops.CONV_PRECISION = "fp32"
     return float(np.abs(u - ref).sum() / np.abs(ref).sum())
+
+
+def roofline_of(ks, prefix, pmc, with_traffic):
+    """Roofline object of the dominant instance (largest total time) of a kernel family.
+    MFMA-bound families: `achieved` = multiply-add flops the kernel EXECUTES on the matrix pipe / time (<= peak); the
+    convolution's algorithmic (direct-form) rate is reported beside it as `algorithmic_tflops` (it exceeds the peak when a Winograd
+    form removes multiplies) with `algorithmic_speedup` = algorithmic / executed flops."""
+    sel = {k: v for k, v in ks.items() if k.startswith(prefix)}
+    if not sel:
+        return None
+    k = max(sel, key=lambda q: sel[q]["seconds"])
+    v = sel[k]
+    hbm = prefix.startswith("jacobian")
+    out = {"kernel": k, "bound": "hbm" if hbm else "mfma", "launches": v["launches"], "avg_launch_ms": v["seconds"] / v["launches"] * 1e3,
+           "work_per_launch": v["work"] / v["launches"]}
+    if hbm:
+        ach = v["work"] / v["seconds"] / 1e9
+        out.update(achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS)
+    else:
+        alg = v["work"] / v["seconds"] / 1e12
+        ratio = EXEC_RATIO.get(prefix)
+        if ratio is None:                                        # weight gradient: depends on the form conv_wgrad.hip picks
+            dims = k.split(" ")[1].split("x")
+            ratio = wgrad_exec_ratio(int(dims[0]), int(dims[1]), int(dims[2])) if len(dims) == 3 else 1.0
+        ach = alg * ratio
+        out.update(achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS,
+                   algorithmic_tflops=alg, algorithmic_speedup=1.0 / ratio,
+                   note="achieved = multiply-add flops EXECUTED on the fp32 matrix pipe / time; algorithmic_tflops = direct-convolution "
+                        "flops / time (the Winograd forms execute 1/algorithmic_speedup of them)")
+    # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE per the gfx950 correction + WRITE_SIZE), collected offline
+    # on the same kernel at the default shape (B = 16, 64x96x64, F = 128)
+    fam = prefix.split("<")[0]
+    out["traffic"] = pmc.get(fam, {}).get("traffic_bytes") if with_traffic else None
+    out["traffic_source"] = "profiles/pmc_latest.json (offline rocprofv3 --pmc passes, not measured in this run)" if out["traffic"] else None
+    return out
+
+
+def timed_steps(tr, x, y, warm, n):
+    import torch
+    for _ in range(warm):
+        tr.train_step(x, y)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        m = tr.train_step(x, y)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, m
+
+
+def extras(out, a, cfg, x, y, vox_per_step, pmc):
+    """Appended at N = 1, clearly separate from `value`: the other BASELINE shapes / the opt-in bf16x3 mode.  An extra must never
+    take the metric line down with it."""
+    import torch
+    from deep_fluids_amd import _lib, ops
+    from deep_fluids_amd.trainer import Trainer, AETrainer, default_config
+
+    def guarded(key, fn):
+        try:
+            out[key] = fn()
+        except Exception as e:
+            out[key] = {"error": repr(e)[:300]}
+        ops.CONV_PRECISION = "fp32"
+        _lib.TIMER = None
+        ops.reset_variables()
+        torch.cuda.empty_cache()
+
+    def alt_bf16x3():
+        rel_alt = l1_vs_oracle(a.filters, "bf16x3")
+        ops.CONV_PRECISION = "bf16x3"
+        ops.reset_variables()
+        el, _ = timed_steps(Trainer(cfg), x, y, 2, 3)
+        return {"ms_per_step": el * 1e3, "value": vox_per_step / el, "unit": "voxels/s", "l1_vs_ref": rel_alt,
+                "note": "opt-in precision mode, not the BASELINE cfg3 dtype: conv operands split into bf16 hi/lo words, 3 bf16 MFMAs per "
+                        "product, fp32 accumulation"}
+
+    def two_d():
+        res = {}
+        g2 = torch.Generator(device="cuda").manual_seed(1)
+        y2 = torch.rand((64, 3), device="cuda", generator=g2) * 2 - 1
+        x2 = ops.curl(torch.rand((64, 128, 96, 1), device="cuda", generator=g2) * 2 - 1)
+        x2 = (x2 / x2.abs().max()).contiguous()
+        cfg2 = default_config(is_3d=False, res_x=96, res_y=128, filters=a.filters, batch_size=64, num_samples=21000)
+        for prec in ("fp32", "bf16x3"):
+            rel = l1_vs_oracle(a.filters, prec, is_3d=False)
+            ops.CONV_PRECISION = prec
+            ops.reset_variables()
+            tr = Trainer(cfg2)
+            for _ in range(3):
+                tr.train_step(x2, y2)
+            timer = _lib.KernelTimer(select_kernel)
+            torch.cuda.synchronize()
+            _lib.TIMER = timer
+            t2 = time.perf_counter()
+            for _ in range(10):
+                tr.train_step(x2, y2)
+            torch.cuda.synchronize(); el = (time.perf_counter() - t2) / 10
+            _lib.TIMER = None
+            r = {"ms_per_step": el * 1e3, "value": 64 * 128 * 96 / el, "unit": "pixels/s", "batch": 64, "l1_vs_ref": rel,
+                 "conv_tflops_reference_equivalent": 3.71e12 / el / 1e12}
+            if prec == "fp32":
+                ks = timer.summary()
+                r["roofline"] = roofline_of(ks, "wino2d_kernel", {}, False)
+                r["roofline_wgrad"] = roofline_of(ks, "wgrad_kernel", {}, False)
+                r["roofline_stencil"] = roofline_of(ks, "jacobian2d_fwd_kernel", {}, False)
+            res[prec] = r
+            del tr
+        f = res["fp32"]
+        f["bf16x3_mode"] = {k: res["bf16x3"][k] for k in ("ms_per_step", "value", "l1_vs_ref")}
+        f["dtype"] = "f32"
+        f["note"] = ("BASELINE cfg2's shape: 2-D 128x96 train step (GeneratorBE filters=128, batch 64); Winograd F(2x2,3x3) forward/dgrad + "
+                     "Winograd-(x,y) weight gradient at the top levels.  cfg2 names bf16: plain bf16 operands miss the 1e-4 velocity "
+                     "tolerance (tests/test_gpu_precision.py), the split-operand bf16x3 mode is the reduced-precision offer")
+        return f
+
+    def cfg4_slice():
+        B4 = 4
+        cfg4 = default_config(is_3d=True, res_x=112, res_y=160, res_z=112, filters=a.filters, batch_size=B4, num_samples=20000)
+        x4, y4 = make_inputs(B4, [112, 160, 112], 7, ops)
+        res = {}
+        for prec in ("fp32", "bf16x3"):
+            ops.CONV_PRECISION = prec
+            ops.reset_variables()
+            tr = Trainer(cfg4)
+            el, m = timed_steps(tr, x4, y4, 1, 2)
+            res[prec] = {"ms_per_step": el * 1e3, "value": B4 * 112 * 160 * 112 / el}
+            n_params = tr.n_params
+            del tr, m
+            torch.cuda.empty_cache()
+        return {"grid": [112, 160, 112], "batch_per_gpu": B4, "params": n_params, "unit": "voxels/s", "dtype": "f32",
+                "ms_per_step": res["fp32"]["ms_per_step"], "value": res["fp32"]["value"], "bf16x3_mode": res["bf16x3"],
+                "note": "BASELINE cfg4's grid and per-GPU batch (32 / 8 GPUs) on ONE GPU: the per-rank work of the 8-GPU batch-DP job; "
+                        "parity: tests/test_gpu_fullsize.py::test_cfg4_*"}
+
+    def ae_cfg5():
+        B5, R = 4, 128
+        cfg5 = default_config(is_3d=True, res_x=R, res_y=R, res_z=R, filters=64, batch_size=B5, num_samples=5000, z_num=16, p_num=2)
+        tr = AETrainer(cfg5)
+        g5 = torch.Generator(device="cuda").manual_seed(1)
+        y5 = torch.rand((B5, 2, 10), device="cuda", generator=g5) * 2 - 1
+        x5 = ops.curl3(torch.rand((B5, R, R, R, 3), device="cuda", generator=g5) * 2 - 1)
+        x5 = (x5 / x5.abs().max()).contiguous()
+        el, m = timed_steps(tr, x5, y5, 1, 2)
+        return {"grid": [R, R, R], "batch_per_gpu": B5, "filters": 64, "z_num": 16, "params": tr.n_params, "ms_per_step": el * 1e3,
+                "value": B5 * R ** 3 / el, "unit": "voxels/s", "dtype": "f32",
+                "note": "BASELINE cfg5's shape (AE3 encoder + decoder train step, 128^3, F = 64), fp32"}
+
+    guarded("alt_bf16x3_mode", alt_bf16x3)
+    guarded("extra_2d_128x96", two_d)
+    guarded("extra_cfg4_slice", cfg4_slice)
+    guarded("extra_ae_cfg5", ae_cfg5)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+
+    import torch
+    import torch.distributed as dist
     from deep_fluids_amd import _lib, ops
     from deep_fluids_amd.dist import init_from_env
     from deep_fluids_amd.trainer import Trainer, default_config
 
     rank, local_rank, world = init_from_env()
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
+
+    if a.scaling == "strong":
+        if a.batch % world:
+            raise SystemExit("--scaling strong: the global batch %d is not divisible by %d GPUs" % (a.batch, world))
+        per_gpu, global_batch = a.batch // world, a.batch
+    else:
+        per_gpu, global_batch = a.batch, a.batch * world
 
     rel_l1 = l1_vs_oracle(a.filters, a.precision) if rank == 0 else None
     ops.CONV_PRECISION = a.precision
 
     Z, Y, X = a.res
-    cfg = default_config(is_3d=True, res_x=X, res_y=Y, res_z=Z, filters=a.filters, batch_size=a.batch * world,
+    cfg = default_config(is_3d=True, res_x=X, res_y=Y, res_z=Z, filters=a.filters, batch_size=global_batch,
                          num_samples=6600, random_seed=123)     # smoke3_obs_buo: 11*4*150 samples (SURVEY B.4)
     tr = Trainer(cfg)                                           # same seed on every rank -> identical init
-    if world > 1:
-        tr.enable_data_parallel()
-    x, y = make_inputs(a.batch, a.res, 123 + rank, ops)
+    sync = tr.enable_data_parallel(profile=True) if world > 1 else None
+    x, y = make_inputs(per_gpu, a.res, 123 + rank, ops)
 
     def sync_all():
         if world > 1:
@@ -177,6 +373,8 @@ def main():
 
     for _ in range(a.warmup):
         tr.train_step(x, y)
+    if sync is not None:
+        sync.timing(reset=True)
     timer = _lib.KernelTimer(select_kernel)
     sync_all()
     _lib.TIMER = timer
@@ -189,14 +387,20 @@ def main():
     _lib.TIMER = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        if dist.get_backend() == "gloo":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(last.g_loss.detach())
     assert loss == loss, "Model diverged with loss = NaN"        # trainer.py:275
+    comm = sync.timing() if sync is not None else None
 
     if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
         return
-    vox_per_step = a.batch * Z * Y * X * world
+    vox_per_step = global_batch * Z * Y * X
     value = vox_per_step * a.steps / elapsed
     ks = timer.summary()
 
@@ -204,108 +408,44 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
     except (OSError, ValueError, KeyError):
         pmc = {}
-
-    default_shape = list(a.res) == [64, 96, 64] and a.batch == 16 and a.filters == 128   # the shape the PMC passes ran on
-
-    def roof(prefix, peak, unit, scale):
-        sel = {k: v for k, v in ks.items() if k.startswith(prefix)}
-        if not sel:
-            return None
-        k = max(sel, key=lambda q: sel[q]["seconds"])          # the dominant instance (top resolution)
-        v = sel[k]
-        ach = v["work"] / v["seconds"] / scale
-        return {"kernel": k, "bound": "mfma" if unit == "TFLOP/s" else "hbm", "achieved": ach, "peak": peak, "unit": unit,
-                "frac": ach / peak,
-                # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
-                # collected offline on the same kernels/shapes: profiles/pmc_latest.json
-                "traffic": pmc.get(prefix, {}).get("traffic_bytes") if default_shape else None, "launches": v["launches"],
-                "avg_launch_ms": v["seconds"] / v["launches"] * 1e3, "work_per_launch": v["work"] / v["launches"]}
+    default_shape = list(a.res) == [64, 96, 64] and per_gpu == 16 and a.filters == 128 and a.precision == "fp32"   # the PMC passes' shape
 
     out = {
         "metric": "velocity-field voxels/sec (3D %dx%dx%d train step), whole job; per-GPU in `per_gpu`" % (Z, Y, X),
         "value": value, "unit": "voxels/s", "per_gpu": value / world,
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
         "dtype": "f32" if a.precision == "fp32" else "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": "cfg3: 3D smoke3 %dx%dx%d (Z,Y,X) fp32, GeneratorBE3 filters=%d num_conv=4, "
-                               "per-GPU batch %d, full train step (fwd+curl3+jacobian3+L1 losses+bwd+Adam)" % (Z, Y, X, a.filters, a.batch),
-                   "global_batch": a.batch * world, "grid": [Z, Y, X], "params": tr.n_params,
+        "config": {"workload": "cfg3: 3D smoke3 %dx%dx%d (Z,Y,X) fp32, GeneratorBE3 filters=%d num_conv=4, per-GPU batch %d, full train "
+                               "step (fwd+curl3+jacobian3+L1 losses+bwd+Adam)" % (Z, Y, X, a.filters, per_gpu),
+                   "global_batch": global_batch, "batch_per_gpu": per_gpu, "grid": [Z, Y, X], "params": tr.n_params,
                    "parallelism": "dp%d" % world},
+        "rccl_ranks": world,
+        "dist_backend": (dist.get_backend() if world > 1 else None),
+        "allreduce": comm,           # per step: bytes, buckets, comm_span_ms, exposed_ms (after backward), hidden_ms (under backward)
         "loss": loss,
         "l1_vs_ref": {"value": rel_l1, "tolerance": 1e-4,
                       "case": "relative L1 of the velocity field vs the fp64 oracle, grid 16x24x16, filters %d" % a.filters},
         "roofline": None,            # filled below: the kernel family with the largest share of the step
-        "roofline_wgrad": roof("wgrad_kernel", PEAK_FP32_MFMA_TFLOPS, "TFLOP/s", 1e12),
-        "roofline_conv": roof("conv_mfma_kernel", PEAK_FP32_MFMA_TFLOPS, "TFLOP/s", 1e12),
-        "roofline_wino": roof("wino3d_kernel", PEAK_FP32_MFMA_TFLOPS, "TFLOP/s", 1e12),
-        "roofline_stencil": roof("jacobian3d_fwd_kernel", PEAK_HBM_GBS, "GB/s", 1e9),
+        "roofline_wgrad": roofline_of(ks, "wgrad_kernel", pmc, default_shape),
+        "roofline_conv": roofline_of(ks, "conv_mfma_kernel", pmc, default_shape),
+        "roofline_wino": roofline_of(ks, "wino3d_kernel", pmc, default_shape),
+        "roofline_stencil": roofline_of(ks, "jacobian3d_fwd_kernel", pmc, default_shape),
+        "roofline_stencil_bwd": roofline_of(ks, "jacobian3d_bwd_kernel<j>", {}, False),
         "kernels": {k: {"launches": v["launches"], "ms_total": v["seconds"] * 1e3} for k, v in sorted(ks.items())},
     }
-    if out["roofline_wgrad"]:
-        # same convention for the weight gradient: Winograd in (x,y,z) (F(2x2x2,3x3x3)) executes 8/27 of the algorithmic flops at the
-        # top levels (conv_wgrad.hip picks direct / x / (x,y) / (x,y,z) by size; the dominant instance is an (x,y,z) one)
-        rg = out["roofline_wgrad"]
-        rg["mfma_executed_tflops"] = rg["achieved"] * 8.0 / 27.0
-        rg["mfma_executed_frac"] = rg["frac"] * 8.0 / 27.0
-        rg["note"] = "achieved = direct-convolution flops / time (can exceed the fp32 MFMA peak); mfma_executed_* = flops the Winograd-(x,y,z) kernel issues"
-    if out["roofline_wino"]:
-        # `achieved` above counts the convolution's algorithmic flops; Winograd F(2x2x2,3x3x3) executes 8/27 of
-        # them on the matrix pipe, so the matrix-pipe utilisation is frac * 8/27 -- both are reported
-        rw = out["roofline_wino"]
-        rw["mfma_executed_tflops"] = rw["achieved"] * 8.0 / 27.0
-        rw["mfma_executed_frac"] = rw["frac"] * 8.0 / 27.0
-        rw["note"] = "achieved = direct-convolution flops / time (can exceed the fp32 MFMA peak); mfma_executed_* = flops the kernel issues"
     fam = {}
     for k, v in ks.items():
         fam[k.split(" ")[0]] = fam.get(k.split(" ")[0], 0.0) + v["seconds"]
-    dom = max((f for f in fam if f != "jacobian3d_fwd_kernel<j,c>"), key=lambda f: fam[f], default=None)
+    dom = max((f for f in fam if not f.startswith("jacobian")), key=lambda f: fam[f], default=None)
     out["roofline"] = {"wgrad_kernel": out["roofline_wgrad"], "conv_mfma_kernel": out["roofline_conv"],
                        "wino3d_kernel": out["roofline_wino"]}.get(dom)
-    # extra, clearly separate from `value`: the same step in the opt-in bf16x3 conv mode (NOT the reported metric)
-    out["alt_bf16x3_mode"] = None
-    try:
-        if world == 1 and a.precision == "fp32" and not a.no_alt:
-            rel_alt = l1_vs_oracle(a.filters, "bf16x3")
-            ops.CONV_PRECISION = "bf16x3"
-            ops.reset_variables()
-            tr2 = Trainer(cfg)
-            for _ in range(2):
-                tr2.train_step(x, y)
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            for _ in range(3):
-                tr2.train_step(x, y)
-            torch.cuda.synchronize(); el2 = (time.perf_counter() - t1) / 3
-            ops.CONV_PRECISION = "fp32"
-            out["alt_bf16x3_mode"] = {"ms_per_step": el2 * 1e3, "value": vox_per_step / el2, "unit": "voxels/s",
-                                      "l1_vs_ref": rel_alt, "note": "opt-in precision mode, not the BASELINE cfg3 dtype: conv operands "
-                                      "split into bf16 hi/lo words, 3 bf16 MFMAs per product, fp32 accumulation"}
-    except Exception as e:      # an extra must never take the metric line down with it
-        out["alt_bf16x3_mode"] = {"error": repr(e)[:300]}
-    ops.CONV_PRECISION = "fp32"
-    # the north star also asks for the 2-D grid: same train step on 128x96, batch 64 (BASELINE cfg2's shape; fp32 here)
-    out["extra_2d_128x96"] = None
-    try:
-        if world == 1 and not a.no_alt:
-            ops.reset_variables()
-            cfg2 = default_config(is_3d=False, res_x=96, res_y=128, filters=a.filters, batch_size=64, num_samples=21000)
-            tr3 = Trainer(cfg2)
-            g2 = torch.Generator(device="cuda").manual_seed(1)
-            y2 = torch.rand((64, 3), device="cuda", generator=g2) * 2 - 1
-            x2 = ops.curl(torch.rand((64, 128, 96, 1), device="cuda", generator=g2) * 2 - 1)
-            x2 = (x2 / x2.abs().max()).contiguous()
-            for _ in range(3):
-                tr3.train_step(x2, y2)
-            torch.cuda.synchronize(); t2 = time.perf_counter()
-            for _ in range(10):
-                tr3.train_step(x2, y2)
-            torch.cuda.synchronize(); el3 = (time.perf_counter() - t2) / 10
-            out["extra_2d_128x96"] = {"ms_per_step": el3 * 1e3, "value": 64 * 128 * 96 / el3, "unit": "pixels/s", "batch": 64,
-                                      "conv_tflops_reference_equivalent": 3.71e12 / el3 / 1e12, "dtype": "f32",
-                                      "note": "2-D 128x96 train step (GeneratorBE filters=128), Winograd F(2x2,3x3) forward/dgrad + Winograd-(x,y) weight gradient at the top levels; not the reported metric"}
-            ops.reset_variables()
-    except Exception as e:      # an extra must never take the metric line down with it
-        out["extra_2d_128x96"] = {"error": repr(e)[:300]}
+    for key in ("alt_bf16x3_mode", "extra_2d_128x96", "extra_cfg4_slice", "extra_ae_cfg5"):
+        out[key] = None
+    if world == 1 and not a.no_alt and a.precision == "fp32":
+        del tr, last
+        extras(out, a, cfg, x, y, vox_per_step, pmc)
     out["cpu_baseline"] = None
     try:
         if world == 1 and not a.no_cpu_baseline:
@@ -313,6 +453,9 @@ def main():
     except Exception as e:      # an extra must never take the metric line down with it
         out["cpu_baseline"] = {"error": repr(e)[:300]}
     print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

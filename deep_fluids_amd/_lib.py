@@ -9,6 +9,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdeepfluids_hip.so")
+TUNING_LIB_PATH = os.path.join(_HERE, "csrc", "libdeepfluids_hip_tuning.so")      # tools/ only: `use_tuning_library()`
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "deepfluids_hip.h")
 
 P, I64, I32, F32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
@@ -81,9 +82,11 @@ SIGNATURES = {
     "df_upconv_wgrad_bf16x3": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
     "df_conv_wgrad_workspace_bytes": (I64, [I64, I64, I64, I64, I64, I64, I32]),
     "df_conv_wgrad": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
+    "df_conv_wgrad_algo": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, I32, P]),
+    "df_upconv_wgrad_algo": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, I32, P]),
 }
 
-DF_CONV_LRELU, DF_CONV_RESIDUAL, DF_CONV_MASK, DF_CONV_BIAS = 1, 2, 4, 8
+DF_CONV_LRELU, DF_CONV_RESIDUAL, DF_CONV_MASK, DF_CONV_BIAS, DF_CONV_ADDUP, DF_CONV_VALU_ONLY = 1, 2, 4, 8, 16, 32
 
 _lib = None
 
@@ -97,6 +100,17 @@ def declared_symbols():
     src = open(HEADER_PATH).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(df_[a-z0-9_]+)\s*\(", src)))
+
+
+def use_tuning_library():
+    """tools/ probes only: bind the -DDF_TUNING build (instrumented kernels + the knobs of deepfluids_hip_debug.h) instead of
+    the release library.  Must be called before the first kernel call of the process."""
+    global LIB_PATH, _lib
+    if _lib is not None:
+        raise DeepFluidsHipError("use_tuning_library() must precede the first call into the library")
+    if not os.path.exists(TUNING_LIB_PATH):
+        raise DeepFluidsHipError("%s not found -- `make -C deep_fluids_amd/csrc tuning`" % TUNING_LIB_PATH)
+    LIB_PATH = TUNING_LIB_PATH
 
 
 def lib():

@@ -18,7 +18,6 @@ namespace {
 
 using df::ceil_div;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-int g_thin_valu = 0;      // debug: 1 = keep the thin-K conv on the vector-ALU kernel (df_debug_set_thin_valu)
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int KZ, int TZ, int TY, int TX, int CO, bool VEC>
@@ -592,17 +591,16 @@ int launch_small_k_t(ConvArgs a, hipStream_t s) {
 }  // namespace
 
 int launch_small_n(const ConvArgs& a, int kz, hipStream_t s) {
-  if (thin_n_mfma_ok(a, kz) && !g_thin_valu) return launch_thin_n_mfma(a, s);
+  if (thin_n_mfma_ok(a, kz) && !(a.flags & DF_CONV_VALU_ONLY)) return launch_thin_n_mfma(a, s);
   if (kz == 3) return a.W >= 12 ? launch_small_n_t<3, 4, 4, 16>(a, s) : launch_small_n_t<3, 4, 8, 8>(a, s);
   return a.W >= 12 ? launch_small_n_t<1, 1, 16, 16>(a, s) : launch_small_n_t<1, 1, 32, 8>(a, s);
 }
 
 int launch_small_k(const ConvArgs& a, int kz, hipStream_t s) {
-  if (thin_k_mfma_ok(a, kz) && !g_thin_valu) return launch_thin_k_mfma(a, s);
+  if (thin_k_mfma_ok(a, kz) && !(a.flags & DF_CONV_VALU_ONLY)) return launch_thin_k_mfma(a, s);
   if (kz == 3) return a.W >= 12 ? launch_small_k_t<3, 2, 4, 16>(a, s) : launch_small_k_t<3, 4, 4, 8>(a, s);
   return a.W >= 12 ? launch_small_k_t<1, 1, 8, 16>(a, s) : launch_small_k_t<1, 1, 16, 8>(a, s);
 }
 
 }  // namespace dfconv
 
-extern "C" void df_debug_set_thin_valu(int v) { dfconv::g_thin_valu = v; }

@@ -1173,15 +1173,15 @@ inline bool wxy_ok(int64_t H, int64_t W, int64_t Cin, int64_t Cout) { return wx_
 inline bool wxyz_ok(int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
   return kz == 3 && wxy_ok(H, W, Cin, Cout) && D % 2 == 0 && D >= 4 && Cin == 128 && Cout == 128 && (W == 64 || W == 32 || W == 16 || W == 112 || W == 56 || W == 128);
 }
-int g_wgrad_ranges = 0;   // debug: override the number of voxel ranges (0 = default)
-int g_wgrad_algo = 0;     // 0: best available, 1: always the direct kernel, 2: at most Winograd-in-x, 3: (x,y) wherever it exists, 4: (x,y,z) wherever it exists (df_debug_set_wgrad_algo)
-// 0 direct | 1 Winograd in x | 2 Winograd in (x,y) | 3 Winograd in (x,y,z)
-inline int wgrad_algo(int64_t rows, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
-  if (g_wgrad_algo == 1) return 0;
-  if ((g_wgrad_algo == 0 || g_wgrad_algo == 4) && wxyz_ok(D, H, W, Cin, Cout, kz) && (rows >= 4096 || g_wgrad_algo == 4)) return 3;
+// `req` = the caller's algorithm request (the `algo` argument of df_conv_wgrad_algo, low 3 bits): 0: best available,
+// 1: always the direct kernel, 2: at most Winograd-in-x, 3: (x,y) wherever it exists, 4: (x,y,z) wherever it exists.
+// returns 0 direct | 1 Winograd in x | 2 Winograd in (x,y) | 3 Winograd in (x,y,z)
+inline int wgrad_algo(int req, int64_t rows, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
+  if (req == 1) return 0;
+  if ((req == 0 || req == 4) && wxyz_ok(D, H, W, Cin, Cout, kz) && (rows >= 4096 || req == 4)) return 3;
   // (x,y) and (x,y,z) pay a larger partial buffer: worth it from ~4096 image rows (measured at batch 16, 128 -> 128:
   //  16x24x16: x 0.68, xy 0.52, xyz 0.51 ms; 32x48x32: 3.72, 2.54, 2.00 ms; 64x96x64: 26.7, 18.9, 15.1 ms)
-  if (g_wgrad_algo != 2 && wxy_ok(H, W, Cin, Cout) && (rows >= 4096 || g_wgrad_algo >= 3)) return 2;
+  if (req != 2 && wxy_ok(H, W, Cin, Cout) && (rows >= 4096 || req >= 3)) return 2;
   return wx_ok(W, Cin, Cout) ? 1 : 0;
 }
 
@@ -1902,7 +1902,7 @@ struct Plan {
   int64_t partial_elems, bpartial_elems;
 };
 
-Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int algo = 0) {
+Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int algo = 0, int ranges = 0) {
   Plan p;
   p.nrows = (int)(algo == 3 ? B * (D / 2) * (H / 2) : algo == 2 ? B * D * (H / 2) : B * D * H);       // image rows, or tile rows
   p.npairs = (p.nrows + 1) / 2;
@@ -1916,7 +1916,7 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   //  the partial traffic of 256)
   // (small problems: the fixed-order reduce of the partial sums costs as much as the products -- 64 ranges measured best below
   //  4096 row pairs: 0.45 -> 0.22 ms at 16 x 8x12x8, 0.84 -> 0.67 ms at 16 x 16x24x16)
-  const int maxr = g_wgrad_ranges > 0 ? g_wgrad_ranges : (p.npairs < 4096 ? 64 : (algo >= 2 ? 128 : kMaxRanges));
+  const int maxr = (ranges > 0 && ranges <= kMaxRanges) ? ranges : (p.npairs < 4096 ? 64 : (algo >= 2 ? 128 : kMaxRanges));
   int nr = p.npairs >= maxr ? maxr : p.npairs;
   p.ppr = (p.npairs + nr - 1) / nr;
   p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
@@ -1957,6 +1957,9 @@ int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W
   return best + zero_row_bytes(W, Cin, Cout);
 }
 
+// "not applicable, take the generic path": a value no hipError_t (> 0) and no DF_E* code (-1..-4) can take, so a real launch
+// failure of the thin kernel is never mistaken for the fall-back signal
+constexpr int kThinNotApplicable = -1000;
 static int launch_thin_wgrad(const float* wide, const float* thin, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
                              int64_t Cw, int64_t Ct, bool swap, void* workspace, df_stream_t stream) {
   ThinWgradArgs ta;
@@ -1969,7 +1972,7 @@ static int launch_thin_wgrad(const float* wide, const float* thin, float* gw, fl
   ta.RS = (int)(W * Ct + 8);
   const uint64_t xb = static_cast<uint64_t>(B * D * H * W) * static_cast<uint64_t>(Cw) * 4u;
   ta.x_bytes_lo = static_cast<unsigned>(xb & 0xffffffffu); ta.x_bytes_hi = static_cast<unsigned>(xb >> 32);
-  if (!(static_cast<int64_t>(ta.rows_per) * W * Cw * 4 < (1LL << 32) && ns >= 4)) return 1;
+  if (!(static_cast<int64_t>(ta.rows_per) * W * Cw * 4 < (1LL << 32) && ns >= 4)) return kThinNotApplicable;
   hipStream_t s = df::as_stream(stream);
   const size_t lds = static_cast<size_t>(4) * 19 * ta.RS * sizeof(float);
   const dim3 grid((unsigned)(ns / 4));
@@ -2000,7 +2003,9 @@ static int launch_thin_wgrad(const float* wide, const float* thin, float* gw, fl
 
 static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
                            int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream,
-                           int prec) {
+                           int prec, int algo_arg) {
+  DF_REQUIRE(algo_arg >= 0 && (algo_arg & 7) <= 4, DF_EINVAL, "df_conv_wgrad: algo must be 0..4 (+ 8 * partial-range override)");
+  const int req = algo_arg & 7, req_ranges = algo_arg >> 3;
   DF_REQUIRE(x && gy && gw && workspace, DF_EINVAL, "df_conv_wgrad: null pointer");
   DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_conv_wgrad: non-positive extent");
   DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_conv_wgrad: kz must be 1 (2-D) or 3 (3-D)");
@@ -2013,10 +2018,10 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     // matrix-core form of the thin layers: F -> 1..4 (wide = x, thin = gy) or 1..4 -> F (SWAP: wide = gy, thin = x)
     const bool swap = Cin <= 4 && Cout >= 64;
     const int64_t Cw = swap ? Cout : Cin, Ct = swap ? Cin : Cout;
-    if ((swap || small_n_ok(Cin, Cout)) && g_wgrad_algo != 1 && prec == 0 && thin_mfma_ok(B, D, H, W, Cw, Ct, kz) &&
+    if ((swap || small_n_ok(Cin, Cout)) && req != 1 && prec == 0 && thin_mfma_ok(B, D, H, W, Cw, Ct, kz) &&
         thin_mfma_inst(W, Cw, Ct, swap) && df::aligned16(x) && df::aligned16(gy)) {
       const int rc = launch_thin_wgrad(swap ? gy : x, swap ? x : gy, gw, gb, B, D, H, W, Cw, Ct, swap, workspace, stream);
-      if (rc != 1) return rc;      // 1: shape outside the kernel's 32-bit stream offsets -> generic path below
+      if (rc != kThinNotApplicable) return rc;      // shape outside the kernel's 32-bit stream offsets -> generic path below
     }
   }
   if (small_n_ok(Cin, Cout)) {
@@ -2044,8 +2049,8 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   }
   const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
-  const int algo = (prec == 0 && xvec && gvec) ? wgrad_algo(B * D * H, D, H, W, Cin, Cout, kz) : 0;
-  const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, algo);
+  const int algo = (prec == 0 && xvec && gvec) ? wgrad_algo(req, B * D * H, D, H, W, Cin, Cout, kz) : 0;
+  const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, algo, req_ranges);
   WgradArgs a;
   a.x = x; a.g = gy;
   a.partial = static_cast<float*>(workspace);
@@ -2156,15 +2161,17 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   return df::launched("df_conv_wgrad");
 }
 
-void df_debug_set_wgrad_algo(int v) { g_wgrad_algo = v & 7; g_wgrad_ranges = v >> 3; }
-
 int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
                   int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {
-  return conv_wgrad_impl(x, gy, gw, gb, B, D, H, W, Cin, Cout, kz, workspace, workspace_bytes, stream, 0);
+  return conv_wgrad_impl(x, gy, gw, gb, B, D, H, W, Cin, Cout, kz, workspace, workspace_bytes, stream, 0, 0);
+}
+int df_conv_wgrad_algo(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
+                       int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, int algo, df_stream_t stream) {
+  return conv_wgrad_impl(x, gy, gw, gb, B, D, H, W, Cin, Cout, kz, workspace, workspace_bytes, stream, 0, algo);
 }
 int df_conv_wgrad_bf16x3(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
                          int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {
-  return conv_wgrad_impl(x, gy, gw, gb, B, D, H, W, Cin, Cout, kz, workspace, workspace_bytes, stream, 1);
+  return conv_wgrad_impl(x, gy, gw, gb, B, D, H, W, Cin, Cout, kz, workspace, workspace_bytes, stream, 1, 0);
 }
 
 static Plan make_up_plan(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
@@ -2182,9 +2189,8 @@ static Plan make_up_plan(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t 
 }
 
 // the 27-point Winograd-(x,y,z) form of the up-sampling-aware weight gradient (fine extents 2Dc x 2Hc x 2Wc)
-static bool up_wxyz_ok(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
-  return wxyz_ok(2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz) && (B * Dc * Hc >= 2048 || g_wgrad_algo == 4) && g_wgrad_algo != 1 &&
-         g_wgrad_algo != 2 && g_wgrad_algo != 3;
+static bool up_wxyz_ok(int req, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
+  return wxyz_ok(2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz) && (B * Dc * Hc >= 2048 || req == 4) && req != 1 && req != 2 && req != 3;
 }
 
 int64_t df_upconv_wgrad_workspace_bytes(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
@@ -2202,7 +2208,8 @@ int64_t df_upconv_wgrad_workspace_bytes(int64_t B, int64_t Dc, int64_t Hc, int64
 
 static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc,
                              int64_t Wc, int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes,
-                             df_stream_t stream, int prec) {
+                             df_stream_t stream, int prec, int req) {
+  DF_REQUIRE(req >= 0 && req <= 4, DF_EINVAL, "df_upconv_wgrad: algo must be 0..4");
   DF_REQUIRE(xc && gy && gw && workspace, DF_EINVAL, "df_upconv_wgrad: null pointer");
   DF_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_upconv_wgrad: non-positive extent");
   DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_upconv_wgrad: kz must be 1 (2-D) or 3 (3-D)");
@@ -2211,7 +2218,7 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   DF_REQUIRE(df::aligned16(workspace), DF_EALIGN, "df_upconv_wgrad: workspace must be 16-byte aligned");
   DF_REQUIRE(workspace_bytes >= df_upconv_wgrad_workspace_bytes(B, Dc, Hc, Wc, Cin, Cout, kz), DF_EWORKSPACE,
              "df_upconv_wgrad: workspace too small");
-  if (prec == 0 && up_wxyz_ok(B, Dc, Hc, Wc, Cin, Cout, kz) && df::aligned16(xc) && df::aligned16(gy)) {
+  if (prec == 0 && up_wxyz_ok(req, B, Dc, Hc, Wc, Cin, Cout, kz) && df::aligned16(xc) && df::aligned16(gy)) {
     const int64_t D = 2 * Dc, H = 2 * Hc, W = 2 * Wc;
     const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, 3);
     WxyzArgs aa;
@@ -2269,11 +2276,11 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   const bool aligned8 = ((reinterpret_cast<uintptr_t>(xc) | reinterpret_cast<uintptr_t>(gy)) & 7u) == 0;
   const dim3 grid2((unsigned)(p.nranges * (p.ndzdy / 2)), grid.y, grid.z);     // one workgroup per x-parity class PAIR
   if (prec == 1 && wgrad_bf16x3_ok(Wc, Cin, Cout)) launch_wgrad_bf16x3(Wc, grid, s, a);
-  else if (prec == 0 && aligned8 && exact && wp8 == 4 && Cin == 128 && Cout == 128 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<4, 128>), grid2, dim3(kThreads), 0, s, a);
-  else if (prec == 0 && aligned8 && exact && wp8 == 6 && Cin == 128 && Cout == 128 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<6, 128>), grid2, dim3(kThreads), 0, s, a);      // 2-D 128x96: coarse W = 48 | 24
-  else if (prec == 0 && aligned8 && exact && wp8 == 3 && Cin == 128 && Cout == 128 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<3, 128>), grid2, dim3(kThreads), 0, s, a);
-  else if (prec == 0 && aligned8 && exact && wp8 == 2 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<2, 0>), grid2, dim3(kThreads), 0, s, a);
-  else if (prec == 0 && aligned8 && exact && wp8 == 1 && g_wgrad_algo != 1) hipLaunchKernelGGL((wgrad_up2_kernel<1, 0>), grid2, dim3(kThreads), 0, s, a);
+  else if (prec == 0 && aligned8 && exact && wp8 == 4 && Cin == 128 && Cout == 128 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<4, 128>), grid2, dim3(kThreads), 0, s, a);
+  else if (prec == 0 && aligned8 && exact && wp8 == 6 && Cin == 128 && Cout == 128 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<6, 128>), grid2, dim3(kThreads), 0, s, a);      // 2-D 128x96: coarse W = 48 | 24
+  else if (prec == 0 && aligned8 && exact && wp8 == 3 && Cin == 128 && Cout == 128 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<3, 128>), grid2, dim3(kThreads), 0, s, a);
+  else if (prec == 0 && aligned8 && exact && wp8 == 2 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<2, 0>), grid2, dim3(kThreads), 0, s, a);
+  else if (prec == 0 && aligned8 && exact && wp8 == 1 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<1, 0>), grid2, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 4) hipLaunchKernelGGL((wgrad_kernel<true, true, 4>), grid, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 2) hipLaunchKernelGGL((wgrad_kernel<true, true, 2>), grid, dim3(kThreads), 0, s, a);
@@ -2288,12 +2295,16 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
 
 int df_upconv_wgrad(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
                     int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {
-  return upconv_wgrad_impl(xc, gy, gw, gb, B, Dc, Hc, Wc, Cin, Cout, kz, workspace, workspace_bytes, stream, 0);
+  return upconv_wgrad_impl(xc, gy, gw, gb, B, Dc, Hc, Wc, Cin, Cout, kz, workspace, workspace_bytes, stream, 0, 0);
+}
+int df_upconv_wgrad_algo(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
+                         int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, int algo, df_stream_t stream) {
+  return upconv_wgrad_impl(xc, gy, gw, gb, B, Dc, Hc, Wc, Cin, Cout, kz, workspace, workspace_bytes, stream, 0, algo);
 }
 int df_upconv_wgrad_bf16x3(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc,
                            int64_t Wc, int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes,
                            df_stream_t stream) {
-  return upconv_wgrad_impl(xc, gy, gw, gb, B, Dc, Hc, Wc, Cin, Cout, kz, workspace, workspace_bytes, stream, 1);
+  return upconv_wgrad_impl(xc, gy, gw, gb, B, Dc, Hc, Wc, Cin, Cout, kz, workspace, workspace_bytes, stream, 1, 0);
 }
 
 }  // extern "C"

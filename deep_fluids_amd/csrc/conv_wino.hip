@@ -56,7 +56,6 @@ struct WinoArgs {
   int nbz, nby, nbx, ntb, ncs;
   int flags;
   float leak;
-  int dbg;
   int spx;
 };
 
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       const int gz = bi.z0 - 1 + hz, gy = bi.y0 - 1 + hy, gx = bi.x0 - 1 + hx;
       bool ok = static_cast<unsigned>(gz) < static_cast<unsigned>(a.D) && static_cast<unsigned>(gy) < static_cast<unsigned>(a.H) &&
                 static_cast<unsigned>(gx) < static_cast<unsigned>(a.W);
-      if ((DBG & 4) || (a.dbg & 2)) ok = false;
+      if (DBG & 4) ok = false;
       if (UP) {
         const int Hc = a.H >> 1, Wc = a.W >> 1;
         so[it] = ok ? static_cast<unsigned>((((gz >> 1) * Hc + (gy >> 1)) * Wc + (gx >> 1)) * a.Cin + q4 * 4) * 4u : 0x80000000u;
@@ -583,17 +582,23 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   }
 }
 
+#ifdef DF_TUNING      // instrumented kernel variants + knobs of the tuning library only (include/deepfluids_hip_debug.h)
 int g_wino_dbg = 0;
-int g_wino_spx = 0;     // debug: slices per XCD override
+int g_wino_spx = 0;     // slices per XCD override
+#else
+constexpr int g_wino_spx = 0;
+#endif
 }  // namespace
 
 extern "C" {
 
+#ifdef DF_TUNING
 void df_debug_set_wino(int v) { g_wino_dbg = v & 0xffff; g_wino_spx = v >> 16; }
 int df_debug_wino_prof(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_prof), z, sizeof(z)); }
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_prof), 32 * sizeof(unsigned long long));
 }
+#endif
 
 int64_t df_wino_packed_elems(int64_t cin, int64_t cout, int mode) {
   (void)mode;
@@ -654,9 +659,14 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
   a.ncs = (int)(Cout / 32);
   DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_conv_fwd: too many workgroups");
   a.ntb = (int)ntb;
-  a.flags = flags; a.leak = leak; a.dbg = g_wino_dbg;
+  a.flags = flags; a.leak = leak;
   const int64_t grid = wino_grid(a, ntb);
-  switch (g_wino_dbg >> 2) {
+#ifdef DF_TUNING
+  const int variant = g_wino_dbg >> 2;
+#else
+  constexpr int variant = 0;
+#endif
+  switch (variant) {
     case 0:
       if (flags == (DF_CONV_BIAS | DF_CONV_LRELU)) hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
       else if (flags == DF_CONV_MASK) hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_MASK>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
@@ -664,6 +674,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
       else if (flags == 0) hipLaunchKernelGGL((wino3d_kernel<0, 0>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
       else hipLaunchKernelGGL((wino3d_kernel<0, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
       break;
+#ifdef DF_TUNING
     case 1: hipLaunchKernelGGL((wino3d_kernel<1, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 2: hipLaunchKernelGGL((wino3d_kernel<2, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 3: hipLaunchKernelGGL((wino3d_kernel<3, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
@@ -677,6 +688,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
       break;
     case 1024: hipLaunchKernelGGL((wino3d_kernel<1024, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 1536: hipLaunchKernelGGL((wino3d_kernel<1536, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+#endif
     default: return df::fail(DF_EINVAL, "df_wino_conv_fwd: unknown debug variant");
   }
   return df::launched("df_wino_conv_fwd");
@@ -701,7 +713,7 @@ int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, floa
   a.ncs = (int)(Cout / 32);
   DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_upconv_fwd: too many workgroups");
   a.ntb = (int)ntb;
-  a.flags = flags; a.leak = leak; a.dbg = 0;
+  a.flags = flags; a.leak = leak;
   const int64_t grid = wino_grid(a, ntb);
   hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
   return df::launched("df_wino_upconv_fwd");
@@ -725,7 +737,7 @@ int df_wino_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B,
   a.ncs = (int)(Cin / 32);
   DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_upconv_dgrad: too many workgroups");
   a.ntb = (int)ntb;
-  a.flags = 0; a.leak = 0.f; a.dbg = 0;
+  a.flags = 0; a.leak = 0.f;
   const int64_t grid = wino_grid(a, ntb);
   hipLaunchKernelGGL((wino3d_kernel<0, 0, 2>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
   return df::launched("df_wino_upconv_dgrad");
@@ -749,7 +761,7 @@ int df_wino_conv_fwd_addup(const float* x, const float* wp, const float* bias, c
   a.ncs = (int)(Cout / 32);
   DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_conv_fwd_addup: too many workgroups");
   a.ntb = (int)ntb;
-  a.flags = DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_ADDUP; a.leak = leak; a.dbg = 0;
+  a.flags = DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_ADDUP; a.leak = leak;
   const int64_t grid = wino_grid(a, ntb);
   hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_ADDUP>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
   return df::launched("df_wino_conv_fwd_addup");

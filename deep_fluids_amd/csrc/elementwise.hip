@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const float* __res
   for (int64_t n = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; n < N;
        n += static_cast<int64_t>(gridDim.x) * kThreads) {
     float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc = fmaf(x[b * K + k], w[k * N + n], acc);
+    for (int k = 0; k < K; ++k) acc = fmaf(x[static_cast<int64_t>(b) * K + k], w[k * N + n], acc);
     y[b * N + n] = bias ? acc + bias[n] : acc;
   }
 }
@@ -403,18 +403,19 @@ __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const float* __res
 __global__ __launch_bounds__(kThreads) void linear_bwd_w_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ gy, float* __restrict__ gw,
                                                                 float* __restrict__ gb, int B, int K, int64_t N) {
-  const int k = blockIdx.y;   // k == K -> bias row
-  for (int64_t n = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; n < N;
-       n += static_cast<int64_t>(gridDim.x) * kThreads) {
-    float acc = 0.f;
-    if (k < K) {
-      for (int b = 0; b < B; ++b) acc = fmaf(x[b * K + k], gy[b * N + n], acc);
-      if (gw) gw[k * N + n] = acc;
-    } else {
-      for (int b = 0; b < B; ++b) acc += gy[b * N + n];
-      if (gb) gb[n] = acc;
+  // rows k = blockIdx.y, blockIdx.y + gridDim.y, ... (grid.y is capped at 65535: any K);  k == K -> bias row
+  for (int k = blockIdx.y; k <= K; k += gridDim.y)
+    for (int64_t n = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; n < N;
+         n += static_cast<int64_t>(gridDim.x) * kThreads) {
+      float acc = 0.f;
+      if (k < K) {
+        for (int b = 0; b < B; ++b) acc = fmaf(x[static_cast<int64_t>(b) * K + k], gy[b * N + n], acc);
+        if (gw) gw[k * N + n] = acc;
+      } else {
+        for (int b = 0; b < B; ++b) acc += gy[b * N + n];
+        if (gb) gb[n] = acc;
+      }
     }
-  }
 }
 
 // gx[b][k] = sum_n gy[b][n] w[k][n]   (one workgroup per (b,k); only used when the FC input needs a gradient)
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_x_kernel(const float* __r
   double acc = 0.0;
   for (int64_t n = threadIdx.x; n < N; n += kThreads) acc += static_cast<double>(gy[b * N + n]) * w[k * N + n];
   const double s = block_sum(acc);
-  if (threadIdx.x == 0) gx[b * K + k] = static_cast<float>(s);
+  if (threadIdx.x == 0) gx[static_cast<int64_t>(b) * K + k] = static_cast<float>(s);
 }
 
 // ---- column sums (bias gradient of a channels-last conv) -------------------------------------------
@@ -596,7 +597,7 @@ int df_linear_fwd(const float* x, const float* w, const float* bias, float* y, i
 int df_linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int64_t B,
                   int64_t K, int64_t N, df_stream_t stream) {
   DF_REQUIRE(x && w && gy, DF_EINVAL, "df_linear_bwd: null pointer");
-  DF_REQUIRE(B > 0 && K > 0 && N > 0 && B < 65536 && (K < 65535 || N <= 32), DF_EINVAL, "df_linear_bwd: bad extent");
+  DF_REQUIRE(B > 0 && K > 0 && N > 0 && B < 65536 && K < (1LL << 31) - 1, DF_EINVAL, "df_linear_bwd: bad extent");
   hipStream_t s = df::as_stream(stream);
   if (N <= 32 && K >= 1024) {
     if (gx || gw) {
@@ -610,7 +611,7 @@ int df_linear_bwd(const float* x, const float* w, const float* gy, float* gx, fl
     return df::launched("df_linear_bwd(small-N)");
   }
   if (gw || gb) {
-    dim3 grid(grid_for(N), (unsigned)(K + 1));
+    dim3 grid(grid_for(N), (unsigned)(K + 1 < 65535 ? K + 1 : 65535));
     hipLaunchKernelGGL(linear_bwd_w_kernel, grid, dim3(kThreads), 0, s, x, gy, gw, gb, (int)B, (int)K, N);
   }
   if (gx) {

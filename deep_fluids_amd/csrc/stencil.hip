@@ -370,8 +370,13 @@ __global__ __launch_bounds__(kThreads) void divergence2d_kernel(const float* __r
   d[o] = (x[(v + 1) * 2 + 0] - x[v * 2 + 0]) + (x[(v + X) * 2 + 1] - x[v * 2 + 1]);
 }
 
-int g_stencil_group = 48;  // runs of 48 blocks per XCD (sweep in tools/stencil_probe.py: best warm+cold)
-int g_stencil_nt = 1;   // tuning knob (df_debug_set): non-temporal output stores
+#ifdef DF_TUNING      // knobs of the tuning library only (include/deepfluids_hip_debug.h); constants in the release library
+int g_stencil_group = 48;
+int g_stencil_nt = 1;
+#else
+constexpr int g_stencil_group = 48;  // runs of 48 blocks per XCD (sweep in tools/stencil_probe.py: best warm+cold)
+constexpr int g_stencil_nt = 1;      // non-temporal output stores
+#endif
 
 int check3(const void* in, int64_t B, int64_t Z, int64_t Y, int64_t X, const char* fn) {
   DF_REQUIRE(in != nullptr, DF_EINVAL, "%s: null input", fn);
@@ -394,9 +399,10 @@ int check2(const void* in, int64_t B, int64_t Y, int64_t X, const char* fn) {
 
 extern "C" {
 
-// not part of the public header: tuning switch used by tools/gpu_probe.py
+#ifdef DF_TUNING
 void df_debug_set_stencil_nt(int v) { g_stencil_nt = v; }
 void df_debug_set_stencil_group(int v) { g_stencil_group = v; }
+#endif
 
 int df_jacobian3d_fwd(const float* x, float* j, float* c, int64_t B, int64_t Z, int64_t Y, int64_t X,
                       df_stream_t stream) {

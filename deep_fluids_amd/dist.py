@@ -10,15 +10,18 @@ block first, so every bucket but the last small one overlaps with the remaining 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are a few MB, large enough to be
 bandwidth- rather than latency-bound per link, small enough to start early.
 
-Device-agnostic on purpose: the same class runs over ``gloo`` on CPU tensors in the world_size-2 tests.
+Device-agnostic on purpose: the same class runs over ``gloo`` on CPU tensors in the world_size-2 tests, and over
+``gloo`` with several ranks sharing ONE GPU (``DF_DIST_BACKEND=gloo``; buckets are staged through host memory) in the
+-m gpu test that runs the real ``Trainer`` with world > 1 on a single-GPU box.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
-    import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -38,17 +41,29 @@ class GradSync(object):
     """Bucketed, backward-overlapped all-reduce of a flat gradient slab.
 
     ``buckets``: list of ``(offset, numel, [param tensors])`` covering ``flat_grad``; each param's ``.grad``
-    must be a view into its bucket's range (Trainer arranges that)."""
+    must be a view into its bucket's range (Trainer arranges that).
 
-    def __init__(self, flat_grad, buckets, group=None):
+    ``profile=True`` brackets the exchange with HIP events (bench.py): per step, ``comm_ms`` = time the communication stream
+    spent on the all-reduces, ``exposed_ms`` = time the compute stream waited for them after backward finished;
+    ``hidden_ms = comm_ms - exposed_ms`` ran under backward compute."""
+
+    def __init__(self, flat_grad, buckets, group=None, profile=False):
         self.flat_grad = flat_grad
         self.buckets = buckets
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.enabled = self.world > 1
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        # gloo with device buffers: stage each bucket through host memory (test-only configuration: ranks sharing one GPU)
+        self._host_staged = bool(self.enabled and flat_grad.is_cuda and self.backend == "gloo")
         self._pending = [0] * len(buckets)
         self._works = []
-        self._comm_stream = torch.cuda.Stream() if (self.enabled and flat_grad.is_cuda) else None
+        self._comm_stream = torch.cuda.Stream() if (self.enabled and flat_grad.is_cuda and not self._host_staged) else None
+        self.profile = bool(profile and self._comm_stream is not None)
+        self._ev = []                  # per step: (first-launch start, [bucket end events], backward-done, finish-done)
+        self._cur = None
+        self.launch_order = []         # bucket indices in the order their all-reduces were issued during the last step
         if self.enabled:
             for bi, (_, _, params) in enumerate(buckets):
                 for p in params:
@@ -58,6 +73,8 @@ class GradSync(object):
     def begin_step(self):
         self._pending = [len(b[2]) for b in self.buckets]
         self._works = []
+        self.launch_order = []
+        self._cur = {"start": None, "ends": []} if self.profile else None
 
     def _make_hook(self, bi):
         def hook(_p):
@@ -69,10 +86,23 @@ class GradSync(object):
     def _launch(self, bi):
         off, n, _ = self.buckets[bi]
         chunk = self.flat_grad[off:off + n]
+        self.launch_order.append(bi)
+        if self._host_staged:
+            host = chunk.cpu()                                       # synchronises with the compute stream
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            chunk.copy_(host)
+            return
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm_stream):
+                if self._cur is not None and self._cur["start"] is None:
+                    self._cur["start"] = torch.cuda.Event(enable_timing=True)
+                    self._cur["start"].record()
                 w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self._cur is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    self._cur["ends"].append(e)
         else:
             w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._works.append(w)
@@ -86,11 +116,39 @@ class GradSync(object):
             if left > 0:                      # a bucket whose hooks did not all fire (unused params): reduce it now
                 self._pending[bi] = 0
                 self._launch(bi)
+        if self._cur is not None:
+            self._cur["bwd_done"] = torch.cuda.Event(enable_timing=True)
+            self._cur["bwd_done"].record()
         for w in self._works:
             w.wait()
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
+        if self._cur is not None:
+            self._cur["done"] = torch.cuda.Event(enable_timing=True)
+            self._cur["done"].record()
+            self._ev.append(self._cur)
+            self._cur = None
         return 1.0 / self.world
+
+    def timing(self, reset=True):
+        """Mean per-step milliseconds over the profiled steps since the last reset (synchronises the device)."""
+        if not self._ev:
+            return None
+        torch.cuda.synchronize()
+        comm = exposed = 0.0
+        for s in self._ev:
+            if s["start"] is None or not s["ends"]:
+                continue
+            # time from the first all-reduce's start to the last one's end on the communication stream: an UPPER bound of
+            # the busy time (the stream idles between buckets while it waits for the next gradients)
+            comm += s["start"].elapsed_time(s["ends"][-1])
+            exposed += max(s["bwd_done"].elapsed_time(s["done"]), 0.0)
+        n = len(self._ev)
+        out = {"steps": n, "comm_span_ms": comm / n, "exposed_ms": exposed / n, "hidden_ms": max(comm - exposed, 0.0) / n,
+               "buckets": len(self.buckets), "bytes": int(self.flat_grad.numel()) * 4}
+        if reset:
+            self._ev = []
+        return out
 
 
 def shard_batch(global_batch, rank, world):

@@ -195,7 +195,8 @@ CONV_PRECISION = "fp32"
 
 def _sfx(cin, cout):
     """'_bf16x3' when that mode is on and the layer is wide enough for it (thin layers stay on the fp32 VALU kernels)."""
-    return "_bf16x3" if (CONV_PRECISION == "bf16x3" and cin >= 16 and cout >= 16 and cin % 4 == 0) else ""
+    # (symmetric in cin / cout: the dgrad runs the same layer with the two swapped and must agree with the packed format)
+    return "_bf16x3" if (CONV_PRECISION == "bf16x3" and cin >= 16 and cout >= 16 and cin % 4 == 0 and cout % 4 == 0) else ""
 
 
 # Algorithm of the wide 3-D stride-1 convs (forward and dgrad), fp32 mode only:
@@ -204,6 +205,25 @@ def _sfx(cin, cout):
 #              implicit-GEMM kernel everywhere else;
 #   "direct"   always the direct kernel;   "winograd"  Winograd wherever the channel counts allow (tests).
 CONV_ALGO = "auto"
+
+
+# Weight-gradient algorithm request handed to df_conv_wgrad_algo / df_upconv_wgrad_algo (a call argument of the C-ABI, not a
+# library global): 0 best available (what df_conv_wgrad does), 1 direct kernels only, 2 at most Winograd in x, 3 Winograd in
+# (x,y), 4 Winograd in (x,y,z) wherever instantiated.  Tests pin the variants against each other and the oracle.
+WGRAD_ALGO = 0
+# True: thin layers (Cin or Cout <= 4) take the general-shape vector-ALU kernels (DF_CONV_VALU_ONLY) instead of the
+# matrix-core forms -- the two are compared in the tests.
+THIN_VALU_ONLY = False
+
+
+def _wgrad(x, dp, gw, gb, B, D, H, W, cin, cout, kz, sfx=""):
+    nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, kz)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    if sfx:
+        call("df_conv_wgrad" + sfx, _ptr(x), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, _ptr(ws), nbytes, _stream())
+    else:
+        call("df_conv_wgrad_algo", _ptr(x), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, _ptr(ws), nbytes,
+             int(WGRAD_ALGO), _stream())
 
 
 def _use_wino(cin, cout, dims, kz):
@@ -215,15 +235,16 @@ def _use_wino(cin, cout, dims, kz):
     return 2 if (CONV_ALGO == "winograd" or (dims[2] >= 16 and dims[3] >= 24)) else 0
 
 
-def _pack(w, taps, cin, cout, mode, dims=None):
-    """Packed MFMA operand of w for the stride-1 conv on `dims` (mode 0: forward, mode 1: dgrad)."""
+def _pack(w, taps, cin, cout, mode, dims=None, fp32=False):
+    """Packed MFMA operand of w for the stride-1 conv on `dims` (mode 0: forward, mode 1: dgrad).  ``fp32=True`` forces the exact-fp32
+    operand format whatever CONV_PRECISION says (kernels that have no bf16x3 variant: the stride-2 forward)."""
     algo = _use_wino(cin, cout, dims, 3 if taps == 27 else 1) if dims is not None else 0
     if algo:
         fn = "df_wino" if algo == 3 else "df_wino2d"
         wp = torch.empty(query(fn + "_packed_elems", cin, cout, mode), dtype=torch.float32, device=w.device)
         call(fn + "_pack_weights", _ptr(w), _ptr(wp), cin, cout, mode, _stream())
         return wp
-    sfx = _sfx(cin, cout)
+    sfx = "" if fp32 else _sfx(cin, cout)
     n = query("df_conv_packed_elems" + sfx, taps, cin, cout, mode)
     wp = torch.empty(n, dtype=torch.float32, device=w.device)
     call("df_conv_pack_weights" + sfx, _ptr(w), _ptr(wp), taps, cin, cout, mode, _stream())
@@ -243,6 +264,8 @@ def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak)
         call("df_wino2d_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, H, W, cin, cout,
              flags, float(leak), _stream())
         return y
+    if THIN_VALU_ONLY:
+        flags |= _lib.DF_CONV_VALU_ONLY
     call("df_conv_fwd" + _sfx(cin, cout), _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, D, H, W,
          cin, cout, kz, flags, float(leak), _stream())
     return y
@@ -283,10 +306,7 @@ class _ConvSame3(torch.autograd.Function):
             dp = gy
         gw = torch.empty_like(w)
         gb = torch.empty(cout, dtype=torch.float32, device=x.device)
-        nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, kz)
-        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
-        call("df_conv_wgrad" + _sfx(cin, cout), _ptr(x), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, _ptr(ws),
-             nbytes, _stream())
+        _wgrad(x, dp, gw, gb, B, D, H, W, cin, cout, kz, _sfx(cin, cout))
         gx = None
         if ctx.needs_input_grad[0]:
             wpd = _pack(w, taps, cin, cout, 1, dims)
@@ -324,6 +344,8 @@ class _GenBlock(torch.autograd.Function):
             raise ValueError("gen_block: residual add needs Cout == Cin of the block")
         y = torch.empty_like(x)
         call("df_add", _ptr(x), _ptr(x0), _ptr(y), x.numel(), _stream())
+        if ACTIVATION_FETCH is not None:
+            ACTIVATION_FETCH.extend(xs[1:])
         ctx.save_for_backward(*(xs + [wb[2 * i] for i in range(n)]))
         ctx.geom = (n, dims, kz, taps, float(leak))
         return y
@@ -344,10 +366,7 @@ class _GenBlock(torch.autograd.Function):
             cin, cout = w.shape[-2], w.shape[-1]
             gw = torch.empty_like(w)
             gb = torch.empty(cout, dtype=torch.float32, device=dy.device)
-            nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, kz)
-            wsb = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
-            call("df_conv_wgrad" + _sfx(cin, cout), _ptr(xs[i - 1]), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz,
-                 _ptr(wsb), nbytes, _stream())
+            _wgrad(xs[i - 1], dp, gw, gb, B, D, H, W, cin, cout, kz, _sfx(cin, cout))
             grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
             wpd = _pack(w, taps, cin, cout, 1, dims)
             if i > 1:      # dgrad, times the lrelu slope of the layer below: directly the next dp
@@ -416,6 +435,8 @@ class _UpGenBlock(torch.autograd.Function):
         if y is None:
             y = torch.empty_like(x)
             call("df_add_up2x", _ptr(x), _ptr(xc), _ptr(y), cdims[0], cdims[1], cdims[2], cdims[3], C, int(is3d), _stream())
+        if ACTIVATION_FETCH is not None:
+            ACTIVATION_FETCH.extend(xs)
         ctx.save_for_backward(*([xc] + xs + [wb[2 * i] for i in range(n)]))
         ctx.geom = (n, cdims, fdims, kz, taps, float(leak), C, is3d)
         return y
@@ -436,17 +457,18 @@ class _UpGenBlock(torch.autograd.Function):
             gw = torch.empty_like(w)
             gb = torch.empty(C, dtype=torch.float32, device=dy.device)
             if i > 1:
-                nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, C, kz)
-                wsb = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
-                call("df_conv_wgrad" + _sfx(C, C), _ptr(xs[i - 2]), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, C, C, kz, _ptr(wsb),
-                     nbytes, _stream())
+                _wgrad(xs[i - 2], dp, gw, gb, B, D, H, W, C, C, kz, _sfx(C, C))
                 wpd = _pack(w, taps, C, C, 1, fdims)
                 dp = _conv_raw(dp, wpd, None, None, xs[i - 2], fdims, C, C, kz, DF_CONV_MASK, leak).view(dy.shape)
             else:
                 nbytes = query("df_upconv_wgrad_workspace_bytes", cdims[0], cdims[1], cdims[2], cdims[3], C, C, kz)
                 wsb = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
-                call("df_upconv_wgrad" + _sfx(C, C), _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
-                     cdims[3], C, C, kz, _ptr(wsb), nbytes, _stream())
+                if _sfx(C, C):
+                    call("df_upconv_wgrad" + _sfx(C, C), _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
+                         cdims[3], C, C, kz, _ptr(wsb), nbytes, _stream())
+                else:
+                    call("df_upconv_wgrad_algo", _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
+                         cdims[3], C, C, kz, _ptr(wsb), nbytes, int(WGRAD_ALGO), _stream())
                 if ctx.needs_input_grad[0]:
                     dxc = torch.empty_like(xc)          # skip path: sum-pool of dy, then += the conv path per parity class
                     call("df_upsample2x_bwd", _ptr(dy), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, int(is3d),
@@ -489,7 +511,7 @@ class _ConvSame3S2(torch.autograd.Function):
             raise NotImplementedError("stride-2 conv: even spatial extents only (the encoder asserts them, model.py:125,161)")
         idims = (x.shape[0], x.shape[1] if nd == 3 else 1, x.shape[-3], x.shape[-2])
         odims = (idims[0], idims[1] // 2 if nd == 3 else 1, idims[2] // 2, idims[3] // 2)
-        wp = _pack(w, taps, cin, cout, 0)
+        wp = _pack(w, taps, cin, cout, 0, fp32=True)       # df_conv_s2_fwd has no bf16x3 variant: always the fp32 operand
         flags = DF_CONV_BIAS | (DF_CONV_LRELU if leak is not None else 0)
         y = torch.empty(odims + (cout,), dtype=torch.float32, device=x.device)
         call("df_conv_s2_fwd", _ptr(x), _ptr(wp), _ptr(b), _ptr(y), odims[0], odims[1], odims[2], odims[3], cin, cout, kz,
@@ -515,9 +537,7 @@ class _ConvSame3S2(torch.autograd.Function):
         call("df_dilate2_odd", _ptr(dp), _ptr(up), odims[0], odims[1], odims[2], odims[3], cout, int(kz == 3), _stream())
         gw = torch.empty_like(w)
         gb = torch.empty(cout, dtype=torch.float32, device=x.device)
-        nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, kz)
-        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
-        call("df_conv_wgrad", _ptr(x), _ptr(up), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, _ptr(ws), nbytes, _stream())
+        _wgrad(x, up, gw, gb, B, D, H, W, cin, cout, kz)
         gx = None
         if ctx.needs_input_grad[0]:
             wpd = _pack(w, taps, cin, cout, 1, idims)
@@ -811,6 +831,11 @@ def mse_mean(a, b):
 
 
 FUSED_BLOCKS = True     # GeneratorBE(3) uses one fused autograd node per block (same kernels, fused backward epilogues)
+
+# Fetch of intermediate tensors (the counterpart of adding a tensor to ``sess.run``'s fetch list): when set to a list, every
+# fused generator block appends its post-lrelu conv outputs (layer order) to it.  Used by the full-size parity tests to hand the
+# oracle the lrelu sign pattern the GPU actually took.  None (default) = no fetch, no cost.
+ACTIVATION_FETCH = None
 
 
 def gen_block(x, filters, names, nd, leak=0.2):

@@ -13,7 +13,10 @@ Reproduces ``build_model`` (trainer.py:136-184; trainer3.py:14-63) and the hot l
 Flag names and defaults are the reference's (config.py:14-70).  Parameters, gradients and Adam slots
 each live in one flat slab (one fused optimizer launch, bucketed all-reduce for data parallelism).
 """
+import json
 import math
+import os
+import time
 from types import SimpleNamespace
 
 import numpy as np
@@ -32,7 +35,8 @@ def default_config(**over):
              w1=1.0, w2=1.0, arch="de", batch_size=8, max_epoch=100, lr_max=1e-4, lr_min=2.5e-6,
              optimizer="adam", beta1=0.5, beta2=0.999, lr_update="decay", lr_update_step=120000,
              start_step=0, random_seed=123, num_samples=21000, c_num=3, use_curl3_alias=True,
-             z_num=16, use_sparse=False, sparsity=0.01, w4=1.0, w5=1.0, p_num=2, x_channels=None, w3=0.005)
+             z_num=16, use_sparse=False, sparsity=0.01, w4=1.0, w5=1.0, p_num=2, x_channels=None, w3=0.005,
+             log_step=500, test_step=1000, test_batch_size=100, model_dir=None)            # config.py:62-68
     c.update(over)
     return SimpleNamespace(**c)
 
@@ -133,7 +137,7 @@ class Trainer(object):
                 self.flat_v[o:o + n].copy_(torch.from_numpy(d[k + "/Adam_1"].reshape(-1)))
             self.step = int(d["step"]); self.g_lr = float(d["g_lr"]); self._adam_t = int(d["beta_power_t"])
 
-    def enable_data_parallel(self, group=None):
+    def enable_data_parallel(self, group=None, profile=False):
         """Bucket the flat gradient slab per generator block (fc | 4 convs | ... | last conv)."""
         groups = {}
         for k in self.var_names:
@@ -145,7 +149,7 @@ class Trainer(object):
             off = self.var_slices[ks[0]][0]
             n = sum(self.var_slices[k][1] for k in ks)
             buckets.append((off, n, [ops._VARS[k] for k in ks]))
-        self.grad_sync = GradSync(self.flat_g, buckets, group)
+        self.grad_sync = GradSync(self.flat_g, buckets, group, profile=profile)
         return self.grad_sync
 
     # ---- graph (trainer.py:136-172 / trainer3.py:14-51) -------------------------------------------------
@@ -190,6 +194,12 @@ class Trainer(object):
         m.g_loss.backward()
         gscale = self.grad_sync.finish() if self.grad_sync is not None else 1.0
         self._apply_adam(gscale)
+        self._advance_lr()
+        return m
+
+    def _advance_lr(self):
+        """``sess.run(g_lr_update)`` after the optimizer step, with the already-incremented global step
+        (trainer.py:74-80, 284-288)."""
         self.step += 1
         if self.lr_update == "decay":
             self.g_lr = self.config.lr_min + 0.5 * (self.config.lr_max - self.config.lr_min) * (
@@ -197,7 +207,95 @@ class Trainer(object):
         elif self.lr_update == "step":
             if (self.step - 1) % self.config.lr_update_step == self.config.lr_update_step - 1:
                 self.g_lr = max(self.g_lr * 0.5, self.config.lr_min)
-        return m
+
+    # ---- `train_` (trainer.py:228-293): the loop, the scalar log, the NaN guard, the final checkpoint -------------------------
+    def _scalars(self, m, ep):
+        """The scalar summaries of trainer.py:190-199 (+ the 'dg' ones, :208-213)."""
+        out = {"loss/g_loss": float(m.g_loss.detach()), "loss/g_loss_l1": float(m.g_loss_l1.detach()),
+               "loss/g_loss_j_l1": float(m.g_loss_j_l1.detach()), "misc/epoch": ep, "misc/g_lr": self.g_lr}
+        for k in ("g_loss_real", "d_loss_real", "d_loss_fake"):
+            if getattr(m, k, None) is not None:
+                out["loss/" + k] = math.sqrt(max(float(getattr(m, k).detach()), 0.0))
+        return out
+
+    def train(self, batch_manager, max_step=None, model_dir=None, log_step=None, test_step=None, on_log=None):
+        """``Trainer.train_``: steps ``start_step .. max_step-1`` on batches dequeued from ``batch_manager``.  Every ``log_step``
+        steps (and at the last) the scalars of the reference's summary op are appended as one JSON line to
+        ``<model_dir>/scalars.jsonl`` (the counterpart of the TensorBoard event file) and the loss is checked for NaN
+        (trainer.py:271-276); every ``test_step`` steps the fixed parameter sweeps are generated (trainer.py:230-241, 281-282;
+        stored as ``<model_dir>/<step>_G.npz`` instead of PNG sheets); the last checkpoint is written at the end
+        (trainer.py:290-292).  Only rank 0 of a data-parallel job writes files.  Returns the logged records."""
+        model_dir = model_dir or self.config.model_dir
+        log_step = log_step or self.config.log_step
+        test_step = test_step or self.config.test_step
+        max_step = self.max_step if max_step is None else max_step
+        rank0 = self.grad_sync is None or not self.grad_sync.enabled or self.grad_sync.rank == 0
+        if model_dir and rank0:
+            os.makedirs(model_dir, exist_ok=True)
+        # test1: each parameter varied over [-1, 1] with the others at 0 (trainer.py:230-241)
+        z_samples = []
+        for i in range(self.c_num):
+            zi = np.zeros((self.b_num, self.c_num), np.float32)
+            zi[:, i] = np.linspace(-1, 1, num=self.b_num)
+            z_samples.append(zi)
+        records = []
+        t0 = time.time()
+        for step in range(self.step, max_step):
+            x, y = batch_manager.batch()
+            m = self.train_step(x, y)
+            if step % log_step == 0 or step == max_step - 1:
+                ep = step * batch_manager.epochs_per_step
+                rec = self._scalars(m, ep)
+                loss = rec["loss/g_loss"]
+                assert not np.isnan(loss), "Model diverged with loss = NaN"            # trainer.py:275
+                rec.update(step=step, wall_s=time.time() - t0)
+                records.append(rec)
+                if rank0:
+                    print("[{}/{}/ep{:.2f}] Loss: {:.6f}".format(step, max_step, ep, loss))
+                    if model_dir:
+                        with open(os.path.join(model_dir, "scalars.jsonl"), "a") as f:
+                            f.write(json.dumps(rec) + "\n")
+                if on_log is not None:
+                    on_log(rec)
+            if model_dir and rank0 and (step % test_step == 0 or step == max_step - 1):
+                G = np.stack([self.generate(torch.from_numpy(z).to(self.device)).cpu().numpy() for z in z_samples])
+                np.savez_compressed(os.path.join(model_dir, "%d_G.npz" % step), G=G, z=np.stack(z_samples))
+        if model_dir and rank0:
+            self.save(os.path.join(model_dir, "model.ckpt-%d.npz" % self.step))
+        if hasattr(batch_manager, "stop_thread"):
+            batch_manager.stop_thread()
+        return records
+
+    # ---- `test_` (trainer.py:314-354): one parameter pair, every frame, de-normalised, one .npz per frame ----------------------
+    def test_(self, batch_manager, model_dir=None, p1=10, p2=2, test_b_num=None):
+        """The inference sweep of ``Trainer.test_``: fix the first two control parameters at grid indices (p1, p2) -> c = p/(num-1)*2-1,
+        sweep the last one (the frame number) over its ``y_num[2]`` values in [-1, 1], run the inference graph in batches of
+        ``test_batch_size``, de-normalise with the dataset's velocity range (``batch_manager.denorm``) and dump frame i to
+        ``<model_dir>/<p1>_<p2>/<i>.npz`` under key ``x`` (np.savez_compressed) -- the files the reference's visualisation scripts read."""
+        model_dir = model_dir or self.config.model_dir
+        test_b_num = test_b_num or self.config.test_batch_size
+        y1, y2, y3 = (int(v) for v in batch_manager.y_num[:3])
+        if y3 % test_b_num != 0:                                     # trainer.py:324 asserts; the default 100 rarely divides test data
+            raise ValueError("test_: the number of frames (%d) must be a multiple of test_batch_size (%d)" % (y3, test_b_num))
+        niter = y3 // test_b_num
+        c1 = p1 / float(y1 - 1) * 2 - 1
+        c2 = p2 / float(y2 - 1) * 2 - 1
+        z_c = np.zeros((y3, self.c_num), np.float32)
+        z_c[:, 0] = c1
+        z_c[:, 1] = c2
+        z_c[:, -1] = np.linspace(-1, 1, num=y3)
+        G = []
+        for b in range(niter):
+            z = torch.from_numpy(z_c[test_b_num * b:test_b_num * (b + 1)]).to(self.device)
+            G_ = self.generate(z).cpu().numpy()
+            G_, _ = batch_manager.denorm(x=G_)
+            G.append(G_)
+        G = np.concatenate(G, axis=0)
+        out_dir = os.path.join(model_dir, "%d_%d" % (p1, p2))
+        os.makedirs(out_dir, exist_ok=True)
+        for i, G_ in enumerate(G):
+            np.savez_compressed(os.path.join(out_dir, "%d.npz" % i), x=G_)
+        return out_dir
 
     def _apply_adam(self, grad_scale):
         if self.config.optimizer == "gd":                       # trainer.py:163-165
@@ -307,10 +405,20 @@ class GANTrainer(Trainer):
                 disc(torch.zeros([1] + spatial + [cin], device=self.device), self.filters)
         self.D = _Slab([k for k in ops.all_variables() if k.startswith("D/")], self.device)
         self._adam_t_d = 0
+        self.grad_sync_d = None
+
+    def enable_data_parallel(self, group=None, profile=False):
+        """Two gradient slabs -> two bucketed exchanges: G's per generator block (as in ``Trainer``), D's as one bucket."""
+        gs = super(GANTrainer, self).enable_data_parallel(group, profile)
+        self.grad_sync_d = GradSync(self.D.g, [(0, self.D.n, list(self.D.vars))], group)
+        return gs
 
     def train_step(self, x, y):
         disc = DiscriminatorPatch3 if self.is_3d else DiscriminatorPatch
         self.flat_g.zero_(); self.D.g.zero_()
+        dp = self.grad_sync is not None
+        if dp:
+            self.grad_sync.begin_step(); self.grad_sync_d.begin_step()
         m = self.build_model(x, y)
         with torch.no_grad():
             x_vort = (jacobian3(x) if self.is_3d else jacobian(x))[1]                 # trainer.py:30,32
@@ -322,16 +430,22 @@ class GANTrainer(Trainer):
         m.d_loss_real = ops.mse_mean(D_x, ones_x)                                      # trainer.py:177
         m.g_loss = m.g_loss + m.g_loss_real * self.w3                                  # trainer.py:179
         m.d_loss = m.d_loss_real + m.d_loss_fake                                       # trainer.py:181
+        # two `minimize` calls on disjoint var_lists (trainer.py:183-184): each backward accumulates into its own slab only, so
+        # the post-accumulate hooks of a slab fire during exactly one of the two passes and its buckets are reduced once
         m.g_loss.backward(inputs=self.G_var, retain_graph=True)
         m.d_loss.backward(inputs=self.D.vars)
-        self._apply_adam(1.0)
-        self._adam_t_d += 1
-        t = self._adam_t_d
-        lr_t = self.g_lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
-        call("df_adam_tf1_step", _ptr(self.D.p), _ptr(self.D.g), _ptr(self.D.m), _ptr(self.D.v), self.D.n, float(lr_t),
-             float(self.beta1), float(self.beta2), float(self.eps), 1.0, _stream())
-        self.step += 1
-        if self.lr_update == "decay":
-            self.g_lr = self.config.lr_min + 0.5 * (self.config.lr_max - self.config.lr_min) * (
-                math.cos(self.step * math.pi / self.max_step) + 1.0)
+        gscale = 1.0
+        if dp:
+            gscale = self.grad_sync.finish()
+            self.grad_sync_d.finish()
+        self._apply_adam(gscale)
+        if self.config.optimizer == "gd":                                              # trainer.py:163-165 (both optimizers)
+            self.D.p.add_(self.D.g, alpha=-self.g_lr * gscale)
+        else:
+            self._adam_t_d += 1
+            t = self._adam_t_d
+            lr_t = self.g_lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+            call("df_adam_tf1_step", _ptr(self.D.p), _ptr(self.D.g), _ptr(self.D.m), _ptr(self.D.v), self.D.n, float(lr_t),
+                 float(self.beta1), float(self.beta2), float(self.eps), float(gscale), _stream())
+        self._advance_lr()
         return m

@@ -16,7 +16,10 @@
  *     synchronises internally, so calls compose with PyTorch's current stream and hipGraph capture;
  *   - return 0 on success, <0 = DF_E* argument error, >0 = hipError_t; never throws, never
  *     aborts; a message for the calling thread's last failure is kept in df_last_error();
- *   - re-entrant; no global state besides read-only kernel handles.
+ *   - re-entrant; no global state besides read-only kernel handles: algorithm choices are call arguments
+ *     (`algo`, DF_CONV_VALU_ONLY), never process-wide switches.  (Tuning builds, `make tuning` with -DDF_TUNING, add
+ *     the instrumented kernels and knobs declared in deepfluids_hip_debug.h to a SEPARATE library; the release
+ *     library exports exactly what this header declares.)
  */
 #ifndef DEEPFLUIDS_HIP_H
 #define DEEPFLUIDS_HIP_H
@@ -43,7 +46,9 @@ enum {
   DF_CONV_RESIDUAL = 2,   /* y += residual (after act)      model.py:35,40,77,82                       */
   DF_CONV_MASK = 4,       /* y *= (mask_src > 0 ? 1 : leak) lrelu backward fused into the dgrad epilogue */
   DF_CONV_BIAS = 8,       /* v += bias[cout]                slim.conv* biases                          */
-  DF_CONV_ADDUP = 16      /* second output y2 = y + nearest_up2x(xc)  (df_wino_conv_fwd_addup only)     */
+  DF_CONV_ADDUP = 16,     /* second output y2 = y + nearest_up2x(xc)  (df_wino_conv_fwd_addup only)     */
+  DF_CONV_VALU_ONLY = 32  /* thin layers (Cin or Cout <= 4): take the general-shape vector-ALU kernel even where the
+                             matrix-core form exists (the parity tests compare the two)                    */
 };
 
 typedef void* df_stream_t; /* hipStream_t */
@@ -185,6 +190,11 @@ int df_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int6
 int64_t df_upconv_wgrad_workspace_bytes(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz);
 int df_upconv_wgrad(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
                     int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream);
+/* algo: 0 best available | 1 generic direct kernel on the parity classes | 2, 3 three-product parity-class kernel |
+ * 4 the 27-point Winograd-(x,y,z) form wherever instantiated (df_upconv_wgrad == algo 0). */
+int df_upconv_wgrad_algo(const float* xc, const float* gy, float* gw, float* gb, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc,
+                         int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, int algo,
+                         df_stream_t stream);
 /* y[fine] = a[fine] + nearest_up2x(bc[coarse])  (block-end residual `x += x0` with x0 = upscale(.), model.py:35-40). */
 int df_add_up2x(const float* a, const float* bc, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
                 df_stream_t stream);
@@ -264,6 +274,15 @@ int df_upconv_wgrad_bf16x3(const float* xc, const float* gy, float* gw, float* g
 int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz);
 int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
                   int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream);
+/* The same with the algorithm chosen by the caller instead of by size (df_conv_wgrad == algo 0):
+ *   algo & 7: 0 best available | 1 direct kernels only | 2 at most Winograd in x | 3 Winograd F(2x2,3x3) in (x,y) wherever
+ *             instantiated | 4 Winograd F(2x2x2,3x3x3) in (x,y,z) wherever instantiated (shapes without that form fall
+ *             back towards 0 -- every choice returns the same gradient up to fp32 summation order);
+ *   algo >> 3: number of voxel ranges of the partial sums (0 = default; <= 256).
+ * Workspace: df_conv_wgrad_workspace_bytes covers every choice. */
+int df_conv_wgrad_algo(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
+                       int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, int algo,
+                       df_stream_t stream);
 
 #ifdef __cplusplus
 }

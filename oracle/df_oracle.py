@@ -343,8 +343,10 @@ def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, l
     return (out, cache) if keep else out
 
 
-def generator_bwd(dout, cache, p, name="G", leak=0.2):
-    """Manual reverse pass of :func:`generator_fwd`; returns grads keyed like ``p``."""
+def generator_bwd(dout, cache, p, name="G", leak=0.2, masks=None):
+    """Manual reverse pass of :func:`generator_fwd`; returns grads keyed like ``p``.  ``masks`` ({layer number: bool array},
+    optional) replaces the oracle's own lrelu sign pattern by the one the implementation under test took: the network is
+    piecewise linear, and a pre-activation within rounding error of zero may pick either slope."""
     g = {}
     ln = cache["last_ln"]
     dx, dw, db = conv_same_bwd(cache["last_in"], p["%s/%d_conv/weights" % (name, ln)], dout)
@@ -354,7 +356,8 @@ def generator_bwd(dout, cache, p, name="G", leak=0.2):
             dx = upscale_nn_bwd(dx, 2)
         dy = dx
         for xin, xout, l in zip(reversed(blk["ins"]), reversed(blk["outs"]), reversed(blk["ln"])):
-            dpre = dx * np.where(xout > 0, 1.0, leak).astype(dx.dtype)
+            pos = (xout > 0) if masks is None else masks[l]
+            dpre = dx * np.where(pos, 1.0, leak).astype(dx.dtype)
             dx, dw, db = conv_same_bwd(xin, p["%s/%d_conv/weights" % (name, l)], dpre)
             g["%s/%d_conv/weights" % (name, l)] = dw; g["%s/%d_conv/biases" % (name, l)] = db
         dx = dx + dy
@@ -647,12 +650,12 @@ def lr_cosine(step, max_step, lr_max=1e-4, lr_min=2.5e-6):
 
 
 def train_step(z, x, p, opt, output_shape, filters, is_3d, num_conv=4, repeat=0, w1=1.0, w2=1.0,
-               name="G"):
+               name="G", masks=None):
     """One full step: G fwd -> curl -> Jacobian -> L1 losses -> bwd -> TF1 Adam (in place on
     copies).  ``opt`` = dict(m, v, t, lr).  Returns (new_p, new_opt, info)."""
     psi, cache = generator_fwd(z, p, output_shape, filters, name, num_conv, repeat, keep=True)
     res = velocity_loss(psi, x, is_3d, w1, w2)
-    grads = generator_bwd(res["dpsi"], cache, p, name)
+    grads = generator_bwd(res["dpsi"], cache, p, name, masks=masks)
     t = opt["t"] + 1
     new_p, new_m, new_v = {}, {}, {}
     for k in p:

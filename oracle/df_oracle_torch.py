@@ -59,8 +59,26 @@ def upscale_nn(x):
     return x
 
 
-def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, leak=0.2):
-    """model.py:5-87 (skip_concat=False)."""
+class _LreluMasked(torch.autograd.Function):
+    """lrelu whose BACKWARD slope pattern is given (``mask`` = where the implementation under test took slope 1).  The
+    network is piecewise linear; a pre-activation within rounding error of zero can pick the other slope in two correct
+    implementations, which moves single gradient elements by O(1).  Gradient parity is therefore checked on the linear
+    region the GPU actually took; the forward value is this oracle's own lrelu."""
+
+    @staticmethod
+    def forward(ctx, pre, mask, leak):
+        ctx.save_for_backward(mask)
+        ctx.leak = leak
+        return F.leaky_relu(pre, leak)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return torch.where(mask, g, g * ctx.leak), None, None
+
+
+def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, leak=0.2, masks=None):
+    """model.py:5-87 (skip_concat=False).  ``masks``: optional {layer number: bool tensor} for :class:`_LreluMasked`."""
     spatial = list(output_shape[:-1])
     repeat_num = int(np.log2(np.max(spatial))) - 2 if repeat == 0 else repeat
     f = 2 ** (repeat_num - 1)
@@ -70,7 +88,8 @@ def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, l
     x0 = x
     for idx in range(repeat_num):
         for _ in range(num_conv):
-            x = F.leaky_relu(conv_same(x, p["%s/%d_conv/weights" % (name, ln)], p["%s/%d_conv/biases" % (name, ln)]), leak)
+            pre = conv_same(x, p["%s/%d_conv/weights" % (name, ln)], p["%s/%d_conv/biases" % (name, ln)])
+            x = F.leaky_relu(pre, leak) if masks is None else _LreluMasked.apply(pre, masks[ln], leak)
             ln += 1
         x = x + x0
         if idx < repeat_num - 1:
@@ -89,12 +108,12 @@ def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0):
 
 
 def train_step(z, x, p, opt, output_shape, filters, is_3d, num_conv=4, repeat=0, w1=1.0, w2=1.0, beta1=0.5,
-               beta2=0.999, eps=1e-8):
+               beta2=0.999, eps=1e-8, masks=None):
     """One step with TF1 Adam, in place on ``p`` (dict of leaf tensors) and ``opt`` (m, v, t, lr)."""
     for v in p.values():
         v.requires_grad_(True)
         v.grad = None
-    psi = generator_fwd(z, p, output_shape, filters, num_conv=num_conv, repeat=repeat)
+    psi = generator_fwd(z, p, output_shape, filters, num_conv=num_conv, repeat=repeat, masks=masks)
     loss, l1, jl1, u = velocity_loss(psi, x, is_3d, w1, w2)
     loss.backward()
     opt["t"] += 1

@@ -18,6 +18,9 @@ def test_library_present_and_exports_every_declared_symbol():
     missing = [s for s in declared if s not in exported]
     assert not missing, missing
     assert sorted(_lib.SIGNATURES) == declared          # the ctypes table binds exactly the header
+    # ... and the release library exports nothing BUT the header: no debug / tuning entry points, no mutable switches
+    extra = sorted(s for s in exported if s.startswith("df_") and s not in declared)
+    assert not extra, extra
 
 
 def test_version_and_error_convention():

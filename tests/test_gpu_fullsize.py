@@ -1,0 +1,425 @@
+"""-m gpu: parity of the DEFAULT dispatch at the benchmark's own shapes (BASELINE cfg3 64x96x64 and cfg4 112x160x112, F = 128).
+
+The kernels are shape-specialised (row-length variants of the weight gradients, XCD-pinned tile maps, 32-bit offsets inside
+one batch volume), so small-shape parity does not transfer automatically.  Three kinds of checks:
+  * the whole train step with the default dispatch against the PyTorch-CPU oracle (oracle/df_oracle_torch.py, fp32 on the
+    box's host cores) on the same weights / inputs: velocity rel-L1 <= 1e-4 (north star), loss, every per-variable gradient
+    with the lrelu sign pattern taken from the GPU (the network is piecewise linear; see _LreluMasked);
+  * every algorithm of a layer against the direct MFMA kernels (which the small cases of test_gpu_layers.py pin against the
+    fp64 oracle) at full size and batch >= 2;
+  * batch 16 (3 GiB activations): first and last batch element bit-identical to the batch-1 result (offset overflow).
+"""
+import numpy as np
+import pytest
+import torch
+
+import df_oracle as orc
+import df_oracle_torch as ort
+from gpu_util import dev, host, rel_l1
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_max(a, b):
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+def _grad_errs(gpu_grads, ref_grads):
+    """Per-variable L-inf error relative to that variable's gradient scale, floored at 1e-3 of the global scale (the last
+    conv's bias gradient is mathematically zero: curl annihilates constants)."""
+    ref = {k: np.asarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v, np.float64) for k, v in ref_grads.items()}
+    gmax = max(np.abs(v).max() for v in ref.values())
+    return {k: float(np.abs(gpu_grads[k] - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-3 * gmax)) for k in gpu_grads}
+
+
+def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True):
+    """One default-dispatch train step (or, backward=False, the inference graph) on the GPU and on the PyTorch-CPU oracle."""
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import Trainer, default_config
+    ops.reset_variables()
+    rng = np.random.RandomState(seed)
+    oshape = list(spatial) + [3]
+    p = orc.generator_init(rng, 3, oshape, filters)
+    for k in p:
+        if k.endswith("biases"):
+            p[k] = rng.uniform(-0.05, 0.05, p[k].shape).astype(np.float32)
+    x, y = orc.synthetic_batch(rng, batch, spatial)
+    cfg = default_config(is_3d=True, res_x=spatial[2], res_y=spatial[1], res_z=spatial[0], filters=filters, batch_size=batch,
+                         num_samples=1000)
+    tr = Trainer(cfg)
+    tr.load_variables(p)
+    torch.set_num_threads(max(1, min(len(__import__("os").sched_getaffinity(0)), 64)))
+    pt = ort.to_torch(p)
+    out = {}
+    if not backward:
+        u = host(tr.generate(dev(y)))
+        with torch.no_grad():
+            psi = ort.generator_fwd(torch.from_numpy(y), pt, oshape, filters)
+            ref = ort.jacobian3(psi)[1].numpy()
+        out["velocity_rel_l1"] = rel_l1(u, ref)
+        ops.reset_variables()
+        return out
+    ops.ACTIVATION_FETCH = []
+    try:
+        m = tr.train_step(dev(x), dev(y))
+        masks = {i + 1: (t > 0).cpu() for i, t in enumerate(ops.ACTIVATION_FETCH)}
+    finally:
+        ops.ACTIVATION_FETCH = None
+    gr = tr.grads_numpy()
+    u, loss = host(m.G_), float(m.g_loss.detach())
+    del m
+    info = ort.train_step(torch.from_numpy(y), torch.from_numpy(x), pt, ort.new_opt(pt), oshape, filters, True, masks=masks)
+    out["velocity_rel_l1"] = rel_l1(u, info["u"].numpy())
+    out["loss_rel"] = abs(loss - info["loss"]) / abs(info["loss"])
+    errs = _grad_errs(gr, info["grads"])
+    out["grad_rel_linf"] = max(errs.values())
+    out["grad_worst"] = max(errs, key=errs.get)
+    out["n_layers_fetched"] = len(masks)
+    ops.reset_variables()
+    return out
+
+
+def test_cfg3_default_dispatch_train_step_vs_torch_oracle_b2():
+    """BASELINE cfg3 (64x96x64, F = 128, 4 levels), batch 2: Winograd forward / dgrad (+ fused skip add), up-sampling-aware
+    27-point forms, Winograd-(x,y,z) weight gradients (W = 64 | 32 | 16 row variants), matrix-core thin layer."""
+    r = _step_vs_torch_oracle((64, 96, 64), 128, 2, seed=11)
+    assert r["n_layers_fetched"] == 16, r
+    assert r["velocity_rel_l1"] <= 1e-4, r           # north-star tolerance (measured ~2e-6: fp32 vs fp32)
+    assert r["loss_rel"] < 1e-5, r
+    assert r["grad_rel_linf"] < 1e-3, r
+
+
+def test_cfg4_full_grid_train_step_vs_torch_oracle():
+    """BASELINE cfg4's grid (112x160x112, 5 levels, x0 = 7x10x7, W = 112 | 56 | 28 | 14 | 7 rows), one sample: forward
+    velocity and -- when the host has the memory for the oracle's autograd tape -- every gradient."""
+    free_gb = 0.0
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                free_gb = float(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    backward = free_gb >= 160.0
+    r = _step_vs_torch_oracle((112, 160, 112), 128, 1, seed=12, backward=backward)
+    assert r["velocity_rel_l1"] <= 1e-4, r
+    if backward:
+        assert r["n_layers_fetched"] == 20, r
+        assert r["loss_rel"] < 1e-5, r
+        assert r["grad_rel_linf"] < 1e-3, r
+
+
+def test_cfg4_geometry_reduced_train_step_vs_fp64_oracle():
+    """cfg4's odd-extent geometry at a quarter of the grid (28x40x28: 3 levels from x0 = 7x10x7, F = 128), batch 2, against the
+    fp64 NumPy oracle (two steps incl. TF1 Adam and the cosine schedule)."""
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import Trainer, default_config
+    ops.reset_variables()
+    spatial, filters, batch = (28, 40, 28), 128, 2
+    rng = np.random.RandomState(13)
+    oshape = list(spatial) + [3]
+    p = orc.generator_init(rng, 3, oshape, filters)
+    x, y = orc.synthetic_batch(rng, batch, spatial)
+    cfg = default_config(is_3d=True, res_x=28, res_y=40, res_z=28, filters=filters, batch_size=batch, num_samples=1000)
+    tr = Trainer(cfg)
+    assert tr.n_params == sum(v.size for v in p.values())
+    tr.load_variables(p)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    opt = {"m": {k: np.zeros_like(v) for k, v in p64.items()}, "v": {k: np.zeros_like(v) for k, v in p64.items()}, "t": 0,
+           "lr": cfg.lr_max}
+    for s in range(2):
+        ops.ACTIVATION_FETCH = []
+        try:
+            m = tr.train_step(dev(x), dev(y))
+            masks = {i + 1: host(t) > 0 for i, t in enumerate(ops.ACTIVATION_FETCH)}
+        finally:
+            ops.ACTIVATION_FETCH = None
+        p64, opt, info = orc.train_step(y.astype(np.float64), x.astype(np.float64), p64, opt, oshape, filters, True, masks=masks)
+        opt["lr"] = orc.lr_cosine(s + 1, tr.max_step)
+        assert rel_l1(host(m.G_), info["u"]) <= 1e-4, s
+        assert abs(float(m.g_loss.detach()) - info["loss"]) / abs(info["loss"]) < (1e-5 if s == 0 else 1e-4), s
+        if s == 0:
+            errs = _grad_errs(tr.grads_numpy(), info["grads"])
+            assert max(errs.values()) < 1e-3, (max(errs, key=errs.get), max(errs.values()))
+    assert abs(tr.g_lr - opt["lr"]) < 1e-12
+    ops.reset_variables()
+
+
+def test_full_size_conv_algorithms_agree_cfg3():
+    """BASELINE cfg3 spatial size (64x96x64, F = 128), batch 2: independently written algorithms must agree -- the direct MFMA
+    kernels (pinned against the fp64 oracle in test_gpu_layers.py) vs the Winograd forward / dgrad incl. its fused mask /
+    residual epilogues, and the weight gradient in all five `algo` settings (0 = the default the bench runs = Winograd-(x,y,z)
+    here, 1 direct, 2 Winograd-x, 3 Winograd-(x,y), 4 Winograd-(x,y,z)); plus linearity of the Winograd conv in its input."""
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream
+    torch.manual_seed(3)
+    B, D, H, W, C = 2, 64, 96, 64, 128
+    s = _stream()
+    x = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    x2 = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    g = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    w = (torch.rand((3, 3, 3, C, C), device="cuda") * 2 - 1) * (1.0 / (27 * C)) ** 0.5
+    bias = torch.rand(C, device="cuda") - 0.5
+    for mode in (0, 1):
+        wd = torch.empty(query("df_conv_packed_elems", 27, C, C, mode), device="cuda")
+        call("df_conv_pack_weights", _ptr(w), _ptr(wd), 27, C, C, mode, s)
+        ww = torch.empty(query("df_wino_packed_elems", C, C, mode), device="cuda")
+        call("df_wino_pack_weights", _ptr(w), _ptr(ww), C, C, mode, s)
+        for flags in ((8, 8 | 1) if mode == 0 else (0, 4, 2)):      # fwd: bias (+lrelu); dgrad: plain, lrelu-mask, residual
+            y0 = torch.empty_like(x); y1 = torch.full_like(x, float("nan"))
+            call("df_conv_fwd", _ptr(x), _ptr(wd), _ptr(bias), _ptr(x2), _ptr(g), _ptr(y0), B, D, H, W, C, C, 3, flags, 0.2, s)
+            call("df_wino_conv_fwd", _ptr(x), _ptr(ww), _ptr(bias), _ptr(x2), _ptr(g), _ptr(y1), B, D, H, W, C, C, flags, 0.2, s)
+            assert _rel_max(y1, y0) < 2e-5, (mode, flags)
+            assert ((y0 - y1).abs().sum() / y0.abs().sum()).item() < 5e-6, (mode, flags)
+            assert _rel_max(y1[1], y0[1]) < 2e-5, (mode, flags)                  # second batch element on its own
+        if mode == 0:       # linearity: conv(2 x - 3 x2) = 2 conv(x) - 3 conv(x2) (no bias)
+            ya = torch.empty_like(x); yb = torch.empty_like(x); yc = torch.empty_like(x)
+            xc = 2 * x - 3 * x2
+            for src, dst in ((x, ya), (x2, yb), (xc, yc)):
+                call("df_wino_conv_fwd", _ptr(src), _ptr(ww), None, None, None, _ptr(dst), B, D, H, W, C, C, 0, 0.0, s)
+            lin = 2 * ya - 3 * yb
+            assert _rel_max(lin, yc) < 2e-5
+            del ya, yb, yc, xc, lin
+    nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, C, 3)
+    ws = torch.empty((nb + 3) // 4, device="cuda")
+    res = {}
+    for algo in (1, 0, 2, 3, 4):
+        gw = torch.full((27, C, C), float("nan"), device="cuda"); gb = torch.full((C,), float("nan"), device="cuda")
+        call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, algo, s)
+        res[algo] = (gw, gb)
+    for algo in (0, 2, 3, 4):
+        assert _rel_max(res[algo][0], res[1][0]) < 2e-5, algo
+        assert _rel_max(res[algo][1], res[1][1]) < 2e-5, algo
+    assert torch.equal(res[0][0], res[4][0])            # the default at this size IS the (x,y,z) form
+    # the bias gradient is a plain column sum: check it against torch in fp64
+    ref = g.double().sum(dim=(0, 1, 2, 3))
+    assert ((res[1][1].double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
+def test_full_size_fused_skip_add_and_thin_layer_kernels_cfg3():
+    """At 64x96x64, batch 2: df_wino_conv_fwd_addup (last conv of an up-sampling block with the skip add fused) vs the plain Winograd
+    conv + df_add_up2x; the thin last layer's three matrix-core kernels (F -> 3 forward, 3 -> F dgrad with the lrelu-mask epilogue,
+    F x 3 weight gradient) vs the general-shape vector-ALU kernels (DF_CONV_VALU_ONLY / algo 1)."""
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream
+    torch.manual_seed(4)
+    B, D, H, W, C = 2, 64, 96, 64, 128
+    s = _stream()
+    x = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    xc = torch.rand((B, D // 2, H // 2, W // 2, C), device="cuda") * 2 - 1
+    w = (torch.rand((3, 3, 3, C, C), device="cuda") * 2 - 1) * (1.0 / (27 * C)) ** 0.5
+    bias = torch.rand(C, device="cuda") - 0.5
+    ww = torch.empty(query("df_wino_packed_elems", C, C, 0), device="cuda")
+    call("df_wino_pack_weights", _ptr(w), _ptr(ww), C, C, 0, s)
+    y0 = torch.empty_like(x); ysum0 = torch.empty_like(x)
+    call("df_wino_conv_fwd", _ptr(x), _ptr(ww), _ptr(bias), None, None, _ptr(y0), B, D, H, W, C, C, 8 | 1, 0.2, s)
+    call("df_add_up2x", _ptr(y0), _ptr(xc), _ptr(ysum0), B, D // 2, H // 2, W // 2, C, 1, s)
+    y1 = torch.full_like(x, float("nan")); ysum1 = torch.full_like(x, float("nan"))
+    call("df_wino_conv_fwd_addup", _ptr(x), _ptr(ww), _ptr(bias), _ptr(xc), _ptr(y1), _ptr(ysum1), B, D, H, W, C, C, 0.2, s)
+    assert torch.equal(y0, y1)                 # same kernel arithmetic: bit-identical
+    assert torch.equal(ysum0, ysum1)
+    del y0, y1, ysum0, ysum1, ww, xc
+    # thin forward F -> 3
+    w3 = (torch.rand((3, 3, 3, C, 3), device="cuda") * 2 - 1) * 0.02
+    b3 = torch.rand(3, device="cuda") - 0.5
+    wp = torch.empty(query("df_conv_packed_elems", 27, C, 3, 0), device="cuda")
+    call("df_conv_pack_weights", _ptr(w3), _ptr(wp), 27, C, 3, 0, s)
+    ys = []
+    for valu in (0, 32):
+        y = torch.full((B, D, H, W, 3), float("nan"), device="cuda")
+        call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(b3), None, None, _ptr(y), B, D, H, W, C, 3, 3, 8 | valu, 0.0, s)
+        ys.append(y)
+    assert _rel_max(ys[0], ys[1]) < 5e-6
+    # thin dgrad 3 -> F with the lrelu-mask epilogue (mask source = x)
+    g3 = torch.rand((B, D, H, W, 3), device="cuda") * 2 - 1
+    wpd = torch.empty(query("df_conv_packed_elems", 27, C, 3, 1), device="cuda")
+    call("df_conv_pack_weights", _ptr(w3), _ptr(wpd), 27, C, 3, 1, s)
+    ds = []
+    for valu in (0, 32):
+        d = torch.full_like(x, float("nan"))
+        call("df_conv_fwd", _ptr(g3), _ptr(wpd), None, None, _ptr(x), _ptr(d), B, D, H, W, 3, C, 3, 4 | valu, 0.2, s)
+        ds.append(d)
+    assert _rel_max(ds[0], ds[1]) < 5e-6
+    del ds
+    # thin weight gradient F x 3
+    nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, 3, 3)
+    ws = torch.empty((nb + 3) // 4, device="cuda")
+    gws = []
+    for algo in (0, 1):
+        gw = torch.full((27, C, 3), float("nan"), device="cuda"); gb = torch.full((3,), float("nan"), device="cuda")
+        call("df_conv_wgrad_algo", _ptr(x), _ptr(g3), _ptr(gw), _ptr(gb), B, D, H, W, C, 3, 3, _ptr(ws), nb, algo, s)
+        gws.append((gw, gb))
+    assert _rel_max(gws[0][0], gws[1][0]) < 2e-5
+    assert _rel_max(gws[0][1], gws[1][1]) < 2e-5
+
+
+def test_full_size_upconv_agrees_with_materialised_upsample_cfg3():
+    """The up-sampling-aware first conv of the top generator block at BASELINE cfg3 size (coarse 32x48x32 -> 64x96x64, C = 128,
+    batch 2): df_upconv_{fwd,dgrad,wgrad} (8-tap parity convs, three-product weight gradient) and their 27-point Winograd forms
+    (df_wino_upconv_fwd / _dgrad, df_upconv_wgrad_algo 0 | 4) must agree with nearest_up2x materialised + the plain direct
+    kernels (which the small cases pin against the oracle)."""
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream
+    torch.manual_seed(5)
+    B, D, H, W, C = 2, 32, 48, 32, 128
+    s = _stream()
+    xc = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    g = torch.rand((B, 2 * D, 2 * H, 2 * W, C), device="cuda") * 2 - 1
+    w = (torch.rand((3, 3, 3, C, C), device="cuda") * 2 - 1) * (1.0 / (27 * C)) ** 0.5
+    bias = torch.rand(C, device="cuda") - 0.5
+    xf = torch.empty((B, 2 * D, 2 * H, 2 * W, C), device="cuda")
+    call("df_upsample2x_fwd", _ptr(xc), _ptr(xf), B, D, H, W, C, 1, s)
+    # references: direct kernels only
+    wd = torch.empty(query("df_conv_packed_elems", 27, C, C, 0), device="cuda")
+    call("df_conv_pack_weights", _ptr(w), _ptr(wd), 27, C, C, 0, s)
+    y0 = torch.empty_like(xf)
+    call("df_conv_fwd", _ptr(xf), _ptr(wd), _ptr(bias), None, None, _ptr(y0), B, 2 * D, 2 * H, 2 * W, C, C, 3, 8, 0.0, s)
+    wdd = torch.empty(query("df_conv_packed_elems", 27, C, C, 1), device="cuda")
+    call("df_conv_pack_weights", _ptr(w), _ptr(wdd), 27, C, C, 1, s)
+    gxf = torch.empty_like(xf)
+    call("df_conv_fwd", _ptr(g), _ptr(wdd), None, None, None, _ptr(gxf), B, 2 * D, 2 * H, 2 * W, C, C, 3, 0, 0.0, s)
+    gxc0 = torch.empty_like(xc)
+    call("df_upsample2x_bwd", _ptr(gxf), _ptr(gxc0), B, D, H, W, C, 1, s)
+    nb0 = query("df_conv_wgrad_workspace_bytes", B, 2 * D, 2 * H, 2 * W, C, C, 3)
+    ws0 = torch.empty((nb0 + 3) // 4, device="cuda")
+    gw0 = torch.empty_like(w); gb0 = torch.empty(C, device="cuda")
+    call("df_conv_wgrad_algo", _ptr(xf), _ptr(g), _ptr(gw0), _ptr(gb0), B, 2 * D, 2 * H, 2 * W, C, C, 3, _ptr(ws0), nb0, 1, s)
+    del xf, gxf, ws0
+    wu = torch.empty(query("df_upconv_packed_elems", C, C, 3, 0), device="cuda")
+    call("df_upconv_pack_weights", _ptr(w), _ptr(wu), C, C, 3, 0, s)
+    y1 = torch.full_like(y0, float("nan"))
+    call("df_upconv_fwd", _ptr(xc), _ptr(wu), _ptr(bias), _ptr(y1), B, D, H, W, C, C, 3, 8, 0.0, s)
+    assert _rel_max(y1, y0) < 2e-5
+    ww = torch.empty(query("df_wino_packed_elems", C, C, 0), device="cuda")
+    call("df_wino_pack_weights", _ptr(w), _ptr(ww), C, C, 0, s)
+    y2 = torch.full_like(y0, float("nan"))
+    call("df_wino_upconv_fwd", _ptr(xc), _ptr(ww), _ptr(bias), _ptr(y2), B, D, H, W, C, C, 9, 1.0, s)      # leak 1: lrelu is the identity
+    assert _rel_max(y2, y0) < 2e-5
+    del y2, ww
+    wud = torch.empty(query("df_upconv_packed_elems", C, C, 3, 1), device="cuda")
+    call("df_upconv_pack_weights", _ptr(w), _ptr(wud), C, C, 3, 1, s)
+    gxc1 = torch.zeros_like(xc)
+    call("df_upconv_dgrad", _ptr(g), _ptr(wud), _ptr(gxc1), B, D, H, W, C, C, 3, s)
+    assert _rel_max(gxc1, gxc0) < 2e-5
+    wwd = torch.empty(query("df_wino_packed_elems", C, C, 1), device="cuda")
+    call("df_wino_pack_weights", _ptr(w), _ptr(wwd), C, C, 1, s)
+    gxc2 = torch.zeros_like(xc)
+    call("df_wino_upconv_dgrad", _ptr(g), _ptr(wwd), _ptr(gxc2), B, D, H, W, C, C, s)
+    assert _rel_max(gxc2, gxc0) < 2e-5
+    del gxc2, wwd
+    nb1 = query("df_upconv_wgrad_workspace_bytes", B, D, H, W, C, C, 3)
+    ws1 = torch.empty((nb1 + 3) // 4, device="cuda")
+    for algo in (2, 0, 4, 1):      # three-product parity-class kernel | default (27-point Winograd here) | 27-point forced | generic direct
+        gw1 = torch.full_like(w, float("nan")); gb1 = torch.full((C,), float("nan"), device="cuda")
+        call("df_upconv_wgrad_algo", _ptr(xc), _ptr(g), _ptr(gw1), _ptr(gb1), B, D, H, W, C, C, 3, _ptr(ws1), nb1, algo, s)
+        assert _rel_max(gw1, gw0) < 2e-5, algo
+        assert _rel_max(gb1, gb0) < 2e-5, algo
+
+
+def test_batch16_first_and_last_element_bit_identical_to_batch1():
+    """BASELINE cfg3's own batch (16 x 64x96x64 x 128 fp32 = 3 GiB per activation; offsets past 2^31 bytes): the layer kernels
+    are per-sample deterministic, so with the same sample in slots 0 and 15 both outputs must equal the batch-1 result BITWISE
+    (Winograd forward / masked dgrad, fused skip add, 27-point up-sampling-aware forward / adjoint, thin layer, jacobian3);
+    the weight gradient (a sum over the batch) with only slot 15 populated must equal the batch-1 gradient to rounding."""
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream
+    torch.manual_seed(6)
+    B, D, H, W, C = 16, 64, 96, 64, 128
+    s = _stream()
+    x1 = torch.rand((1, D, H, W, C), device="cuda") * 2 - 1
+    m1 = torch.rand((1, D, H, W, C), device="cuda") * 2 - 1
+    xB = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    mB = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    for t1, tB in ((x1, xB), (m1, mB)):
+        tB[0].copy_(t1[0]); tB[B - 1].copy_(t1[0])
+    w = (torch.rand((3, 3, 3, C, C), device="cuda") * 2 - 1) * (1.0 / (27 * C)) ** 0.5
+    bias = torch.rand(C, device="cuda") - 0.5
+    ww = [None, None]
+    for mode in (0, 1):
+        ww[mode] = torch.empty(query("df_wino_packed_elems", C, C, mode), device="cuda")
+        call("df_wino_pack_weights", _ptr(w), _ptr(ww[mode]), C, C, mode, s)
+
+    def both(fn, out_shape1, out_shapeB, init=None):
+        o1 = torch.full(out_shape1, float("nan"), device="cuda") if init is None else init(out_shape1)
+        oB = torch.full(out_shapeB, float("nan"), device="cuda") if init is None else init(out_shapeB)
+        fn(1, o1, x1, m1); fn(B, oB, xB, mB)
+        assert torch.equal(oB[0], o1[0]) and torch.equal(oB[B - 1], o1[0])
+        assert not torch.isnan(oB).any()
+        del o1, oB
+
+    shp = lambda b, c=C: (b, D, H, W, c)
+    both(lambda b, o, x, m: call("df_wino_conv_fwd", _ptr(x), _ptr(ww[0]), _ptr(bias), None, None, _ptr(o), b, D, H, W, C, C, 9, 0.2, s),
+         shp(1), shp(B))
+    both(lambda b, o, x, m: call("df_wino_conv_fwd", _ptr(x), _ptr(ww[1]), None, None, _ptr(m), _ptr(o), b, D, H, W, C, C, 4, 0.2, s),
+         shp(1), shp(B))
+    # 27-point up-sampling-aware forward (coarse input = the top-left-front octant of x viewed as a coarse tensor) and adjoint
+    Dc, Hc, Wc = D // 2, H // 2, W // 2
+    xc1 = x1[:, :Dc, :Hc, :Wc].contiguous(); xcB = xB[:, :Dc, :Hc, :Wc].contiguous()
+    o1 = torch.full(shp(1), float("nan"), device="cuda"); oB = torch.full(shp(B), float("nan"), device="cuda")
+    call("df_wino_upconv_fwd", _ptr(xc1), _ptr(ww[0]), _ptr(bias), _ptr(o1), 1, Dc, Hc, Wc, C, C, 9, 0.2, s)
+    call("df_wino_upconv_fwd", _ptr(xcB), _ptr(ww[0]), _ptr(bias), _ptr(oB), B, Dc, Hc, Wc, C, C, 9, 0.2, s)
+    assert torch.equal(oB[0], o1[0]) and torch.equal(oB[B - 1], o1[0])
+    y21 = torch.full(shp(1), float("nan"), device="cuda"); y2B = torch.full(shp(B), float("nan"), device="cuda")
+    call("df_wino_conv_fwd_addup", _ptr(x1), _ptr(ww[0]), _ptr(bias), _ptr(xc1), _ptr(o1), _ptr(y21), 1, D, H, W, C, C, 0.2, s)
+    call("df_wino_conv_fwd_addup", _ptr(xB), _ptr(ww[0]), _ptr(bias), _ptr(xcB), _ptr(oB), _ptr(y2B), B, D, H, W, C, C, 0.2, s)
+    assert torch.equal(oB[B - 1], o1[0]) and torch.equal(y2B[B - 1], y21[0]) and torch.equal(y2B[0], y21[0])
+    del o1, oB, y21, y2B
+    a1 = torch.zeros_like(xc1); aB = torch.zeros_like(xcB)
+    call("df_wino_upconv_dgrad", _ptr(x1), _ptr(ww[1]), _ptr(a1), 1, Dc, Hc, Wc, C, C, s)
+    call("df_wino_upconv_dgrad", _ptr(xB), _ptr(ww[1]), _ptr(aB), B, Dc, Hc, Wc, C, C, s)
+    assert torch.equal(aB[0], a1[0]) and torch.equal(aB[B - 1], a1[0])
+    del a1, aB, xc1, xcB
+    # thin last layer: forward F -> 3, dgrad 3 -> F (masked)
+    w3 = (torch.rand((3, 3, 3, C, 3), device="cuda") * 2 - 1) * 0.02
+    b3 = torch.rand(3, device="cuda") - 0.5
+    wp = torch.empty(query("df_conv_packed_elems", 27, C, 3, 0), device="cuda")
+    call("df_conv_pack_weights", _ptr(w3), _ptr(wp), 27, C, 3, 0, s)
+    wpd = torch.empty(query("df_conv_packed_elems", 27, C, 3, 1), device="cuda")
+    call("df_conv_pack_weights", _ptr(w3), _ptr(wpd), 27, C, 3, 1, s)
+    both(lambda b, o, x, m: call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(b3), None, None, _ptr(o), b, D, H, W, C, 3, 3, 8, 0.0, s),
+         shp(1, 3), shp(B, 3))
+    g31 = x1[..., :3].contiguous(); g3B = xB[..., :3].contiguous()
+    d1 = torch.full(shp(1), float("nan"), device="cuda"); dB = torch.full(shp(B), float("nan"), device="cuda")
+    call("df_conv_fwd", _ptr(g31), _ptr(wpd), None, None, _ptr(m1), _ptr(d1), 1, D, H, W, 3, C, 3, 4, 0.2, s)
+    call("df_conv_fwd", _ptr(g3B), _ptr(wpd), None, None, _ptr(mB), _ptr(dB), B, D, H, W, 3, C, 3, 4, 0.2, s)
+    assert torch.equal(dB[0], d1[0]) and torch.equal(dB[B - 1], d1[0])
+    del d1, dB
+    # stencil: jacobian3 (j and c) on the 3-channel field
+    j1 = torch.empty(shp(1, 9), device="cuda"); c1 = torch.empty(shp(1, 3), device="cuda")
+    jB = torch.empty(shp(B, 9), device="cuda"); cB = torch.empty(shp(B, 3), device="cuda")
+    call("df_jacobian3d_fwd", _ptr(g31), _ptr(j1), _ptr(c1), 1, D, H, W, s)
+    call("df_jacobian3d_fwd", _ptr(g3B), _ptr(jB), _ptr(cB), B, D, H, W, s)
+    assert torch.equal(jB[B - 1], j1[0]) and torch.equal(cB[B - 1], c1[0]) and torch.equal(jB[0], j1[0])
+    del j1, c1, jB, cB
+    # weight gradients: only slot 15 populated (x and g zero elsewhere)
+    xB[:B - 1].zero_(); mB[:B - 1].zero_()
+    nbB = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, C, 3)
+    wsB = torch.empty((nbB + 3) // 4, device="cuda")
+    gwB = torch.full((27, C, C), float("nan"), device="cuda"); gbB = torch.full((C,), float("nan"), device="cuda")
+    gw1 = torch.full((27, C, C), float("nan"), device="cuda"); gb1 = torch.full((C,), float("nan"), device="cuda")
+    call("df_conv_wgrad", _ptr(xB), _ptr(mB), _ptr(gwB), _ptr(gbB), B, D, H, W, C, C, 3, _ptr(wsB), nbB, s)
+    call("df_conv_wgrad", _ptr(x1), _ptr(m1), _ptr(gw1), _ptr(gb1), 1, D, H, W, C, C, 3, _ptr(wsB), nbB, s)
+    assert _rel_max(gwB, gw1) < 2e-5 and _rel_max(gbB, gb1) < 2e-5
+    g3B[:B - 1].zero_()
+    gwtB = torch.full((27, C, 3), float("nan"), device="cuda"); gbtB = torch.full((3,), float("nan"), device="cuda")
+    gwt1 = torch.full((27, C, 3), float("nan"), device="cuda"); gbt1 = torch.full((3,), float("nan"), device="cuda")
+    nbt = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, 3, 3)
+    wst = torch.empty((nbt + 3) // 4, device="cuda")
+    call("df_conv_wgrad", _ptr(xB), _ptr(g3B), _ptr(gwtB), _ptr(gbtB), B, D, H, W, C, 3, 3, _ptr(wst), nbt, s)
+    call("df_conv_wgrad", _ptr(x1), _ptr(g31), _ptr(gwt1), _ptr(gbt1), 1, D, H, W, C, 3, 3, _ptr(wst), nbt, s)
+    assert _rel_max(gwtB, gwt1) < 2e-5 and _rel_max(gbtB, gbt1) < 2e-5
+
+
+def test_batch16_generator_outputs_identical_across_batch_cfg3():
+    """Whole inference graph at BASELINE cfg3 (B = 16, F = 128): 16 identical parameter rows must give 16 bit-identical velocity
+    fields, equal to the batch-1 result."""
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import Trainer, default_config
+    ops.reset_variables()
+    cfg = default_config(is_3d=True, res_x=64, res_y=96, res_z=64, filters=128, batch_size=16, num_samples=1000)
+    tr = Trainer(cfg)
+    z1 = torch.tensor([[0.3, -0.7, 0.1]], device="cuda")
+    u1 = tr.generate(z1)
+    u16 = tr.generate(z1.repeat(16, 1).contiguous())
+    for b in (0, 7, 15):
+        assert torch.equal(u16[b], u1[0]), b
+    ops.reset_variables()

@@ -83,12 +83,11 @@ CASES_2D = [
 def test_conv_wgrad_algorithms(ops, shape, cin, cout, leak, algo):
     """df_conv_wgrad forced to the direct kernel (1), Winograd in x (2) and Winograd in (x,y) (3) -- the default picks by size --
     against the fp64 oracle; the last case is 2-D (kz = 1)."""
-    from deep_fluids_amd._lib import lib
-    lib().df_debug_set_wgrad_algo(ctypes.c_int(algo))
+    ops.WGRAD_ALGO = algo
     try:
         errs = _conv_case(ops, shape, cin, cout, leak, seed=algo + cin + cout)
     finally:
-        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+        ops.WGRAD_ALGO = 0
     assert max(errs.values()) < TOL, errs
 
 
@@ -96,12 +95,11 @@ def test_conv_wgrad_algorithms(ops, shape, cin, cout, leak, algo):
 def test_conv_wgrad_winograd_xyz(ops, shape, leak):
     """df_conv_wgrad forced to the Winograd F(2x2x2,3x3x3) form (algo 4: 64 transform-domain products per 2x2x2 positions, four launches of
     (xi_z, xi_y) workgroup types, z/y/x G^T in the reduce) against the fp64 oracle; odd tile-row counts, several batches."""
-    from deep_fluids_amd._lib import lib
-    lib().df_debug_set_wgrad_algo(ctypes.c_int(4))
+    ops.WGRAD_ALGO = 4
     try:
         errs = _conv_case(ops, shape, 128, 128, leak, seed=sum(shape), mask_from_gpu=True)
     finally:
-        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+        ops.WGRAD_ALGO = 0
     assert max(errs.values()) < TOL, errs
 
 
@@ -358,12 +356,11 @@ def test_wino_upconv_dgrad_vs_oracle(ops, cshape, cin, cout):
 def test_upconv_block_wgrad_winograd_xyz_27point(ops, cshape):
     """The up-sampling-aware weight gradient in its 27-point Winograd-(x,y,z) form (wgrad_wxyz_kernel<.., UP>: coarse operand reads,
     9 workgroup types, xi_x = 2 skipped), forced on small grids; whole fused block against the oracle."""
-    from deep_fluids_amd._lib import lib
-    lib().df_debug_set_wgrad_algo(ctypes.c_int(4))
+    ops.WGRAD_ALGO = 4
     try:
         test_upconv_block_vs_materialised_upsample(ops, cshape, 128)
     finally:
-        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+        ops.WGRAD_ALGO = 0
 
 
 @pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 32), ((1, 3, 5, 7), 128), ((1, 2, 2, 32), 64), ((1, 5, 9), 128), ((2, 8, 16), 32),
@@ -396,13 +393,9 @@ def test_thin_wgrad_mfma_and_valu_vs_oracle(ops, shape, cout, algo):
     s = _stream()
     xt, gt = dev(x), dev(g)
     gw = torch.full((3, 3, 3, cin, cout), float("nan"), device="cuda"); gb = torch.full((cout,), float("nan"), device="cuda")
-    lib().df_debug_set_wgrad_algo(ctypes.c_int(algo))
-    try:
-        nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, 3)
-        ws = torch.empty((nb + 3) // 4, device="cuda")
-        call("df_conv_wgrad", _ptr(xt), _ptr(gt), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, 3, _ptr(ws), nb, s)
-    finally:
-        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+    nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, 3)
+    ws = torch.empty((nb + 3) // 4, device="cuda")
+    call("df_conv_wgrad_algo", _ptr(xt), _ptr(gt), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, 3, _ptr(ws), nb, algo, s)
     w0 = np.zeros((3, 3, 3, cin, cout))
     _, dw, db = orc.conv_same_bwd(x.astype(np.float64), w0, g.astype(np.float64))
     assert rel_linf(host(gw), dw) < TOL
@@ -444,14 +437,10 @@ def test_thin_k_conv_mfma_epilogues_match_valu_kernel(ops, flags):
     wp = torch.empty(query("df_conv_packed_elems", 27, N, C, 1), device="cuda")
     call("df_conv_pack_weights", _ptr(w), _ptr(wp), 27, N, C, 1, s)
     ys = []
-    for valu in (0, 1):
-        lib().df_debug_set_thin_valu(ctypes.c_int(valu))
-        try:
-            y = torch.full((B, D, H, W, N), float("nan"), device="cuda")
-            call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(res), _ptr(msk), _ptr(y), B, D, H, W, C, N, 3, flags, 0.2, s)
-            ys.append(y)
-        finally:
-            lib().df_debug_set_thin_valu(ctypes.c_int(0))
+    for valu in (0, 32):      # 32 = DF_CONV_VALU_ONLY
+        y = torch.full((B, D, H, W, N), float("nan"), device="cuda")
+        call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(res), _ptr(msk), _ptr(y), B, D, H, W, C, N, 3, flags | valu, 0.2, s)
+        ys.append(y)
     assert ((ys[0] - ys[1]).abs().max() / ys[1].abs().max()).item() < 2e-6
 
 
@@ -523,125 +512,3 @@ def test_upconv_block_bf16x3_mode(ops, bf16x3):
     for i in reversed(range(n)):
         dx, _, _ = orc.conv_same_bwd(ins[i], ws[i].astype(np.float64), dx * np.where(outs[i] > 0, 1.0, 0.2))
     assert rel_linf(host(xt.grad), orc.upscale_nn_bwd(dx + go)) < 1e-4
-
-
-def test_full_size_conv_algorithms_agree_cfg3(ops):
-    """BASELINE cfg3 spatial size (64x96x64, F = 128, one batch element): too large for the NumPy oracle, so the parity check is a
-    property -- three independently written algorithms must agree: the direct MFMA kernels (pinned against the oracle above) vs the
-    Winograd forward / dgrad (conv_wino.hip) and the direct vs Winograd-x vs Winograd-(x,y) weight gradients (conv_wgrad.hip);
-    plus linearity of the Winograd conv in its input."""
-    from deep_fluids_amd._lib import call, query, lib
-    from deep_fluids_amd.ops import _ptr, _stream
-    torch.manual_seed(3)
-    B, D, H, W, C = 1, 64, 96, 64, 128
-    s = _stream()
-    x = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
-    x2 = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
-    g = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
-    w = (torch.rand((3, 3, 3, C, C), device="cuda") * 2 - 1) * (1.0 / (27 * C)) ** 0.5
-    bias = torch.rand(C, device="cuda") - 0.5
-    for mode in (0, 1):
-        wd = torch.empty(query("df_conv_packed_elems", 27, C, C, mode), device="cuda")
-        call("df_conv_pack_weights", _ptr(w), _ptr(wd), 27, C, C, mode, s)
-        ww = torch.empty(query("df_wino_packed_elems", C, C, mode), device="cuda")
-        call("df_wino_pack_weights", _ptr(w), _ptr(ww), C, C, mode, s)
-        y0 = torch.empty_like(x); y1 = torch.full_like(x, float("nan"))
-        call("df_conv_fwd", _ptr(x), _ptr(wd), _ptr(bias), None, None, _ptr(y0), B, D, H, W, C, C, 3, 8, 0.0, s)
-        call("df_wino_conv_fwd", _ptr(x), _ptr(ww), _ptr(bias), None, None, _ptr(y1), B, D, H, W, C, C, 8, 0.0, s)
-        assert ((y0 - y1).abs().max() / y0.abs().max()).item() < 2e-5, mode
-        assert ((y0 - y1).abs().sum() / y0.abs().sum()).item() < 5e-6, mode
-        if mode == 0:       # linearity: conv(2 x - 3 x2) = 2 conv(x) - 3 conv(x2) (no bias)
-            ya = torch.empty_like(x); yb = torch.empty_like(x); yc = torch.empty_like(x)
-            xc = 2 * x - 3 * x2
-            for src, dst in ((x, ya), (x2, yb), (xc, yc)):
-                call("df_wino_conv_fwd", _ptr(src), _ptr(ww), None, None, None, _ptr(dst), B, D, H, W, C, C, 0, 0.0, s)
-            lin = 2 * ya - 3 * yb
-            assert ((lin - yc).abs().max() / yc.abs().max()).item() < 2e-5
-            del ya, yb, yc, xc, lin
-    nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, C, 3)
-    ws = torch.empty((nb + 3) // 4, device="cuda")
-    res = []
-    for algo in (1, 2, 3):
-        lib().df_debug_set_wgrad_algo(ctypes.c_int(algo))
-        gw = torch.full((27, C, C), float("nan"), device="cuda"); gb = torch.full((C,), float("nan"), device="cuda")
-        call("df_conv_wgrad", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, s)
-        res.append((gw, gb))
-    lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
-    for gw, gb in res[1:]:
-        assert ((gw - res[0][0]).abs().max() / res[0][0].abs().max()).item() < 2e-5
-        assert ((gb - res[0][1]).abs().max() / res[0][1].abs().max()).item() < 2e-5
-    # the bias gradient is a plain column sum: check it against torch in fp64
-    ref = g.double().sum(dim=(0, 1, 2, 3))
-    assert ((res[0][1].double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
-
-
-def test_full_size_upconv_agrees_with_materialised_upsample_cfg3(ops):
-    """The up-sampling-aware first conv of the top generator block at BASELINE cfg3 size (coarse 32x48x32 -> 64x96x64, C = 128, one
-    batch element): df_upconv_{fwd,dgrad,wgrad} (8-tap parity convs with 32-channel chunks, wgrad_up2_kernel<4,128>) must agree with
-    nearest_up2x materialised + the plain direct kernels (which the small cases above pin against the oracle)."""
-    from deep_fluids_amd._lib import call, query, lib
-    from deep_fluids_amd.ops import _ptr, _stream
-    torch.manual_seed(5)
-    B, D, H, W, C = 1, 32, 48, 32, 128
-    s = _stream()
-    xc = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
-    g = torch.rand((B, 2 * D, 2 * H, 2 * W, C), device="cuda") * 2 - 1
-    w = (torch.rand((3, 3, 3, C, C), device="cuda") * 2 - 1) * (1.0 / (27 * C)) ** 0.5
-    bias = torch.rand(C, device="cuda") - 0.5
-    xf = torch.empty((B, 2 * D, 2 * H, 2 * W, C), device="cuda")
-    call("df_upsample2x_fwd", _ptr(xc), _ptr(xf), B, D, H, W, C, 1, s)
-    lib().df_debug_set_wgrad_algo(ctypes.c_int(1))           # references: direct kernels only
-    try:
-        wd = torch.empty(query("df_conv_packed_elems", 27, C, C, 0), device="cuda")
-        call("df_conv_pack_weights", _ptr(w), _ptr(wd), 27, C, C, 0, s)
-        y0 = torch.empty_like(xf)
-        call("df_conv_fwd", _ptr(xf), _ptr(wd), _ptr(bias), None, None, _ptr(y0), B, 2 * D, 2 * H, 2 * W, C, C, 3, 8, 0.0, s)
-        wdd = torch.empty(query("df_conv_packed_elems", 27, C, C, 1), device="cuda")
-        call("df_conv_pack_weights", _ptr(w), _ptr(wdd), 27, C, C, 1, s)
-        gxf = torch.empty_like(xf)
-        call("df_conv_fwd", _ptr(g), _ptr(wdd), None, None, None, _ptr(gxf), B, 2 * D, 2 * H, 2 * W, C, C, 3, 0, 0.0, s)
-        gxc0 = torch.empty_like(xc)
-        call("df_upsample2x_bwd", _ptr(gxf), _ptr(gxc0), B, D, H, W, C, 1, s)
-        nb0 = query("df_conv_wgrad_workspace_bytes", B, 2 * D, 2 * H, 2 * W, C, C, 3)
-        ws0 = torch.empty((nb0 + 3) // 4, device="cuda")
-        gw0 = torch.empty_like(w); gb0 = torch.empty(C, device="cuda")
-        call("df_conv_wgrad", _ptr(xf), _ptr(g), _ptr(gw0), _ptr(gb0), B, 2 * D, 2 * H, 2 * W, C, C, 3, _ptr(ws0), nb0, s)
-    finally:
-        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
-    del xf, gxf, ws0
-    wu = torch.empty(query("df_upconv_packed_elems", C, C, 3, 0), device="cuda")
-    call("df_upconv_pack_weights", _ptr(w), _ptr(wu), C, C, 3, 0, s)
-    y1 = torch.full_like(y0, float("nan"))
-    call("df_upconv_fwd", _ptr(xc), _ptr(wu), _ptr(bias), _ptr(y1), B, D, H, W, C, C, 3, 8, 0.0, s)
-    assert ((y0 - y1).abs().max() / y0.abs().max()).item() < 2e-5
-    ww = torch.empty(query("df_wino_packed_elems", C, C, 0), device="cuda")
-    call("df_wino_pack_weights", _ptr(w), _ptr(ww), C, C, 0, s)
-    y2 = torch.full_like(y0, float("nan"))
-    call("df_wino_upconv_fwd", _ptr(xc), _ptr(ww), _ptr(bias), _ptr(y2), B, D, H, W, C, C, 9, 1.0, s)      # leak 1: lrelu is the identity
-    assert ((y0 - y2).abs().max() / y0.abs().max()).item() < 2e-5
-    del y2, ww
-    wud = torch.empty(query("df_upconv_packed_elems", C, C, 3, 1), device="cuda")
-    call("df_upconv_pack_weights", _ptr(w), _ptr(wud), C, C, 3, 1, s)
-    gxc1 = torch.zeros_like(xc)
-    call("df_upconv_dgrad", _ptr(g), _ptr(wud), _ptr(gxc1), B, D, H, W, C, C, 3, s)
-    assert ((gxc0 - gxc1).abs().max() / gxc0.abs().max()).item() < 2e-5
-    wwd = torch.empty(query("df_wino_packed_elems", C, C, 1), device="cuda")
-    call("df_wino_pack_weights", _ptr(w), _ptr(wwd), C, C, 1, s)
-    gxc2 = torch.zeros_like(xc)
-    call("df_wino_upconv_dgrad", _ptr(g), _ptr(wwd), _ptr(gxc2), B, D, H, W, C, C, s)
-    assert ((gxc0 - gxc2).abs().max() / gxc0.abs().max()).item() < 2e-5
-    del gxc2, wwd
-    nb1 = query("df_upconv_wgrad_workspace_bytes", B, D, H, W, C, C, 3)
-    ws1 = torch.empty((nb1 + 3) // 4, device="cuda")
-    gw1 = torch.full_like(w, float("nan")); gb1 = torch.full((C,), float("nan"), device="cuda")
-    call("df_upconv_wgrad", _ptr(xc), _ptr(g), _ptr(gw1), _ptr(gb1), B, D, H, W, C, C, 3, _ptr(ws1), nb1, s)
-    assert ((gw0 - gw1).abs().max() / gw0.abs().max()).item() < 2e-5
-    assert ((gb0 - gb1).abs().max() / gb0.abs().max()).item() < 2e-5
-    lib().df_debug_set_wgrad_algo(ctypes.c_int(4))           # the 27-point Winograd-(x,y,z) form (default from 2048 coarse rows)
-    try:
-        gw2 = torch.full_like(w, float("nan")); gb2 = torch.full((C,), float("nan"), device="cuda")
-        call("df_upconv_wgrad", _ptr(xc), _ptr(g), _ptr(gw2), _ptr(gb2), B, D, H, W, C, C, 3, _ptr(ws1), nb1, s)
-    finally:
-        lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
-    assert ((gw0 - gw2).abs().max() / gw0.abs().max()).item() < 2e-5
-    assert ((gb0 - gb2).abs().max() / gb0.abs().max()).item() < 2e-5

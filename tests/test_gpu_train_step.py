@@ -177,3 +177,55 @@ def test_checkpoint_resume_and_dataset_reader(tmp_path):
     with np.load(ck) as d:
         assert "G/0_fc/weights" in d and "G/1_conv/biases/Adam_1" in d
     ops.reset_variables()
+
+
+def test_train_loop_scalars_nan_guard_and_test_sweep(tmp_path):
+    """`Trainer.train` (trainer.py:228-293: loop, JSON-lines scalars in place of the TensorBoard event file, NaN guard, periodic
+    parameter sweeps, final checkpoint) and `Trainer.test_` (trainer.py:314-354: (p1,p2) fixed, frame swept, de-normalised,
+    one compressed .npz per frame under <model_dir>/<p1>_<p2>/)."""
+    import json as js
+    from types import SimpleNamespace
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.data import BatchManager, write_synthetic_dataset
+    from deep_fluids_amd.trainer import Trainer, default_config
+    root = str(tmp_path / "smoke_tiny")
+    n = write_synthetic_dataset(root, (16, 8), num_p=(3, 2), num_frames=4)
+    model_dir = str(tmp_path / "run")
+    cfg = default_config(is_3d=False, res_x=8, res_y=16, filters=16, batch_size=4, num_samples=n, model_dir=model_dir,
+                         log_step=2, test_step=2, test_batch_size=2)
+    dcfg = SimpleNamespace(random_seed=123, data_path=root, is_3d=False, arch="de", data_type="velocity", batch_size=4,
+                           res_x=8, res_y=16, res_z=1, num_worker=2)
+    bm = BatchManager(dcfg)
+    ops.reset_variables()
+    tr = Trainer(cfg)
+    recs = tr.train(bm, max_step=5)
+    assert [r["step"] for r in recs] == [0, 2, 4] and tr.step == 5
+    lines = [js.loads(l) for l in open(os.path.join(model_dir, "scalars.jsonl"))]
+    assert len(lines) == 3 and {"loss/g_loss", "loss/g_loss_l1", "loss/g_loss_j_l1", "misc/epoch", "misc/g_lr", "step"} <= set(lines[0])
+    assert abs(lines[1]["misc/epoch"] - 2 * 4 / float(n)) < 1e-12
+    assert abs(lines[0]["loss/g_loss"] - (lines[0]["loss/g_loss_l1"] + lines[0]["loss/g_loss_j_l1"])) < 1e-5
+    assert os.path.exists(os.path.join(model_dir, "model.ckpt-5.npz"))
+    with np.load(os.path.join(model_dir, "4_G.npz")) as d:
+        assert d["G"].shape == (3, 4, 16, 8, 2) and d["z"].shape == (3, 4, 3)
+    # NaN guard: poison the parameters -> the next logged step must raise the reference's assertion
+    tr2 = Trainer(cfg, name="G2")
+    tr2.flat_p.fill_(float("nan"))
+    bm2 = BatchManager(dcfg)
+    with pytest.raises(AssertionError, match="Model diverged with loss = NaN"):
+        tr2.train(bm2, max_step=1, model_dir=str(tmp_path / "nan"))
+    bm2.stop_thread()
+    # test_: 4 frames in batches of 2
+    bm3 = BatchManager(dcfg)
+    out_dir = tr.test_(bm3, p1=1, p2=1)
+    assert out_dir == os.path.join(model_dir, "1_1")
+    files = sorted(os.listdir(out_dir), key=lambda f: int(f[:-4]))
+    assert files == ["0.npz", "1.npz", "2.npz", "3.npz"]
+    z = np.zeros((4, 3), np.float32); z[:, 0] = 1 / 2.0 * 2 - 1; z[:, 1] = 1 / 1.0 * 2 - 1; z[:, 2] = np.linspace(-1, 1, 4)
+    ref = host(tr.generate(dev(z))).copy()
+    ref *= bm3.x_range                                   # the same in-place float32 op as BatchManager.denorm (data.py:188-189)
+    for i, f in enumerate(files):
+        with np.load(os.path.join(out_dir, f)) as d:
+            np.testing.assert_array_equal(d["x"], ref[i])
+    with pytest.raises(ValueError):
+        tr.test_(bm3, p1=1, p2=1, test_b_num=3)
+    ops.reset_variables()

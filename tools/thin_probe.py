@@ -28,20 +28,14 @@ t = timeit(lambda: call("df_conv_wgrad", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B
 print("wgrad 128x3       : %.3f ms" % (t * 1e3))
 import ctypes
 from deep_fluids_amd._lib import lib
-lib().df_debug_set_wgrad_algo(ctypes.c_int(1))
 gw1 = torch.empty_like(w); gb1 = torch.empty(3, device="cuda")
-t = timeit(lambda: call("df_conv_wgrad", _ptr(x), _ptr(g), _ptr(gw1), _ptr(gb1), B, Z, Y, X, F, 3, 3, _ptr(ws), nb, s), 5, 2)
-lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
+t = timeit(lambda: call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw1), _ptr(gb1), B, Z, Y, X, F, 3, 3, _ptr(ws), nb, 1, s), 5, 2)
 print("wgrad 128x3 (VALU): %.3f ms   mfma-vs-valu rel diff gw %.2e gb %.2e" % (
     t * 1e3, ((gw - gw1).abs().max() / gw1.abs().max()).item(), ((gb - gb1).abs().max() / gb1.abs().max()).item()))
-lib().df_debug_set_thin_valu(ctypes.c_int(1))
 dx1 = torch.empty_like(x)
-t = timeit(lambda: call("df_conv_fwd", _ptr(g), _ptr(wpd), None, None, _ptr(x), _ptr(dx1), B, Z, Y, X, 3, F, 3, 4, 0.2, s), 5, 2)
-lib().df_debug_set_thin_valu(ctypes.c_int(0))
+t = timeit(lambda: call("df_conv_fwd", _ptr(g), _ptr(wpd), None, None, _ptr(x), _ptr(dx1), B, Z, Y, X, 3, F, 3, 4 | 32, 0.2, s), 5, 2)
 print("conv 3->128 dgrad (VALU): %.3f ms   mfma-vs-valu rel diff %.2e" % (t * 1e3, ((dx - dx1).abs().max() / dx1.abs().max()).item()))
-lib().df_debug_set_thin_valu(ctypes.c_int(1))
 y1 = torch.empty_like(y)
-t = timeit(lambda: call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(b), None, None, _ptr(y1), B, Z, Y, X, F, 3, 3, 8, 0.0, s), 5, 2)
-lib().df_debug_set_thin_valu(ctypes.c_int(0))
+t = timeit(lambda: call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(b), None, None, _ptr(y1), B, Z, Y, X, F, 3, 3, 8 | 32, 0.0, s), 5, 2)
 call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(b), None, None, _ptr(y), B, Z, Y, X, F, 3, 3, 8, 0.0, s)
 print("conv 128->3 fwd (VALU): %.3f ms   mfma-vs-valu rel diff %.2e" % (t * 1e3, ((y - y1).abs().max() / y1.abs().max()).item()))

@@ -22,13 +22,11 @@ def run(B, Dc, Hc, Wc, C, iters=3):
     ws = torch.empty((nb + 3) // 4, device="cuda")
     out = []
     for algo in (3, 4):
-        lib().df_debug_set_wgrad_algo(ctypes.c_int(algo | (RANGES << 3)))
         gw = torch.empty((27, C, C), device="cuda"); gb = torch.empty(C, device="cuda")
-        f = lambda: call("df_upconv_wgrad", _ptr(xc), _ptr(g), _ptr(gw), _ptr(gb), B, Dc, Hc, Wc, C, C, 3, _ptr(ws), nb, s)
+        f = lambda: call("df_upconv_wgrad_algo", _ptr(xc), _ptr(g), _ptr(gw), _ptr(gb), B, Dc, Hc, Wc, C, C, 3, _ptr(ws), nb, algo, s)
         f(); torch.cuda.synchronize()
         t = timeit(f, iters, 1)
         out.append((gw.clone(), gb.clone(), t))
-    lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
     (w0, b0, t0), (w1, b1, t1) = out
     print("B%d coarse %dx%dx%d C%d: parity-class %.3f ms | winograd-xyz 27-point %.3f ms  gw %.1e gb %.1e" % (
         B, Dc, Hc, Wc, C, t0 * 1e3, t1 * 1e3, ((w0 - w1).abs().max() / w0.abs().max()).item(), ((b0 - b1).abs().max() / b0.abs().max()).item()), flush=True)

@@ -23,13 +23,12 @@ def run(B, D, H, W, C, N, kz=3, iters=3):
     ws = torch.empty((nb + 3) // 4, device="cuda")
     out = []
     for algo in (1, 2, 3, 4, 0):
-        lib().df_debug_set_wgrad_algo(ctypes.c_int(algo | (RANGES << 3)))
         gw = torch.empty((taps, C, N), device="cuda"); gb = torch.empty(N, device="cuda")
-        f = lambda: call("df_conv_wgrad", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, N, kz, _ptr(ws), nb, s)
+        f = lambda: call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, N, kz, _ptr(ws), nb,
+                         algo | (RANGES << 3), s)
         f(); torch.cuda.synchronize()
         t = timeit(f, iters, 1)
         out.append((gw.clone(), gb.clone(), t))
-    lib().df_debug_set_wgrad_algo(ctypes.c_int(0))
     w0, b0, t0 = out[0]
     fl = 2.0 * taps * C * N * B * D * H * W
     msg = "B%d %dx%dx%d C%d N%d: direct %.3f ms (%.0f TF)" % (B, D, H, W, C, N, t0 * 1e3, fl / t0 / 1e12)

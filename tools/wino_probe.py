@@ -7,6 +7,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from deep_fluids_amd import _lib as _libmod  # noqa: E402
+_libmod.use_tuning_library()      # needs `make -C deep_fluids_amd/csrc tuning`
 from deep_fluids_amd._lib import call, query  # noqa: E402
 from deep_fluids_amd.ops import _ptr, _stream  # noqa: E402
 from tools.gpu_probe import timeit  # noqa: E402
