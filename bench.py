@@ -95,6 +95,12 @@ def select_kernel(name, args):
         B, Z, Y, X = args[3:7]
         nb = (36.0 if args[0] is not None else 0.0) + (12.0 if args[1] is not None else 0.0) + 12.0
         return ("jacobian3d_bwd_kernel<%s>" % ("j" if args[0] is not None else "c"), nb * B * Z * Y * X)
+    if name == "df_velocity_loss3d_fwd":
+        B, Z, Y, X = args[5:9]
+        return ("velocity_loss3d_fwd_kernel", 36.0 * B * Z * Y * X)          # psi 12 + x 12 read, u 12 written
+    if name == "df_velocity_loss3d_bwd":
+        B, Z, Y, X = args[5:9]
+        return ("velocity_loss3d_bwd_kernel+curl_adjoint", 60.0 * B * Z * Y * X)   # (u, x) -> du 36, du -> dpsi 24
     if name == "df_jacobian2d_fwd":
         B, Y, X = args[3:6]
         return ("jacobian2d_fwd_kernel", 28.0 * B * Y * X)
@@ -194,7 +200,7 @@ def roofline_of(ks, prefix, pmc, with_traffic):
         return None
     k = max(sel, key=lambda q: sel[q]["seconds"])
     v = sel[k]
-    hbm = prefix.startswith("jacobian")
+    hbm = prefix.startswith("jacobian") or prefix.startswith("velocity_loss")
     out = {"kernel": k, "bound": "hbm" if hbm else "mfma", "launches": v["launches"], "avg_launch_ms": v["seconds"] / v["launches"] * 1e3,
            "work_per_launch": v["work"] / v["launches"]}
     if hbm:
@@ -216,6 +222,58 @@ def roofline_of(ks, prefix, pmc, with_traffic):
     fam = prefix.split("<")[0]
     out["traffic"] = pmc.get(fam, {}).get("traffic_bytes") if with_traffic else None
     out["traffic_source"] = "profiles/pmc_latest.json (offline rocprofv3 --pmc passes, not measured in this run)" if out["traffic"] else None
+    return out
+
+
+def stencil_rooflines(B, Z, Y, X):
+    """Standalone launches of the stencil kernels at the workload's shape, HIP-event timed on the launch stream, over ROTATING
+    buffers (8 inputs x 75 MB: the 256 MB Infinity Cache cannot hold the working set, so this is the cold-HBM figure).
+    Algorithmic bytes per voxel: jacobian3 60, curl3 24, their adjoints 48 / 24, fused tail 36 fwd / 60 bwd."""
+    import torch
+    from deep_fluids_amd import _lib
+    from deep_fluids_amd.ops import _ptr, _stream
+    call, query = _lib.call, _lib.query
+    s = _stream()
+    nv = B * Z * Y * X
+    xs = [torch.rand((B, Z, Y, X, 3), device="cuda") * 2 - 1 for _ in range(8)]
+    js = [torch.empty((B, Z, Y, X, 9), device="cuda") for _ in range(3)]
+    cs = [torch.empty((B, Z, Y, X, 3), device="cuda") for _ in range(4)]
+    nb = query("df_velocity_loss3d_workspace_bytes", B, Z, Y, X)
+    ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device="cuda")
+    l1 = torch.empty((), device="cuda"); jl1 = torch.empty((), device="cuda")
+    k = [0]
+
+    def nxt():
+        k[0] += 1
+        return k[0]
+    cases = {
+        "jacobian3d_fwd_kernel<j,c>": (60.0, lambda i: call("df_jacobian3d_fwd", _ptr(xs[i % 8]), _ptr(js[i % 3]), _ptr(cs[i % 4]), B, Z, Y, X, s)),
+        "jacobian3d_fwd_kernel<c> (curl3)": (24.0, lambda i: call("df_jacobian3d_fwd", _ptr(xs[i % 8]), None, _ptr(cs[i % 4]), B, Z, Y, X, s)),
+        "jacobian3d_bwd_kernel<j>": (48.0, lambda i: call("df_jacobian3d_bwd", _ptr(js[i % 3]), None, _ptr(cs[i % 4]), B, Z, Y, X, s)),
+        "jacobian3d_bwd_kernel<c> (curl3 adjoint)": (24.0, lambda i: call("df_jacobian3d_bwd", None, _ptr(xs[i % 8]), _ptr(cs[i % 4]), B, Z, Y, X, s)),
+        "velocity_loss3d_fwd_kernel": (36.0, lambda i: call("df_velocity_loss3d_fwd", _ptr(xs[i % 8]), _ptr(xs[(i + 3) % 8]), _ptr(cs[i % 4]),
+                                                            _ptr(l1), _ptr(jl1), B, Z, Y, X, _ptr(ws), nb, s)),
+        "velocity_loss3d_bwd_kernel+curl_adjoint": (60.0, lambda i: call("df_velocity_loss3d_bwd", _ptr(xs[i % 8]), _ptr(xs[(i + 3) % 8]), _ptr(l1),
+                                                                         _ptr(jl1), _ptr(cs[i % 4]), B, Z, Y, X, _ptr(ws), nb, s)),
+    }
+    for j in js:
+        j.uniform_(-1, 1)
+    l1.fill_(1.0); jl1.fill_(1.0)
+    out = {}
+    for name, (bpv, fn) in cases.items():
+        for _ in range(3):
+            fn(nxt())
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            fn(nxt())
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / n
+        ach = bpv * nv / t / 1e9
+        out[name] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                     "avg_launch_us": t * 1e6, "algorithmic_bytes_per_voxel": bpv, "traffic": None}
     return out
 
 
@@ -431,18 +489,31 @@ def main():
         "roofline_wgrad": roofline_of(ks, "wgrad_kernel", pmc, default_shape),
         "roofline_conv": roofline_of(ks, "conv_mfma_kernel", pmc, default_shape),
         "roofline_wino": roofline_of(ks, "wino3d_kernel", pmc, default_shape),
-        "roofline_stencil": roofline_of(ks, "jacobian3d_fwd_kernel", pmc, default_shape),
-        "roofline_stencil_bwd": roofline_of(ks, "jacobian3d_bwd_kernel<j>", {}, False),
+        # in-step stencil work = the fused tail (velocity_loss.hip); the standalone kernels are timed below (stencils_standalone)
+        "roofline_stencil": None,
+        "roofline_tail_fwd": roofline_of(ks, "velocity_loss3d_fwd_kernel", {}, False),
+        "roofline_tail_bwd": roofline_of(ks, "velocity_loss3d_bwd_kernel", {}, False),
+        "stencils_standalone": None,
         "kernels": {k: {"launches": v["launches"], "ms_total": v["seconds"] * 1e3} for k, v in sorted(ks.items())},
     }
     fam = {}
     for k, v in ks.items():
         fam[k.split(" ")[0]] = fam.get(k.split(" ")[0], 0.0) + v["seconds"]
-    dom = max((f for f in fam if not f.startswith("jacobian")), key=lambda f: fam[f], default=None)
+    dom = max((f for f in fam if not (f.startswith("jacobian") or f.startswith("velocity_loss"))), key=lambda f: fam[f], default=None)
     out["roofline"] = {"wgrad_kernel": out["roofline_wgrad"], "conv_mfma_kernel": out["roofline_conv"],
                        "wino3d_kernel": out["roofline_wino"]}.get(dom)
     for key in ("alt_bf16x3_mode", "extra_2d_128x96", "extra_cfg4_slice", "extra_ae_cfg5"):
         out[key] = None
+    if world == 1:
+        try:
+            out["stencils_standalone"] = stencil_rooflines(per_gpu, Z, Y, X)
+            out["roofline_stencil"] = dict(out["stencils_standalone"]["jacobian3d_fwd_kernel<j,c>"], kernel="jacobian3d_fwd_kernel<j,c>",
+                                           traffic=pmc.get("jacobian3d_fwd_kernel", {}).get("traffic_bytes") if default_shape else None,
+                                           traffic_source="profiles/pmc_latest.json" if default_shape else None,
+                                           note="standalone launches over rotating buffers (cold HBM); the train step itself runs the fused "
+                                                "tail (roofline_tail_fwd / _bwd)")
+        except Exception as e:
+            out["stencils_standalone"] = {"error": repr(e)[:300]}
     if world == 1 and not a.no_alt and a.precision == "fp32":
         del tr, last
         extras(out, a, cfg, x, y, vox_per_step, pmc)

@@ -26,6 +26,12 @@ SIGNATURES = {
     "df_jacobian3d_bwd": (I32, [P, P, P, I64, I64, I64, I64, P]),
     "df_divergence2d": (I32, [P, P, I64, I64, I64, P]),
     "df_divergence3d": (I32, [P, P, I64, I64, I64, I64, P]),
+    "df_velocity_loss3d_workspace_bytes": (I64, [I64, I64, I64, I64]),
+    "df_velocity_loss3d_fwd": (I32, [P, P, P, P, P, I64, I64, I64, I64, P, I64, P]),
+    "df_velocity_loss3d_bwd": (I32, [P, P, P, P, P, I64, I64, I64, I64, P, I64, P]),
+    "df_velocity_loss2d_workspace_bytes": (I64, [I64, I64, I64]),
+    "df_velocity_loss2d_fwd": (I32, [P, P, P, P, P, I64, I64, I64, P, I64, P]),
+    "df_velocity_loss2d_bwd": (I32, [P, P, P, P, P, I64, I64, I64, P, I64, P]),
     "df_l1_mean_workspace_bytes": (I64, [I64]),
     "df_l1_mean_fwd": (I32, [P, P, I64, P, P, I64, P]),
     "df_l1_mean_bwd": (I32, [P, P, P, F32, P, I64, P]),

@@ -24,7 +24,7 @@ __all__ = [
     "lrelu", "conv2d", "conv3d", "linear", "upscale", "upscale3", "resize_nearest_neighbor", "reshape",
     "int_shape", "get_conv_shape", "nchw_to_nhwc", "nhwc_to_nchw", "add", "concat", "sigmoid", "mse_mean",
     "jacobian", "jacobian3", "curl", "curl3", "divergence", "divergence3",
-    "vort_np", "curl_np", "grad_np", "jacobian_np3", "l1_mean",
+    "vort_np", "curl_np", "grad_np", "jacobian_np3", "l1_mean", "velocity_loss",
     "variable_scope", "get_variables", "get_variable", "reset_variables", "set_random_seed", "all_variables",
 ]
 
@@ -794,6 +794,54 @@ class _L1Mean(torch.autograd.Function):
         return ga, gb
 
 
+class _VelocityLoss(torch.autograd.Function):
+    """Fused tail: (psi, x) -> (l1, jl1, u) with u = curl(psi) | jacobian3(psi)[1], l1 = mean|u - x|, jl1 = mean|J(u) - J(x)|
+    (velocity_loss.hip).  x is data: no gradient."""
+
+    @staticmethod
+    def forward(ctx, psi, x):
+        psi = _prep(psi, "psi"); x = _prep(x, "x")
+        is3d = psi.dim() == 5
+        if is3d:
+            B, Z, Y, X, C = psi.shape
+            if C != 3 or tuple(x.shape) != (B, Z, Y, X, 3):
+                raise ValueError("velocity_loss: psi [B,Z,Y,X,3] and x [B,Z,Y,X,3] expected, got %s / %s" % (tuple(psi.shape), tuple(x.shape)))
+            geom = (B, Z, Y, X)
+            u = _empty((B, Z, Y, X, 3), psi)
+        else:
+            B, Y, X, C = psi.shape
+            if C != 1 or tuple(x.shape) != (B, Y, X, 2):
+                raise ValueError("velocity_loss: psi [B,Y,X,1] and x [B,Y,X,2] expected, got %s / %s" % (tuple(psi.shape), tuple(x.shape)))
+            geom = (B, Y, X)
+            u = _empty((B, Y, X, 2), psi)
+        fn = "df_velocity_loss3d" if is3d else "df_velocity_loss2d"
+        nbytes = query(fn + "_workspace_bytes", *geom)
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=psi.device)
+        l1, jl1 = _empty((), psi), _empty((), psi)
+        call(fn + "_fwd", _ptr(psi), _ptr(x), _ptr(u), _ptr(l1), _ptr(jl1), *geom, _ptr(ws), nbytes, _stream())
+        ctx.save_for_backward(u, x)
+        ctx.geom = (fn, geom, nbytes, tuple(psi.shape))
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(u)          # u is handed out for logging / metrics; differentiate through curl()/curl3() instead
+        return l1, jl1, u
+
+    @staticmethod
+    def backward(ctx, g1, g9, _gu):
+        u, x = ctx.saved_tensors
+        fn, geom, nbytes, pshape = ctx.geom
+        if g1 is None and g9 is None:
+            return None, None
+        zero = None
+        if g1 is None or g9 is None:
+            zero = torch.zeros((), dtype=torch.float32, device=u.device)
+        g1 = _prep(g1, "grad") if g1 is not None else zero
+        g9 = _prep(g9, "grad") if g9 is not None else zero
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=u.device)
+        gpsi = _empty(pshape, u)
+        call(fn + "_bwd", _ptr(u), _ptr(x), _ptr(g1), _ptr(g9), _ptr(gpsi), *geom, _ptr(ws), nbytes, _stream())
+        return gpsi, None
+
+
 # --------------------------------------------------------------------------------------------------
 # the reference's call surface
 # --------------------------------------------------------------------------------------------------
@@ -1014,6 +1062,14 @@ def divergence3(x):
 def l1_mean(a, b):
     """``tf.reduce_mean(tf.abs(a - b))`` (trainer.py:170-171) as one fused reduction."""
     return _L1Mean.apply(a, b)
+
+
+def velocity_loss(psi, x):
+    """The tail of ``build_model`` as ONE fused op (SURVEY 8(b) ``velocity_loss2d/3d``; trainer.py:140-146,170-172 and the
+    ground-truth Jacobian of trainer.py:29-32 / trainer3.py:18-24,49-51):  returns ``(l1, j_l1, u)`` with
+    ``u = curl(psi) | jacobian3(psi)[1]``, ``l1 = reduce_mean(abs(u - x))``, ``j_l1 = reduce_mean(abs(jacobian(u)[0] - jacobian(x)[0]))``.
+    Gradients flow to ``psi`` through ``l1`` and ``j_l1``; ``u`` is returned detached (for metrics / summaries)."""
+    return _VelocityLoss.apply(psi, x)
 
 
 # ---- NumPy-facing twins (ops.py:305-324, 344-374): ndarray in, ndarray out, computed on the GPU ----

@@ -36,7 +36,8 @@ def default_config(**over):
              optimizer="adam", beta1=0.5, beta2=0.999, lr_update="decay", lr_update_step=120000,
              start_step=0, random_seed=123, num_samples=21000, c_num=3, use_curl3_alias=True,
              z_num=16, use_sparse=False, sparsity=0.01, w4=1.0, w5=1.0, p_num=2, x_channels=None, w3=0.005,
-             log_step=500, test_step=1000, test_batch_size=100, model_dir=None)            # config.py:62-68
+             log_step=500, test_step=1000, test_batch_size=100, model_dir=None,            # config.py:62-68
+             fused_tail=True)
     c.update(over)
     return SimpleNamespace(**c)
 
@@ -56,6 +57,7 @@ class Trainer(object):
             self.output_shape = spatial + [3 if self.is_3d else 2]
         self.filters, self.num_conv, self.repeat = config.filters, config.num_conv, config.repeat
         self.w1, self.w2 = config.w1, config.w2
+        self.fused_tail = bool(getattr(config, "fused_tail", False))    # Trainer ('de') only; the AE / GAN graphs need J(u) / vorticity tensors
         self.beta1, self.beta2, self.eps = config.beta1, config.beta2, 1e-8
         self.step = config.start_step                            # trainer.py:65
         epochs_per_step = config.batch_size / float(config.num_samples)          # data.py:50
@@ -155,10 +157,18 @@ class Trainer(object):
     # ---- graph (trainer.py:136-172 / trainer3.py:14-51) -------------------------------------------------
     def build_model(self, x, y):
         gen = GeneratorBE3 if self.is_3d else GeneratorBE
-        with torch.no_grad():                                   # trainer.py:29-32: Jacobian of the ground truth
-            x_jaco = (jacobian3(x) if self.is_3d else jacobian(x))[0]
         out, _ = gen(y, self.filters, self.output_shape, name=self.name, num_conv=self.num_conv, repeat=self.repeat,
                      reuse=True)
+        if self.config.use_curl and self.fused_tail:
+            # the whole tail -- curl, both Jacobians (the ground truth's, trainer.py:29-32, recomputed on the fly), both L1 means --
+            # as one fused op: 36 B/voxel instead of 240, no 9-channel tensors (velocity_loss.hip); G_jaco_ / G_vort_ are not
+            # materialised (the summaries that show them, trainer.py:186-189, are out of scope)
+            g_loss_l1, g_loss_j_l1, G_ = ops.velocity_loss(out, x)
+            g_loss = g_loss_l1 * self.w1 + g_loss_j_l1 * self.w2    # trainer.py:172
+            return SimpleNamespace(G_s=out, G_=G_, G_jaco_=None, G_vort_=None, x_jaco=None, g_loss_l1=g_loss_l1,
+                                   g_loss_j_l1=g_loss_j_l1, g_loss=g_loss)
+        with torch.no_grad():                                   # trainer.py:29-32: Jacobian of the ground truth
+            x_jaco = (jacobian3(x) if self.is_3d else jacobian(x))[0]
         if self.config.use_curl:
             if self.is_3d:
                 # `_, self.G_ = jacobian3(self.G_s)` (trainer3.py:18); TF prunes the unused j, eager cannot -> curl3
@@ -397,6 +407,7 @@ class GANTrainer(Trainer):
     def __init__(self, config, device="cuda", name="G"):
         self.w3 = config.w3
         super(GANTrainer, self).__init__(config, device, name)
+        self.fused_tail = False                                   # the discriminator reads the vorticity of G_ (trainer.py:155-156)
         disc = DiscriminatorPatch3 if self.is_3d else DiscriminatorPatch
         cin = 6 if self.is_3d else 3                              # concat([x, x_vort]): 3+3 | 2+1 channels
         spatial = ([config.res_z] if self.is_3d else []) + [config.res_y, config.res_x]

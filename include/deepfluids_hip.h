@@ -83,6 +83,26 @@ int df_jacobian3d_bwd(const float* gj, const float* gc, float* gx, int64_t B, in
 int df_divergence2d(const float* x, float* d, int64_t B, int64_t Y, int64_t X, df_stream_t stream);
 int df_divergence3d(const float* x, float* d, int64_t B, int64_t Z, int64_t Y, int64_t X, df_stream_t stream);
 
+/* ---- fused tail of the velocity-field train step (trainer.py:140-146,170-172; trainer3.py:18-24,49-51) ----------------------
+ * u = curl(psi) | jacobian3(psi)[1];  l1 = mean|u - x|;  jl1 = mean|J(u) - J(x)|  with J = jacobian(.)[0] | jacobian3(.)[0] and
+ * the ground-truth Jacobian of trainer.py:29-32 recomputed on the fly: one kernel over psi and x (36 B/voxel in 3-D instead of the
+ * 240 B/voxel of the five reference ops; the 9-channel Jacobians are never materialised).
+ *   psi [B,Z,Y,X,3] | [B,Y,X,1], x [B,Z,Y,X,3] | [B,Y,X,2];  u (nullable) receives the velocity field, bit-identical to
+ *   df_jacobian3d_fwd(psi, NULL, u) | df_curl2d_fwd;  l1 / jl1: device scalars.
+ * Backward: gpsi = curl^T( g_l1/N1 sign(u - x) + J^T( g_jl1/NJ sign(J(u) - J(x)) ) ) from the saved u and x;  g_l1 / g_jl1 are
+ * device scalars (NULL = 1).  One workspace serves both directions (df_velocity_loss*_workspace_bytes, 16-byte aligned). */
+int64_t df_velocity_loss3d_workspace_bytes(int64_t B, int64_t Z, int64_t Y, int64_t X);
+int df_velocity_loss3d_fwd(const float* psi, const float* x, float* u, float* l1, float* jl1, int64_t B, int64_t Z, int64_t Y,
+                           int64_t X, void* workspace, int64_t workspace_bytes, df_stream_t stream);
+int df_velocity_loss3d_bwd(const float* u, const float* x, const float* g_l1, const float* g_jl1, float* gpsi, int64_t B, int64_t Z,
+                           int64_t Y, int64_t X, void* workspace, int64_t workspace_bytes, df_stream_t stream);
+int64_t df_velocity_loss2d_workspace_bytes(int64_t B, int64_t Y, int64_t X);
+int df_velocity_loss2d_fwd(const float* psi, const float* x, float* u, float* l1, float* jl1, int64_t B, int64_t Y, int64_t X,
+                           void* workspace, int64_t workspace_bytes, df_stream_t stream);
+int df_velocity_loss2d_bwd(const float* u, const float* x, const float* g_l1, const float* g_jl1, float* gpsi, int64_t B, int64_t Y,
+                           int64_t X, void* workspace, int64_t workspace_bytes, df_stream_t stream);
+
+
 /* ---- losses (trainer.py:170-172, trainer3.py:49-51) -------------------------------------- */
 
 /* workspace for df_l1_mean_fwd (bytes). */

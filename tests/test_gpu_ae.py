@@ -40,11 +40,11 @@ def test_conv_stride2_fwd_bwd(shape, cin, cout, leak):
     assert max(errs.values()) < TOL, errs
 
 
-@pytest.mark.parametrize("shape,cin,cout", [((1, 4, 8, 32), 16, 128), ((2, 16, 32), 32, 64), ((1, 4, 4, 16), 16, 18)])
+@pytest.mark.parametrize("shape,cin,cout", [((1, 4, 8, 32), 16, 128), ((2, 16, 32), 32, 64), ((1, 4, 4, 16), 16, 20)])
 def test_conv_stride2_in_bf16x3_mode(shape, cin, cout):
     """CONV_PRECISION = 'bf16x3' must not change the operand format of the stride-2 forward (df_conv_s2_fwd has no bf16x3
     variant: the weights are packed fp32), and its backward (stride-1 dgrad / wgrad kernels on the zero-inserted gradient) stays
-    within the split-precision bound; 16 -> 18: a layer whose channel counts are not both multiples of 4 stays fp32 end to end."""
+    within the split-precision bound."""
     from deep_fluids_amd import ops
     from deep_fluids_amd.ops import _ConvSame3S2
     rng = np.random.RandomState(cin + cout)
@@ -67,6 +67,31 @@ def test_conv_stride2_in_bf16x3_mode(shape, cin, cout):
     dx, dw, db = orc.conv_same_bwd(x64, w64, dpre, stride=2)
     assert rel_linf(host(y), ref) < TOL                       # exact-fp32 forward
     assert rel_linf(host(xt.grad), dx) < 1e-4 and rel_linf(host(wt.grad), dw) < 1e-4 and rel_linf(host(bt.grad), db) < TOL
+
+
+def test_conv_bf16x3_mode_asymmetric_channel_counts():
+    """16 -> 18 (Cin a multiple of 4, Cout not): forward and dgrad must agree on ONE operand format -- such a layer stays on
+    the exact-fp32 kernels in bf16x3 mode (ops._sfx is symmetric in cin / cout)."""
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.ops import _ConvSame3
+    rng = np.random.RandomState(9)
+    shape, cin, cout = (1, 3, 5, 8), 16, 18
+    x = rng.uniform(-1, 1, shape + (cin,)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (3, 3, 3, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    go = rng.uniform(-1, 1, shape + (cout,)).astype(np.float32)
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    ops.CONV_PRECISION = "bf16x3"
+    try:
+        assert ops._sfx(cin, cout) == "" and ops._sfx(cout, cin) == ""
+        y = _ConvSame3.apply(xt, wt, bt, None)
+        (y * dev(go)).sum().backward()
+    finally:
+        ops.CONV_PRECISION = "fp32"
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    dx, dw, db = orc.conv_same_bwd(x64, w64, go.astype(np.float64))
+    assert rel_linf(host(y), orc.conv_same(x64, w64, b.astype(np.float64))) < TOL
+    assert rel_linf(host(xt.grad), dx) < TOL and rel_linf(host(wt.grad), dw) < TOL and rel_linf(host(bt.grad), db) < TOL
 
 
 def test_concat_sigmoid_mse_bigfc():

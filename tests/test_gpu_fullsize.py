@@ -25,11 +25,21 @@ def _rel_max(a, b):
 
 
 def _grad_errs(gpu_grads, ref_grads):
-    """Per-variable L-inf error relative to that variable's gradient scale, floored at 1e-3 of the global scale (the last
-    conv's bias gradient is mathematically zero: curl annihilates constants)."""
+    """Per-variable L-inf error relative to that variable's gradient scale, floored at 1e-3 of the global scale.  The LAST conv's
+    bias gradient is mathematically zero (curl annihilates constants): in any finite precision it is the roundoff of a
+    sign-cancelling sum over all voxels, so two correct implementations share no digits of it -- it is checked separately to be
+    roundoff-sized (key '__last_bias_abs' = max|g| / global scale) and excluded from the relative comparison."""
     ref = {k: np.asarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v, np.float64) for k, v in ref_grads.items()}
     gmax = max(np.abs(v).max() for v in ref.values())
-    return {k: float(np.abs(gpu_grads[k] - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-3 * gmax)) for k in gpu_grads}
+    last_bias = sorted((k for k in ref if k.endswith("biases")), key=lambda k: int(k.split("/")[1].split("_")[0]))[-1]
+    errs = {k: float(np.abs(gpu_grads[k] - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-3 * gmax)) for k in gpu_grads if k != last_bias}
+    errs["__last_bias_abs"] = float(np.abs(gpu_grads[last_bias]).max() / gmax)
+    return errs
+
+
+def _worst(errs, n=4):
+    rel = {k: v for k, v in errs.items() if not k.startswith("__")}
+    return sorted(rel.items(), key=lambda kv: -kv[1])[:n]
 
 
 def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True):
@@ -72,9 +82,12 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True):
     out["velocity_rel_l1"] = rel_l1(u, info["u"].numpy())
     out["loss_rel"] = abs(loss - info["loss"]) / abs(info["loss"])
     errs = _grad_errs(gr, info["grads"])
-    out["grad_rel_linf"] = max(errs.values())
-    out["grad_worst"] = max(errs, key=errs.get)
+    out["grad_worst"] = _worst(errs)
+    out["grad_rel_linf"] = out["grad_worst"][0][1]
+    out["last_bias_abs"] = errs["__last_bias_abs"]
     out["n_layers_fetched"] = len(masks)
+    print("step vs torch oracle %s F=%d B=%d: velocity rel-L1 %.2e  loss rel %.1e  worst gradients %s  |last-bias grad|/gmax %.1e" % (
+        "x".join(map(str, spatial)), filters, batch, out["velocity_rel_l1"], out["loss_rel"], out["grad_worst"], out["last_bias_abs"]))
     ops.reset_variables()
     return out
 
@@ -87,6 +100,7 @@ def test_cfg3_default_dispatch_train_step_vs_torch_oracle_b2():
     assert r["velocity_rel_l1"] <= 1e-4, r           # north-star tolerance (measured ~2e-6: fp32 vs fp32)
     assert r["loss_rel"] < 1e-5, r
     assert r["grad_rel_linf"] < 1e-3, r
+    assert r["last_bias_abs"] < 1e-3, r
 
 
 def test_cfg4_full_grid_train_step_vs_torch_oracle():
@@ -106,6 +120,7 @@ def test_cfg4_full_grid_train_step_vs_torch_oracle():
         assert r["n_layers_fetched"] == 20, r
         assert r["loss_rel"] < 1e-5, r
         assert r["grad_rel_linf"] < 1e-3, r
+        assert r["last_bias_abs"] < 1e-3, r
 
 
 def test_cfg4_geometry_reduced_train_step_vs_fp64_oracle():
@@ -139,7 +154,7 @@ def test_cfg4_geometry_reduced_train_step_vs_fp64_oracle():
         assert abs(float(m.g_loss.detach()) - info["loss"]) / abs(info["loss"]) < (1e-5 if s == 0 else 1e-4), s
         if s == 0:
             errs = _grad_errs(tr.grads_numpy(), info["grads"])
-            assert max(errs.values()) < 1e-3, (max(errs, key=errs.get), max(errs.values()))
+            assert _worst(errs)[0][1] < 1e-3 and errs["__last_bias_abs"] < 1e-3, (_worst(errs), errs["__last_bias_abs"])
     assert abs(tr.g_lr - opt["lr"]) < 1e-12
     ops.reset_variables()
 

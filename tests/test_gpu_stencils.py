@@ -64,7 +64,8 @@ def test_golden_composites(ops, golden_stencils):
     np.testing.assert_array_equal(host(ops.jacobian(u2)[0]), g["composite2_ju"])
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 7, 9), (1, 2, 2, 2), (3, 16, 24, 16), (1, 3, 4, 1031), (2, 33, 2, 5)])
+@pytest.mark.parametrize("shape", [(2, 5, 7, 9), (1, 2, 2, 2), (3, 16, 24, 16), (1, 3, 4, 1031), (2, 33, 2, 5),
+                                   (1, 2, 2, 4), (2, 3, 2, 8), (1, 4, 3, 12), (1, 2, 5, 1028)])      # X % 4 == 0: the 4-voxels-per-thread kernels
 def test_jacobian3_vs_oracle_fwd_bwd(ops, shape):
     rng = np.random.RandomState(sum(shape))
     x = rng.uniform(-1, 1, shape + (3,)).astype(np.float32)
@@ -113,6 +114,45 @@ def test_2d_vs_oracle_fwd_bwd(ops, shape):
     np.testing.assert_array_equal(host(vt.grad), orc.jacobian_bwd(gj, gw))
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 7, 9), (1, 2, 2, 2), (2, 16, 24, 16), (1, 3, 4, 1031), (2, 33, 2, 5), (1, 2, 3, 4), (2, 8, 6), (1, 2, 2),
+                                   (3, 128, 96), (1, 3, 1029), (2, 37, 2)])
+def test_fused_velocity_loss_vs_oracle_and_unfused_path(ops, shape):
+    """ops.velocity_loss (velocity_loss.hip: curl + both Jacobians + both L1 means in one kernel; the adjoint rebuilt from (u, x))
+    against the oracle's restatement of the reference graph (trainer.py:140-146,170-172 / trainer3.py:18-24,49-51) and against the
+    unfused op-by-op path on the GPU; 3-D and 2-D, ragged extents, size-2 axes."""
+    is_3d = len(shape) == 4
+    rng = np.random.RandomState(sum(shape) + 1)
+    psi = rng.uniform(-1, 1, shape + (3 if is_3d else 1,)).astype(np.float32)
+    x = rng.uniform(-1, 1, shape + (3 if is_3d else 2,)).astype(np.float32)
+    w1, w2 = 0.7, 1.3
+    pt = dev(psi).requires_grad_(True)
+    l1, jl1, u = ops.velocity_loss(pt, dev(x))
+    (l1 * w1 + jl1 * w2).backward()
+    ref = orc.velocity_loss(psi.astype(np.float64), x.astype(np.float64), is_3d, w1, w2)
+    np.testing.assert_array_equal(host(u), orc.curl3(psi) if is_3d else orc.curl(psi))          # bit-exact velocity
+    assert abs(float(l1) - ref["l1"]) <= 2e-6 * ref["l1"] and abs(float(jl1) - ref["j_l1"]) <= 2e-6 * ref["j_l1"]
+    scale = np.abs(ref["dpsi"]).max()
+    assert np.abs(host(pt.grad) - ref["dpsi"]).max() <= 1e-5 * scale
+    # the unfused path: same kernels the GAN / AE graphs use
+    pt2 = dev(psi).requires_grad_(True)
+    xt = dev(x)
+    u2 = ops.curl3(pt2) if is_3d else ops.curl(pt2)
+    ju = (ops.jacobian3(u2) if is_3d else ops.jacobian(u2))[0]
+    with torch.no_grad():
+        jx = (ops.jacobian3(xt) if is_3d else ops.jacobian(xt))[0]
+    a, b = ops.l1_mean(u2, xt), ops.l1_mean(ju, jx)
+    (a * w1 + b * w2).backward()
+    assert torch.equal(u2.detach(), u)
+    assert abs(float(a) - float(l1)) <= 1e-6 * abs(float(a)) and abs(float(b) - float(jl1)) <= 1e-6 * abs(float(b))
+    assert float((pt2.grad - pt.grad).abs().max()) <= 1e-6 * scale
+    # gradient through only one of the two losses
+    pt3 = dev(psi).requires_grad_(True)
+    l1b, _, _ = ops.velocity_loss(pt3, dev(x))
+    l1b.backward()
+    ref1 = orc.velocity_loss(psi.astype(np.float64), x.astype(np.float64), is_3d, 1.0, 0.0)
+    assert np.abs(host(pt3.grad) - ref1["dpsi"]).max() <= 1e-5 * np.abs(ref1["dpsi"]).max()
+
+
 def test_full_size_properties_cfg3(ops):
     """BASELINE cfg3 shape [16,64,96,64,3]: size-independent properties instead of a CPU oracle run."""
     torch.manual_seed(0)
@@ -136,6 +176,19 @@ def test_full_size_properties_cfg3(ops):
     lhs = (j.double() * g.double()).sum()
     rhs = (psi.double() * xt.grad.double()).sum()
     assert abs(float(lhs - rhs)) <= 1e-6 * float(j.double().abs().sum())
+    # fused tail at the full shape == the op-by-op path (loss values to fp32 rounding of the fp64-accumulated means, gradient to
+    # fp32 summation order)
+    x = ops.curl3(torch.rand_like(psi) * 2 - 1)
+    pa = psi.clone().requires_grad_(True)
+    l1, jl1, uf = ops.velocity_loss(pa, x)
+    (l1 + jl1).backward()
+    pb = psi.clone().requires_grad_(True)
+    ub = ops.curl3(pb)
+    la, lb = ops.l1_mean(ub, x), ops.l1_mean(ops.jacobian3(ub)[0], ops.jacobian3(x)[0])
+    (la + lb).backward()
+    assert torch.equal(uf, u)
+    assert abs(float(l1) - float(la)) <= 1e-6 * float(la) and abs(float(jl1) - float(lb)) <= 1e-6 * float(lb)
+    assert float((pa.grad - pb.grad).abs().max()) <= 1e-6 * float(pb.grad.abs().max())
 
 
 def test_errors_are_loud(ops):
