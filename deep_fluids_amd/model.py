@@ -36,10 +36,9 @@ def _generator(z, filters, output_shape, name, num_conv, conv_k, last_k, repeat,
             x = reshape(x, x0_shape[0], x0_shape[1], x0_shape[2])              # model.py:21
         x0 = x
 
-        if skip_concat:
-            raise NotImplementedError("skip_concat=True is never enabled by the reference trainers (model.py:30-33); "
-                                      "not built")
-        fused = (ops_mod.FUSED_BLOCKS and act is lrelu and conv_k == 3 and int(x.shape[-1]) == int(filters)
+        # skip_concat=True (model.py:30-33 / :72-75; never enabled by the reference trainers) runs layer by layer: the fused block
+        # nodes assume the residual form
+        fused = (ops_mod.FUSED_BLOCKS and not skip_concat and act is lrelu and conv_k == 3 and int(x.shape[-1]) == int(filters)
                  and int(filters) >= 8 and int(filters) % 4 == 0)     # (the fused kernels are MFMA-only: no thin-channel path)
         pending_up = False      # fused path: the 2x up-sampling is folded into the NEXT block (never materialised)
         for idx in range(repeat_num):
@@ -55,10 +54,17 @@ def _generator(z, filters, output_shape, name, num_conv, conv_k, last_k, repeat,
                 for _ in range(num_conv):
                     x = conv(x, filters, k=conv_k, s=1, act=act, name=str(layer_num) + "_conv")
                     layer_num += 1
-                x = add(x, x0)                                                 # model.py:35,40 / :77,82
                 if idx < repeat_num - 1:
-                    x = up(x, 2)                                               # model.py:36 / :78
-                    x0 = x
+                    if skip_concat:                                            # model.py:30-33 / :72-75
+                        x = up(x, 2)
+                        x0 = up(x0, 2)
+                        x = concat([x, x0], axis=-1)
+                    else:
+                        x = add(x, x0)                                         # model.py:35 / :77
+                        x = up(x, 2)                                           # model.py:36 / :78
+                        x0 = x
+                elif not skip_concat:
+                    x = add(x, x0)                                             # model.py:40 / :82
 
         out = conv(x, output_shape[-1], k=last_k, s=1, name=str(layer_num) + "_conv")
     variables = get_variables(vs)

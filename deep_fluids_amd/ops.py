@@ -23,7 +23,7 @@ from ._lib import call, query, DF_CONV_BIAS, DF_CONV_LRELU, DF_CONV_MASK, DF_CON
 __all__ = [
     "lrelu", "conv2d", "conv3d", "linear", "upscale", "upscale3", "resize_nearest_neighbor", "reshape",
     "int_shape", "get_conv_shape", "nchw_to_nhwc", "nhwc_to_nchw", "add", "concat", "sigmoid", "mse_mean",
-    "jacobian", "jacobian3", "curl", "curl3", "divergence", "divergence3",
+    "jacobian", "jacobian3", "curl", "curl3", "divergence", "divergence3", "pgrad",
     "vort_np", "curl_np", "grad_np", "jacobian_np3", "l1_mean", "velocity_loss",
     "variable_scope", "get_variables", "get_variable", "reset_variables", "set_random_seed", "all_variables",
 ]
@@ -1057,6 +1057,17 @@ def divergence3(x):
     d = _empty((B, Z - 1, Y - 1, X - 1, 1), x)
     call("df_divergence3d", _ptr(x), _ptr(d), B, Z, Y, X, _stream())
     return d
+
+
+def pgrad(x, data_format):
+    """ops.py:292-303: pressure gradient ``(D_x p, D_y p)`` of channel 0 with the last difference replicated.  The two
+    differences are exactly the curl kernel's outputs re-ordered -- ``curl(p) = (D_y p, -D_x p)`` (ops.py:267-271) and negation
+    is exact -- so the stencil runs on ``df_curl2d_fwd`` / ``_bwd``; only the channel swap is a tensor view op."""
+    if data_format == "NCHW":
+        x = nchw_to_nhwc(x)
+    c = _Curl2d.apply(x[..., :1].contiguous())
+    g = torch.stack([-c[..., 1], c[..., 0]], dim=-1)
+    return nhwc_to_nchw(g) if data_format == "NCHW" else g
 
 
 def l1_mean(a, b):

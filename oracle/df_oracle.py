@@ -166,6 +166,12 @@ def divergence3(x):
     return (dudx + dvdy + dwdz)[..., None]
 
 
+def pgrad(x):
+    """ops.py:292-303: pressure gradient (D_x p, D_y p) of channel 0, last difference replicated; x [B,Y,X,C] -> [B,Y,X,2]."""
+    p = np.asarray(x)[..., 0]
+    return np.stack([fdiff(p, 2), fdiff(p, 1)], axis=-1)
+
+
 def vort_np(x):
     """ops.py:305-310."""
     x = np.asarray(x)
@@ -298,16 +304,18 @@ def xavier_uniform(rng, shape):
     return rng.uniform(-lim, lim, size=shape).astype(np.float32)
 
 
-def generator_init(rng, c_num, output_shape, filters, name="G", num_conv=4, conv_k=3, last_k=3, repeat=0):
-    """Variables in TF/slim naming order: '<name>/<n>_fc|_conv/{weights,biases}'."""
+def generator_init(rng, c_num, output_shape, filters, name="G", num_conv=4, conv_k=3, last_k=3, repeat=0, skip_concat=False):
+    """Variables in TF/slim naming order: '<name>/<n>_fc|_conv/{weights,biases}'.  skip_concat (model.py:30-33 / :72-75): the first
+    conv of every block after the first reads concat([upscale(x), upscale(x0)]) = 2 x filters channels."""
     nd = len(output_shape) - 1
     repeat_num, x0_shape, _ = generator_plan(output_shape, filters, num_conv, repeat)
     p = {}
     p["%s/0_fc/weights" % name] = xavier_uniform(rng, (c_num, int(np.prod(x0_shape))))
     p["%s/0_fc/biases" % name] = np.zeros(int(np.prod(x0_shape)), np.float32)
     ln = 1
-    for _ in range(repeat_num * num_conv):
-        p["%s/%d_conv/weights" % (name, ln)] = xavier_uniform(rng, (conv_k,) * nd + (filters, filters))
+    for i in range(repeat_num * num_conv):
+        cin = 2 * filters if (skip_concat and i >= num_conv and i % num_conv == 0) else filters
+        p["%s/%d_conv/weights" % (name, ln)] = xavier_uniform(rng, (conv_k,) * nd + (cin, filters))
         p["%s/%d_conv/biases" % (name, ln)] = np.zeros(filters, np.float32)
         ln += 1
     p["%s/%d_conv/weights" % (name, ln)] = xavier_uniform(rng, (last_k,) * nd + (filters, output_shape[-1]))
@@ -315,7 +323,7 @@ def generator_init(rng, c_num, output_shape, filters, name="G", num_conv=4, conv
     return p
 
 
-def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, leak=0.2, keep=False):
+def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, leak=0.2, keep=False, skip_concat=False):
     """GeneratorBE (model.py:5-46) / GeneratorBE3 (model.py:48-87), skip_concat=False.
     Returns out (and, if keep, the cache needed by :func:`generator_bwd`)."""
     repeat_num, x0_shape, _ = generator_plan(output_shape, filters, num_conv, repeat)
@@ -332,8 +340,14 @@ def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, l
             x = lrelu(conv_same(x, W(ln, "conv"), Bv(ln, "conv")), leak)
             blk["outs"].append(x)
             ln += 1
-        x = x + x0                                   # model.py:35 / :40
         blk["up"] = idx < repeat_num - 1
+        if skip_concat:                              # model.py:30-33 / :72-75 (forward only: no cache for generator_bwd)
+            assert not keep, "oracle: skip_concat reverse pass not restated (use df_oracle_torch)"
+            if blk["up"]:
+                x = upscale_nn(x, 2); x0 = upscale_nn(x0, 2)
+                x = np.concatenate([x, x0], axis=-1)
+            continue
+        x = x + x0                                   # model.py:35 / :40
         if blk["up"]:
             x = upscale_nn(x, 2)                     # model.py:36 / :78
             x0 = x
@@ -613,9 +627,11 @@ def gan_losses_and_grads(z, x, pG, pD, output_shape, filters, is_3d, w1=1.0, w2=
 # Train step (trainer.py:136-184, trainer3.py:14-63) + TF1 Adam + LR schedule
 # ----------------------------------------------------------------------------------------
 
-def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, need_grad=True):
+def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, need_grad=True, sign_u=None):
     """G_ = curl(psi) | jacobian3(psi)[1];  loss = w1*mean|G_-x| + w2*mean|J(G_)-J(x)|.
-    Returns dict(loss, l1, j_l1, u, dpsi)."""
+    Returns dict(loss, l1, j_l1, u, dpsi).  ``sign_u`` (optional): take the sign pattern of the two |.| terms in the reverse
+    pass from this velocity field (the one the implementation under test produced) -- |.| is piecewise linear and values within
+    rounding error of zero may sit on either piece, which moves the heavily cancelling parameter gradients at the 1e-3 level."""
     if is_3d:
         u = curl3(psi); ju, _ = jacobian3(u); jx, _ = jacobian3(x)
     else:
@@ -623,8 +639,10 @@ def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, need_grad=True):
     l1 = l1_mean(u, x); jl1 = l1_mean(ju, jx)
     res = {"loss": w1 * l1 + w2 * jl1, "l1": l1, "j_l1": jl1, "u": u, "ju": ju, "jx": jx}
     if need_grad:
-        du = l1_mean_bwd(u, x, w1)
-        dj = l1_mean_bwd(ju, jx, w2)
+        us = u if sign_u is None else np.asarray(sign_u)
+        js = ju if sign_u is None else (jacobian3(us)[0] if is_3d else jacobian(us)[0])
+        du = l1_mean_bwd(us, x, w1)
+        dj = l1_mean_bwd(js, jx, w2)
         if is_3d:
             du = du + jacobian3_bwd(gj=dj)
             res["dpsi"] = jacobian3_bwd(gc=du)
@@ -650,11 +668,11 @@ def lr_cosine(step, max_step, lr_max=1e-4, lr_min=2.5e-6):
 
 
 def train_step(z, x, p, opt, output_shape, filters, is_3d, num_conv=4, repeat=0, w1=1.0, w2=1.0,
-               name="G", masks=None):
+               name="G", masks=None, sign_u=None):
     """One full step: G fwd -> curl -> Jacobian -> L1 losses -> bwd -> TF1 Adam (in place on
     copies).  ``opt`` = dict(m, v, t, lr).  Returns (new_p, new_opt, info)."""
     psi, cache = generator_fwd(z, p, output_shape, filters, name, num_conv, repeat, keep=True)
-    res = velocity_loss(psi, x, is_3d, w1, w2)
+    res = velocity_loss(psi, x, is_3d, w1, w2, sign_u=sign_u)
     grads = generator_bwd(res["dpsi"], cache, p, name, masks=masks)
     t = opt["t"] + 1
     new_p, new_m, new_v = {}, {}, {}

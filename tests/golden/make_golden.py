@@ -157,11 +157,13 @@ def capture_stencils(ops):
         j, w = ops.jacobian(_t(v))
         out["jacobian_%s_j" % tag] = np.asarray(j); out["jacobian_%s_w" % tag] = np.asarray(w)
         out["vort_np_%s_out" % tag] = ops.vort_np(v)
+        out["pgrad_%s_out" % tag] = np.asarray(ops.pgrad(_t(s), "NHWC"))
         if y > 1 and x > 1:
             out["divergence_%s_out" % tag] = np.asarray(ops.divergence(_t(v)))
     # NCHW entry points (transposes in/out, ops.py:206-207,222-224,265,273)
     s = rnd(2, 1, 8, 6); v = rnd(2, 2, 8, 6)
     out["curl_nchw_in"] = s; out["curl_nchw_out"] = np.asarray(ops.curl(_t(s), data_format="NCHW"))
+    out["pgrad_nchw_out"] = np.asarray(ops.pgrad(_t(s), "NCHW"))
     out["jacobian_nchw_in"] = v
     j, w = ops.jacobian(_t(v), data_format="NCHW")
     out["jacobian_nchw_j"] = np.asarray(j); out["jacobian_nchw_w"] = np.asarray(w)
@@ -203,20 +205,24 @@ def capture_generators(model):
         "g2_small": ("GeneratorBE", 3, [16, 8, 1], 8, 2),
         "g3_small": ("GeneratorBE3", 3, [8, 16, 8, 3], 8, 2),
         "g3_odd": ("GeneratorBE3", 2, [12, 8, 4, 3], 4, 1),
+        # skip_concat=True (model.py:30-33 / :72-75; never enabled by the reference trainers): concat skips instead of residual adds
+        "g2_skip": ("GeneratorBE", 3, [16, 8, 1], 8, 2),
+        "g3_skip": ("GeneratorBE3", 3, [8, 16, 8, 3], 8, 1),
     }
     for tag, (fn, c_num, oshape, filters, batch) in cases.items():
         rng = np.random.RandomState(123)
         WEIGHTS.clear(); del PLAN[:]
-        WEIGHTS.update(orc.generator_init(rng, c_num, oshape, filters))
+        skip = tag.endswith("_skip")
+        WEIGHTS.update(orc.generator_init(rng, c_num, oshape, filters, skip_concat=skip))
         for k in list(WEIGHTS):                      # non-zero biases so bias handling is exercised
             if k.endswith("biases"):
                 WEIGHTS[k] = rng.uniform(-0.1, 0.1, size=WEIGHTS[k].shape).astype(np.float32)
         z = rng.uniform(-1, 1, size=(batch, c_num)).astype(np.float32)
-        out, var_names = getattr(model, fn)(_t(z), filters, oshape)
+        out, var_names = getattr(model, fn)(_t(z), filters, oshape, skip_concat=skip)
         res[tag + "_z"] = z; res[tag + "_out"] = np.asarray(out)
         for k, v in WEIGHTS.items():
             res[tag + "|" + k] = v
-        plans[tag] = {"fn": fn, "c_num": c_num, "output_shape": oshape, "filters": filters,
+        plans[tag] = {"fn": fn, "c_num": c_num, "output_shape": oshape, "filters": filters, "skip_concat": skip,
                       "layers": list(PLAN), "variables": list(var_names)}
     np.savez_compressed(os.path.join(HERE, "generators.npz"), **res)
 

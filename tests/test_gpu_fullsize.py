@@ -4,7 +4,8 @@ The kernels are shape-specialised (row-length variants of the weight gradients, 
 one batch volume), so small-shape parity does not transfer automatically.  Three kinds of checks:
   * the whole train step with the default dispatch against the PyTorch-CPU oracle (oracle/df_oracle_torch.py, fp32 on the
     box's host cores) on the same weights / inputs: velocity rel-L1 <= 1e-4 (north star), loss, every per-variable gradient
-    with the lrelu sign pattern taken from the GPU (the network is piecewise linear; see _LreluMasked);
+    on the linear piece the GPU is on (lrelu slopes and the signs of the two |.| loss terms taken from the GPU's activations /
+    velocity field: the graph is piecewise linear; see df_oracle_torch._LreluMasked / velocity_loss);
   * every algorithm of a layer against the direct MFMA kernels (which the small cases of test_gpu_layers.py pin against the
     fp64 oracle) at full size and batch >= 2;
   * batch 16 (3 GiB activations): first and last batch element bit-identical to the batch-1 result (offset overflow).
@@ -78,7 +79,8 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True):
     gr = tr.grads_numpy()
     u, loss = host(m.G_), float(m.g_loss.detach())
     del m
-    info = ort.train_step(torch.from_numpy(y), torch.from_numpy(x), pt, ort.new_opt(pt), oshape, filters, True, masks=masks)
+    info = ort.train_step(torch.from_numpy(y), torch.from_numpy(x), pt, ort.new_opt(pt), oshape, filters, True, masks=masks,
+                          sign_u=torch.from_numpy(u))
     out["velocity_rel_l1"] = rel_l1(u, info["u"].numpy())
     out["loss_rel"] = abs(loss - info["loss"]) / abs(info["loss"])
     errs = _grad_errs(gr, info["grads"])
@@ -148,7 +150,8 @@ def test_cfg4_geometry_reduced_train_step_vs_fp64_oracle():
             masks = {i + 1: host(t) > 0 for i, t in enumerate(ops.ACTIVATION_FETCH)}
         finally:
             ops.ACTIVATION_FETCH = None
-        p64, opt, info = orc.train_step(y.astype(np.float64), x.astype(np.float64), p64, opt, oshape, filters, True, masks=masks)
+        p64, opt, info = orc.train_step(y.astype(np.float64), x.astype(np.float64), p64, opt, oshape, filters, True, masks=masks,
+                                        sign_u=host(m.G_))
         opt["lr"] = orc.lr_cosine(s + 1, tr.max_step)
         assert rel_l1(host(m.G_), info["u"]) <= 1e-4, s
         assert abs(float(m.g_loss.detach()) - info["loss"]) / abs(info["loss"]) < (1e-5 if s == 0 else 1e-4), s

@@ -29,9 +29,11 @@ def test_golden_2d(ops, golden_stencils, tag):
     np.testing.assert_array_equal(ops.curl_np(g["curl_%s_in" % tag]), g["curl_np_%s_out" % tag])
     np.testing.assert_array_equal(ops.vort_np(g["jacobian_%s_in" % tag]), g["vort_np_%s_out" % tag])
     np.testing.assert_array_equal(ops.grad_np(g["curl_%s_in" % tag]), g["grad_np_%s_out" % tag])
+    np.testing.assert_array_equal(host(ops.pgrad(dev(g["curl_%s_in" % tag]), "NHWC")), g["pgrad_%s_out" % tag])     # ops.py:292-303
 
 
 def test_golden_nchw(ops, golden_stencils):
+    np.testing.assert_array_equal(host(ops.pgrad(dev(golden_stencils["curl_nchw_in"]), "NCHW")), golden_stencils["pgrad_nchw_out"])
     g = golden_stencils
     np.testing.assert_array_equal(host(ops.curl(dev(g["curl_nchw_in"]), data_format="NCHW")), g["curl_nchw_out"])
     j, w = ops.jacobian(dev(g["jacobian_nchw_in"]), data_format="NCHW")

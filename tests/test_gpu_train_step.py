@@ -15,7 +15,7 @@ from gpu_util import dev, host, rel_l1, rel_linf
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tag", ["g2_small", "g3_small", "g3_odd"])
+@pytest.mark.parametrize("tag", ["g2_small", "g3_small", "g3_odd", "g2_skip", "g3_skip"])
 def test_generator_vs_reference_model_py(golden_generators, tag):
     from deep_fluids_amd import ops
     from deep_fluids_amd.model import GeneratorBE, GeneratorBE3
@@ -26,10 +26,40 @@ def test_generator_vs_reference_model_py(golden_generators, tag):
         if k.startswith(tag + "|"):
             ops.set_variable(k.split("|", 1)[1], v)
     gen = GeneratorBE3 if pl["fn"] == "GeneratorBE3" else GeneratorBE
-    out, variables = gen(dev(g[tag + "_z"]), pl["filters"], pl["output_shape"], reuse=True)
+    out, variables = gen(dev(g[tag + "_z"]), pl["filters"], pl["output_shape"], skip_concat=pl.get("skip_concat", False), reuse=True)
     assert len(variables) == len(pl["variables"])
     assert rel_linf(host(out), g[tag + "_out"]) < 2e-5
     assert rel_l1(host(out), g[tag + "_out"]) < 1e-5
+    ops.reset_variables()
+
+
+def test_generator_skip_concat_gradients_vs_torch_oracle():
+    """skip_concat=True (model.py:30-33 / :72-75): the concat-skip generator through autograd (stride-1 convs with Cin = 2F,
+    up-sampling, channel concat) against the PyTorch-CPU oracle's autograd on the same weights."""
+    import df_oracle_torch as ort
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.model import GeneratorBE3
+    rng = np.random.RandomState(21)
+    oshape, filters = [8, 16, 8, 3], 16
+    p = orc.generator_init(rng, 3, oshape, filters, skip_concat=True)
+    for k in p:
+        if k.endswith("biases"):
+            p[k] = rng.uniform(-0.05, 0.05, p[k].shape).astype(np.float32)
+    z = rng.uniform(-1, 1, (2, 3)).astype(np.float32)
+    go = rng.uniform(-1, 1, [2] + oshape).astype(np.float32)
+    ops.reset_variables()
+    vs = {k: ops.set_variable(k, v) for k, v in p.items()}
+    out, variables = GeneratorBE3(dev(z), filters, oshape, skip_concat=True, reuse=True)
+    assert len(variables) == len(p)
+    (out * dev(go)).sum().backward()
+    pt = ort.to_torch(p, torch.float64)
+    for v in pt.values():
+        v.requires_grad_(True)
+    ref = ort.generator_fwd(torch.from_numpy(z).double(), pt, oshape, filters, skip_concat=True)
+    (ref * torch.from_numpy(go).double()).sum().backward()
+    assert rel_linf(host(out), ref.detach().numpy()) < 2e-5
+    for k in p:
+        assert rel_linf(host(vs[k].grad), pt[k].grad.numpy()) < 1e-4, k
     ops.reset_variables()
 
 
@@ -63,7 +93,8 @@ def _run_step_case(is_3d, spatial, filters, batch, steps=2):
         finally:
             ops.ACTIVATION_FETCH = None
         masks = {i + 1: host(t) > 0 for i, t in enumerate(fetched)} if fetched else None
-        p64, opt, info = orc.train_step(y.astype(np.float64), x.astype(np.float64), p64, opt, oshape, filters, is_3d, masks=masks)
+        p64, opt, info = orc.train_step(y.astype(np.float64), x.astype(np.float64), p64, opt, oshape, filters, is_3d, masks=masks,
+                                        sign_u=host(m.G_))
         opt["lr"] = orc.lr_cosine(s + 1, tr.max_step)
         out["velocity_rel_l1_step%d" % s] = rel_l1(host(m.G_), info["u"])
         out["loss_rel_step%d" % s] = abs(float(m.g_loss) - info["loss"]) / abs(info["loss"])

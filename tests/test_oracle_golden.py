@@ -28,6 +28,7 @@ def test_curl_jacobian_2d_bit_exact(golden_stencils, tag):
     np.testing.assert_array_equal(w, g["jacobian_%s_w" % tag])
     np.testing.assert_array_equal(orc.vort_np(v), g["vort_np_%s_out" % tag])
     np.testing.assert_array_equal(orc.divergence(v), g["divergence_%s_out" % tag])
+    np.testing.assert_array_equal(orc.pgrad(s), g["pgrad_%s_out" % tag])                 # ops.py:292-303
 
 
 def test_nchw_entry_points(golden_stencils):
@@ -81,7 +82,7 @@ def test_layers_vs_reference_source(golden_stencils):
     np.testing.assert_array_equal(orc.upscale_nn(g["upscale3_in"]), g["upscale3_out"])    # ops.py:79-91
 
 
-@pytest.mark.parametrize("tag", ["g2_small", "g3_small", "g3_odd"])
+@pytest.mark.parametrize("tag", ["g2_small", "g3_small", "g3_odd", "g2_skip", "g3_skip"])
 def test_generator_graph_structure(golden_generators, tag):
     """generator_fwd (restated) == the reference's model.py executed under the stub, bit for bit
     (same layer arithmetic underneath, so any difference is a graph-structure difference)."""
@@ -89,7 +90,7 @@ def test_generator_graph_structure(golden_generators, tag):
     plans = json.load(open(os.path.join(GOLDEN, "layer_plans.json")))
     pl = plans[tag]
     p = {k.split("|", 1)[1]: v for k, v in g.items() if k.startswith(tag + "|")}
-    out = orc.generator_fwd(g[tag + "_z"], p, pl["output_shape"], pl["filters"])
+    out = orc.generator_fwd(g[tag + "_z"], p, pl["output_shape"], pl["filters"], skip_concat=pl.get("skip_concat", False))
     np.testing.assert_array_equal(out, g[tag + "_out"])
     assert sorted(p) == pl["variables"]
     rep, x0, nl = orc.generator_plan(pl["output_shape"], pl["filters"])
