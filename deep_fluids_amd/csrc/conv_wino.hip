@@ -155,6 +155,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* p, unsign
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// the same with a cache-policy operand (gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX>
+__device__ __forceinline__ f32x4 buf_load16_aux(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
 
 // Barrier that orders LDS traffic only.  __syncthreads() is a full fence: its s_waitcnt vmcnt(0) also waits for the acknowledgement of
 // every global STORE issued before it -- in the epilogue that exposed two HBM write round trips per tile block.
@@ -265,7 +270,8 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   };
   auto stage_load = [&](int it, __amdgpu_buffer_rsrc_t srd, unsigned chunkbytes) -> f32x4 {
     if (DBG & 256) return buf_load16(wsrd_dbg, static_cast<unsigned>(lane) * 16u, 0u);      // always-cached address (latency experiment)
-    return buf_load16(srd, so[it], chunkbytes);
+    constexpr int SAUX = (DBG >> 11) & 31;      // (experiment: cache policy of the staging loads)
+    return buf_load16_aux<SAUX>(srd, so[it], chunkbytes);
   };
   char* sInB = reinterpret_cast<char*>(sIn);
   auto stage_store = [&](int it, int bufbytes, const f32x4& v) {
@@ -329,8 +335,12 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   const unsigned laneb = static_cast<unsigned>(lane) * 16u;
   const __amdgpu_buffer_rsrc_t wsrd = make_srd(a.wp, static_cast<unsigned>(a.Cin) * a.Cout * 256u);
   const unsigned wbase_b = static_cast<unsigned>((cs * 4 + mz) * nk4) * 8192u + static_cast<unsigned>(hnb) * 4096u;
+  // (experiment, DBG & 1024) odd cout slices walk the 16-channel chunks pairwise swapped (1,0,3,2,...): the two slices that share an XCD
+  // then request the two 64-byte halves of each 128-byte line of the input at the same time
+  const int cperm = ((DBG & 1024) && ((a.Cin / CKW) & 1) == 0) ? (cs & 1) : 0;
   auto issue_b = [&](int nb, int k4) {
-    const int k2 = k4 < nk4 ? k4 : 0;        // wraps to the first k-step of the next tile block
+    const int kl = k4 < nk4 ? k4 : 0;        // wraps to the first k-step of the next tile block
+    const int k2 = (((kl >> 2) ^ cperm) << 2) | (kl & 3);
     const unsigned sb = wbase_b + static_cast<unsigned>(k2) * 8192u + nb * 4096u;      // wave-uniform
 #pragma unroll
     for (int q = 0; q < 4; ++q) bq[nb][q] = buf_load16(wsrd, laneb + q * 1024u, sb);
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const __amdgpu_buffer_rsrc_t srd0 = make_srd(cur.xb, vol_bytes);
     f32x4 stg[NLOAD];
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, srd0, 0u);
+    for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, srd0, static_cast<unsigned>(cperm) * (CKW * 4u));
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) stage_store(it, 0, stg[it]);
   }
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       const bool lastc = chunk + 1 == nchunk;
       if (lastc) set_offs(nxt);                      // the last chunk stages the next tile block's first chunk
       const __amdgpu_buffer_rsrc_t ssrd = make_srd(lastc ? nxt.xb : cur.xb, vol_bytes);
-      const unsigned schunk = lastc ? 0u : static_cast<unsigned>(chunk + 1) * (CKW * 4u);
+      const unsigned schunk = static_cast<unsigned>((lastc ? 0 : chunk + 1) ^ cperm) * (CKW * 4u);
       f32x4 stg[NLOAD];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -593,7 +603,7 @@ constexpr int g_wino_spx = 0;
 extern "C" {
 
 #ifdef DF_TUNING
-void df_debug_set_wino(int v) { g_wino_dbg = v & 0xffff; g_wino_spx = v >> 16; }
+void df_debug_set_wino(int v) { g_wino_dbg = v & 0xfffff; g_wino_spx = v >> 20; }
 int df_debug_wino_prof(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_prof), z, sizeof(z)); }
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_prof), 32 * sizeof(unsigned long long));
@@ -686,8 +696,26 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
       else if (flags == DF_CONV_MASK) hipLaunchKernelGGL((wino3d_kernel<16, DF_CONV_MASK>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
       else hipLaunchKernelGGL((wino3d_kernel<16, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
       break;
-    case 1024: hipLaunchKernelGGL((wino3d_kernel<1024, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 1024: hipLaunchKernelGGL((wino3d_kernel<1024, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case (1024 | (1 << 11)): hipLaunchKernelGGL((wino3d_kernel<(1024 | (1 << 11)), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 1536: hipLaunchKernelGGL((wino3d_kernel<1536, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    // diagnosis variants (results are wrong by construction, timing only): 4 no staging at all | 8 no weight loads | 64 staging loads
+    // kept alive but not written to LDS | 128 staging loads replaced by zeros | 256 staging loads read an always-cached address
+    case 4: hipLaunchKernelGGL((wino3d_kernel<4, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 8: hipLaunchKernelGGL((wino3d_kernel<8, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 12: hipLaunchKernelGGL((wino3d_kernel<12, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 64: hipLaunchKernelGGL((wino3d_kernel<64, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 128: hipLaunchKernelGGL((wino3d_kernel<128, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 256: hipLaunchKernelGGL((wino3d_kernel<256, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 512: hipLaunchKernelGGL((wino3d_kernel<512, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 9: hipLaunchKernelGGL((wino3d_kernel<9, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    // cache policy of the staging loads: aux << 11  (sc0 | nt | sc0+nt | sc1 | sc1+nt | sc0+sc1)
+    case (1 << 11): hipLaunchKernelGGL((wino3d_kernel<(1 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case (2 << 11): hipLaunchKernelGGL((wino3d_kernel<(2 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case (3 << 11): hipLaunchKernelGGL((wino3d_kernel<(3 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case (16 << 11): hipLaunchKernelGGL((wino3d_kernel<(16 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case (18 << 11): hipLaunchKernelGGL((wino3d_kernel<(18 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case (17 << 11): hipLaunchKernelGGL((wino3d_kernel<(17 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
 #endif
     default: return df::fail(DF_EINVAL, "df_wino_conv_fwd: unknown debug variant");
   }

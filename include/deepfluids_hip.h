@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DF_VERSION 100 /* 0.1.0 */
+#define DF_VERSION 200 /* 0.2.0: + df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d */
 
 enum {
   DF_OK = 0,
