@@ -14,32 +14,12 @@
 //   bank-conflict-free, the read-back is ds_read_b128) so that every global store instruction of a
 //   wave writes 1 KiB of contiguous output.
 #include "df_common.hpp"
+#include "stencil_common.hpp"
 
 namespace {
 
 using df::ceil_div;
-
-constexpr int kThreads = 256;
-constexpr int kVoxPerThread = 4;
-constexpr int kVoxPerBlock = kThreads * kVoxPerThread;   // 1024
-
-struct Dims3 {
-  int64_t nvox;   // B*Z*Y*X
-  int Z, Y, X;
-  int group;      // XCD remap granularity (blocks); 0 = one contiguous chunk per XCD
-};
-
-// XCD-aware, bijective block remap: workgroup b runs on XCD b % 8 (observed); hand each XCD a contiguous run of
-// blocks so the y/z neighbour records a block re-reads were fetched into the SAME XCD's L2 by its own neighbours.
-// Speed only (measured: halves FETCH_SIZE of jacobian3d_fwd), never correctness.
-__device__ __forceinline__ int64_t xcd_block(int bid, int nblk, int group) {
-  const int xcd = bid & 7, idx = bid >> 3;
-  if (group > 0) {                  // runs of `group` consecutive blocks dealt round-robin to the XCDs (nblk % (8*group) == 0)
-    return (static_cast<int64_t>(idx / group) * 8 + xcd) * group + idx % group;
-  }
-  const int q = nblk >> 3, rem = nblk & 7;
-  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-}
+using namespace dfst;
 
 // forward difference of one 3-float record along one axis with the replicate-the-difference rule
 __device__ __forceinline__ void diff3(const float* __restrict__ x, int64_t v, int64_t stride, bool last,
@@ -50,27 +30,6 @@ __device__ __forceinline__ void diff3(const float* __restrict__ x, int64_t v, in
   d[0] = last ? own[0] - n0 : n0 - own[0];
   d[1] = last ? own[1] - n1 : n1 - own[1];
   d[2] = last ? own[2] - n2 : n2 - own[2];
-}
-
-// copy `nfloats` floats from LDS (16-byte aligned) to global `dst` (16-byte aligned base) with
-// 16-byte stores; the ragged tail (only in the last workgroup) falls back to dword stores.
-template <bool NT>
-__device__ __forceinline__ void flush_lds(const float* __restrict__ s, float* __restrict__ dst, int64_t nfloats,
-                                          int tid) {
-  const int64_t nq = nfloats >> 2;
-  const float4* s4 = reinterpret_cast<const float4*>(s);
-  float4* d4 = reinterpret_cast<float4*>(dst);
-  for (int64_t q = tid; q < nq; q += kThreads) {
-    if (NT) {
-      typedef float v4 __attribute__((ext_vector_type(4)));
-      const v4 val = reinterpret_cast<const v4*>(s)[q];
-      __builtin_nontemporal_store(val, reinterpret_cast<v4*>(dst) + q);
-    } else {
-      d4[q] = s4[q];
-    }
-  }
-  const int64_t done = nq << 2;
-  if (tid < nfloats - done) dst[done + tid] = s[done + tid];
 }
 
 template <bool WJ, bool WC>
@@ -125,8 +84,6 @@ __global__ __launch_bounds__(kThreads) void jacobian3d_fwd_kernel(const float* _
 // voxel); the y and z neighbours are the same three float4 one row / one slice further (16-byte aligned because
 // 3*X*4 bytes is a multiple of 16).  10 global_load_dwordx4 per 4 voxels instead of 48 dword loads; all but the
 // own records are L1/L2 hits.  Results leave through the same LDS transpose -> 1 KiB-contiguous stores.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 template <bool WJ, bool WC, bool NT>
 __global__ __launch_bounds__(kThreads) void jacobian3d_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ j,
                                                                       float* __restrict__ c, Dims3 dm) {
@@ -484,7 +441,7 @@ __global__ __launch_bounds__(kThreads) void divergence2d_kernel(const float* __r
 int g_stencil_group = 48;
 int g_stencil_nt = 1;
 #else
-constexpr int g_stencil_group = 48;  // runs of 48 blocks per XCD (sweep in tools/stencil_probe.py: best warm+cold)
+constexpr int g_stencil_group = dfst::kXcdGroup;
 constexpr int g_stencil_nt = 1;      // non-temporal output stores
 #endif
 

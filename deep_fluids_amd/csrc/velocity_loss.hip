@@ -14,11 +14,15 @@
 // arithmetic as stencil.hip (u is bit-identical to df_jacobian3d_fwd / df_curl2d_fwd).  Sums: fp32 per thread (<= 12 terms),
 // fp64 per workgroup and across workgroups in a fixed order (deterministic).
 #include "df_common.hpp"
+#include "stencil_common.hpp"
 
 namespace {
 
 using df::ceil_div;
-constexpr int kThreads = 256;
+using dfst::Dims3;
+using dfst::f32x4;
+using dfst::kVoxPerBlock;
+constexpr int kThreads = dfst::kThreads;
 
 __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -160,6 +164,221 @@ __global__ __launch_bounds__(kThreads) void velocity_loss3d_bwd_kernel(const flo
   }
 }
 
+// ================================ 3-D fast path (X % 4 == 0): 4 voxels of one row per thread ========================================
+// Forward = two launches: u = curl3(psi) by stencil.hip's 16-byte-load kernel (24 B/voxel), then this reduction over (u, x):
+// 24 B/voxel read, nothing written -- 48 B/voxel in total (the one-kernel form below is 36 B/voxel but needs psi at ten offsets per
+// voxel: L1-bound at 2 TB/s; u comes back from the Infinity Cache / L2 it was just written through).  Loads as in
+// jacobian3d_fwd_vec_kernel: own quad + the next record, the quads one row / one slice further (backward on the last row / slice).
+__global__ __launch_bounds__(kThreads) void velocity_jl1_3d_vec_kernel(const float* __restrict__ u, const float* __restrict__ x,
+                                                                       double* __restrict__ partial, Dims3 dm) {
+  const int tid = threadIdx.x;
+  const int64_t v0 = dfst::xcd_block(blockIdx.x, gridDim.x, dm.group) * kVoxPerBlock;
+  const int64_t vq = v0 + 4 * static_cast<int64_t>(tid);
+  const int64_t sy = dm.X, sz = static_cast<int64_t>(dm.X) * dm.Y;
+  double s1 = 0.0, s9 = 0.0;
+  if (vq < dm.nvox) {
+    const int64_t row = vq / dm.X;
+    const int xx = static_cast<int>(vq - row * dm.X);
+    const int64_t slab = row / dm.Y;
+    const int yy = static_cast<int>(row - slab * dm.Y);
+    const int zz = static_cast<int>(slab % dm.Z);
+    const bool ly = yy == dm.Y - 1, lz = zz == dm.Z - 1;
+    const bool tail = vq + 4 >= dm.nvox;
+    auto load = [&](const float* base, int64_t w, float (&o)[16], bool four) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(base + w * 3);
+      const f32x4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = four ? p[3] : p[2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = a0[e]; o[4 + e] = a1[e]; o[8 + e] = a2[e]; o[12 + e] = a3[e]; }
+    };
+    float uo[16], xo[16], uy[16], xy[16], uz[16], xz[16];
+    load(u, vq, uo, !tail); load(x, vq, xo, !tail);
+    load(u, ly ? vq - sy : vq + sy, uy, false); load(x, ly ? vq - sy : vq + sy, xy, false);
+    load(u, lz ? vq - sz : vq + sz, uz, false); load(x, lz ? vq - sz : vq + sz, xz, false);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool lx = xx + i == dm.X - 1;                      // only possible for i == 3
+      const float a1 = (fabsf(uo[i * 3] - xo[i * 3]) + fabsf(uo[i * 3 + 1] - xo[i * 3 + 1])) + fabsf(uo[i * 3 + 2] - xo[i * 3 + 2]);
+      float a9 = 0.f;
+#pragma unroll
+      for (int axis = 0; axis < 3; ++axis) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float fu = uo[i * 3 + c], fx = xo[i * 3 + c];
+          float nu, nx;
+          bool last;
+          if (axis == 0) { last = i == 3 && lx; nu = last ? uo[(i - 1) * 3 + c] : uo[(i + 1) * 3 + c]; nx = last ? xo[(i - 1) * 3 + c] : xo[(i + 1) * 3 + c]; }
+          else if (axis == 1) { last = ly; nu = uy[i * 3 + c]; nx = xy[i * 3 + c]; }
+          else { last = lz; nu = uz[i * 3 + c]; nx = xz[i * 3 + c]; }
+          const float ju = last ? fu - nu : nu - fu;
+          const float jx = last ? fx - nx : nx - fx;
+          a9 += fabsf(ju - jx);
+        }
+      }
+      s1 += a1; s9 += a9;
+    }
+  }
+  block_sum2(s1, s9);
+  if (tid == 0) { partial[2 * blockIdx.x] = s1; partial[2 * blockIdx.x + 1] = s9; }
+}
+
+// du of 4 consecutive voxels per thread: the adjoint of D along an axis at position k needs f = (u, x) at k-1, k, k+1 only
+// (on the last two positions the replicated difference folds back onto the same three values), i.e. the quads one
+// row / slice before and after and the two records left / right of the quad.  Same operation order as velocity_loss3d_bwd_kernel.
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void velocity_du3d_vec_kernel(const float* __restrict__ u, const float* __restrict__ x,
+                                                                     const float* __restrict__ g_l1, const float* __restrict__ g_jl1,
+                                                                     float inv_n1, float inv_nj, float* __restrict__ du, Dims3 dm) {
+  __shared__ __attribute__((aligned(16))) float so[kVoxPerBlock * 3];
+  const int tid = threadIdx.x;
+  const int64_t v0 = dfst::xcd_block(blockIdx.x, gridDim.x, dm.group) * kVoxPerBlock;
+  const int64_t vq = v0 + 4 * static_cast<int64_t>(tid);
+  const int64_t sy = dm.X, sz = static_cast<int64_t>(dm.X) * dm.Y;
+  if (vq < dm.nvox) {
+    const float s1 = inv_n1 * (g_l1 ? g_l1[0] : 1.f), s9 = inv_nj * (g_jl1 ? g_jl1[0] : 1.f);
+    const int64_t row = vq / dm.X;
+    const int xx = static_cast<int>(vq - row * dm.X);
+    const int64_t slab = row / dm.Y;
+    const int yy = static_cast<int>(row - slab * dm.Y);
+    const int zz = static_cast<int>(slab % dm.Z);
+    auto load = [&](const float* base, int64_t w, float (&o)[12]) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(base + w * 3);
+      const f32x4 a0 = p[0], a1 = p[1], a2 = p[2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = a0[e]; o[4 + e] = a1[e]; o[8 + e] = a2[e]; }
+    };
+    // adjoint at position k of an axis of extent n from the three values (fm, f0, fp) of u and x around it; exactly
+    // adj_at(line(...)): g(i) = sgn(D u(i) - D x(i)) * s9, gp(n-2) = g(n-2) + g(n-1) with D(n-1) == D(n-2)
+    auto adj = [&](float um, float u0, float up, float xm, float x0, float xp, int k, int n) -> float {
+      const float gm = sgn((u0 - um) - (x0 - xm)) * s9;      // g(k-1)   (k >= 1)
+      const float gk = sgn((up - u0) - (xp - x0)) * s9;      // g(k)     (k <= n-2)
+      if (k == n - 1) return gm + gm;                        // gp(n-2)
+      const float gpk = k == n - 2 ? gk + gk : gk;
+      return k == 0 ? -gpk : gm - gpk;
+    };
+    float uo[12], xo[12], um[12] = {0.f}, xm[12] = {0.f}, up[12] = {0.f}, xp[12] = {0.f}, out[12];
+    load(u, vq, uo); load(x, vq, xo);
+    float uL[3] = {0.f, 0.f, 0.f}, xL[3] = {0.f, 0.f, 0.f}, uR[3] = {0.f, 0.f, 0.f}, xR[3] = {0.f, 0.f, 0.f};
+    if (xx > 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { uL[c] = u[(vq - 1) * 3 + c]; xL[c] = x[(vq - 1) * 3 + c]; }
+    }
+    if (xx + 4 < dm.X) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { uR[c] = u[(vq + 4) * 3 + c]; xR[c] = x[(vq + 4) * 3 + c]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int e = i * 3 + c;
+        out[e] = adj(i > 0 ? uo[e - 3] : uL[c], uo[e], i < 3 ? uo[e + 3] : uR[c], i > 0 ? xo[e - 3] : xL[c], xo[e], i < 3 ? xo[e + 3] : xR[c],
+                     xx + i, dm.X);
+      }
+#pragma unroll
+    for (int axis = 1; axis < 3; ++axis) {
+      const int k = axis == 1 ? yy : zz, n = axis == 1 ? dm.Y : dm.Z;
+      const int64_t st = axis == 1 ? sy : sz;
+      if (k > 0) { load(u, vq - st, um); load(x, vq - st, xm); }
+      if (k < n - 1) { load(u, vq + st, up); load(x, vq + st, xp); }
+#pragma unroll
+      for (int e = 0; e < 12; ++e) out[e] += adj(um[e], uo[e], up[e], xm[e], xo[e], xp[e], k, n);
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) out[e] = sgn(uo[e] - xo[e]) * s1 + out[e];
+    f32x4* q = reinterpret_cast<f32x4*>(so + tid * 12);
+    q[0] = f32x4{out[0], out[1], out[2], out[3]};
+    q[1] = f32x4{out[4], out[5], out[6], out[7]};
+    q[2] = f32x4{out[8], out[9], out[10], out[11]};
+  }
+  __syncthreads();
+  const int64_t left = dm.nvox - v0;
+  const int64_t nv = left < kVoxPerBlock ? left : kVoxPerBlock;
+  dfst::flush_lds<NT>(so, du + v0 * 3, nv * 3, tid);
+}
+
+// ================================ 3-D, one voxel per lane with 12-byte record loads =================================================
+// A wave's 64 records form ONE contiguous 768-byte span per load (6 cache lines; the 16-byte-per-lane quads above touch 24 lines per
+// load instruction, which bounds them at ~3 TB/s in the texture-address unit).  hipcc merges the struct copies into
+// global_load_dwordx3 (own + x-neighbour: dwordx4 + dwordx2).  Any extents >= 2.
+struct F3 {
+  float a, b, c;
+};
+__device__ __forceinline__ F3 ld3(const float* __restrict__ p) { return *reinterpret_cast<const F3*>(p); }
+
+__global__ __launch_bounds__(kThreads) void velocity_jl1_3d_kernel(const float* __restrict__ u, const float* __restrict__ x,
+                                                                   double* __restrict__ partial, Geo3 g) {
+  const int64_t sy = g.X, sz = static_cast<int64_t>(g.X) * g.Y;
+  double s1 = 0.0, s9 = 0.0;
+#pragma unroll
+  for (int it = 0; it < kVpt3; ++it) {
+    const int64_t v = (static_cast<int64_t>(blockIdx.x) * kVpt3 + it) * kThreads + threadIdx.x;
+    if (v < g.nvox) {
+      int xx, yy, zz;
+      coords3(v, g, xx, yy, zz);
+      const bool lx = xx == g.X - 1, ly = yy == g.Y - 1, lz = zz == g.Z - 1;
+      const int64_t nx = lx ? v - 1 : v + 1, ny = ly ? v - sy : v + sy, nz = lz ? v - sz : v + sz;
+      const F3 uc = ld3(u + v * 3), ux = ld3(u + nx * 3), uy = ld3(u + ny * 3), uz = ld3(u + nz * 3);
+      const F3 xc = ld3(x + v * 3), xx_ = ld3(x + nx * 3), xy = ld3(x + ny * 3), xz = ld3(x + nz * 3);
+      const float a1 = (fabsf(uc.a - xc.a) + fabsf(uc.b - xc.b)) + fabsf(uc.c - xc.c);
+      auto d = [](bool last, float f, float n) { return last ? f - n : n - f; };
+      float a9 = 0.f;
+      a9 += fabsf(d(lx, uc.a, ux.a) - d(lx, xc.a, xx_.a)); a9 += fabsf(d(lx, uc.b, ux.b) - d(lx, xc.b, xx_.b)); a9 += fabsf(d(lx, uc.c, ux.c) - d(lx, xc.c, xx_.c));
+      a9 += fabsf(d(ly, uc.a, uy.a) - d(ly, xc.a, xy.a)); a9 += fabsf(d(ly, uc.b, uy.b) - d(ly, xc.b, xy.b)); a9 += fabsf(d(ly, uc.c, uy.c) - d(ly, xc.c, xy.c));
+      a9 += fabsf(d(lz, uc.a, uz.a) - d(lz, xc.a, xz.a)); a9 += fabsf(d(lz, uc.b, uz.b) - d(lz, xc.b, xz.b)); a9 += fabsf(d(lz, uc.c, uz.c) - d(lz, xc.c, xz.c));
+      s1 += a1; s9 += a9;
+    }
+  }
+  block_sum2(s1, s9);
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s1; partial[2 * blockIdx.x + 1] = s9; }
+}
+
+__global__ __launch_bounds__(kThreads) void velocity_du3d_kernel(const float* __restrict__ u, const float* __restrict__ x,
+                                                                 const float* __restrict__ g_l1, const float* __restrict__ g_jl1,
+                                                                 float inv_n1, float inv_nj, float* __restrict__ du, Geo3 g) {
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (v >= g.nvox) return;
+  const float s1 = inv_n1 * (g_l1 ? g_l1[0] : 1.f), s9 = inv_nj * (g_jl1 ? g_jl1[0] : 1.f);
+  int xx, yy, zz;
+  coords3(v, g, xx, yy, zz);
+  const int64_t sy = g.X, sz = static_cast<int64_t>(g.X) * g.Y;
+  // the three values around position k of an axis (clamped at the ends: adj() ignores the clamped side there)
+  auto adj = [&](float um, float u0, float up, float xm, float x0, float xp, int k, int n) -> float {
+    const float gm = sgn((u0 - um) - (x0 - xm)) * s9;      // g(k-1)   (k >= 1)
+    const float gk = sgn((up - u0) - (xp - x0)) * s9;      // g(k)     (k <= n-2)
+    if (k == n - 1) return gm + gm;                        // gp(n-2) = g(n-2) + g(n-1), D(n-1) == D(n-2)
+    const float gpk = k == n - 2 ? gk + gk : gk;
+    return k == 0 ? -gpk : gm - gpk;
+  };
+  const F3 u0 = ld3(u + v * 3), x0 = ld3(x + v * 3);
+  F3 acc;
+  {
+    const int64_t m = xx > 0 ? v - 1 : v, p = xx < g.X - 1 ? v + 1 : v;
+    const F3 um = ld3(u + m * 3), up = ld3(u + p * 3), xm = ld3(x + m * 3), xp = ld3(x + p * 3);
+    acc.a = adj(um.a, u0.a, up.a, xm.a, x0.a, xp.a, xx, g.X);
+    acc.b = adj(um.b, u0.b, up.b, xm.b, x0.b, xp.b, xx, g.X);
+    acc.c = adj(um.c, u0.c, up.c, xm.c, x0.c, xp.c, xx, g.X);
+  }
+  {
+    const int64_t m = yy > 0 ? v - sy : v, p = yy < g.Y - 1 ? v + sy : v;
+    const F3 um = ld3(u + m * 3), up = ld3(u + p * 3), xm = ld3(x + m * 3), xp = ld3(x + p * 3);
+    acc.a += adj(um.a, u0.a, up.a, xm.a, x0.a, xp.a, yy, g.Y);
+    acc.b += adj(um.b, u0.b, up.b, xm.b, x0.b, xp.b, yy, g.Y);
+    acc.c += adj(um.c, u0.c, up.c, xm.c, x0.c, xp.c, yy, g.Y);
+  }
+  {
+    const int64_t m = zz > 0 ? v - sz : v, p = zz < g.Z - 1 ? v + sz : v;
+    const F3 um = ld3(u + m * 3), up = ld3(u + p * 3), xm = ld3(x + m * 3), xp = ld3(x + p * 3);
+    acc.a += adj(um.a, u0.a, up.a, xm.a, x0.a, xp.a, zz, g.Z);
+    acc.b += adj(um.b, u0.b, up.b, xm.b, x0.b, xp.b, zz, g.Z);
+    acc.c += adj(um.c, u0.c, up.c, xm.c, x0.c, xp.c, zz, g.Z);
+  }
+  F3 o;
+  o.a = sgn(u0.a - x0.a) * s1 + acc.a;
+  o.b = sgn(u0.b - x0.b) * s1 + acc.b;
+  o.c = sgn(u0.c - x0.c) * s1 + acc.c;
+  *reinterpret_cast<F3*>(du + v * 3) = o;
+}
+
 // ================================================= 2-D ===========================================================================
 struct Geo2 {
   int64_t npix;
@@ -247,10 +466,21 @@ int check(const void* a, const void* b, int64_t B, int64_t Z, int64_t Y, int64_t
 
 inline int64_t nblocks_fwd(int64_t n) { return ceil_div(n, static_cast<int64_t>(kThreads) * kVpt3); }
 
+#ifdef DF_TUNING      // tuning library only: 0 = default dispatch, 1 = force the 16-byte quad kernels, 2 = force the record-per-lane kernels
+int g_tail_variant = 0;
+#else
+constexpr int g_tail_variant = 0;
+#endif
+
 }  // namespace
 
 extern "C" {
 
+#ifdef DF_TUNING
+void df_debug_set_tail(int v) { g_tail_variant = v; }
+#endif
+
+int df_jacobian3d_fwd(const float* x, float* j, float* c, int64_t B, int64_t Z, int64_t Y, int64_t X, df_stream_t stream);
 int df_jacobian3d_bwd(const float* gj, const float* gc, float* gx, int64_t B, int64_t Z, int64_t Y, int64_t X, df_stream_t stream);
 int df_curl2d_bwd(const float* gu, float* gpsi, int64_t B, int64_t Y, int64_t X, df_stream_t stream);
 
@@ -272,6 +502,24 @@ int df_velocity_loss3d_fwd(const float* psi, const float* x, float* u, float* l1
   DF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, DF_EALIGN, "df_velocity_loss3d_fwd: workspace must be 8-byte aligned");
   hipStream_t s = df::as_stream(stream);
   double* part = static_cast<double*>(workspace);
+  if (u && g_tail_variant == 2) {
+    if (int e = df_jacobian3d_fwd(psi, nullptr, u, B, Z, Y, X, stream)) return e;
+    hipLaunchKernelGGL(velocity_jl1_3d_kernel, dim3((unsigned)nb), dim3(kThreads), 0, s, u, x, part, g);
+    hipLaunchKernelGGL(velocity_loss_final_kernel, dim3(1), dim3(kThreads), 0, s, part, (int)nb, 1.0 / (3.0 * static_cast<double>(g.nvox)),
+                       1.0 / (9.0 * static_cast<double>(g.nvox)), l1, jl1);
+    return df::launched("df_velocity_loss3d_fwd");
+  }
+  if (u && X % 4 == 0 && df::aligned16(psi) && df::aligned16(x) && df::aligned16(u)) {
+    // fast path: u = curl3(psi) with the 16-byte-load stencil kernel, then one reduction pass over (u, x)
+    if (int e = df_jacobian3d_fwd(psi, nullptr, u, B, Z, Y, X, stream)) return e;
+    Dims3 dm{g.nvox, (int)Z, (int)Y, (int)X, 0};
+    const int64_t nbv = ceil_div(g.nvox, kVoxPerBlock);      // <= nb: the workspace covers it
+    if (nbv % (8 * dfst::kXcdGroup) == 0) dm.group = dfst::kXcdGroup;
+    hipLaunchKernelGGL(velocity_jl1_3d_vec_kernel, dim3((unsigned)nbv), dim3(kThreads), 0, s, u, x, part, dm);
+    hipLaunchKernelGGL(velocity_loss_final_kernel, dim3(1), dim3(kThreads), 0, s, part, (int)nbv, 1.0 / (3.0 * static_cast<double>(g.nvox)),
+                       1.0 / (9.0 * static_cast<double>(g.nvox)), l1, jl1);
+    return df::launched("df_velocity_loss3d_fwd");
+  }
   hipLaunchKernelGGL(velocity_loss3d_fwd_kernel, dim3((unsigned)nb), dim3(kThreads), 0, s, psi, x, u, part, g);
   hipLaunchKernelGGL(velocity_loss_final_kernel, dim3(1), dim3(kThreads), 0, s, part, (int)nb, 1.0 / (3.0 * static_cast<double>(g.nvox)),
                      1.0 / (9.0 * static_cast<double>(g.nvox)), l1, jl1);
@@ -286,6 +534,16 @@ int df_velocity_loss3d_bwd(const float* u, const float* x, const float* g_l1, co
   DF_REQUIRE(workspace_bytes >= g.nvox * 3 * static_cast<int64_t>(sizeof(float)), DF_EWORKSPACE, "df_velocity_loss3d_bwd: workspace too small");
   DF_REQUIRE(df::aligned16(workspace), DF_EALIGN, "df_velocity_loss3d_bwd: workspace must be 16-byte aligned");
   float* du = static_cast<float*>(workspace);
+  if (g_tail_variant == 2) {
+    hipLaunchKernelGGL(velocity_du3d_kernel, dim3((unsigned)ceil_div(g.nvox, kThreads)), dim3(kThreads), 0, df::as_stream(stream), u, x, g_l1,
+                       g_jl1, 1.f / static_cast<float>(3 * g.nvox), 1.f / static_cast<float>(9 * g.nvox), du, g);
+  } else if (X % 4 == 0 && df::aligned16(u) && df::aligned16(x)) {
+    Dims3 dm{g.nvox, (int)Z, (int)Y, (int)X, 0};
+    const int64_t nbv = ceil_div(g.nvox, kVoxPerBlock);
+    if (nbv % (8 * dfst::kXcdGroup) == 0) dm.group = dfst::kXcdGroup;
+    hipLaunchKernelGGL((velocity_du3d_vec_kernel<false>), dim3((unsigned)nbv), dim3(kThreads), 0, df::as_stream(stream), u, x, g_l1, g_jl1,
+                       1.f / static_cast<float>(3 * g.nvox), 1.f / static_cast<float>(9 * g.nvox), du, dm);
+  } else
   hipLaunchKernelGGL(velocity_loss3d_bwd_kernel, dim3((unsigned)ceil_div(g.nvox, kThreads)), dim3(kThreads), 0, df::as_stream(stream), u, x,
                      g_l1, g_jl1, 1.f / static_cast<float>(3 * g.nvox), 1.f / static_cast<float>(9 * g.nvox), du, g);
   if (int e = df::launched("df_velocity_loss3d_bwd")) return e;
