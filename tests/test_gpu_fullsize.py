@@ -101,7 +101,7 @@ def test_cfg3_default_dispatch_train_step_vs_torch_oracle_b2():
     assert r["n_layers_fetched"] == 16, r
     assert r["velocity_rel_l1"] <= 1e-4, r           # north-star tolerance (measured ~2e-6: fp32 vs fp32)
     assert r["loss_rel"] < 1e-5, r
-    assert r["grad_rel_linf"] < 1e-3, r
+    assert r["grad_rel_linf"] < 2e-4, r              # measured 1.4e-5 (on the GPU's linear piece; 2-4e-3 with the oracle's own signs)
     assert r["last_bias_abs"] < 1e-3, r
 
 
@@ -121,7 +121,7 @@ def test_cfg4_full_grid_train_step_vs_torch_oracle():
     if backward:
         assert r["n_layers_fetched"] == 20, r
         assert r["loss_rel"] < 1e-5, r
-        assert r["grad_rel_linf"] < 1e-3, r
+        assert r["grad_rel_linf"] < 2e-4, r          # measured 2.5e-5
         assert r["last_bias_abs"] < 1e-3, r
 
 
