@@ -81,6 +81,21 @@ __global__ __launch_bounds__(kThreads) void upconv_pack_kernel(const float* __re
     const int k = k8 * 8 + half * 4 + s;
     const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
     float v = 0.f;
+    if (mode == 2) {
+      // dgrad operand of the STRIDE-2 conv (TF SAME on even extents: y[o] = sum_t x[2o + t] w[t]):
+      //   dx[2m]   = g[m-1] w[2] + g[m] w[0]     -> class p = 0, taps d = 0 (offset -1), d = 1 (offset 0)
+      //   dx[2m+1] = g[m] w[1]                    -> class p = 1, tap  d = 0 (offset 0);  d = 1 (offset +1) is zero
+      // per axis -- exactly the class / offset structure of the up-sampling-aware forward conv, with K = cout, N = cin.
+      if (k < K && n < N) {
+        const int dzt = kz == 3 ? (tap >> 2) & 1 : 0, dyt = (tap >> 1) & 1, dxt = tap & 1;
+        const int pz = kz == 3 ? (c >> 2) & 1 : 0, py = (c >> 1) & 1, px = c & 1;
+        auto src = [](int p, int d) { return p == 0 ? (d == 0 ? 2 : 0) : (d == 0 ? 1 : -1); };
+        const int tz = kz == 3 ? src(pz, dzt) : 0, ty = src(py, dyt), tx = src(px, dxt);
+        if (tz >= 0 && ty >= 0 && tx >= 0) v = w[(static_cast<int64_t>((tz * 3 + ty) * 3 + tx) * cin + n) * cout + k];
+      }
+      wp[i] = v;
+      continue;
+    }
     if (k < K && n < N) {
       if (mode == 1) tap = ntap - 1 - tap;                       // mirrored taps
       const int dzt = kz == 3 ? (tap >> 2) & 1 : 0, dyt = (tap >> 1) & 1, dxt = tap & 1;
@@ -409,8 +424,8 @@ int64_t df_upconv_packed_elems(int64_t cin, int64_t cout, int kz, int mode) {
 
 int df_upconv_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, int kz, int mode, df_stream_t stream) {
   DF_REQUIRE(w && wp, DF_EINVAL, "df_upconv_pack_weights: null pointer");
-  DF_REQUIRE((kz == 1 || kz == 3) && cin > 0 && cout > 0 && (mode == 0 || mode == 1), DF_EINVAL,
-             "df_upconv_pack_weights: kz must be 1|3, mode 0|1");
+  DF_REQUIRE((kz == 1 || kz == 3) && cin > 0 && cout > 0 && mode >= 0 && mode <= 2, DF_EINVAL,
+             "df_upconv_pack_weights: kz must be 1|3, mode 0|1|2");
   const int64_t K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
   const int Kpad = (int)round_up(K, CK), Npad = (int)round_up(N, ntile_for(N));
   const int64_t total = df_upconv_packed_elems(cin, cout, kz, mode);

@@ -2051,6 +2051,9 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
   const int algo = (prec == 0 && xvec && gvec) ? wgrad_algo(req, B * D * H, D, H, W, Cin, Cout, kz) : 0;
   const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, algo, req_ranges);
+  // a caller-chosen number of partial ranges may need more room than df_conv_wgrad_workspace_bytes (sized for the defaults) promises
+  DF_REQUIRE(workspace_bytes >= (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(W, Cin, Cout),
+             DF_EWORKSPACE, "df_conv_wgrad: workspace too small for %d partial ranges", p.nranges);
   WgradArgs a;
   a.x = x; a.g = gy;
   a.partial = static_cast<float*>(workspace);

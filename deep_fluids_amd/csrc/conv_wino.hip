@@ -421,6 +421,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           for (int it = 0; it < NLOAD; ++it) asm volatile("" :: "v"(stg[it]));
         }
         if (ks == 3) __syncthreads();       // next chunk staged by everyone; everyone is done reading the planes it overwrote
+        else if (DBG & 16384) lds_barrier();     // (experiment: lock-step k-steps -- both waves of a SIMD transform, then both multiply)
         if (!(DBG & 2)) raw_read(ks < 3 ? bo + (ks + 1) * 16 * CP : bn);     // raw inputs of the next k-step
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long q2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
@@ -715,6 +716,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case (3 << 11): hipLaunchKernelGGL((wino3d_kernel<(3 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case (16 << 11): hipLaunchKernelGGL((wino3d_kernel<(16 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case (18 << 11): hipLaunchKernelGGL((wino3d_kernel<(18 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 16384: hipLaunchKernelGGL((wino3d_kernel<16384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case (17 << 11): hipLaunchKernelGGL((wino3d_kernel<(17 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
 #endif
     default: return df::fail(DF_EINVAL, "df_wino_conv_fwd: unknown debug variant");

@@ -100,6 +100,9 @@ class GradSync(object):
                     self._cur["start"].record()
                 w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 if self._cur is not None:
+                    # RCCL runs the collective on its own internal stream: make the communication stream wait for it so that
+                    # the end event really marks the end of this bucket's all-reduce (device-side wait, the host does not block)
+                    w.wait()
                     e = torch.cuda.Event(enable_timing=True)
                     e.record()
                     self._cur["ends"].append(e)

@@ -198,7 +198,12 @@ int df_conv_s2_fwd(const float* x, const float* wp, const float* bias, float* y,
  * model.py:36-37 / 78-79 feed `upscale(x, 2)` into the next block's first conv.  conv(nearest_up2x(xc), w) is computed
  * WITHOUT materialising the up-sampled tensor as 8 (3-D) / 4 (2-D) parity-class convs with 2x2x2 / 2x2 pre-summed taps
  * on the coarse grid (27/8 = 3.4x fewer FLOPs; identical up to fp32 summation order).
- *   xc [B,Dc|1,Hc,Wc,Cin] (coarse)  ->  y [B,2Dc|1,2Hc,2Wc,Cout] (fine).  Weights: TF layout [kz,3,3,Cin,Cout]. */
+ *   xc [B,Dc|1,Hc,Wc,Cin] (coarse)  ->  y [B,2Dc|1,2Hc,2Wc,Cout] (fine).  Weights: TF layout [kz,3,3,Cin,Cout].
+ * Pack modes: 0 forward operand; 1 operand of df_upconv_dgrad; 2 DGRAD OPERAND OF THE STRIDE-2 CONV (df_conv_s2_fwd): the adjoint of
+ *   y[o] = sum_t x[2o+t] w[t] is dx[2m] = g[m-1] w[2] + g[m] w[0], dx[2m+1] = g[m] w[1] per axis, i.e. the same parity-class / offset
+ *   structure; run it as  df_upconv_fwd(g [B,Do,Ho,Wo,Cout], wp(mode 2), NULL, dx [B,2Do,2Ho,2Wo,Cin], B, Do, Ho, Wo, Cin := Cout,
+ *   Cout := Cin, kz, 0, 0, stream)  -- 64 tap-products per coarse voxel instead of the 216 of a stride-1 dgrad on the
+ *   zero-inserted gradient (model.py:141-143, 177-179: the encoder's / discriminator's down-sampling layers). */
 int64_t df_upconv_packed_elems(int64_t cin, int64_t cout, int kz, int mode);
 int df_upconv_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, int kz, int mode, df_stream_t stream);
 int df_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
@@ -299,7 +304,8 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
  *             instantiated | 4 Winograd F(2x2x2,3x3x3) in (x,y,z) wherever instantiated (shapes without that form fall
  *             back towards 0 -- every choice returns the same gradient up to fp32 summation order);
  *   algo >> 3: number of voxel ranges of the partial sums (0 = default; <= 256).
- * Workspace: df_conv_wgrad_workspace_bytes covers every choice. */
+ * Workspace: df_conv_wgrad_workspace_bytes covers every `algo & 7` with the default range count; a range override that needs
+ * more is rejected with DF_EWORKSPACE. */
 int df_conv_wgrad_algo(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
                        int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, int algo,
                        df_stream_t stream);

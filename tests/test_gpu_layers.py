@@ -512,3 +512,26 @@ def test_upconv_block_bf16x3_mode(ops, bf16x3):
     for i in reversed(range(n)):
         dx, _, _ = orc.conv_same_bwd(ins[i], ws[i].astype(np.float64), dx * np.where(outs[i] > 0, 1.0, 0.2))
     assert rel_linf(host(xt.grad), orc.upscale_nn_bwd(dx + go)) < 1e-4
+
+
+def test_conv_wgrad_range_override_is_bounds_checked(ops):
+    """df_conv_wgrad_algo's optional partial-range override (algo >> 3) must never write past the caller's workspace: a count that
+    needs more than df_conv_wgrad_workspace_bytes promises is rejected (DF_EWORKSPACE), a smaller one gives the same gradient."""
+    from deep_fluids_amd._lib import call, query, DeepFluidsHipError
+    from deep_fluids_amd.ops import _ptr, _stream
+    torch.manual_seed(2)
+    B, D, H, W, C = 2, 16, 24, 32, 128
+    s = _stream()
+    x = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    g = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
+    nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, C, 3)
+    ws = torch.empty((nb + 3) // 4, device="cuda")
+    ref = torch.empty((27, C, C), device="cuda"); gb = torch.empty(C, device="cuda")
+    call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(ref), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, 4, s)
+    gw = torch.full((27, C, C), float("nan"), device="cuda")
+    call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, 4 | (32 << 3), s)
+    assert ((gw - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    with pytest.raises(DeepFluidsHipError, match="workspace too small"):
+        call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, 4 | (256 << 3), s)
+    with pytest.raises(DeepFluidsHipError):
+        call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, 5, s)       # algo out of range
