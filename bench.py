@@ -78,7 +78,7 @@ def select_kernel(name, args):
         B, D, H, W, cin, cout, kz = args[6:13]
         if cin >= 64 and cout >= 64:
             return ("conv_mfma_kernel fwd/dgrad %dx%dx%d C%d->%d" % (D, H, W, cin, cout), 2.0 * (27 if kz == 3 else 9) * cin * cout * B * D * H * W)
-    if name in ("df_wino_conv_fwd", "df_wino_conv_fwd_addup"):
+    if name in ("df_wino_conv_fwd", "df_wino_conv_fwd_addup", "df_wino_conv_fwd_bits"):
         B, D, H, W, cin, cout = args[6:12]
         return ("wino3d_kernel fwd/dgrad %dx%dx%d C%d->%d" % (D, H, W, cin, cout), 2.0 * 27 * cin * cout * B * D * H * W)
     if name == "df_wino2d_conv_fwd":

@@ -72,6 +72,9 @@ SIGNATURES = {
     "df_wino_conv_fwd_addup": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, F32, P]),
     "df_wino_upconv_fwd": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, F32, P]),
     "df_wino_upconv_dgrad": (I32, [P, P, P, I64, I64, I64, I64, I64, I64, P]),
+    "df_wino_signbits_bytes": (I64, [I64, I64, I64, I64, I64]),
+    "df_wino_conv_fwd_bits": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, F32, P]),
+    "df_wino_upconv_fwd_bits": (I32, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, F32, P]),
     "df_wino2d_packed_elems": (I64, [I64, I64, I32]),
     "df_wino2d_pack_weights": (I32, [P, P, I64, I64, I32, P]),
     "df_wino2d_conv_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, F32, P]),

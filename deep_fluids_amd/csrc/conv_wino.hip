@@ -41,6 +41,12 @@ constexpr int CP = 866;                   // dwords per channel plane (6*144 = 8
 constexpr int HY = 10, HX = 10, HV = 600; // halo block 6 x 10 x 10
 constexpr int NLOAD = 5;                  // ceil(600 * 4 float4 pieces / 512 threads)
 constexpr int BUF = CKW * CP;             // dwords per LDS buffer
+// internal epilogue flags (beyond the public DF_CONV_*), part of the compile-time FL of the specialised instantiations:
+//   kSignBits: also emit the sign pattern of the output, one byte per lane and cout block holding the signs of the lane's 8 outputs
+//              (what a later masked dgrad of the same geometry needs of it: 1/32 of the activation's bytes);
+//   kMaskBits: DF_CONV_MASK reads those bytes (2 byte loads per lane and tile block) instead of 16 fp32 activations per lane.
+constexpr int kSignBits = 64, kMaskBits = 128;
+constexpr int kBitBytesPerBlock = 1024;    // 8 waves x 2 cout blocks x 64 lanes, per (tile block, cout slice)
 constexpr int kZeroFloats = 1024;         // zeroed tail of the packed weights: SAME padding reads it, one 64-byte step per chunk
 
 struct WinoArgs {
@@ -52,6 +58,8 @@ struct WinoArgs {
   const float* mask_src;
   float* y;
   float* y2;           // DF_CONV_ADDUP: second output  y2 = y + nearest_up2x(residual)  (residual = the COARSE tensor)
+  unsigned char* bits_out;        // kSignBits: sign pattern of y, one byte per (tile block, cout slice, wave, cout block, lane): bit s = output s
+  const unsigned char* bits_in;   // kMaskBits: the lrelu mask of DF_CONV_MASK as such bytes instead of mask_src
   int B, D, H, W, Cin, Cout;
   int nbz, nby, nbx, ntb, ncs;
   int flags;
@@ -146,6 +154,7 @@ struct BlockInfo {
   const float* xb;     // &x[b][0][0][0][0]
   int hoff;            // element offset of the block's halo origin (z0-1, y0-1, x0-1) inside the batch volume (may be < 0)
   int b, z0, y0, x0;
+  int id;              // tile block index (for the sign-bit words)
 };
 
 // raw buffer descriptor (gfx9 data format word): out-of-range offsets read as zero -- the SAME padding of the staging loads
@@ -221,6 +230,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
   auto decode = [&](int t) -> BlockInfo {
     BlockInfo bi;
+    bi.id = t;
     const int bx = t % a.nbx;
     int t2 = t / a.nbx;
     const int by = t2 % a.nby; t2 /= a.nby;
@@ -499,11 +509,15 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       const int64_t obase = (((static_cast<int64_t>(cur.b) * a.D + oz0) * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl;
       const bool full = cur.z0 + 4 <= a.D && cur.y0 + 8 <= a.H && cur.x0 + 8 <= a.W;
       const unsigned lane_off = static_cast<unsigned>(((oz0 * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl) * 4u;      // bytes within the batch volume
-      if (full && (eflags & DF_CONV_MASK)) mask_dma();
+      constexpr bool SB = FL >= 0 && (FL & kSignBits) != 0, MB = FL >= 0 && (FL & kMaskBits) != 0;
+      if (full && (eflags & DF_CONV_MASK) && !MB) mask_dma();
+      const int64_t wbase = (static_cast<int64_t>(cur.id) * a.ncs + cs) * kBitBytesPerBlock + wave * 128 + lane;
       float rres[2][8];
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         const float bv = sBias[nb * 16 + tl];
+        unsigned mbyte = 0u, sbyte = 0u;      // kMaskBits: this lane's 8 mask bits of the cout block (one byte load, used after the combine)
+        if (MB) mbyte = a.bits_in[wbase + nb * 64];
         auto emit = [&](const f32x4 (&c)[16]) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -545,7 +559,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         }
         // mask DMA of THIS cout block landed: the 16 loads were issued block 0 first and vmcnt retires in order, so "at most 8
         // outstanding" covers block 0 while block 1's eight are still in flight, and block 1 while block 0's eight stores are
-        if (full && (eflags & DF_CONV_MASK)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (full && (eflags & DF_CONV_MASK) && !MB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         float rup = 0.f;      // DF_CONV_ADDUP: the 2x2x2 outputs of this lane's tile share ONE coarse voxel of the skip tensor
         if ((eflags & DF_CONV_ADDUP) && oz0 < a.D && oy0 < a.H && ox0 < a.W)
           rup = a.residual[(((static_cast<int64_t>(cur.b) * (a.D >> 1) + (oz0 >> 1)) * (a.H >> 1) + (oy0 >> 1)) * (a.W >> 1) + (ox0 >> 1)) * a.Cout +
@@ -555,9 +569,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           float v = (s < 4 ? lo[s & 3] : hi[s & 3]) + bv;
           if (eflags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
           const int64_t o = obase + nb * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW;
+          if (SB) sbyte |= v > 0.f ? (1u << s) : 0u;      // (outputs outside the tensor carry don't-care bits)
+          const bool mpos = !MB || ((mbyte >> s) & 1u) != 0u;
           if (full) {
             if (eflags & DF_CONV_RESIDUAL) v += rres[nb][s];
-            if (eflags & DF_CONV_MASK) v = sM[(nb * 8 + s) * kT + tid] > 0.f ? v : a.leak * v;
+            if (eflags & DF_CONV_MASK) v = (MB ? mpos : sM[(nb * 8 + s) * kT + tid] > 0.f) ? v : a.leak * v;
             // wave-uniform base (batch volume + this output's scalar offset) + 32-bit lane offset: no 64-bit address per output
             char* yb = reinterpret_cast<char*>(a.y + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
                                                ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
@@ -570,11 +586,12 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
             }
           } else if (oz0 + (s >> 2) < a.D && oy0 + ((s >> 1) & 1) < a.H && ox0 + (s & 1) < a.W) {
             if (eflags & DF_CONV_RESIDUAL) v += a.residual[o];
-            if (eflags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
+            if (eflags & DF_CONV_MASK) v = (MB ? mpos : a.mask_src[o] > 0.f) ? v : a.leak * v;
             a.y[o] = v;
             if (eflags & DF_CONV_ADDUP) a.y2[o] = v + rup;
           }
         }
+        if (SB) a.bits_out[wbase + nb * 64] = static_cast<unsigned char>(sbyte);
         const unsigned long long e3 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         __syncthreads();
         if (DBG & 16) {
@@ -663,7 +680,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
   DF_REQUIRE(df::aligned16(wp) && df::aligned16(x), DF_EALIGN, "df_wino_conv_fwd: x and packed weights must be 16-byte aligned");
   WinoArgs a;
   a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
-  a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y; a.y2 = nullptr;
+  a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y; a.y2 = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
   a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
   a.nbz = (int)ceil_div(D, 4); a.nby = (int)ceil_div(H, 8); a.nbx = (int)ceil_div(W, 8);
   const int64_t ntb = B * a.nbz * a.nby * a.nbx;
@@ -736,7 +753,7 @@ int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, floa
   DF_REQUIRE(df::aligned16(wp) && df::aligned16(xc), DF_EALIGN, "df_wino_upconv_fwd: xc and packed weights must be 16-byte aligned");
   WinoArgs a;
   a.x = xc; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
-  a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y; a.y2 = nullptr;
+  a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y; a.y2 = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
   a.B = (int)B; a.D = (int)(2 * Dc); a.H = (int)(2 * Hc); a.W = (int)(2 * Wc); a.Cin = (int)Cin; a.Cout = (int)Cout;      // OUTPUT (fine) extents
   a.nbz = (int)ceil_div(a.D, 4); a.nby = (int)ceil_div(a.H, 8); a.nbx = (int)ceil_div(a.W, 8);
   const int64_t ntb = B * a.nbz * a.nby * a.nbx;
@@ -747,6 +764,65 @@ int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, floa
   const int64_t grid = wino_grid(a, ntb);
   hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
   return df::launched("df_wino_upconv_fwd");
+}
+
+int64_t df_wino_signbits_bytes(int64_t B, int64_t D, int64_t H, int64_t W, int64_t C) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32) return 0;
+  return B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 8) * (C / 32) * kBitBytesPerBlock;
+}
+
+int df_wino_conv_fwd_bits(const float* x, const float* wp, const float* bias, const void* mask_bits, float* y, void* sign_bits, int64_t B,
+                          int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream) {
+  DF_REQUIRE(x && wp && y, DF_EINVAL, "df_wino_conv_fwd_bits: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, DF_EINVAL, "df_wino_conv_fwd_bits: non-positive extent");
+  DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE, "df_wino_conv_fwd_bits: Cin, Cout must be multiples of 32");
+  DF_REQUIRE(D * H * W * (Cin > Cout ? Cin : Cout) <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
+             "df_wino_conv_fwd_bits: one batch volume must stay below 2 GiB");
+  const bool fwd = flags == (DF_CONV_BIAS | DF_CONV_LRELU) && bias && sign_bits && !mask_bits;
+  const bool dgr = flags == DF_CONV_MASK && mask_bits && !sign_bits;
+  DF_REQUIRE(fwd || dgr, DF_EINVAL, "df_wino_conv_fwd_bits: either (BIAS|LRELU, bias, sign_bits out) or (MASK, mask_bits in)");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x) && df::aligned16(mask_bits) && df::aligned16(sign_bits), DF_EALIGN,
+             "df_wino_conv_fwd_bits: x, packed weights and bit words must be 16-byte aligned");
+  WinoArgs a;
+  a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
+  a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y; a.y2 = nullptr;
+  a.bits_out = static_cast<unsigned char*>(sign_bits); a.bits_in = static_cast<const unsigned char*>(mask_bits);
+  a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.nbz = (int)ceil_div(D, 4); a.nby = (int)ceil_div(H, 8); a.nbx = (int)ceil_div(W, 8);
+  const int64_t ntb = B * a.nbz * a.nby * a.nbx;
+  a.ncs = (int)(Cout / 32);
+  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_conv_fwd_bits: too many workgroups");
+  a.ntb = (int)ntb;
+  a.flags = flags; a.leak = leak;
+  const int64_t grid = wino_grid(a, ntb);
+  if (fwd) hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU | kSignBits>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+  else hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_MASK | kMaskBits>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+  return df::launched("df_wino_conv_fwd_bits");
+}
+
+int df_wino_upconv_fwd_bits(const float* xc, const float* wp, const float* bias, float* y, void* sign_bits, int64_t B, int64_t Dc,
+                            int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, float leak, df_stream_t stream) {
+  DF_REQUIRE(xc && wp && y && bias && sign_bits, DF_EINVAL, "df_wino_upconv_fwd_bits: null pointer");
+  DF_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0, DF_EINVAL, "df_wino_upconv_fwd_bits: non-positive extent");
+  DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE, "df_wino_upconv_fwd_bits: Cin, Cout must be multiples of 32");
+  DF_REQUIRE(8 * Dc * Hc * Wc * Cout <= (1LL << 29) && Dc * Hc * Wc * Cin <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
+             "df_wino_upconv_fwd_bits: one batch volume must stay below 2 GiB");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(xc) && df::aligned16(sign_bits), DF_EALIGN,
+             "df_wino_upconv_fwd_bits: xc, packed weights and bit words must be 16-byte aligned");
+  WinoArgs a;
+  a.x = xc; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
+  a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y; a.y2 = nullptr;
+  a.bits_out = static_cast<unsigned char*>(sign_bits); a.bits_in = nullptr;
+  a.B = (int)B; a.D = (int)(2 * Dc); a.H = (int)(2 * Hc); a.W = (int)(2 * Wc); a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.nbz = (int)ceil_div(a.D, 4); a.nby = (int)ceil_div(a.H, 8); a.nbx = (int)ceil_div(a.W, 8);
+  const int64_t ntb = B * a.nbz * a.nby * a.nbx;
+  a.ncs = (int)(Cout / 32);
+  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_upconv_fwd_bits: too many workgroups");
+  a.ntb = (int)ntb;
+  a.flags = DF_CONV_BIAS | DF_CONV_LRELU; a.leak = leak;
+  const int64_t grid = wino_grid(a, ntb);
+  hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU | kSignBits, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+  return df::launched("df_wino_upconv_fwd_bits");
 }
 
 int df_wino_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin,
@@ -760,7 +836,7 @@ int df_wino_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B,
   DF_REQUIRE(df::aligned16(wp) && df::aligned16(g), DF_EALIGN, "df_wino_upconv_dgrad: g and packed weights must be 16-byte aligned");
   WinoArgs a;      // the adjoint conv reads g (Cout channels, fine grid) and produces Cin channels
   a.x = g; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
-  a.bias = nullptr; a.residual = nullptr; a.mask_src = nullptr; a.y = acc; a.y2 = nullptr;
+  a.bias = nullptr; a.residual = nullptr; a.mask_src = nullptr; a.y = acc; a.y2 = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
   a.B = (int)B; a.D = (int)(2 * Dc); a.H = (int)(2 * Hc); a.W = (int)(2 * Wc); a.Cin = (int)Cout; a.Cout = (int)Cin;
   a.nbz = (int)ceil_div(a.D, 4); a.nby = (int)ceil_div(a.H, 8); a.nbx = (int)ceil_div(a.W, 8);
   const int64_t ntb = B * a.nbz * a.nby * a.nbx;
@@ -784,7 +860,7 @@ int df_wino_conv_fwd_addup(const float* x, const float* wp, const float* bias, c
   DF_REQUIRE(df::aligned16(wp) && df::aligned16(x), DF_EALIGN, "df_wino_conv_fwd_addup: x and packed weights must be 16-byte aligned");
   WinoArgs a;
   a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
-  a.bias = bias; a.residual = xc; a.mask_src = nullptr; a.y = y; a.y2 = y2;
+  a.bias = bias; a.residual = xc; a.mask_src = nullptr; a.y = y; a.y2 = y2; a.bits_out = nullptr; a.bits_in = nullptr;
   a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
   a.nbz = (int)ceil_div(D, 4); a.nby = (int)ceil_div(H, 8); a.nbx = (int)ceil_div(W, 8);
   const int64_t ntb = B * a.nbz * a.nby * a.nbx;

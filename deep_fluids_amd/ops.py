@@ -251,15 +251,34 @@ def _pack(w, taps, cin, cout, mode, dims=None, fp32=False):
     return wp
 
 
-def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak):
+# Sign-bit masks (conv_wino.hip): the forward convs of a fused generator block whose outputs only serve, in the backward pass, as the
+# lrelu mask of the next layer's dgrad also emit that mask as bit words (1/32 of the bytes); the masked dgrad then reads the words
+# instead of the fp32 activation.  Same arithmetic, bit-identical results; only the 3-D Winograd kernels have the path.
+import os as _os
+SIGN_BIT_MASKS = _os.environ.get("DF_SIGN_BIT_MASKS", "1") != "0"
+
+
+def _new_bits(dims, c, like):
+    B, D, H, W = dims
+    nbytes = query("df_wino_signbits_bytes", B, D, H, W, c)
+    return torch.empty(nbytes // 8, dtype=torch.int64, device=like.device)
+
+
+def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak, sign_bits=None, mask_bits=None):
     """`wp` must come from ``_pack(..., dims)`` with the same dims (the two agree on the algorithm)."""
     B, D, H, W = dims
     y = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
     algo = _use_wino(cin, cout, dims, kz)
     if algo == 3:
+        if sign_bits is not None or mask_bits is not None:
+            call("df_wino_conv_fwd_bits", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_bits), _ptr(y), _ptr(sign_bits), B, D, H, W, cin, cout,
+                 flags, float(leak), _stream())
+            return y
         call("df_wino_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, D, H, W, cin, cout,
              flags, float(leak), _stream())
         return y
+    if sign_bits is not None or mask_bits is not None:
+        raise _lib.DeepFluidsHipError("sign-bit masks exist for the 3-D Winograd kernels only")
     if algo == 2:
         call("df_wino2d_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, H, W, cin, cout,
              flags, float(leak), _stream())
@@ -330,6 +349,7 @@ class _GenBlock(torch.autograd.Function):
         taps = 27 if nd == 3 else 9
         dims = (x0.shape[0], x0.shape[1] if nd == 3 else 1, x0.shape[-3], x0.shape[-2])
         xs = [x0]
+        bits = []
         x = x0
         for i in range(n):
             w = _prep(wb[2 * i], "weights"); b = _prep(wb[2 * i + 1], "biases")
@@ -337,7 +357,10 @@ class _GenBlock(torch.autograd.Function):
             if tuple(w.shape[:-2]) != (3,) * nd or x.shape[-1] != cin:
                 raise ValueError("gen_block: weights %s do not match input %s" % (tuple(w.shape), tuple(x.shape)))
             wp = _pack(w, taps, cin, cout, 0, dims)
-            x = _conv_raw(x, wp, b, None, None, dims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak).view(
+            # outputs of convs 1 .. n-1 are the masks of the dgrads of convs 2 .. n
+            sb = _new_bits(dims, cout, x0) if (SIGN_BIT_MASKS and i < n - 1 and _use_wino(cin, cout, dims, kz) == 3) else None
+            bits.append(sb)
+            x = _conv_raw(x, wp, b, None, None, dims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak, sign_bits=sb).view(
                 x0.shape[:-1] + (cout,))
             xs.append(x)
         if x.shape != x0.shape:
@@ -348,6 +371,7 @@ class _GenBlock(torch.autograd.Function):
             ACTIVATION_FETCH.extend(xs[1:])
         ctx.save_for_backward(*(xs + [wb[2 * i] for i in range(n)]))
         ctx.geom = (n, dims, kz, taps, float(leak))
+        ctx.bits = bits
         return y
 
     @staticmethod
@@ -370,7 +394,9 @@ class _GenBlock(torch.autograd.Function):
             grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
             wpd = _pack(w, taps, cin, cout, 1, dims)
             if i > 1:      # dgrad, times the lrelu slope of the layer below: directly the next dp
-                dp = _conv_raw(dp, wpd, None, None, xs[i - 1], dims, cout, cin, kz, DF_CONV_MASK, leak).view(xs[i - 1].shape)
+                mb = ctx.bits[i - 2]      # sign bits of conv i-1's output, if its forward emitted them
+                dp = _conv_raw(dp, wpd, None, None, None if mb is not None else xs[i - 1], dims, cout, cin, kz, DF_CONV_MASK, leak,
+                               mask_bits=mb).view(xs[i - 1].shape)
             elif ctx.needs_input_grad[0]:   # dgrad of the first layer + the skip gradient
                 dx0 = _conv_raw(dp, wpd, None, dy, None, dims, cout, cin, kz, DF_CONV_RESIDUAL, 0.0).view(xs[0].shape)
         return (dx0, None) + tuple(grads)
@@ -395,18 +421,25 @@ class _UpGenBlock(torch.autograd.Function):
         C = int(xc.shape[-1])
         fshape = (xc.shape[0],) + tuple(2 * int(d) for d in xc.shape[1:-1]) + (C,)
         xs = []
+        bits = []
         y = None
         for i in range(n):
             w = _prep(wb[2 * i], "weights"); b = _prep(wb[2 * i + 1], "biases")
             cin, cout = w.shape[-2], w.shape[-1]
             if tuple(w.shape[:-2]) != (3,) * nd or cin != C or cout != C:
                 raise ValueError("up_gen_block: weights %s do not match %d channels" % (tuple(w.shape), C))
+            sb = _new_bits(fdims, cout, xc) if (SIGN_BIT_MASKS and i < n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3) else None
+            bits.append(sb)
             if i == 0 and is3d and _use_wino(cin, cout, fdims, kz) == 3:
                 # 27-point up-sampling-aware Winograd form (conv_wino.hip, UP variant): same packed operand as a plain conv
                 wp = _pack(w, taps, cin, cout, 0, fdims)
                 x = torch.empty(fshape, dtype=torch.float32, device=xc.device)
-                call("df_wino_upconv_fwd", _ptr(xc), _ptr(wp), _ptr(b), _ptr(x), cdims[0], cdims[1], cdims[2], cdims[3], cin, cout,
-                     DF_CONV_BIAS | DF_CONV_LRELU, float(leak), _stream())
+                if sb is not None:
+                    call("df_wino_upconv_fwd_bits", _ptr(xc), _ptr(wp), _ptr(b), _ptr(x), _ptr(sb), cdims[0], cdims[1], cdims[2], cdims[3],
+                         cin, cout, float(leak), _stream())
+                else:
+                    call("df_wino_upconv_fwd", _ptr(xc), _ptr(wp), _ptr(b), _ptr(x), cdims[0], cdims[1], cdims[2], cdims[3], cin, cout,
+                         DF_CONV_BIAS | DF_CONV_LRELU, float(leak), _stream())
             elif i == 0 and not is3d and _use_wino(cin, cout, fdims, kz) == 2:
                 # 2-D twin: 9 of the 16 Winograd products (conv_wino2d.hip, UP variant)
                 wp = _pack(w, taps, cin, cout, 0, fdims)
@@ -430,7 +463,7 @@ class _UpGenBlock(torch.autograd.Function):
                     call("df_wino_conv_fwd_addup", _ptr(x_in), _ptr(wp), _ptr(b), _ptr(xc), _ptr(x), _ptr(y), fdims[0], fdims[1],
                          fdims[2], fdims[3], cin, cout, float(leak), _stream())
                 else:
-                    x = _conv_raw(x, wp, b, None, None, fdims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak).view(fshape)
+                    x = _conv_raw(x, wp, b, None, None, fdims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak, sign_bits=sb).view(fshape)
             xs.append(x)
         if y is None:
             y = torch.empty_like(x)
@@ -439,6 +472,7 @@ class _UpGenBlock(torch.autograd.Function):
             ACTIVATION_FETCH.extend(xs)
         ctx.save_for_backward(*([xc] + xs + [wb[2 * i] for i in range(n)]))
         ctx.geom = (n, cdims, fdims, kz, taps, float(leak), C, is3d)
+        ctx.bits = bits
         return y
 
     @staticmethod
@@ -459,7 +493,9 @@ class _UpGenBlock(torch.autograd.Function):
             if i > 1:
                 _wgrad(xs[i - 2], dp, gw, gb, B, D, H, W, C, C, kz, _sfx(C, C))
                 wpd = _pack(w, taps, C, C, 1, fdims)
-                dp = _conv_raw(dp, wpd, None, None, xs[i - 2], fdims, C, C, kz, DF_CONV_MASK, leak).view(dy.shape)
+                mb = ctx.bits[i - 2]      # sign bits of conv i-1's output (xs[i-2]), if its forward emitted them
+                dp = _conv_raw(dp, wpd, None, None, None if mb is not None else xs[i - 2], fdims, C, C, kz, DF_CONV_MASK, leak,
+                               mask_bits=mb).view(dy.shape)
             else:
                 nbytes = query("df_upconv_wgrad_workspace_bytes", cdims[0], cdims[1], cdims[2], cdims[3], C, C, kz)
                 wsb = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)

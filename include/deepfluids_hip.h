@@ -252,8 +252,23 @@ int df_wino_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B,
 int df_wino_conv_fwd_addup(const float* x, const float* wp, const float* bias, const float* xc, float* y, float* y2, int64_t B,
                            int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, float leak, df_stream_t stream);
 
+/* Sign-bit masks.  A masked dgrad (DF_CONV_MASK) multiplies its output by the lrelu slope of the layer below, i.e. it needs ONE BIT
+ * per element of that layer's activation; read from the fp32 activation that is 3.2 GB per top-level launch at cfg3.  The forward
+ * conv that produced the activation can emit the bits instead (one byte per lane: the signs of its 8 outputs, 1/32 of the bytes) and
+ * the dgrad of the SAME geometry (B, D, H, W and channel count) reads those:
+ *   df_wino_conv_fwd_bits(flags = DF_CONV_BIAS | DF_CONV_LRELU, bias, mask_bits = NULL, sign_bits = out)   forward, writes y and bits(y > 0)
+ *   df_wino_upconv_fwd_bits(...)                                                                            the same for the 27-point form
+ *   df_wino_conv_fwd_bits(flags = DF_CONV_MASK, bias = NULL, mask_bits = in, sign_bits = NULL)             masked dgrad (mode-1 weights)
+ * The byte layout is private to the two kernels (tile block, cout slice, wave, cout block, lane); df_wino_signbits_bytes sizes it. */
+int64_t df_wino_signbits_bytes(int64_t B, int64_t D, int64_t H, int64_t W, int64_t C);
+int df_wino_conv_fwd_bits(const float* x, const float* wp, const float* bias, const void* mask_bits, float* y, void* sign_bits, int64_t B,
+                          int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream);
+int df_wino_upconv_fwd_bits(const float* xc, const float* wp, const float* bias, float* y, void* sign_bits, int64_t B, int64_t Dc,
+                            int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, float leak, df_stream_t stream);
+
 /* 2-D twin: Winograd F(2x2, 3x3) form of the stride-1 3x3 convolution (conv_wino2d.hip): 2.25x fewer matrix-core FLOPs than df_conv_fwd
  * with kz = 1, fp32 throughout, same epilogue flags.  Needs Cin % 32 == 0, Cout % 32 == 0, H*W*max(Cin,Cout) <= 2^29. */
+
 int64_t df_wino2d_packed_elems(int64_t cin, int64_t cout, int mode);
 int df_wino2d_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, int mode, df_stream_t stream);
 int df_wino2d_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src,

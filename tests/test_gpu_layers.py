@@ -535,3 +535,37 @@ def test_conv_wgrad_range_override_is_bounds_checked(ops):
         call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, 4 | (256 << 3), s)
     with pytest.raises(DeepFluidsHipError):
         call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, 5, s)       # algo out of range
+
+
+@pytest.mark.parametrize("shape,C,up", [((1, 8, 12, 8), 32, False), ((2, 6, 10, 12), 32, False), ((1, 5, 7, 9), 64, False), ((1, 4, 6, 4), 32, True),
+                                        ((2, 3, 5, 6), 64, True), ((1, 8, 12, 8), 128, True)])
+def test_sign_bit_masks_are_bit_identical_to_activation_masks(ops, shape, C, up):
+    """The masked dgrads of a fused generator block read the lrelu mask either from the fp32 activation of the layer below
+    (DF_CONV_MASK + mask_src) or from the sign-bit words its forward conv emitted (df_wino_conv_fwd_bits / df_wino_upconv_fwd_bits:
+    1/32 of the bytes).  Same arithmetic: outputs and every gradient must agree bit for bit -- full and ragged tile blocks, plain and
+    up-sampling blocks."""
+    from deep_fluids_amd.ops import _GenBlock, _UpGenBlock
+    rng = np.random.RandomState(sum(shape) + C)
+    n = 4
+    x = rng.uniform(-1, 1, shape + (C,)).astype(np.float32)
+    ws = [(rng.uniform(-1, 1, (3, 3, 3, C, C)) / np.sqrt(C * 27)).astype(np.float32) for _ in range(n)]
+    bs = [rng.uniform(-0.3, 0.3, C).astype(np.float32) for _ in range(n)]
+    fshape = tuple(shape[:1]) + tuple(2 * d for d in shape[1:]) if up else shape
+    go = rng.uniform(-1, 1, fshape + (C,)).astype(np.float32)
+    old_algo, old_bits = ops.CONV_ALGO, ops.SIGN_BIT_MASKS
+    ops.CONV_ALGO = "winograd"
+    res = []
+    try:
+        for use_bits in (True, False):
+            ops.SIGN_BIT_MASKS = use_bits
+            xt = dev(x).requires_grad_(True)
+            args = []
+            for w, b in zip(ws, bs):
+                args += [dev(w).requires_grad_(True), dev(b).requires_grad_(True)]
+            y = (_UpGenBlock if up else _GenBlock).apply(xt, 0.2, *args)
+            (y * dev(go)).sum().backward()
+            res.append([host(y), host(xt.grad)] + [host(a.grad) for a in args])
+    finally:
+        ops.CONV_ALGO, ops.SIGN_BIT_MASKS = old_algo, old_bits
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
