@@ -1916,7 +1916,14 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   //  the partial traffic of 256)
   // (small problems: the fixed-order reduce of the partial sums costs as much as the products -- 64 ranges measured best below
   //  4096 row pairs: 0.45 -> 0.22 ms at 16 x 8x12x8, 0.84 -> 0.67 ms at 16 x 16x24x16)
-  const int maxr = (ranges > 0 && ranges <= kMaxRanges) ? ranges : (p.npairs < 4096 ? 64 : (algo >= 2 ? 128 : kMaxRanges));
+  // ... but never fewer ranges than it takes to put one workgroup on every CU: a LAUNCH has ndzdy (direct, x), ndzdy / 2 ((x,y): two
+  // launches) or 4 ((x,y,z): four launches) workgroup types -- in 2-D that is only 3 | 2 types, and 64 ranges left half of the chip
+  // idle (2-D 128x96, batch 64: Winograd-(x,y) 1.59 -> 0.92 ms with 128 ranges)
+  const int per_launch = algo == 3 ? 4 : algo == 2 ? p.ndzdy / 2 : p.ndzdy;
+  const int fill = (256 + per_launch - 1) / per_launch;
+  int heur = p.npairs < 4096 ? 64 : (algo >= 2 ? 128 : kMaxRanges);
+  if (algo >= 2 && heur < fill) heur = fill <= kMaxRanges ? fill : kMaxRanges;      // (the direct / x kernels measured slower with more ranges)
+  const int maxr = (ranges > 0 && ranges <= kMaxRanges) ? ranges : heur;
   int nr = p.npairs >= maxr ? maxr : p.npairs;
   p.ppr = (p.npairs + nr - 1) / nr;
   p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
