@@ -1,0 +1,59 @@
+"""CPU-side checks of bench.py's contract pieces that need no GPU: argument defaults, the self-launch command line, the kernel
+selector's algorithmic work figures and the shape of the `roofline` object (executed-MFMA fraction <= 1, algorithmic rate separate)."""
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_defaults_and_self_launch_command(monkeypatch):
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = b.parse()
+    assert (a.gpus, a.scaling, a.batch, a.res, a.filters, a.precision) == (1, "weak", 16, [64, 96, 64], 128, "fp32")
+    assert a.steps > 0 and a.warmup >= 0
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--scaling", "strong"])
+    a = b.parse()
+    seen = {}
+    monkeypatch.setattr(b.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    assert b.self_launch(a) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-7:] == ["--gpus", "8", "--steps", "3", "--warmup", "1", "--scaling", "strong"][-7:]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_kernel_selector_and_roofline_object():
+    b = _bench()
+    B, D, H, W, C = 16, 64, 96, 64, 128
+    # df_wino_conv_fwd(x, wp, bias, residual, mask, y, B, D, H, W, Cin, Cout, flags, leak, stream)
+    key, work = b.select_kernel("df_wino_conv_fwd", (1, 2, 3, None, None, 4, B, D, H, W, C, C, 9, 0.2, None))
+    assert key == "wino3d_kernel fwd/dgrad 64x96x64 C128->128" and work == 2.0 * 27 * C * C * B * D * H * W      # 5.566 TFLOP
+    key, work = b.select_kernel("df_jacobian3d_fwd", (1, 2, 3, B, D, H, W, None))
+    assert key == "jacobian3d_fwd_kernel<j,c>" and work == 60.0 * B * D * H * W                                    # 60 B/voxel
+    assert b.select_kernel("df_jacobian3d_fwd", (1, None, 3, B, D, H, W, None)) is None
+    key, work = b.select_kernel("df_conv_wgrad_algo", (1, 2, 3, 4, B, D, H, W, C, C, 3, 5, 6, 0, None))
+    assert key == "wgrad_kernel 64x96x64 C128x128"
+    ks = {"wino3d_kernel fwd/dgrad 64x96x64 C128->128": {"launches": 10, "seconds": 0.170, "work": 10 * 5.566277615616e12},
+          "wino3d_kernel fwd/dgrad 8x12x8 C128->128": {"launches": 10, "seconds": 0.001, "work": 10 * 1.0872e10},
+          "wgrad_kernel 64x96x64 C128x128": {"launches": 5, "seconds": 0.075, "work": 5 * 5.566277615616e12}}
+    r = b.roofline_of(ks, "wino3d_kernel", {"wino3d_kernel": {"traffic_bytes": 3.2e10}}, True)
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and r["kernel"].startswith("wino3d_kernel fwd/dgrad 64x96x64")
+    assert abs(r["algorithmic_tflops"] - 327.43) < 0.1 and abs(r["algorithmic_speedup"] - 3.375) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_tflops"] * 8 / 27) < 1e-9 and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / 157.3) < 1e-12
+    assert r["traffic"] == 3.2e10 and r["traffic_source"]
+    w = b.roofline_of(ks, "wgrad_kernel", {}, False)
+    assert abs(w["algorithmic_speedup"] - 3.375) < 1e-12 and w["traffic"] is None and w["frac"] <= 1.0
+    assert b.wgrad_exec_ratio(1, 128, 96) == 4.0 / 9.0 and b.wgrad_exec_ratio(64, 96, 64) == 8.0 / 27.0 and b.wgrad_exec_ratio(7, 10, 7) == 1.0
+    json.dumps(r)      # the object must be JSON-serialisable as is
