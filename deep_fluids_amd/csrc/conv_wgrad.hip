@@ -1372,7 +1372,9 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_bf16x3_kernel(const WgradAr
 }
 
 inline bool wgrad_bf16x3_ok(int64_t W, int64_t Cin, int64_t Cout) {
-  return (W == 16 || W == 32 || W == 64 || W == 96 || W == 112) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 16 && Cout >= 16;
+  // W = 112 (cfg4) is NOT listed: its 28-step unrolled variant spilt 720 B of scratch per lane and ran 148 ms per launch on
+  // MI355X; those rows take the fp32 Winograd weight gradients instead (more accurate, ~40x faster)
+  return (W == 16 || W == 32 || W == 64 || W == 96) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 16 && Cout >= 16;
 }
 template <typename A>
 inline void launch_wgrad_bf16x3(int64_t W, dim3 grid, hipStream_t s, const A& a) {
@@ -1380,8 +1382,7 @@ inline void launch_wgrad_bf16x3(int64_t W, dim3 grid, hipStream_t s, const A& a)
     case 1: hipLaunchKernelGGL((wgrad_bf16x3_kernel<1>), grid, dim3(kThreads), 0, s, a); break;
     case 2: hipLaunchKernelGGL((wgrad_bf16x3_kernel<2>), grid, dim3(kThreads), 0, s, a); break;
     case 4: hipLaunchKernelGGL((wgrad_bf16x3_kernel<4>), grid, dim3(kThreads), 0, s, a); break;
-    case 6: hipLaunchKernelGGL((wgrad_bf16x3_kernel<6>), grid, dim3(kThreads), 0, s, a); break;
-    default: hipLaunchKernelGGL((wgrad_bf16x3_kernel<7>), grid, dim3(kThreads), 0, s, a); break;
+    default: hipLaunchKernelGGL((wgrad_bf16x3_kernel<6>), grid, dim3(kThreads), 0, s, a); break;
   }
 }
 
@@ -2056,7 +2057,9 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   }
   const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
-  const int algo = (prec == 0 && xvec && gvec) ? wgrad_algo(req, B * D * H, D, H, W, Cin, Cout, kz) : 0;
+  // bf16x3 mode: rows without a bf16x3 variant (W = 56 | 28 | ... of cfg4) take the fp32 Winograd forms, not the 2.6x slower direct kernel
+  const bool use_bf16x3 = prec == 1 && xvec && gvec && wgrad_bf16x3_ok(W, Cin, Cout);
+  const int algo = (!use_bf16x3 && xvec && gvec) ? wgrad_algo(req, B * D * H, D, H, W, Cin, Cout, kz) : 0;
   const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, algo, req_ranges);
   // a caller-chosen number of partial ranges may need more room than df_conv_wgrad_workspace_bytes (sized for the defaults) promises
   DF_REQUIRE(workspace_bytes >= (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(W, Cin, Cout),
@@ -2077,7 +2080,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   hipStream_t s = df::as_stream(stream);
   if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(W, Cin, Cout), s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)ceil_div(Cin, 128), (unsigned)ceil_div(Cout, 128));
-  if (prec == 1 && xvec && gvec && wgrad_bf16x3_ok(W, Cin, Cout)) {
+  if (use_bf16x3) {
     launch_wgrad_bf16x3(W, grid, s, a);
   } else if (algo == 3) {
     WxyzArgs aa;
@@ -2228,7 +2231,7 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   DF_REQUIRE(df::aligned16(workspace), DF_EALIGN, "df_upconv_wgrad: workspace must be 16-byte aligned");
   DF_REQUIRE(workspace_bytes >= df_upconv_wgrad_workspace_bytes(B, Dc, Hc, Wc, Cin, Cout, kz), DF_EWORKSPACE,
              "df_upconv_wgrad: workspace too small");
-  if (prec == 0 && up_wxyz_ok(req, B, Dc, Hc, Wc, Cin, Cout, kz) && df::aligned16(xc) && df::aligned16(gy)) {
+  if ((prec == 0 || !wgrad_bf16x3_ok(Wc, Cin, Cout)) && up_wxyz_ok(req, B, Dc, Hc, Wc, Cin, Cout, kz) && df::aligned16(xc) && df::aligned16(gy)) {
     const int64_t D = 2 * Dc, H = 2 * Hc, W = 2 * Wc;
     const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, 3);
     WxyzArgs aa;
@@ -2286,11 +2289,11 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   const bool aligned8 = ((reinterpret_cast<uintptr_t>(xc) | reinterpret_cast<uintptr_t>(gy)) & 7u) == 0;
   const dim3 grid2((unsigned)(p.nranges * (p.ndzdy / 2)), grid.y, grid.z);     // one workgroup per x-parity class PAIR
   if (prec == 1 && wgrad_bf16x3_ok(Wc, Cin, Cout)) launch_wgrad_bf16x3(Wc, grid, s, a);
-  else if (prec == 0 && aligned8 && exact && wp8 == 4 && Cin == 128 && Cout == 128 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<4, 128>), grid2, dim3(kThreads), 0, s, a);
-  else if (prec == 0 && aligned8 && exact && wp8 == 6 && Cin == 128 && Cout == 128 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<6, 128>), grid2, dim3(kThreads), 0, s, a);      // 2-D 128x96: coarse W = 48 | 24
-  else if (prec == 0 && aligned8 && exact && wp8 == 3 && Cin == 128 && Cout == 128 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<3, 128>), grid2, dim3(kThreads), 0, s, a);
-  else if (prec == 0 && aligned8 && exact && wp8 == 2 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<2, 0>), grid2, dim3(kThreads), 0, s, a);
-  else if (prec == 0 && aligned8 && exact && wp8 == 1 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<1, 0>), grid2, dim3(kThreads), 0, s, a);
+  else if (aligned8 && exact && wp8 == 4 && Cin == 128 && Cout == 128 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<4, 128>), grid2, dim3(kThreads), 0, s, a);
+  else if (aligned8 && exact && wp8 == 6 && Cin == 128 && Cout == 128 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<6, 128>), grid2, dim3(kThreads), 0, s, a);      // 2-D 128x96: coarse W = 48 | 24
+  else if (aligned8 && exact && wp8 == 3 && Cin == 128 && Cout == 128 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<3, 128>), grid2, dim3(kThreads), 0, s, a);
+  else if (aligned8 && exact && wp8 == 2 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<2, 0>), grid2, dim3(kThreads), 0, s, a);
+  else if (aligned8 && exact && wp8 == 1 && req != 1) hipLaunchKernelGGL((wgrad_up2_kernel<1, 0>), grid2, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 8) hipLaunchKernelGGL((wgrad_kernel<true, true, 8>), grid, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 4) hipLaunchKernelGGL((wgrad_kernel<true, true, 4>), grid, dim3(kThreads), 0, s, a);
   else if (exact && wp8 == 2) hipLaunchKernelGGL((wgrad_kernel<true, true, 2>), grid, dim3(kThreads), 0, s, a);

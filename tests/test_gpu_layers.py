@@ -482,7 +482,7 @@ def bf16x3(ops):
                                                   ((2, 2, 3, 32), 64, 64, None), ((1, 5, 96), 32, 64, 0.2)])
 def test_conv_bf16x3_mode(ops, bf16x3, shape, cin, cout, leak):
     """Opt-in split-precision mode: forward and dgrad on the bf16 matrix pipe (hi*hi + hi*lo + lo*hi); 16 significand
-    bits per operand -> relative L-inf ~1e-5 (bound 1e-4); rows of 16/32/64/96/112 voxels use the bf16x3 wgrad kernel."""
+    bits per operand -> relative L-inf ~1e-5 (bound 1e-4); rows of 16/32/64/96 voxels use the bf16x3 wgrad kernel (112 takes the fp32 Winograd forms)."""
     errs = _conv_case(ops, shape, cin, cout, leak, seed=cin + cout + sum(shape), mask_from_gpu=True)
     assert errs["y"] < 1e-4 and errs["dx"] < 1e-4, errs
     assert errs["y"] > 1e-7, "suspiciously exact: is the bf16x3 kernel really running?"
