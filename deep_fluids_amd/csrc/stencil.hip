@@ -104,13 +104,21 @@ __global__ __launch_bounds__(kThreads) void jacobian3d_fwd_vec_kernel(const floa
     const f32x4* p = reinterpret_cast<const f32x4*>(x + vq * 3);
     const f32x4* py = reinterpret_cast<const f32x4*>(x + (ly ? vq - sy : vq + sy) * 3);
     const f32x4* pz = reinterpret_cast<const f32x4*>(x + (lz ? vq - sz : vq + sz) * 3);
+    asm volatile("" :: "v"(py), "v"(pz));      // addresses first, then all the loads back to back
     float o[16], ny[12], nz[12], jo[36], co[12];
     const bool tail = vq + 4 >= dm.nvox;                       // very last quad: nothing to read behind it
-    const f32x4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = tail ? p[2] : p[3];
+    // the x+1 record of the quad's last voxel: address select (a branch between the loads makes hipcc wait for the earlier ones) and
+    // a 12-byte load (hipcc reuses a dead fourth register at once, behind a vmcnt(0) that serialises every later load)
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    const f32x4 a0 = p[0], a1 = p[1], a2 = p[2];
+    const f32x3 a3 = *reinterpret_cast<const f32x3*>(p + (tail ? 2 : 3));
     const f32x4 b0 = py[0], b1 = py[1], b2 = py[2];
     const f32x4 c0 = pz[0], c1 = pz[1], c2 = pz[2];
+    // all ten loads in flight before the first use: one empty asm that consumes every loaded register (hipcc otherwise sinks the
+    // y / z loads below the first uses of the own quad -- two dependent memory round trips)
+    asm volatile("" :: "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(c0), "v"(c1), "v"(c2));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { o[e] = a0[e]; o[4 + e] = a1[e]; o[8 + e] = a2[e]; o[12 + e] = a3[e];
+    for (int e = 0; e < 4; ++e) { o[e] = a0[e]; o[4 + e] = a1[e]; o[8 + e] = a2[e]; o[12 + e] = e < 3 ? a3[e < 3 ? e : 0] : 0.f;
                                   ny[e] = b0[e]; ny[4 + e] = b1[e]; ny[8 + e] = b2[e];
                                   nz[e] = c0[e]; nz[4 + e] = c1[e]; nz[8 + e] = c2[e]; }
 #pragma unroll
@@ -268,19 +276,26 @@ __global__ __launch_bounds__(kThreads) void jacobian3d_bwd_vec_kernel(const floa
       }
       return r;
     };
-    float own[4][9], up[4][9];
+    // every load of the common path is issued up front, unconditionally (a branch between two groups of loads makes hipcc wait
+    // for the first before it issues the second: three dependent memory round trips instead of one); unused values (k == 0)
+    // come from a valid address and are masked below
+    float own[4][9], upy[4][9], upz[4][9], gm1[3];
     float out[4][3];
     load_quad(vq, own);
+    load_quad(yy > 0 ? vq - sy : vq, upy);
+    load_quad(zz > 0 ? vq - sz : vq, upz);
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) gm1[comp] = G1(xx > 0 ? vq - 1 : vq, comp * 3);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- x axis: inside the row; the quad never straddles a row and X % 4 == 0, so k = n-2, n-1 sit in the last quad ----
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
       const int e = comp * 3;
-      const float gm1 = xx > 0 ? G1(vq - 1, e) : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = xx + i;
         const float gk = own[i][e];
-        const float gkm = i > 0 ? own[i - 1][e] : gm1;
+        const float gkm = i > 0 ? own[i - 1][e] : gm1[comp];
         float r;
         if (k == dm.X - 1) r = gkm + gk;                                   // gp(n-2) = g(n-2) + g(n-1)
         else if (k == dm.X - 2) r = (k > 0 ? gkm : 0.f) - (gk + own[i < 3 ? i + 1 : 3][e]);   // gp(k-1) - (g(n-2) + g(n-1))
@@ -293,19 +308,25 @@ __global__ __launch_bounds__(kThreads) void jacobian3d_bwd_vec_kernel(const floa
     for (int axis = 1; axis < 3; ++axis) {
       const int k = axis == 1 ? yy : zz, n = axis == 1 ? dm.Y : dm.Z;
       const int64_t st = axis == 1 ? sy : sz;
-      if (k > 0) load_quad(vq - st, up);
+      float far[4][3];                                // g at k + 1, needed next to the far face only (k == n - 2): one batch of loads
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) far[i][comp] = 0.f;
+      if (k == n - 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int comp = 0; comp < 3; ++comp) far[i][comp] = G1(vq + i + st, comp * 3 + axis);
+      }
 #pragma unroll
       for (int comp = 0; comp < 3; ++comp) {
         const int e = comp * 3 + axis;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float gk = own[i][e];
-          const float gkm = k > 0 ? up[i][e] : 0.f;
-          float r;
-          if (k == n - 1) r = gkm + gk;
-          else if (k == n - 2) r = gkm - (gk + G1(vq + i + st, e));
-          else r = gkm - gk;
-          out[i][comp] += r;
+          const float gkm = k > 0 ? (axis == 1 ? upy[i][e] : upz[i][e]) : 0.f;
+          out[i][comp] += k == n - 1 ? gkm + gk : gkm - (gk + far[i][comp]);
         }
       }
     }
@@ -318,6 +339,183 @@ __global__ __launch_bounds__(kThreads) void jacobian3d_bwd_vec_kernel(const floa
   const int64_t left = dm.nvox - v0;
   const int64_t nv = left < kVoxPerBlock ? left : kVoxPerBlock;
   flush_lds<NT>(so, gx + v0 * 3, nv * 3, tid);
+}
+
+// ---- LDS-staged adjoint (X % 4 == 0, X <= 128, ONE incoming gradient) ---------------------------------------------------------
+// The register-only kernel above is bound by the vector-memory front end, not by HBM: a lane's quad is 144 (gj) / 48 (gc) bytes, so
+// every 16-byte-per-lane load instruction of a wave touches 72 / 24 cache lines for 1 KiB of data, and a thread issues 27 of them.
+// Here the workgroup copies the three record spans it needs -- its own 1024 records plus the X records before them (the y-1 row
+// of its first row, the x-1 record of its first voxel), and the 1024 records one slice up -- into LDS with lane-consecutive 16-byte
+// loads (8 lines per instruction), and the threads pick their quads out of LDS (ds_read_b128 at a 144- / 48-byte lane stride is
+// bank-conflict-free).  HBM still sees each byte once (the z-1 / y-1 spans are L2 hits).
+constexpr int kLdsMaxX = 128;
+
+template <int R>
+__device__ __forceinline__ float fold_rec(const float* rec, int e) {   // G[e] of one record (9 = gj, 3 = gc folded through the curl)
+  if (R == 9) return rec[e];
+  switch (e) {
+    case 1: return -rec[2];
+    case 2: return rec[1];
+    case 3: return rec[2];
+    case 5: return -rec[0];
+    case 6: return -rec[1];
+    case 7: return rec[0];
+    default: return 0.f;
+  }
+}
+
+template <int R, bool NT>
+__global__ __launch_bounds__(kThreads) void jacobian3d_bwd_lds_kernel(const float* __restrict__ g, float* __restrict__ gx, Dims3 dm) {
+  constexpr int QB = kVoxPerBlock * R / 4;       // float4 per 1024-record span
+  constexpr int PER = QB / kThreads;             // 9 | 3 per thread
+  __shared__ __attribute__((aligned(16))) float sA[(kVoxPerBlock + kLdsMaxX) * R];   // records [v0 - X, v0 + 1024)
+  // records [v0 - X*Y, v0 - X*Y + 1024), later the output.  With gj only the three d/dz components of each record are kept
+  // (12 instead of 36 KB: 53.8 KB in all, THREE workgroups per CU)
+  constexpr bool ZF = R == 9;
+  __shared__ __attribute__((aligned(16))) float sZ[kVoxPerBlock * 3];
+  const int tid = threadIdx.x;
+  const int64_t v0 = xcd_block(blockIdx.x, gridDim.x, dm.group) * kVoxPerBlock;
+  const int64_t sy = dm.X, sz = static_cast<int64_t>(dm.X) * dm.Y;
+  const int P = dm.X;
+  {
+    const int64_t z_first = (v0 - sz) * R / 4;                        // float4 index of the z-1 span in g (negative: before the tensor)
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    f32x4 ta[PER], tz[PER], tp[2];
+    const int npre = P * R / 4;                                       // <= 288
+    // every load is unconditional with a CLAMPED index (a branch around a load makes hipcc drain vmcnt(0) before the next one):
+    // float4 that do not exist (before the tensor, past its end) read a neighbouring valid one and are never used
+    const int64_t g_last = dm.nvox * R / 4 - 1;
+    const int64_t own_first = v0 * R / 4;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int64_t q = own_first + k * kThreads + tid;
+      ta[k] = g4[q < g_last ? q : g_last];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int64_t q = z_first + k * kThreads + tid;
+      tz[k] = g4[q > 0 ? q : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t q = own_first - npre + k * kThreads + tid;        // second round: only the first npre - 256 lanes are kept
+      tp[k] = g4[q > 0 ? q : 0];
+      asm volatile("" : "+v"(tp[k]));                                 // keep the load up here (not sunk into the guarded LDS write)
+    }
+    f32x4* a4 = reinterpret_cast<f32x4*>(sA);
+    f32x4* z4 = reinterpret_cast<f32x4*>(sZ);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) a4[npre + k * kThreads + tid] = ta[k];
+    if (ZF) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned idx = static_cast<unsigned>(k * kThreads + tid) * 4u + j;     // float index inside the span
+          const unsigned rec = idx / 9u, c = idx - rec * 9u;
+          if (c % 3u == 2u) sZ[rec * 3u + c / 3u] = tz[k][j];
+        }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) z4[k * kThreads + tid] = tz[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = k * kThreads + tid;
+      if (q < npre) a4[q] = tp[k];
+    }
+  }
+  __syncthreads();
+  const int64_t vq = v0 + 4 * static_cast<int64_t>(tid);
+  float out[4][3];
+  const bool live = vq < dm.nvox;
+  if (live) {
+    const int64_t row = vq / dm.X;
+    const int xx = static_cast<int>(vq - row * dm.X);
+    const int64_t slab = row / dm.Y;
+    const int yy = static_cast<int>(row - slab * dm.Y);
+    const int zz = static_cast<int>(slab % dm.Z);
+    const float* la = sA + (P + 4 * tid) * R;         // own quad
+    const float* lym = la - P * R;                    // the quad one row up
+    const float* lzm = sZ + 4 * tid * 3;              // the quad one slice up (ZF: its d/dz components only)
+    auto load_quad = [&](const float* src, float (&q)[4][9]) {
+      float raw[4 * R];
+      const f32x4* p = reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+      for (int k = 0; k < R; ++k) { const f32x4 t = p[k]; raw[4 * k] = t[0]; raw[4 * k + 1] = t[1]; raw[4 * k + 2] = t[2]; raw[4 * k + 3] = t[3]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) q[i][e] = fold_rec<R>(raw + i * R, e);
+    };
+    float own[4][9], up[4][9];
+    load_quad(la, own);
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+      const int e = comp * 3;
+      const float gm1 = fold_rec<R>(la - R, e);         // unused when xx == 0
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = xx + i;
+        const float gk = own[i][e];
+        const float gkm = i > 0 ? own[i - 1][e] : gm1;
+        float r;
+        if (k == dm.X - 1) r = gkm + gk;
+        else if (k == dm.X - 2) r = (k > 0 ? gkm : 0.f) - (gk + own[i < 3 ? i + 1 : 3][e]);
+        else r = (k > 0 ? gkm : 0.f) - gk;
+        out[i][comp] = r;
+      }
+    }
+#pragma unroll
+    for (int axis = 1; axis < 3; ++axis) {
+      const int k = axis == 1 ? yy : zz, n = axis == 1 ? dm.Y : dm.Z;
+      const int64_t st = axis == 1 ? sy : sz;
+      // unused (k == 0) values are whatever the span held and are masked below
+      if (ZF && axis == 2) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(lzm);
+        const f32x4 t0 = p[0], t1 = p[1], t2 = p[2];
+        const float z[12] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int comp = 0; comp < 3; ++comp) up[i][comp * 3 + 2] = z[i * 3 + comp];
+      } else {
+        load_quad(axis == 1 ? lym : lzm, up);
+      }
+      float far[4][3];                                // g at k + 1, needed next to the far face only (k == n - 2): one batch of loads
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) far[i][comp] = 0.f;
+      if (k == n - 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int comp = 0; comp < 3; ++comp) far[i][comp] = fold_rec<R>(g + (vq + i + st) * R, comp * 3 + axis);
+      }
+#pragma unroll
+      for (int comp = 0; comp < 3; ++comp) {
+        const int e = comp * 3 + axis;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float gk = own[i][e];
+          const float gkm = k > 0 ? up[i][e] : 0.f;
+          out[i][comp] += k == n - 1 ? gkm + gk : gkm - (gk + far[i][comp]);
+        }
+      }
+    }
+  }
+  __syncthreads();                                     // every quad has left sZ: it becomes the output staging buffer
+  if (live) {
+    f32x4* q = reinterpret_cast<f32x4*>(sZ + tid * 12);
+    q[0] = f32x4{out[0][0], out[0][1], out[0][2], out[1][0]};
+    q[1] = f32x4{out[1][1], out[1][2], out[2][0], out[2][1]};
+    q[2] = f32x4{out[2][2], out[3][0], out[3][1], out[3][2]};
+  }
+  __syncthreads();
+  const int64_t left = dm.nvox - v0;
+  const int64_t nv = left < kVoxPerBlock ? left : kVoxPerBlock;
+  flush_lds<NT>(sZ, gx + v0 * 3, nv * 3, tid);
 }
 
 __global__ __launch_bounds__(kThreads) void divergence3d_kernel(const float* __restrict__ x, float* __restrict__ d,
@@ -440,9 +638,11 @@ __global__ __launch_bounds__(kThreads) void divergence2d_kernel(const float* __r
 #ifdef DF_TUNING      // knobs of the tuning library only (include/deepfluids_hip_debug.h); constants in the release library
 int g_stencil_group = 48;
 int g_stencil_nt = 1;
+int g_stencil_lds = 1;
 #else
 constexpr int g_stencil_group = dfst::kXcdGroup;
 constexpr int g_stencil_nt = 1;      // non-temporal output stores
+constexpr int g_stencil_lds = 1;     // LDS-staged adjoints where they apply
 #endif
 
 int check3(const void* in, int64_t B, int64_t Z, int64_t Y, int64_t X, const char* fn) {
@@ -469,6 +669,7 @@ extern "C" {
 #ifdef DF_TUNING
 void df_debug_set_stencil_nt(int v) { g_stencil_nt = v; }
 void df_debug_set_stencil_group(int v) { g_stencil_group = v; }
+void df_debug_set_stencil_lds(int v) { g_stencil_lds = v; }
 #endif
 
 int df_jacobian3d_fwd(const float* x, float* j, float* c, int64_t B, int64_t Z, int64_t Y, int64_t X,
@@ -504,7 +705,10 @@ int df_jacobian3d_bwd(const float* gj, const float* gc, float* gx, int64_t B, in
   if (X % 4 == 0 && df::aligned16(gj) && df::aligned16(gc) && df::aligned16(gx)) {
     dim3 gridv((unsigned)ceil_div(dm.nvox, kVoxPerBlock)), blockv(kThreads);
     if (g_stencil_group > 0 && gridv.x % (8 * g_stencil_group) == 0) dm.group = g_stencil_group;
+    const bool lds = X <= kLdsMaxX && g_stencil_lds;
     if (gj && gc) hipLaunchKernelGGL((jacobian3d_bwd_vec_kernel<true, true, true>), gridv, blockv, 0, s, gj, gc, gx, dm);
+    else if (gj && lds) hipLaunchKernelGGL((jacobian3d_bwd_lds_kernel<9, true>), gridv, blockv, 0, s, gj, gx, dm);
+    else if (gc && lds) hipLaunchKernelGGL((jacobian3d_bwd_lds_kernel<3, true>), gridv, blockv, 0, s, gc, gx, dm);
     else if (gj) hipLaunchKernelGGL((jacobian3d_bwd_vec_kernel<true, false, true>), gridv, blockv, 0, s, gj, gc, gx, dm);
     else hipLaunchKernelGGL((jacobian3d_bwd_vec_kernel<false, true, true>), gridv, blockv, 0, s, gj, gc, gx, dm);
     return df::launched("df_jacobian3d_bwd");

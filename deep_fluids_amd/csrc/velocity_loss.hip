@@ -186,14 +186,20 @@ __global__ __launch_bounds__(kThreads) void velocity_jl1_3d_vec_kernel(const flo
     const bool tail = vq + 4 >= dm.nvox;
     auto load = [&](const float* base, int64_t w, float (&o)[16], bool four) {
       const f32x4* p = reinterpret_cast<const f32x4*>(base + w * 3);
-      const f32x4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = four ? p[3] : p[2];
+      // the x+1 record of the last voxel: address select (no branch between the loads), and a 12-byte load -- a dead fourth
+      // register would be reused at once by hipcc, behind a vmcnt(0) that serialises everything after it
+      typedef float f32x3 __attribute__((ext_vector_type(3)));
+      const f32x4 a0 = p[0], a1 = p[1], a2 = p[2];
+      const f32x3 a3 = *reinterpret_cast<const f32x3*>(p + (four ? 3 : 2));
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { o[e] = a0[e]; o[4 + e] = a1[e]; o[8 + e] = a2[e]; o[12 + e] = a3[e]; }
+      for (int e = 0; e < 4; ++e) { o[e] = a0[e]; o[4 + e] = a1[e]; o[8 + e] = a2[e]; }
+      o[12] = a3[0]; o[13] = a3[1]; o[14] = a3[2]; o[15] = 0.f;
     };
     float uo[16], xo[16], uy[16], xy[16], uz[16], xz[16];
     load(u, vq, uo, !tail); load(x, vq, xo, !tail);
     load(u, ly ? vq - sy : vq + sy, uy, false); load(x, ly ? vq - sy : vq + sy, xy, false);
     load(u, lz ? vq - sz : vq + sz, uz, false); load(x, lz ? vq - sz : vq + sz, xz, false);
+    __builtin_amdgcn_sched_barrier(0);      // all 22 loads in flight before the first use (hipcc otherwise sinks them into 4 round trips)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool lx = xx + i == dm.X - 1;                      // only possible for i == 3
@@ -255,17 +261,22 @@ __global__ __launch_bounds__(kThreads) void velocity_du3d_vec_kernel(const float
       const float gpk = k == n - 2 ? gk + gk : gk;
       return k == 0 ? -gpk : gm - gpk;
     };
-    float uo[12], xo[12], um[12] = {0.f}, xm[12] = {0.f}, up[12] = {0.f}, xp[12] = {0.f}, out[12];
+    // every load is issued up front and unconditionally: at the ends of an axis the missing neighbour is replaced by a valid
+    // address (the quad itself) and adj() ignores that side there.  A branch around a group of loads makes hipcc wait for all
+    // earlier ones first -- four dependent memory round trips instead of one.
+    float uo[12], xo[12], umy[12], xmy[12], upy[12], xpy[12], umz[12], xmz[12], upz[12], xpz[12], out[12];
+    float uL[3], xL[3], uR[3], xR[3];
     load(u, vq, uo); load(x, vq, xo);
-    float uL[3] = {0.f, 0.f, 0.f}, xL[3] = {0.f, 0.f, 0.f}, uR[3] = {0.f, 0.f, 0.f}, xR[3] = {0.f, 0.f, 0.f};
-    if (xx > 0) {
+    {
+      const int64_t my = yy > 0 ? vq - sy : vq, py = yy < dm.Y - 1 ? vq + sy : vq;
+      const int64_t mz = zz > 0 ? vq - sz : vq, pz = zz < dm.Z - 1 ? vq + sz : vq;
+      load(u, my, umy); load(x, my, xmy); load(u, py, upy); load(x, py, xpy);
+      load(u, mz, umz); load(x, mz, xmz); load(u, pz, upz); load(x, pz, xpz);
+      const int64_t l = xx > 0 ? vq - 1 : vq, r = xx + 4 < dm.X ? vq + 4 : vq + 3;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { uL[c] = u[(vq - 1) * 3 + c]; xL[c] = x[(vq - 1) * 3 + c]; }
+      for (int c = 0; c < 3; ++c) { uL[c] = u[l * 3 + c]; xL[c] = x[l * 3 + c]; uR[c] = u[r * 3 + c]; xR[c] = x[r * 3 + c]; }
     }
-    if (xx + 4 < dm.X) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { uR[c] = u[(vq + 4) * 3 + c]; xR[c] = x[(vq + 4) * 3 + c]; }
-    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -275,14 +286,9 @@ __global__ __launch_bounds__(kThreads) void velocity_du3d_vec_kernel(const float
                      xx + i, dm.X);
       }
 #pragma unroll
-    for (int axis = 1; axis < 3; ++axis) {
-      const int k = axis == 1 ? yy : zz, n = axis == 1 ? dm.Y : dm.Z;
-      const int64_t st = axis == 1 ? sy : sz;
-      if (k > 0) { load(u, vq - st, um); load(x, vq - st, xm); }
-      if (k < n - 1) { load(u, vq + st, up); load(x, vq + st, xp); }
+    for (int e = 0; e < 12; ++e) out[e] += adj(umy[e], uo[e], upy[e], xmy[e], xo[e], xpy[e], yy, dm.Y);
 #pragma unroll
-      for (int e = 0; e < 12; ++e) out[e] += adj(um[e], uo[e], up[e], xm[e], xo[e], xp[e], k, n);
-    }
+    for (int e = 0; e < 12; ++e) out[e] += adj(umz[e], uo[e], upz[e], xmz[e], xo[e], xpz[e], zz, dm.Z);
 #pragma unroll
     for (int e = 0; e < 12; ++e) out[e] = sgn(uo[e] - xo[e]) * s1 + out[e];
     f32x4* q = reinterpret_cast<f32x4*>(so + tid * 12);

@@ -47,13 +47,15 @@ class GradSync(object):
     spent on the all-reduces, ``exposed_ms`` = time the compute stream waited for them after backward finished;
     ``hidden_ms = comm_ms - exposed_ms`` ran under backward compute."""
 
-    def __init__(self, flat_grad, buckets, group=None, profile=False):
+    def __init__(self, flat_grad, buckets, group=None, profile=False, force=False):
+        """``force=True`` runs the exchange even with world_size 1 (the -m gpu test that drives the RCCL path -- side stream,
+        hooks, async all-reduce, event profile -- on a single-GPU box, where the all-reduce is the identity)."""
         self.flat_grad = flat_grad
         self.buckets = buckets
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.enabled = self.world > 1
+        self.enabled = self.world > 1 or bool(force and dist.is_initialized())
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
         # gloo with device buffers: stage each bucket through host memory (test-only configuration: ranks sharing one GPU)
         self._host_staged = bool(self.enabled and flat_grad.is_cuda and self.backend == "gloo")

@@ -139,7 +139,7 @@ class Trainer(object):
                 self.flat_v[o:o + n].copy_(torch.from_numpy(d[k + "/Adam_1"].reshape(-1)))
             self.step = int(d["step"]); self.g_lr = float(d["g_lr"]); self._adam_t = int(d["beta_power_t"])
 
-    def enable_data_parallel(self, group=None, profile=False):
+    def enable_data_parallel(self, group=None, profile=False, force=False):
         """Bucket the flat gradient slab per generator block (fc | 4 convs | ... | last conv)."""
         groups = {}
         for k in self.var_names:
@@ -151,7 +151,7 @@ class Trainer(object):
             off = self.var_slices[ks[0]][0]
             n = sum(self.var_slices[k][1] for k in ks)
             buckets.append((off, n, [ops._VARS[k] for k in ks]))
-        self.grad_sync = GradSync(self.flat_g, buckets, group, profile=profile)
+        self.grad_sync = GradSync(self.flat_g, buckets, group, profile=profile, force=force)
         return self.grad_sync
 
     # ---- graph (trainer.py:136-172 / trainer3.py:14-51) -------------------------------------------------

@@ -20,6 +20,7 @@ int df_debug_wino_prof(unsigned long long* out, int reset);
 /* jacobian3d_fwd launch knobs: non-temporal stores on/off; XCD run length of the block remap */
 void df_debug_set_stencil_nt(int v);
 void df_debug_set_stencil_group(int v);
+void df_debug_set_stencil_lds(int v);      /* 0: register-only adjoints (jacobian3d_bwd_vec_kernel) even where the LDS-staged kernel applies */
 /* fused-tail kernel choice: 0 default dispatch, 1 16-byte quad kernels, 2 record-per-lane (12-byte load) kernels */
 void df_debug_set_tail(int v);
 

@@ -36,7 +36,7 @@ def make_batch(cfg_kw, global_batch, seed=5):
     return x, y
 
 
-def run(case, world, rank):
+def run(case, world, rank, force_sync=False):
     from deep_fluids_amd import ops, trainer as T
     from deep_fluids_amd.dist import shard_batch
     name, kw, gb, steps = make_case(case)
@@ -46,6 +46,8 @@ def run(case, world, rank):
     tr = getattr(T, name)(cfg)                              # same seed on every rank -> identical initial variables
     if world > 1:
         tr.enable_data_parallel()
+    elif force_sync:
+        tr.enable_data_parallel(profile=True, force=True)
     x, y = make_batch(kw, gb)
     xs = torch.from_numpy(x[lo:lo + n]).cuda(); ys = torch.from_numpy(y[lo:lo + n]).cuda()
     out = {"p_init": tr.flat_p.cpu().numpy()}
@@ -64,12 +66,26 @@ def run(case, world, rank):
         out["pd"] = tr.D.p.cpu().numpy()
     out["loss"] = np.float64(float(m.g_loss.detach()))
     out["g_lr"] = np.float64(tr.g_lr)
+    if force_sync:
+        t = tr.grad_sync.timing()
+        out["comm_span_ms"] = np.float64(t["comm_span_ms"]); out["exposed_ms"] = np.float64(t["exposed_ms"])
+        out["timed_steps"] = np.int64(t["steps"])
     return out
 
 
 if __name__ == "__main__":
     from deep_fluids_amd.dist import init_from_env
     case, path = sys.argv[1], sys.argv[2]
+    if len(sys.argv) > 3 and sys.argv[3] == "rccl1":
+        # ONE rank over RCCL ("nccl"), exchange forced on: the production communication path on a single-GPU box
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        res = run(case, 1, 0, force_sync=True)
+        res["backend"] = np.asarray(dist.get_backend())
+        np.savez(path, **res)
+        dist.destroy_process_group()
+        sys.exit(0)
     rank, local_rank, world = init_from_env()
     res = run(case, world, rank)
     if world > 1:
