@@ -9,10 +9,16 @@ namespace {
 using df::ceil_div;
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 2048;
+constexpr int kEwUnroll = 4;          // float4 per thread of the lrelu / add kernels (one tile per workgroup, no grid-stride loop)
 
 inline unsigned grid_for(int64_t work_items) {
   int64_t g = ceil_div(work_items, kThreads);
   return static_cast<unsigned>(g < 1 ? 1 : (g > kMaxBlocks ? kMaxBlocks : g));
+}
+
+inline unsigned ew_grid(int64_t n) {   // tiles of kEwUnroll * 256 float4; >= 1 so that the < 4-element tail is written
+  const int64_t g = ceil_div(n >> 2, static_cast<int64_t>(kEwUnroll) * kThreads);
+  return static_cast<unsigned>(g < 1 ? 1 : g);
 }
 
 // ---- block reduction: wave shuffle -> LDS -> first wave ------------------------------------------
@@ -101,14 +107,26 @@ __global__ __launch_bounds__(kThreads) void ew_kernel(const float* __restrict__ 
   const float4* a4 = reinterpret_cast<const float4*>(a);
   const float4* b4 = reinterpret_cast<const float4*>(b);
   float4* y4 = reinterpret_cast<float4*>(y);
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4;
-       i += static_cast<int64_t>(gridDim.x) * kThreads) {
-    const float4 p = a4[i];
-    float4 q = p;
-    if (OP != 0) q = b4[i];
-    float4 r;
-    r.x = f(p.x, q.x); r.y = f(p.y, q.y); r.z = f(p.z, q.z); r.w = f(p.w, q.w);
-    y4[i] = r;
+  // one workgroup = one contiguous tile of kEwUnroll * 256 float4 (16 KiB per operand); all loads first, clamped index
+  // instead of a branch.  Measured at 805 M floats: 4.9 TB/s as a grid-stride loop, the tile form below as torch's add (6.0)
+  constexpr int U = kEwUnroll;
+  const int64_t i0 = static_cast<int64_t>(blockIdx.x) * (U * kThreads) + threadIdx.x;
+  if (i0 - threadIdx.x < n4) {          // workgroup-uniform (false only for n < 4)
+    float4 p[U], q[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t i = i0 + k * kThreads;
+      const int64_t ic = i < n4 ? i : n4 - 1;
+      p[k] = a4[ic];
+      q[k] = OP != 0 ? b4[ic] : p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t i = i0 + k * kThreads;
+      float4 r;
+      r.x = f(p[k].x, q[k].x); r.y = f(p[k].y, q[k].y); r.z = f(p[k].z, q[k].z); r.w = f(p[k].w, q[k].w);
+      if (i < n4) y4[i] = r;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;
@@ -507,7 +525,7 @@ int df_lrelu_fwd(const float* x, float* y, float leak, int64_t n, df_stream_t st
   if (int e = check_n(x, n, "df_lrelu_fwd")) return e;
   DF_REQUIRE(y, DF_EINVAL, "df_lrelu_fwd: null output");
   DF_REQUIRE(df::aligned16(x) && df::aligned16(y), DF_EALIGN, "df_lrelu_fwd: 16-byte alignment");
-  hipLaunchKernelGGL((ew_kernel<0>), dim3(grid_for(ceil_div(n, 4))), dim3(kThreads), 0, df::as_stream(stream), x, x, y,
+  hipLaunchKernelGGL((ew_kernel<0>), dim3(ew_grid(n)), dim3(kThreads), 0, df::as_stream(stream), x, x, y,
                      leak, n);
   return df::launched("df_lrelu_fwd");
 }
@@ -516,7 +534,7 @@ int df_lrelu_bwd(const float* gy, const float* y, float* gx, float leak, int64_t
   if (int e = check_n(gy, n, "df_lrelu_bwd")) return e;
   DF_REQUIRE(y && gx, DF_EINVAL, "df_lrelu_bwd: null pointer");
   DF_REQUIRE(df::aligned16(gy) && df::aligned16(y) && df::aligned16(gx), DF_EALIGN, "df_lrelu_bwd: 16-byte alignment");
-  hipLaunchKernelGGL((ew_kernel<1>), dim3(grid_for(ceil_div(n, 4))), dim3(kThreads), 0, df::as_stream(stream), gy, y,
+  hipLaunchKernelGGL((ew_kernel<1>), dim3(ew_grid(n)), dim3(kThreads), 0, df::as_stream(stream), gy, y,
                      gx, leak, n);
   return df::launched("df_lrelu_bwd");
 }
@@ -525,7 +543,7 @@ int df_add(const float* a, const float* b, float* y, int64_t n, df_stream_t stre
   if (int e = check_n(a, n, "df_add")) return e;
   DF_REQUIRE(b && y, DF_EINVAL, "df_add: null pointer");
   DF_REQUIRE(df::aligned16(a) && df::aligned16(b) && df::aligned16(y), DF_EALIGN, "df_add: 16-byte alignment");
-  hipLaunchKernelGGL((ew_kernel<2>), dim3(grid_for(ceil_div(n, 4))), dim3(kThreads), 0, df::as_stream(stream), a, b, y,
+  hipLaunchKernelGGL((ew_kernel<2>), dim3(ew_grid(n)), dim3(kThreads), 0, df::as_stream(stream), a, b, y,
                      0.f, n);
   return df::launched("df_add");
 }
