@@ -67,7 +67,8 @@ def test_golden_composites(ops, golden_stencils):
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 7, 9), (1, 2, 2, 2), (3, 16, 24, 16), (1, 3, 4, 1031), (2, 33, 2, 5),
-                                   (1, 2, 2, 4), (2, 3, 2, 8), (1, 4, 3, 12), (1, 2, 5, 1028)])      # X % 4 == 0: the 4-voxels-per-thread kernels
+                                   (1, 2, 2, 4), (2, 3, 2, 8), (1, 4, 3, 12), (1, 2, 5, 1028),       # X % 4 == 0: the 4-voxels-per-thread kernels
+                                   (2, 5, 6, 112), (1, 3, 9, 128), (2, 4, 10, 132)])                  # LDS-staged adjoint up to X = 128, ragged last block
 def test_jacobian3_vs_oracle_fwd_bwd(ops, shape):
     rng = np.random.RandomState(sum(shape))
     x = rng.uniform(-1, 1, shape + (3,)).astype(np.float32)
