@@ -35,6 +35,10 @@ inline int64_t zero_row_bytes(int64_t W, int64_t Cin, int64_t Cout) {
 }
 constexpr int kSmallStreams = 2048;  // wave streams of the small-N kernel
 
+#ifdef DF_TUNING
+int g_wgrad_dbg = 0;      // df_debug_set_wgrad (include/deepfluids_hip_debug.h)
+#endif
+
 struct WgradArgs {
   const float* x;
   const float* g;
@@ -892,8 +896,16 @@ struct WxyzArgs {
 // UP: x is the COARSE tensor of an up-sampling-aware conv (fine position p reads xc[p >> 1] on every axis; a.D/H/W are the fine extents):
 // the transform points with index 2 vanish for the duplicated input, so only xi_z, xi_y in {0, 1, 3} workgroup types exist and the
 // xi_x = 2 products are skipped -- 27 of the 64 products (wgrad_up2_kernel's parity-class form needs 48 per coarse voxel).
-template <int WP8, int CS, bool GZ, bool GY, bool UP = false>
-__global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs aa) {
+// XCD-aware bijective block remap shared by the kernels below: workgroup b runs on XCD b % 8; every XCD gets a contiguous run
+__device__ __forceinline__ int wxyz_wg(int nwg) {
+  const int bid = blockIdx.x, q = nwg >> 3, rem = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+}
+
+// the work of ONE workgroup: voxel range `range`, transform point (xi_z, xi_y) number `sel` of the (GZ, GY) class
+template <int WP8, int CS, bool GZ, bool GY, bool UP, int DBG>
+__device__ __forceinline__ void wgrad_wxyz_body(const WxyzArgs& aa, int range, int sel) {
   const WgradArgs& a = aa.w;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -903,15 +915,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
   constexpr int Wc = WP8 * 8;
   const int half = lane >> 5, r = lane & 31;
 
-  constexpr int NTZ = (UP && GZ) ? 1 : 2, NTY = (UP && GY) ? 1 : 2, NT = NTZ * NTY;      // workgroup types of this launch
-  const int nwg = a.nranges * NT;
-  int wg;
-  {
-    const int bid = blockIdx.x, q = nwg >> 3, rem = nwg & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-  }
-  const int range = wg / NT, sel = wg % NT;
+  constexpr int NTY = (UP && GY) ? 1 : 2;
   const int xiz = GZ ? 1 + sel / NTY : 3 * (sel / NTY);
   const int xiy = GY ? 1 + sel % NTY : 3 * (sel % NTY);
   const int zy = xiz * 4 + xiy;                        // partial slot group
@@ -965,6 +969,10 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
         rw.g[pz][py] = (need && ok && co_ok0) ? a.g + ((bbase + gz) * a.H + gy) * a.W * a.Cout + coa : zb;
       }
     }
+    if (DBG & 1) {        // (tuning library) latency experiment: every operand load reads the cached zero row
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { rw.x[q >> 1][q & 1] = zb; rw.g[q >> 1][q & 1] = zb; }
+    }
     return rw;
   };
   const int xs = CS ? CS : a.Cin, gs = CS ? CS : a.Cout;
@@ -1006,10 +1014,12 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
     if (GZ && GY) gr[1][1][slot] = ld(lr.g[1][1], pos, gs);
   };
   auto xcomb = [&](int slot) -> f32x2 {
+    if (DBG & 2) return xr[0][0][slot];      // (tuning library) no (z, y) combination
     const f32x2 ta = pkfma(xr[0][1][slot], sy2, xr[0][0][slot]), tb = pkfma(xr[1][1][slot], sy2, xr[1][0][slot]);
     return pkfma(tb, sz2, ta);
   };
   auto gcomb = [&](int slot) -> f32x2 {
+    if (DBG & 2) return gr[0][0][slot];
     if (GZ && GY) {
       const f32x2 ta = pkfma(gr[0][1][slot], sgy2, gr[0][0][slot]), tb = pkfma(gr[1][1][slot], sgy2, gr[1][0][slot]);
       return pkfma(tb, sgz2, ta);
@@ -1031,9 +1041,10 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
     f32x2 dm = xc[(u + 7) & 7], d0 = xc[u], d1 = xc[(u + 1) & 7], d2 = xc[(u + 2) & 7];
     if (x == 0) dm = f32x2{0.f, 0.f};
     if (x == Wc - 2) d2 = f32x2{0.f, 0.f};
-    const f32x2 v0 = wpk_sub(dm, d1), v1 = wpk_add(d0, d1), v2 = wpk_sub(d1, d0), v3 = wpk_sub(d0, d2);
-    const f32x2 m1 = wpk_add(g0, g1), m2 = wpk_sub(g0, g1);
-    bsum = wpk_add(bsum, m1);
+    const f32x2 v0 = (DBG & 4) ? dm : wpk_sub(dm, d1), v1 = (DBG & 4) ? d0 : wpk_add(d0, d1), v2 = (DBG & 4) ? d1 : wpk_sub(d1, d0),
+                v3 = (DBG & 4) ? d2 : wpk_sub(d0, d2);      // (DBG & 4, tuning library: no x transform)
+    const f32x2 m1 = (DBG & 4) ? g0 : wpk_add(g0, g1), m2 = (DBG & 4) ? g1 : wpk_sub(g0, g1);
+    if (!(DBG & 4)) bsum = wpk_add(bsum, m1);
     __builtin_amdgcn_sched_barrier(0);
     load_pos(lr, (u + 6) & 7, lpos);
     load_pos(lr, (u + 7) & 7, lpos + 1);
@@ -1094,6 +1105,29 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs 
       pb[0] = bsum[0]; pb[1] = bsum[1];
     }
   }
+}
+
+template <int WP8, int CS, bool GZ, bool GY, bool UP = false, int DBG = 0>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs aa) {
+  constexpr int NT = ((UP && GZ) ? 1 : 2) * ((UP && GY) ? 1 : 2);      // workgroup types of this launch
+  const int wg = wxyz_wg(aa.w.nranges * NT);
+  wgrad_wxyz_body<WP8, CS, GZ, GY, UP, DBG>(aa, wg / NT, wg % NT);
+}
+
+// All 16 (xi_z, xi_y) types of a voxel range in ONE launch, adjacent in the grid: they run at the same time on the same XCD, so the
+// rows of x and g a range streams are fetched from the fabric once and the other 15 readers hit that XCD's L2 (four launches by
+// (GZ, GY) class re-read both tensors from HBM four times, and an HBM miss outlasts the 6-position register prefetch).
+template <int WP8, int CS, int DBG = 0>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_fused_kernel(const WxyzArgs aa) {
+  const int wg = wxyz_wg(aa.w.nranges * 16);
+  const int range = wg >> 4, type = wg & 15;
+  const int xiz = type >> 2, xiy = type & 3;
+  const bool gz = xiz == 1 || xiz == 2, gy = xiy == 1 || xiy == 2;
+  const int sel = (gz ? xiz - 1 : xiz / 3) * 2 + (gy ? xiy - 1 : xiy / 3);
+  if (gz && gy) wgrad_wxyz_body<WP8, CS, true, true, false, DBG>(aa, range, sel);
+  else if (gz) wgrad_wxyz_body<WP8, CS, true, false, false, DBG>(aa, range, sel);
+  else if (gy) wgrad_wxyz_body<WP8, CS, false, true, false, DBG>(aa, range, sel);
+  else wgrad_wxyz_body<WP8, CS, false, false, false, DBG>(aa, range, sel);
 }
 
 // gw[dz][dy][dx][ci][co] = G^T_z G^T_y G^T_x of the summed (fixed order) partials U[xi_z][xi_y][xi_x]; index 3 of every axis carries a
@@ -1918,11 +1952,12 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   // (small problems: the fixed-order reduce of the partial sums costs as much as the products -- 64 ranges measured best below
   //  4096 row pairs: 0.45 -> 0.22 ms at 16 x 8x12x8, 0.84 -> 0.67 ms at 16 x 16x24x16)
   // ... but never fewer ranges than it takes to put one workgroup on every CU: a LAUNCH has ndzdy (direct, x), ndzdy / 2 ((x,y): two
-  // launches) or 4 ((x,y,z): four launches) workgroup types -- in 2-D that is only 3 | 2 types, and 64 ranges left half of the chip
+  // launches) or 16 ((x,y,z): one launch) workgroup types -- in 2-D that is only 3 | 2 types, and 64 ranges left half of the chip
   // idle (2-D 128x96, batch 64: Winograd-(x,y) 1.59 -> 0.92 ms with 128 ranges)
-  const int per_launch = algo == 3 ? 4 : algo == 2 ? p.ndzdy / 2 : p.ndzdy;
+  const int per_launch = algo == 3 ? 16 : algo == 2 ? p.ndzdy / 2 : p.ndzdy;
   const int fill = (256 + per_launch - 1) / per_launch;
-  int heur = p.npairs < 4096 ? 64 : (algo >= 2 ? 128 : kMaxRanges);
+  // ((x,y,z), one launch of 16 types: 16 ranges = one whole round below 4096 row pairs -- 0.45 -> 0.30 ms at 16 x 16x24x16)
+  int heur = p.npairs < 4096 ? (algo == 3 ? 16 : 64) : (algo >= 2 ? 128 : kMaxRanges);
   if (algo >= 2 && heur < fill) heur = fill <= kMaxRanges ? fill : kMaxRanges;      // (the direct / x kernels measured slower with more ranges)
   const int maxr = (ranges > 0 && ranges <= kMaxRanges) ? ranges : heur;
   int nr = p.npairs >= maxr ? maxr : p.npairs;
@@ -1941,6 +1976,10 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
 }  // namespace
 
 extern "C" {
+
+#ifdef DF_TUNING
+void df_debug_set_wgrad(int v) { g_wgrad_dbg = v; }
+#endif
 
 int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
   if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
@@ -2085,14 +2124,27 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   } else if (algo == 3) {
     WxyzArgs aa;
     aa.w = a; aa.Ht = (int)(H / 2); aa.Dt = (int)(D / 2); aa.ntrows = p.nrows;
+#ifdef DF_TUNING
     const dim3 gridq((unsigned)(p.nranges * 4), grid.y, grid.z);      // 4 workgroup types per launch
-#define DF_WXYZ(WP)                                                                                         \
-  do {                                                                                                      \
-    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, true, true>), gridq, dim3(kThreads), 0, s, aa);          \
-    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, true, false>), gridq, dim3(kThreads), 0, s, aa);         \
-    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, true>), gridq, dim3(kThreads), 0, s, aa);         \
-    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, false>), gridq, dim3(kThreads), 0, s, aa);        \
+#endif
+    const dim3 gridf((unsigned)(p.nranges * 16), grid.y, grid.z);       // all 16 (xi_z, xi_y) types of a range, adjacent
+#define DF_WXYZ(WP) hipLaunchKernelGGL((wgrad_wxyz_fused_kernel<WP, 128>), gridf, dim3(kThreads), 0, s, aa)
+#ifdef DF_TUNING
+    // experiments of tools/wgrad_diag.py (W = 64 rows): four launches by (GZ, GY) class (the round-1 form) with DBGV variants
+#define DF_WXYZ_DBG(DBGV)                                                                                              \
+  do {                                                                                                                 \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<8, 128, true, true, false, DBGV>), gridq, dim3(kThreads), 0, s, aa);         \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<8, 128, true, false, false, DBGV>), gridq, dim3(kThreads), 0, s, aa);        \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<8, 128, false, true, false, DBGV>), gridq, dim3(kThreads), 0, s, aa);        \
+    hipLaunchKernelGGL((wgrad_wxyz_kernel<8, 128, false, false, false, DBGV>), gridq, dim3(kThreads), 0, s, aa);       \
   } while (0)
+    if (W == 64 && g_wgrad_dbg == 1) DF_WXYZ_DBG(1); else if (W == 64 && g_wgrad_dbg == 2) DF_WXYZ_DBG(2);
+    else if (W == 64 && g_wgrad_dbg == 3) DF_WXYZ_DBG(3); else if (W == 64 && g_wgrad_dbg == 6) DF_WXYZ_DBG(6);
+    else if (W == 64 && g_wgrad_dbg == 7) DF_WXYZ_DBG(7); else if (W == 64 && g_wgrad_dbg == 8) DF_WXYZ_DBG(0);
+    else if (W == 64 && g_wgrad_dbg == 9) hipLaunchKernelGGL((wgrad_wxyz_fused_kernel<8, 128, 1>), gridf, dim3(kThreads), 0, s, aa);
+    else
+#undef DF_WXYZ_DBG
+#endif
     if (W == 64) DF_WXYZ(8); else if (W == 32) DF_WXYZ(4); else if (W == 16) DF_WXYZ(2); else if (W == 112) DF_WXYZ(14); else if (W == 128) DF_WXYZ(16); else DF_WXYZ(7);
 #undef DF_WXYZ
     const int64_t rgx = ceil_div(Cin * Cout, 32);

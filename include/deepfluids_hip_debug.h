@@ -23,6 +23,9 @@ void df_debug_set_stencil_group(int v);
 void df_debug_set_stencil_lds(int v);      /* 0: register-only adjoints (jacobian3d_bwd_vec_kernel) even where the LDS-staged kernel applies */
 /* fused-tail kernel choice: 0 default dispatch, 1 16-byte quad kernels, 2 record-per-lane (12-byte load) kernels */
 void df_debug_set_tail(int v);
+void df_debug_set_wgrad(int v);            /* wgrad_wxyz_kernel experiments (results wrong by construction): bit 1 = every operand load reads
+                                             the cached zero row (no memory latency), 2 = no (z, y) operand combinations, 4 = no x transform; values
+                                             1, 2, 3, 6, 7 are instantiated (W = 64 rows) */
 
 #ifdef __cplusplus
 }
