@@ -23,6 +23,7 @@ namespace {
 using df::ceil_div;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
 constexpr int kMaxRanges = 256;
@@ -1645,7 +1646,7 @@ template <int CT, int NJ, bool SWAP, int NP>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_thin_mfma_kernel(const ThinWgradArgs a) {
   constexpr int NM = 27 * CT, MB = (NM + 31) / 32, MBC = (13 * CT) / 32;      // MBC: the M block that holds the centre tap
   constexpr int NCH = NJ * 32;
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
+
   typedef float vt __attribute__((ext_vector_type(NJ)));
   extern __shared__ __attribute__((aligned(16))) float smem_thin[];
   const int lane = threadIdx.x & 63;

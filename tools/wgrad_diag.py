@@ -22,7 +22,7 @@ for (B, D, H, W) in ((16, 64, 96, 64), (4, 64, 96, 64)):
     ws = torch.empty((nb + 3) // 4, device="cuda")
     gw = torch.empty((27, C, C), device="cuda"); gb = torch.empty(C, device="cuda")
     fl = 2.0 * 27 * C * C * B * D * H * W / 3.375
-    for dbg in (0, 8, 9, 1, 7):
+    for dbg in (0, 8, 9, 1, 3, 7):
         lib().df_debug_set_wgrad(ctypes.c_int(dbg))
         f = lambda: call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, 4, s)
         f(); torch.cuda.synchronize()
@@ -33,6 +33,6 @@ for (B, D, H, W) in ((16, 64, 96, 64), (4, 64, 96, 64)):
         lib().df_debug_set_wgrad(ctypes.c_int(dbg))
         call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, 4, s)
         res[dbg] = (gw.clone(), gb.clone())
-    print("  fused launch (8) vs four launches (0): gw equal %s, gb equal %s" % (torch.equal(res[0][0], res[8][0]), torch.equal(res[0][1], res[8][1])))
+    print("  one fused launch (0) vs four launches (8): gw equal %s, gb equal %s" % (torch.equal(res[0][0], res[8][0]), torch.equal(res[0][1], res[8][1])))
     lib().df_debug_set_wgrad(ctypes.c_int(0))
     del x, g, ws
