@@ -19,7 +19,7 @@ FAMILIES = [  # (key, regex on the kernel name, algorithmic read bytes, algorith
     ("velocity_du3d (tail backward, before the curl3 adjoint)", r"velocity_du3d_vec_kernel", 150994944, 75497472),
     ("wino3d_kernel<fwd>", r"wino3d_kernel<0, 9, 0>", 3221225472, 3221225472),
     ("wino3d_kernel<dgrad+mask>", r"wino3d_kernel<0, 4, 0>", 6442450944, 3221225472),
-    ("wgrad_wxyz_kernel(4 launches)", r"wgrad_wxyz_kernel<8, 128", 6442450944, 1769472),
+    ("wgrad_wxyz_kernel(16 types)", r"wgrad_wxyz_(fused_)?kernel<8, 128", 6442450944, 1769472),
     ("wgrad_wxyz_reduce_kernel", r"wgrad_wxyz_reduce_kernel", 0, 1769472),
 ]
 
