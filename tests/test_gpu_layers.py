@@ -218,14 +218,17 @@ def test_linear_upsample_lrelu_add(ops):
         np.testing.assert_array_equal(host(up), orc.upscale_nn(a))
         (up * dev(g)).sum().backward()
         assert rel_linf(host(at.grad), orc.upscale_nn_bwd(g.astype(np.float64))) < 1e-6
-    a = rng.uniform(-1, 1, (1003,)).astype(np.float32)
-    c = rng.uniform(-1, 1, (1003,)).astype(np.float32)
-    at = dev(a).requires_grad_(True)
-    y = ops.lrelu(at)
-    np.testing.assert_array_equal(host(y), orc.lrelu(a).astype(np.float32))
-    (y * dev(c)).sum().backward()
-    np.testing.assert_array_equal(host(at.grad), (c * np.where(a > 0, 1.0, 0.2).astype(np.float32)))
-    np.testing.assert_array_equal(host(ops.add(dev(a), dev(c))), a + c)
+    # sizes around the element-wise kernels' tile (4 x 256 float4 per workgroup): fewer than one float4, a ragged float4 tail, exactly
+    # one tile, one element more, several tiles with a partial last one
+    for n in (1, 3, 5, 1003, 4096, 4097, 3 * 4096 + 7, 1 << 20):
+        a = rng.uniform(-1, 1, (n,)).astype(np.float32)
+        c = rng.uniform(-1, 1, (n,)).astype(np.float32)
+        at = dev(a).requires_grad_(True)
+        y = ops.lrelu(at)
+        np.testing.assert_array_equal(host(y), orc.lrelu(a).astype(np.float32))
+        (y * dev(c)).sum().backward()
+        np.testing.assert_array_equal(host(at.grad), (c * np.where(a > 0, 1.0, 0.2).astype(np.float32)))
+        np.testing.assert_array_equal(host(ops.add(dev(a), dev(c))), a + c)
 
 
 def test_l1_mean_and_adam(ops):
