@@ -40,6 +40,7 @@ SIGNATURES = {
     "df_add": (I32, [P, P, P, I64, P]),
     "df_upsample2x_fwd": (I32, [P, P, I64, I64, I64, I64, I64, I32, P]),
     "df_upsample2x_bwd": (I32, [P, P, I64, I64, I64, I64, I64, I32, P]),
+    "df_lrelu_bwd_pool2x": (I32, [P, P, P, P, F32, I64, I64, I64, I64, I64, I32, P]),
     "df_linear_workspace_bytes": (I64, [I64, I64, I64]),
     "df_linear_fwd": (I32, [P, P, P, P, I64, I64, I64, P, I64, P]),
     "df_linear_bwd": (I32, [P, P, P, P, P, P, I64, I64, I64, P]),

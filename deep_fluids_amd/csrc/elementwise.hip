@@ -384,6 +384,49 @@ __global__ __launch_bounds__(kThreads) void upsample_bwd_kernel(const float4* __
   }
 }
 
+// The tail of an up-sampling generator block in backward (model.py:36-40 / 78-82): from the incoming gradient dy of
+// `lrelu(conv4(.)) + upscale(xc)` BOTH consumers in one pass over dy --
+//   gx   = dy * (y > 0 ? 1 : leak)        (the gradient entering conv4: df_lrelu_bwd)
+//   gpool = 2x2(x2) sum-pool of dy         (the skip path's gradient w.r.t. xc: df_upsample2x_bwd)
+// One thread = one coarse voxel x 4 channels: its 4 | 8 fine float4 of dy and y are read once; summation order (dz, dy, dx)
+// ascending as upsample_bwd_kernel (bit-identical results).
+template <bool IS3D>
+__global__ __launch_bounds__(kThreads) void lrelu_bwd_pool_kernel(const float4* __restrict__ gy, const float4* __restrict__ y,
+                                                                  float4* __restrict__ gx, float4* __restrict__ gpool, float leak,
+                                                                  int64_t nsrc4, int D, int H, int W, int C4) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= nsrc4) return;
+  const int c = static_cast<int>(i % C4);
+  int64_t r = i / C4;
+  const int w = static_cast<int>(r % W); r /= W;
+  const int h = static_cast<int>(r % H); r /= H;
+  const int d = static_cast<int>(r % D);
+  const int64_t b = r / D;
+  const int64_t W2 = 2 * W, H2 = 2 * H;
+  const int64_t D2 = IS3D ? 2 * D : 1;
+  constexpr int ND = IS3D ? 2 : 1;
+  float4 g[ND * 4], a[ND * 4];
+  int64_t idx[ND * 4];
+#pragma unroll
+  for (int k = 0; k < ND * 4; ++k) {
+    const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+    const int64_t zz = IS3D ? 2 * d + dz : 0;
+    idx[k] = (((b * D2 + zz) * H2 + (2 * h + dy)) * W2 + (2 * w + dx)) * C4 + c;
+  }
+#pragma unroll
+  for (int k = 0; k < ND * 4; ++k) { g[k] = gy[idx[k]]; a[k] = y[idx[k]]; }      // all loads first
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < ND * 4; ++k) {
+    acc.x += g[k].x; acc.y += g[k].y; acc.z += g[k].z; acc.w += g[k].w;
+    float4 o;
+    o.x = a[k].x > 0.f ? g[k].x : leak * g[k].x; o.y = a[k].y > 0.f ? g[k].y : leak * g[k].y;
+    o.z = a[k].z > 0.f ? g[k].z : leak * g[k].z; o.w = a[k].w > 0.f ? g[k].w : leak * g[k].w;
+    gx[idx[k]] = o;
+  }
+  gpool[i] = acc;
+}
+
 // y = a + nearest_up2x(bc): the block-end residual add when the block input is kept only at the coarse resolution
 template <bool IS3D>
 __global__ __launch_bounds__(kThreads) void add_up_kernel(const float4* __restrict__ a, const float4* __restrict__ bc,
@@ -584,6 +627,30 @@ int df_upsample2x_bwd(const float* gy, float* gx, int64_t B, int64_t D, int64_t 
     hipLaunchKernelGGL((upsample_bwd_kernel<false>), dim3(grid_for(n4)), dim3(kThreads), 0, df::as_stream(stream), g4, x4,
                        n4, (int)D, (int)H, (int)W, (int)(C / 4));
   return df::launched("df_upsample2x_bwd");
+}
+
+int df_lrelu_bwd_pool2x(const float* gy, const float* y, float* gx, float* gpool, float leak, int64_t B, int64_t D, int64_t H,
+                        int64_t W, int64_t C, int is_3d, df_stream_t stream) {
+  DF_REQUIRE(gy && y && gx && gpool, DF_EINVAL, "df_lrelu_bwd_pool2x: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, DF_EINVAL, "df_lrelu_bwd_pool2x: non-positive extent");
+  DF_REQUIRE(C % 4 == 0, DF_ESHAPE, "df_lrelu_bwd_pool2x: C must be a multiple of 4 (got %lld)", (long long)C);
+  DF_REQUIRE(is_3d || D == 1, DF_ESHAPE, "df_lrelu_bwd_pool2x: D must be 1 for 2-D");
+  DF_REQUIRE(df::aligned16(gy) && df::aligned16(y) && df::aligned16(gx) && df::aligned16(gpool), DF_EALIGN,
+             "df_lrelu_bwd_pool2x: 16-byte alignment");
+  const int64_t n4 = B * D * H * W * (C / 4);
+  DF_REQUIRE(ceil_div(n4, kThreads) < (1LL << 31), DF_ESHAPE, "df_lrelu_bwd_pool2x: tensor too large");
+  const dim3 grid((unsigned)ceil_div(n4, kThreads));
+  const float4* g4 = reinterpret_cast<const float4*>(gy);
+  const float4* y4 = reinterpret_cast<const float4*>(y);
+  float4* x4 = reinterpret_cast<float4*>(gx);
+  float4* p4 = reinterpret_cast<float4*>(gpool);
+  if (is_3d)
+    hipLaunchKernelGGL((lrelu_bwd_pool_kernel<true>), grid, dim3(kThreads), 0, df::as_stream(stream), g4, y4, x4, p4, leak, n4, (int)D,
+                       (int)H, (int)W, (int)(C / 4));
+  else
+    hipLaunchKernelGGL((lrelu_bwd_pool_kernel<false>), grid, dim3(kThreads), 0, df::as_stream(stream), g4, y4, x4, p4, leak, n4, (int)D,
+                       (int)H, (int)W, (int)(C / 4));
+  return df::launched("df_lrelu_bwd_pool2x");
 }
 
 int64_t df_linear_workspace_bytes(int64_t B, int64_t K, int64_t N) {

@@ -483,9 +483,15 @@ class _UpGenBlock(torch.autograd.Function):
         B, D, H, W = fdims
         dy = _prep(dy, "grad")
         dp = torch.empty_like(dy)
-        call("df_lrelu_bwd", _ptr(dy), _ptr(xs[n - 1]), _ptr(dp), leak, dy.numel(), _stream())
-        grads = [None] * (2 * n)
         dxc = None
+        if ctx.needs_input_grad[0]:
+            # both consumers of dy in one pass: the masked gradient entering the last conv and the skip path's 2x2(x2) sum-pool
+            dxc = torch.empty_like(xc)
+            call("df_lrelu_bwd_pool2x", _ptr(dy), _ptr(xs[n - 1]), _ptr(dp), _ptr(dxc), leak, cdims[0], cdims[1], cdims[2], cdims[3], C,
+                 int(is3d), _stream())
+        else:
+            call("df_lrelu_bwd", _ptr(dy), _ptr(xs[n - 1]), _ptr(dp), leak, dy.numel(), _stream())
+        grads = [None] * (2 * n)
         for i in range(n, 0, -1):
             w = ws[i - 1]
             gw = torch.empty_like(w)
@@ -506,9 +512,7 @@ class _UpGenBlock(torch.autograd.Function):
                     call("df_upconv_wgrad_algo", _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
                          cdims[3], C, C, kz, _ptr(wsb), nbytes, int(WGRAD_ALGO), _stream())
                 if ctx.needs_input_grad[0]:
-                    dxc = torch.empty_like(xc)          # skip path: sum-pool of dy, then += the conv path per parity class
-                    call("df_upsample2x_bwd", _ptr(dy), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, int(is3d),
-                         _stream())
+                    # dxc holds the skip path's sum-pool of dy (df_lrelu_bwd_pool2x above); += the conv path per parity class
                     if is3d and _use_wino(C, C, fdims, kz) == 3:
                         # pooled-output Winograd form (conv_wino.hip, POOL variant): 27 of the 64 products, coarse stores
                         wpd = _pack(w, taps, C, C, 1, fdims)

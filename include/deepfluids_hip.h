@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DF_VERSION 200 /* 0.2.0: + df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d */
+#define DF_VERSION 201 /* 0.2.1: + df_lrelu_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
 
 enum {
   DF_OK = 0,
@@ -127,6 +127,12 @@ int df_add(const float* a, const float* b, float* y, int64_t n, df_stream_t stre
  * upscale ops.py:75-77 (D=1), upscale3 ops.py:79-91.  x [B,D,H,W,C] -> y [B,2D|1,2H,2W,C]; C % 4 == 0. */
 int df_upsample2x_fwd(const float* x, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
                       df_stream_t stream);
+/* The backward tail of an up-sampling generator block (`x = lrelu(conv4(.)) + upscale(xc)`, model.py:36-40 / 78-82) in ONE pass
+ * over the incoming gradient: gx = gy * (y > 0 ? 1 : leak)  (== df_lrelu_bwd; y = conv4's saved output, fine resolution
+ * [B,2D|1,2H,2W,C]) and gpool = 2x2(x2) sum-pool of gy  (== df_upsample2x_bwd, the skip gradient w.r.t. xc, [B,D,H,W,C]).
+ * B, D, H, W are the COARSE extents; C % 4 == 0.  Bit-identical to the two separate calls. */
+int df_lrelu_bwd_pool2x(const float* gy, const float* y, float* gx, float* gpool, float leak, int64_t B, int64_t D, int64_t H,
+                        int64_t W, int64_t C, int is_3d, df_stream_t stream);
 /* adjoint (2x2(x2) sum-pool): gy [B,2D|1,2H,2W,C] -> gx [B,D,H,W,C]. */
 int df_upsample2x_bwd(const float* gy, float* gx, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
                       df_stream_t stream);

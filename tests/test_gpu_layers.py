@@ -572,3 +572,26 @@ def test_sign_bit_masks_are_bit_identical_to_activation_masks(ops, shape, C, up)
         ops.CONV_ALGO, ops.SIGN_BIT_MASKS = old_algo, old_bits
     for a, b in zip(*res):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7, 8), (1, 1, 4, 6, 12), (3, 2, 2, 2, 128), (2, 8, 12, 8, 128)])
+def test_lrelu_bwd_pool2x_equals_the_two_separate_passes(ops, shape):
+    """df_lrelu_bwd_pool2x (the backward tail of an up-sampling generator block in one pass over dy) == df_lrelu_bwd + df_upsample2x_bwd,
+    bit for bit, 3-D and 2-D (D = 1 shapes run both ways)."""
+    from deep_fluids_amd._lib import call
+    from deep_fluids_amd.ops import _ptr, _stream
+    B, D, H, W, C = shape
+    for is3d in ((1, 0) if D == 1 else (1,)):
+        fD = 2 * D if is3d else 1
+        g = torch.Generator(device="cuda").manual_seed(sum(shape) + is3d)
+        dy = torch.rand((B, fD, 2 * H, 2 * W, C), device="cuda", generator=g) * 2 - 1
+        y = torch.rand((B, fD, 2 * H, 2 * W, C), device="cuda", generator=g) * 2 - 1
+        y[0, 0, 0, 0, :4] = 0.0                                                     # y == 0 takes the leak branch (y > 0 is false)
+        gx1 = torch.empty_like(dy); p1 = torch.empty((B, D if is3d else 1, H, W, C), device="cuda")
+        gx2 = torch.empty_like(dy); p2 = torch.empty_like(p1)
+        call("df_lrelu_bwd_pool2x", _ptr(dy), _ptr(y), _ptr(gx1), _ptr(p1), 0.2, B, D if is3d else 1, H, W, C, is3d, _stream())
+        call("df_lrelu_bwd", _ptr(dy), _ptr(y), _ptr(gx2), 0.2, dy.numel(), _stream())
+        call("df_upsample2x_bwd", _ptr(dy), _ptr(p2), B, D if is3d else 1, H, W, C, is3d, _stream())
+        assert torch.equal(gx1, gx2) and torch.equal(p1, p2)
+        ref = torch.where(y > 0, dy, 0.2 * dy)
+        assert torch.equal(gx1, ref)

@@ -20,6 +20,8 @@ def run(B, D, H, W, C, N, kz=3, iters=3):
     g = torch.rand((B, D, H, W, N), device="cuda") * 2 - 1
     taps = 27 if kz == 3 else 9
     nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, N, kz)
+    if RANGES:
+        nb = max(nb, RANGES * 64 * 128 * 128 * 4 * 2 + (1 << 20))      # room for a caller-chosen number of partial ranges
     ws = torch.empty((nb + 3) // 4, device="cuda")
     out = []
     for algo in (1, 2, 3, 4, 0):
