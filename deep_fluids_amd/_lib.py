@@ -71,6 +71,8 @@ SIGNATURES = {
     "df_wino_pack_weights": (I32, [P, P, I64, I64, I32, P]),
     "df_wino_conv_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, F32, P]),
     "df_wino_conv_fwd_addup": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, F32, P]),
+    "df_wino_conv_fwd_addup_bits": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, F32, P]),
+    "df_lrelu_bits_bwd_pool2x": (I32, [P, P, P, P, F32, I64, I64, I64, I64, I64, P]),
     "df_wino_upconv_fwd": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, F32, P]),
     "df_wino_upconv_dgrad": (I32, [P, P, P, I64, I64, I64, I64, I64, I64, P]),
     "df_wino_signbits_bytes": (I64, [I64, I64, I64, I64, I64]),

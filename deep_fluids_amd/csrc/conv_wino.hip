@@ -46,6 +46,8 @@ constexpr int BUF = CKW * CP;             // dwords per LDS buffer
 //              (what a later masked dgrad of the same geometry needs of it: 1/32 of the activation's bytes);
 //   kMaskBits: DF_CONV_MASK reads those bytes (2 byte loads per lane and tile block) instead of 16 fp32 activations per lane.
 constexpr int kSignBits = 64, kMaskBits = 128;
+constexpr int kNoPrimary = 256;            // with DF_CONV_ADDUP + kSignBits: y (the pre-add activation) is NOT written -- its sign bits are all
+                                           // the backward pass needs of it (df_wino_conv_fwd_addup_bits / df_lrelu_bits_bwd_pool2x)
 constexpr int kBitBytesPerBlock = 1024;    // 8 waves x 2 cout blocks x 64 lanes, per (tile block, cout slice)
 constexpr int kZeroFloats = 1024;         // zeroed tail of the packed weights: SAME padding reads it, one 64-byte step per chunk
 
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       const int64_t obase = (((static_cast<int64_t>(cur.b) * a.D + oz0) * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl;
       const bool full = cur.z0 + 4 <= a.D && cur.y0 + 8 <= a.H && cur.x0 + 8 <= a.W;
       const unsigned lane_off = static_cast<unsigned>(((oz0 * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl) * 4u;      // bytes within the batch volume
-      constexpr bool SB = FL >= 0 && (FL & kSignBits) != 0, MB = FL >= 0 && (FL & kMaskBits) != 0;
+      constexpr bool SB = FL >= 0 && (FL & kSignBits) != 0, MB = FL >= 0 && (FL & kMaskBits) != 0, NOY = FL >= 0 && (FL & kNoPrimary) != 0;
       if (full && (eflags & DF_CONV_MASK) && !MB) mask_dma();
       const int64_t wbase = (static_cast<int64_t>(cur.id) * a.ncs + cs) * kBitBytesPerBlock + wave * 128 + lane;
       float rres[2][8];
@@ -577,8 +579,8 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
             // wave-uniform base (batch volume + this output's scalar offset) + 32-bit lane offset: no 64-bit address per output
             char* yb = reinterpret_cast<char*>(a.y + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
                                                ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
-            if (DBG & 512) asm volatile("" :: "v"(v)); else      // (experiment: no stores)
-            *reinterpret_cast<float*>(yb + lane_off) = v;
+            if (DBG & 512) asm volatile("" :: "v"(v));      // (experiment: no stores)
+            else if (!NOY) *reinterpret_cast<float*>(yb + lane_off) = v;
             if (eflags & DF_CONV_ADDUP) {
               char* yb2 = reinterpret_cast<char*>(a.y2 + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
                                                   ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           } else if (oz0 + (s >> 2) < a.D && oy0 + ((s >> 1) & 1) < a.H && ox0 + (s & 1) < a.W) {
             if (eflags & DF_CONV_RESIDUAL) v += a.residual[o];
             if (eflags & DF_CONV_MASK) v = (MB ? mpos : a.mask_src[o] > 0.f) ? v : a.leak * v;
-            a.y[o] = v;
+            if (!NOY) a.y[o] = v;
             if (eflags & DF_CONV_ADDUP) a.y2[o] = v + rup;
           }
         }
@@ -608,6 +610,51 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     pb = (pb + nchunk) & 1;
     cur = nxt;
   }
+}
+
+// The backward tail of an up-sampling generator block from the SIGN BITS of its last conv (kSignBits of wino3d_kernel):
+//   gx = gy * (bit ? 1 : leak),   gpool = 2x2x2 sum-pool of gy.
+// One thread = one coarse voxel x 4 channels.  The 8 fine voxels under a coarse voxel are exactly the 8 outputs of ONE lane of the
+// producing kernel's epilogue (oz0 = z0 + 2 th, oy0 = y0 + 2 kq, ox0 = x0 + 2 xi_z; bit s = (dz, dy, dx)), so the 8 signs of a channel
+// are one byte and the thread's 4 channels one aligned 32-bit word.  Summation order (dz, dy, dx) ascending as upsample_bwd_kernel.
+__global__ __launch_bounds__(256) void lrelu_bits_bwd_pool_kernel(const float4* __restrict__ gy, const unsigned* __restrict__ bits,
+                                                                  float4* __restrict__ gx, float4* __restrict__ gpool, float leak,
+                                                                  int64_t nsrc4, int Dc, int Hc, int Wc, int C4, int nbz, int nby, int nbx,
+                                                                  int ncs) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= nsrc4) return;
+  const int c4 = static_cast<int>(i % C4);
+  int64_t r = i / C4;
+  const int xc = static_cast<int>(r % Wc); r /= Wc;
+  const int yc = static_cast<int>(r % Hc); r /= Hc;
+  const int zc = static_cast<int>(r % Dc);
+  const int64_t b = r / Dc;
+  const int64_t id = ((b * nbz + (zc >> 1)) * nby + (yc >> 2)) * nbx + (xc >> 2);
+  const int wave = (zc & 1) * 4 + (xc & 3), kq = yc & 3;
+  const int cs = c4 >> 3, nb = (c4 >> 2) & 1, tl = (c4 & 3) * 4;
+  const unsigned word = bits[((id * ncs + cs) * kBitBytesPerBlock + wave * 128 + nb * 64 + kq * 16 + tl) >> 2];
+  const int64_t W2 = 2 * Wc, H2 = 2 * Hc, D2 = 2 * Dc;
+  float4 g[8];
+  int64_t idx[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+    idx[k] = (((b * D2 + (2 * zc + dz)) * H2 + (2 * yc + dy)) * W2 + (2 * xc + dx)) * C4 + c4;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) g[k] = gy[idx[k]];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    acc.x += g[k].x; acc.y += g[k].y; acc.z += g[k].z; acc.w += g[k].w;
+    float4 o;
+    o.x = ((word >> k) & 1u) ? g[k].x : leak * g[k].x;
+    o.y = ((word >> (8 + k)) & 1u) ? g[k].y : leak * g[k].y;
+    o.z = ((word >> (16 + k)) & 1u) ? g[k].z : leak * g[k].z;
+    o.w = ((word >> (24 + k)) & 1u) ? g[k].w : leak * g[k].w;
+    gx[idx[k]] = o;
+  }
+  gpool[i] = acc;
 }
 
 #ifdef DF_TUNING      // instrumented kernel variants + knobs of the tuning library only (include/deepfluids_hip_debug.h)
@@ -871,6 +918,49 @@ int df_wino_conv_fwd_addup(const float* x, const float* wp, const float* bias, c
   const int64_t grid = wino_grid(a, ntb);
   hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_ADDUP>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
   return df::launched("df_wino_conv_fwd_addup");
+}
+
+int df_wino_conv_fwd_addup_bits(const float* x, const float* wp, const float* bias, const float* xc, float* y2, void* sign_bits,
+                                int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, float leak, df_stream_t stream) {
+  DF_REQUIRE(x && wp && bias && xc && y2 && sign_bits, DF_EINVAL, "df_wino_conv_fwd_addup_bits: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, DF_EINVAL,
+             "df_wino_conv_fwd_addup_bits: extents must be positive and even (the output of a 2x up-sampling block)");
+  DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE, "df_wino_conv_fwd_addup_bits: Cin, Cout must be multiples of 32");
+  DF_REQUIRE(D * H * W * (Cin > Cout ? Cin : Cout) <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
+             "df_wino_conv_fwd_addup_bits: one batch volume must stay below 2 GiB");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x) && df::aligned16(sign_bits), DF_EALIGN,
+             "df_wino_conv_fwd_addup_bits: x, packed weights and bit words must be 16-byte aligned");
+  WinoArgs a;
+  a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
+  a.bias = bias; a.residual = xc; a.mask_src = nullptr; a.y = nullptr; a.y2 = y2;
+  a.bits_out = static_cast<unsigned char*>(sign_bits); a.bits_in = nullptr;
+  a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.nbz = (int)ceil_div(D, 4); a.nby = (int)ceil_div(H, 8); a.nbx = (int)ceil_div(W, 8);
+  const int64_t ntb = B * a.nbz * a.nby * a.nbx;
+  a.ncs = (int)(Cout / 32);
+  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino_conv_fwd_addup_bits: too many workgroups");
+  a.ntb = (int)ntb;
+  a.flags = DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_ADDUP; a.leak = leak;
+  const int64_t grid = wino_grid(a, ntb);
+  hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_ADDUP | kSignBits | kNoPrimary>), dim3((unsigned)grid), dim3(kT), 0,
+                     df::as_stream(stream), a);
+  return df::launched("df_wino_conv_fwd_addup_bits");
+}
+
+int df_lrelu_bits_bwd_pool2x(const float* gy, const void* mask_bits, float* gx, float* gpool, float leak, int64_t B, int64_t Dc, int64_t Hc,
+                             int64_t Wc, int64_t C, df_stream_t stream) {
+  DF_REQUIRE(gy && mask_bits && gx && gpool, DF_EINVAL, "df_lrelu_bits_bwd_pool2x: null pointer");
+  DF_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0, DF_EINVAL, "df_lrelu_bits_bwd_pool2x: non-positive extent");
+  DF_REQUIRE(C > 0 && C % 32 == 0, DF_ESHAPE, "df_lrelu_bits_bwd_pool2x: C must be a multiple of 32 (the sign bits' cout slices)");
+  DF_REQUIRE(df::aligned16(gy) && df::aligned16(gx) && df::aligned16(gpool) && df::aligned16(mask_bits), DF_EALIGN,
+             "df_lrelu_bits_bwd_pool2x: 16-byte alignment");
+  const int64_t n4 = B * Dc * Hc * Wc * (C / 4);
+  DF_REQUIRE(ceil_div(n4, 256) < (1LL << 31), DF_ESHAPE, "df_lrelu_bits_bwd_pool2x: tensor too large");
+  hipLaunchKernelGGL(lrelu_bits_bwd_pool_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, df::as_stream(stream),
+                     reinterpret_cast<const float4*>(gy), static_cast<const unsigned*>(mask_bits), reinterpret_cast<float4*>(gx),
+                     reinterpret_cast<float4*>(gpool), leak, n4, (int)Dc, (int)Hc, (int)Wc, (int)(C / 4), (int)ceil_div(2 * Dc, 4),
+                     (int)ceil_div(2 * Hc, 8), (int)ceil_div(2 * Wc, 8), (int)(C / 32));
+  return df::launched("df_lrelu_bits_bwd_pool2x");
 }
 
 }  // extern "C"

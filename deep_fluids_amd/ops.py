@@ -423,6 +423,7 @@ class _UpGenBlock(torch.autograd.Function):
         xs = []
         bits = []
         y = None
+        tail_bits = None
         for i in range(n):
             w = _prep(wb[2 * i], "weights"); b = _prep(wb[2 * i + 1], "biases")
             cin, cout = w.shape[-2], w.shape[-1]
@@ -456,8 +457,16 @@ class _UpGenBlock(torch.autograd.Function):
                      kz, DF_CONV_BIAS | DF_CONV_LRELU, float(leak), _stream())
             else:
                 wp = _pack(w, taps, cin, cout, 0, fdims)
-                if i == n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3:
-                    # block-end skip add fused into the last conv's epilogue: second output y = x + upscale(xc)
+                if i == n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3 and SIGN_BIT_MASKS and ACTIVATION_FETCH is None:
+                    # block-end skip add fused into the last conv's epilogue, and of the conv's own activation only the sign bits are
+                    # kept (all the backward tail needs of it): y = lrelu(conv(x)) + upscale(xc), tail_bits = (lrelu(conv(x)) > 0)
+                    tail_bits = _new_bits(fdims, cout, xc)
+                    y = torch.empty(fshape, dtype=torch.float32, device=xc.device)
+                    call("df_wino_conv_fwd_addup_bits", _ptr(x), _ptr(wp), _ptr(b), _ptr(xc), _ptr(y), _ptr(tail_bits), fdims[0], fdims[1],
+                         fdims[2], fdims[3], cin, cout, float(leak), _stream())
+                    x = None
+                elif i == n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3:
+                    # (fp32 masks: the activation is a second output)
                     x_in, x = x, torch.empty(fshape, dtype=torch.float32, device=xc.device)
                     y = torch.empty(fshape, dtype=torch.float32, device=xc.device)
                     call("df_wino_conv_fwd_addup", _ptr(x_in), _ptr(wp), _ptr(b), _ptr(xc), _ptr(x), _ptr(y), fdims[0], fdims[1],
@@ -473,6 +482,7 @@ class _UpGenBlock(torch.autograd.Function):
         ctx.save_for_backward(*([xc] + xs + [wb[2 * i] for i in range(n)]))
         ctx.geom = (n, cdims, fdims, kz, taps, float(leak), C, is3d)
         ctx.bits = bits
+        ctx.tail_bits = tail_bits
         return y
 
     @staticmethod
@@ -484,7 +494,13 @@ class _UpGenBlock(torch.autograd.Function):
         dy = _prep(dy, "grad")
         dp = torch.empty_like(dy)
         dxc = None
-        if ctx.needs_input_grad[0]:
+        if ctx.tail_bits is not None:
+            # the lrelu mask of the last conv from its sign bits (its fp32 activation was never written): 6.9 GB moved at the cfg3 top
+            # level instead of 12.9; the pooled skip gradient comes with it (dropped below if xc needs no gradient)
+            dxc = torch.empty_like(xc)
+            call("df_lrelu_bits_bwd_pool2x", _ptr(dy), _ptr(ctx.tail_bits), _ptr(dp), _ptr(dxc), leak, cdims[0], cdims[1], cdims[2], cdims[3],
+                 C, _stream())
+        elif ctx.needs_input_grad[0]:
             # both consumers of dy in one pass: the masked gradient entering the last conv and the skip path's 2x2(x2) sum-pool
             dxc = torch.empty_like(xc)
             call("df_lrelu_bwd_pool2x", _ptr(dy), _ptr(xs[n - 1]), _ptr(dp), _ptr(dxc), leak, cdims[0], cdims[1], cdims[2], cdims[3], C,
@@ -529,7 +545,7 @@ class _UpGenBlock(torch.autograd.Function):
                         call("df_upconv_dgrad" + sfx, _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, C,
                              kz, _stream())
             grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
-        return (dxc, None) + tuple(grads)
+        return (dxc if ctx.needs_input_grad[0] else None, None) + tuple(grads)
 
 
 class _ConvSame3S2(torch.autograd.Function):

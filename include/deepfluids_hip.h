@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DF_VERSION 201 /* 0.2.1: + df_lrelu_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
+#define DF_VERSION 201 /* 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
 
 enum {
   DF_OK = 0,
@@ -271,6 +271,15 @@ int df_wino_conv_fwd_bits(const float* x, const float* wp, const float* bias, co
                           int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream);
 int df_wino_upconv_fwd_bits(const float* xc, const float* wp, const float* bias, float* y, void* sign_bits, int64_t B, int64_t Dc,
                             int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, float leak, df_stream_t stream);
+/* The block tail on sign bits: df_wino_conv_fwd_addup without its first output -- y2 = lrelu(conv_same(x, w) + bias) + nearest_up2x(xc)
+ * and the sign bits of the lrelu output (sized by df_wino_signbits_bytes(B, D, H, W, Cout)); the pre-add activation itself (3.2 GB per
+ * top-level layer at cfg3) is never written.  df_lrelu_bits_bwd_pool2x is the matching backward tail (== df_lrelu_bwd_pool2x with the
+ * mask read from those bits: gx = gy * (bit ? 1 : leak), gpool = 2x2x2 sum-pool of gy); B, Dc, Hc, Wc the COARSE extents
+ * (gy / gx [B,2Dc,2Hc,2Wc,C], gpool [B,Dc,Hc,Wc,C]), C % 32 == 0. */
+int df_wino_conv_fwd_addup_bits(const float* x, const float* wp, const float* bias, const float* xc, float* y2, void* sign_bits,
+                                int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, float leak, df_stream_t stream);
+int df_lrelu_bits_bwd_pool2x(const float* gy, const void* mask_bits, float* gx, float* gpool, float leak, int64_t B, int64_t Dc, int64_t Hc,
+                             int64_t Wc, int64_t C, df_stream_t stream);
 
 /* 2-D twin: Winograd F(2x2, 3x3) form of the stride-1 3x3 convolution (conv_wino2d.hip): 2.25x fewer matrix-core FLOPs than df_conv_fwd
  * with kz = 1, fp32 throughout, same epilogue flags.  Needs Cin % 32 == 0, Cout % 32 == 0, H*W*max(Cin,Cout) <= 2^29. */

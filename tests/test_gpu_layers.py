@@ -595,3 +595,30 @@ def test_lrelu_bwd_pool2x_equals_the_two_separate_passes(ops, shape):
         assert torch.equal(gx1, gx2) and torch.equal(p1, p2)
         ref = torch.where(y > 0, dy, 0.2 * dy)
         assert torch.equal(gx1, ref)
+
+
+@pytest.mark.parametrize("dims", [(2, 8, 16, 16), (1, 6, 10, 12), (3, 4, 8, 24)])
+def test_block_tail_on_sign_bits_equals_the_fp32_mask_path(ops, dims):
+    """df_wino_conv_fwd_addup_bits (no fp32 activation written, sign bits instead) + df_lrelu_bits_bwd_pool2x ==
+    df_wino_conv_fwd_addup + df_lrelu_bwd_pool2x bit for bit; full and ragged tile blocks (4 x 8 x 8 voxels)."""
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream, _pack
+    B, D, H, W = dims
+    C = 64
+    g = torch.Generator(device="cuda").manual_seed(sum(dims))
+    x = torch.rand((B, D, H, W, C), device="cuda", generator=g) - 0.5
+    xc = torch.rand((B, D // 2, H // 2, W // 2, C), device="cuda", generator=g) - 0.5
+    w = (torch.rand((3, 3, 3, C, C), device="cuda", generator=g) - 0.5) * 0.1
+    b = torch.rand(C, device="cuda", generator=g) - 0.5
+    dy = torch.rand((B, D, H, W, C), device="cuda", generator=g) - 0.5
+    wp = torch.empty(query("df_wino_packed_elems", C, C, 0), device="cuda")
+    call("df_wino_pack_weights", _ptr(w), _ptr(wp), C, C, 0, _stream())
+    y1 = torch.empty_like(x); y2a = torch.empty_like(x); y2b = torch.empty_like(x)
+    call("df_wino_conv_fwd_addup", _ptr(x), _ptr(wp), _ptr(b), _ptr(xc), _ptr(y1), _ptr(y2a), B, D, H, W, C, C, 0.2, _stream())
+    bits = torch.zeros(query("df_wino_signbits_bytes", B, D, H, W, C) // 8, dtype=torch.int64, device="cuda")
+    call("df_wino_conv_fwd_addup_bits", _ptr(x), _ptr(wp), _ptr(b), _ptr(xc), _ptr(y2b), _ptr(bits), B, D, H, W, C, C, 0.2, _stream())
+    assert torch.equal(y2a, y2b)
+    gx1 = torch.empty_like(dy); p1 = torch.empty_like(xc); gx2 = torch.empty_like(dy); p2 = torch.empty_like(xc)
+    call("df_lrelu_bwd_pool2x", _ptr(dy), _ptr(y1), _ptr(gx1), _ptr(p1), 0.2, B, D // 2, H // 2, W // 2, C, 1, _stream())
+    call("df_lrelu_bits_bwd_pool2x", _ptr(dy), _ptr(bits), _ptr(gx2), _ptr(p2), 0.2, B, D // 2, H // 2, W // 2, C, _stream())
+    assert torch.equal(gx1, gx2) and torch.equal(p1, p2)

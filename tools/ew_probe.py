@@ -31,3 +31,11 @@ t = timeit(lambda: y.copy_(a)); print("torch copy %7.1f us %7.1f GB/s" % (t * 1e
 t = timeit(lambda: torch.add(a, b, out=y)); print("torch add  %7.1f us %7.1f GB/s" % (t * 1e6, n * 12 / t / 1e9))
 gx = torch.empty(n // 8, device="cuda")
 t = timeit(lambda: call("df_upsample2x_bwd", _ptr(a), _ptr(gx), B, D // 2, H // 2, W // 2, C, 1, s)); print("upsample_bwd %7.1f us %7.1f GB/s" % (t * 1e6, n * 4.5 / t / 1e9))
+# the backward tail of an up-sampling block: separate passes / one pass on the fp32 activation / one pass on its sign bits
+from deep_fluids_amd._lib import query  # noqa: E402
+gp = torch.empty(n // 8, device="cuda")
+t = timeit(lambda: call("df_lrelu_bwd_pool2x", _ptr(a), _ptr(b), _ptr(y), _ptr(gp), 0.2, B, D // 2, H // 2, W // 2, C, 1, s))
+print("lrelu_bwd_pool2x       %7.1f us  (%.1f GB moved)" % (t * 1e6, n * 12.5 / 1e9))
+bits = torch.zeros(query("df_wino_signbits_bytes", B, D, H, W, C) // 8, dtype=torch.int64, device="cuda")
+t = timeit(lambda: call("df_lrelu_bits_bwd_pool2x", _ptr(a), _ptr(bits), _ptr(y), _ptr(gp), 0.2, B, D // 2, H // 2, W // 2, C, s))
+print("lrelu_bits_bwd_pool2x  %7.1f us  (%.1f GB moved)" % (t * 1e6, n * 8.6 / 1e9))
