@@ -1131,6 +1131,21 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_fused_kernel(const Wxy
   else wgrad_wxyz_body<WP8, CS, false, false, false, DBG>(aa, range, sel);
 }
 
+// The up-sampling-aware form has 9 live (xi_z, xi_y) types (xi in {0, 1, 3} per axis): one launch as well (four launches by class
+// had 4 | 2 | 2 | 1 types -- grids of nranges x {4, 2, 2, 1} workgroups, three of them at most one round of the chip).
+template <int WP8, int CS>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_up_fused_kernel(const WxyzArgs aa) {
+  const int wg = wxyz_wg(aa.w.nranges * 9);
+  const int range = wg / 9, t9 = wg % 9;
+  const int zi = t9 / 3, yi = t9 % 3;                      // 0 -> xi = 0, 1 -> xi = 1, 2 -> xi = 3
+  const bool gz = zi == 1, gy = yi == 1;
+  const int selz = zi == 2 ? 1 : 0, sely = yi == 2 ? 1 : 0;
+  if (gz && gy) wgrad_wxyz_body<WP8, CS, true, true, true, 0>(aa, range, 0);
+  else if (gz) wgrad_wxyz_body<WP8, CS, true, false, true, 0>(aa, range, sely);
+  else if (gy) wgrad_wxyz_body<WP8, CS, false, true, true, 0>(aa, range, selz);
+  else wgrad_wxyz_body<WP8, CS, false, false, true, 0>(aa, range, selz * 2 + sely);
+}
+
 // gw[dz][dy][dx][ci][co] = G^T_z G^T_y G^T_x of the summed (fixed order) partials U[xi_z][xi_y][xi_x]; index 3 of every axis carries a
 // flipped sign.  Workgroup = 32 consecutive (ci, co) elements x 8 range groups; every group applies the (linear) transform to its own
 // sums, the 8 x 27 results are combined in a fixed order through LDS.
@@ -2259,10 +2274,14 @@ static bool up_wxyz_ok(int req, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, i
   return wxyz_ok(2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz) && (B * Dc * Hc >= 2048 || req == 4) && req != 1 && req != 2 && req != 3;
 }
 
+// partial ranges of the 27-point (x,y,z) form: 9 workgroup types per range in one launch -- 28 ranges (252 workgroups: one round of
+// the 256 CUs) below 4096 tile-row pairs, 113 (1017: four rounds) above
+static int up_wxyz_ranges(int64_t B, int64_t Dc, int64_t Hc) { return (B * Dc * Hc + 1) / 2 < 4096 ? 28 : 113; }
+
 int64_t df_upconv_wgrad_workspace_bytes(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
   if (B <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || Cin <= 0 || Cout <= 0) return 0;
   if (wxyz_ok(2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz)) {      // sized for either form (the choice depends on a debug switch)
-    const Plan q = make_plan(B, 2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz, 3);
+    const Plan q = make_plan(B, 2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz, 3, up_wxyz_ranges(B, Dc, Hc));
     const Plan p = make_up_plan(B, Dc, Hc, Wc, Cin, Cout, kz);
     const int64_t nq = (q.partial_elems + q.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(2 * Wc, Cin, Cout);
     const int64_t np = (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(Wc, Cin, Cout);
@@ -2286,7 +2305,7 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
              "df_upconv_wgrad: workspace too small");
   if ((prec == 0 || !wgrad_bf16x3_ok(Wc, Cin, Cout)) && up_wxyz_ok(req, B, Dc, Hc, Wc, Cin, Cout, kz) && df::aligned16(xc) && df::aligned16(gy)) {
     const int64_t D = 2 * Dc, H = 2 * Hc, W = 2 * Wc;
-    const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, 3);
+    const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, 3, up_wxyz_ranges(B, Dc, Hc));
     WxyzArgs aa;
     WgradArgs& a = aa.w;
     a.x = xc; a.g = gy;
@@ -2305,14 +2324,8 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
     hipStream_t s = df::as_stream(stream);
     if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(W, Cin, Cout), s)) return df::fail((int)e, "df_upconv_wgrad: memset: %s", hipGetErrorString(e));
     const unsigned gy_ = (unsigned)ceil_div(Cin, 128), gz_ = (unsigned)ceil_div(Cout, 128);
-    // largest launch first: 4 | 2 | 2 | 1 workgroup types
-#define DF_UWXYZ(WP)                                                                                                                \
-  do {                                                                                                                              \
-    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, false, true>), dim3((unsigned)(p.nranges * 4), gy_, gz_), dim3(kThreads), 0, s, aa);  \
-    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, true, false, true>), dim3((unsigned)(p.nranges * 2), gy_, gz_), dim3(kThreads), 0, s, aa);   \
-    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, false, true, true>), dim3((unsigned)(p.nranges * 2), gy_, gz_), dim3(kThreads), 0, s, aa);   \
-    hipLaunchKernelGGL((wgrad_wxyz_kernel<WP, 128, true, true, true>), dim3((unsigned)(p.nranges * 1), gy_, gz_), dim3(kThreads), 0, s, aa);    \
-  } while (0)
+    const dim3 gridu((unsigned)(p.nranges * 9), gy_, gz_);          // all 9 live (xi_z, xi_y) types of a range, adjacent
+#define DF_UWXYZ(WP) hipLaunchKernelGGL((wgrad_wxyz_up_fused_kernel<WP, 128>), gridu, dim3(kThreads), 0, s, aa)
     if (W == 64) DF_UWXYZ(8); else if (W == 32) DF_UWXYZ(4); else if (W == 16) DF_UWXYZ(2); else if (W == 112) DF_UWXYZ(14); else if (W == 128) DF_UWXYZ(16); else DF_UWXYZ(7);
 #undef DF_UWXYZ
     const int64_t rgx = ceil_div(Cin * Cout, 32);
