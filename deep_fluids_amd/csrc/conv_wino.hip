@@ -580,6 +580,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
             char* yb = reinterpret_cast<char*>(a.y + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
                                                ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
             if (DBG & 512) asm volatile("" :: "v"(v));      // (experiment: no stores)
+            else if (DBG & 65536) __builtin_nontemporal_store(v, reinterpret_cast<float*>(yb + lane_off));      // (experiment: nt stores)
             else if (!NOY) *reinterpret_cast<float*>(yb + lane_off) = v;
             if (eflags & DF_CONV_ADDUP) {
               char* yb2 = reinterpret_cast<char*>(a.y2 + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
@@ -781,6 +782,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case (16 << 11): hipLaunchKernelGGL((wino3d_kernel<(16 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case (18 << 11): hipLaunchKernelGGL((wino3d_kernel<(18 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 16384: hipLaunchKernelGGL((wino3d_kernel<16384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 65536: hipLaunchKernelGGL((wino3d_kernel<65536, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case (17 << 11): hipLaunchKernelGGL((wino3d_kernel<(17 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
 #endif
     default: return df::fail(DF_EINVAL, "df_wino_conv_fwd: unknown debug variant");

@@ -20,7 +20,7 @@ NAMES = {0: "production kernel", 1: "no transform (VALU)", 2: "no raw LDS reads"
          256: "staging loads read an always-cached address", 512: "no output stores", 32: "setprio 3 around the MFMAs", 7: "MFMA only (no transform / raw reads / staging)",
          16384: "lock-step k-steps (LDS barrier every k-step)", 1024: "odd slices walk chunk pairs swapped", 1024 | (1 << 11): "swapped chunk pairs + staging sc0",
          1 << 11: "staging loads sc0", 2 << 11: "staging loads nt", 3 << 11: "staging loads sc0 nt", 16 << 11: "staging loads sc1",
-         18 << 11: "staging loads sc1 nt", 17 << 11: "staging loads sc0 sc1"}
+         18 << 11: "staging loads sc1 nt", 17 << 11: "staging loads sc0 sc1", 65536: "non-temporal output stores"}
 
 
 def main():
