@@ -887,8 +887,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_wxy_reduce_kernel(const float*
 //   X_c = (X[za][ya] + sy X[za][yb]) + sz (X[zb][ya] + sy X[zb][yb]),   G_c likewise over (1 | 2 planes) x (1 | 2 rows).
 // 64 transform-domain products per 2x2x2 positions instead of 96 in the (x,y) form (216 direct): 1.5x fewer matrix FLOPs for twice the
 // operand loads per x-tile (16 8-byte loads, 17 packed-fp32 ops, 16 MFMAs).  Tile rows are (b, z pair, y pair); D, H, W even.
-// GZ / GY: xi_z / xi_y in {1, 2} (the gradient combination needs the second plane / row); {0, 3} use one.  Four launches of 4
-// workgroup types.
+// GZ / GY: xi_z / xi_y in {1, 2} (the gradient combination needs the second plane / row); {0, 3} use one: four compile-time
+// specialisations of the body, dispatched per workgroup by the one-launch kernels below (wgrad_wxyz_fused_kernel / _up_fused_kernel).
 struct WxyzArgs {
   WgradArgs w;
   int Ht, Dt, ntrows;      // tile rows per plane pair = H/2; plane pairs per batch = D/2; B*Dt*Ht
