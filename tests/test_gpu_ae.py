@@ -116,7 +116,7 @@ def test_concat_sigmoid_mse_bigfc():
     pt = dev(p).requires_grad_(True)
     l = ops.mse_mean(pt, dev(q))
     (l * 2.0).backward()
-    assert abs(float(l) - ((p.astype(np.float64) - q) ** 2).mean()) < 1e-7
+    assert abs(float(l.detach()) - ((p.astype(np.float64) - q) ** 2).mean()) < 1e-7
     np.testing.assert_allclose(host(pt.grad), 2 * 2 * (p - q) / p.size, rtol=1e-5, atol=1e-8)
     # encoder head geometry: K = 24576 -> N = 16
     B, K, N = 3, 24576 + 100, 16
@@ -149,7 +149,10 @@ def test_ae_vs_reference_model_py(tag):
     ops.reset_variables()
 
 
-@pytest.mark.parametrize("is_3d,spatial,filters", [(True, (8, 16, 8), 16), (False, (16, 16), 16)])
+@pytest.mark.parametrize("is_3d,spatial,filters", [(True, (8, 16, 8), 16), (False, (16, 16), 16),
+                                                   # wide enough for the matrix-core paths: Winograd forward / dgrad with Cin != Cout
+                                                   # (64 -> 32, 128 -> 64, 192 -> 64), stride-2 dgrad as parity-class convs, W = 32 rows
+                                                   (True, (16, 16, 16), 32), (True, (16, 16, 32), 64)])
 def test_ae_train_step_vs_oracle(is_3d, spatial, filters):
     _ae_step_case(is_3d, spatial, filters, False)
 
