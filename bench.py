@@ -35,8 +35,8 @@ EXEC_RATIO = {"wino3d_kernel": 8.0 / 27.0, "wino2d_kernel": 4.0 / 9.0, "conv_mfm
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="weak: per-GPU batch; strong: GLOBAL batch (split over the GPUs)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--res", type=int, nargs=3, default=[64, 96, 64], metavar=("Z", "Y", "X"))
@@ -78,7 +78,7 @@ def select_kernel(name, args):
         B, D, H, W, cin, cout, kz = args[6:13]
         if cin >= 64 and cout >= 64:
             return ("conv_mfma_kernel fwd/dgrad %dx%dx%d C%d->%d" % (D, H, W, cin, cout), 2.0 * (27 if kz == 3 else 9) * cin * cout * B * D * H * W)
-    if name in ("df_wino_conv_fwd", "df_wino_conv_fwd_addup", "df_wino_conv_fwd_bits"):
+    if name in ("df_wino_conv_fwd", "df_wino_conv_fwd_addup", "df_wino_conv_fwd_addup_bits", "df_wino_conv_fwd_bits"):
         B, D, H, W, cin, cout = args[6:12]
         return ("wino3d_kernel fwd/dgrad %dx%dx%d C%d->%d" % (D, H, W, cin, cout), 2.0 * 27 * cin * cout * B * D * H * W)
     if name == "df_wino2d_conv_fwd":
@@ -87,7 +87,7 @@ def select_kernel(name, args):
     if name == "df_conv_wgrad_algo":
         B, D, H, W, cin, cout, kz = args[4:11]
         if cin >= 64 and cout >= 64:
-            return ("wgrad_kernel %dx%dx%d C%dx%d" % (D, H, W, cin, cout), 2.0 * (27 if kz == 3 else 9) * cin * cout * B * D * H * W)
+            return ("wgrad_kernel %dx%dx%d C%dx%d B%d" % (D, H, W, cin, cout, B), 2.0 * (27 if kz == 3 else 9) * cin * cout * B * D * H * W)
     if name == "df_jacobian3d_fwd" and args[1] is not None and args[2] is not None:
         B, Z, Y, X = args[3:7]
         return ("jacobian3d_fwd_kernel<j,c>", 60.0 * B * Z * Y * X)
@@ -107,12 +107,13 @@ def select_kernel(name, args):
     return None
 
 
-def wgrad_exec_ratio(D, H, W):
-    """Executed / algorithmic multiply-adds of the default weight-gradient form at 128 -> 128 (conv_wgrad.hip::wgrad_algo):
-    Winograd-(x,y,z) 8/27 from 4096 image rows at the W the kernel is instantiated for, (x,y) 4/9 in 2-D."""
-    if D > 1:
-        return 8.0 / 27.0 if (W in (16, 32, 64, 56, 112, 128) and D % 2 == 0 and H % 2 == 0) else 1.0
-    return 4.0 / 9.0 if (W in (16, 32, 64, 56, 112, 128, 96, 48) and H % 2 == 0) else 1.0
+def wgrad_exec_ratio(B, D, H, W, cin, cout):
+    """Executed / algorithmic multiply-adds of the weight-gradient form the LIBRARY picks for this call (df_conv_wgrad_form = the
+    predicate of conv_wgrad.hip::wgrad_algo): Winograd-(x,y,z) 8/27, (x,y) 4/9 (2-D) | 12/27 (3-D, direct in z), x 2/3, direct 1."""
+    from deep_fluids_amd import _lib
+    kz = 3 if D > 1 else 1
+    form = _lib.query("df_conv_wgrad_form", B, D, H, W, cin, cout, kz, 0)
+    return {3: 8.0 / 27.0, 2: 4.0 / 9.0, 1: 2.0 / 3.0}.get(form, 1.0), form
 
 
 def cpu_baseline(res, filters, budget_s):
@@ -156,11 +157,52 @@ def cpu_baseline(res, filters, budget_s):
                 break
     except OSError:
         pass
-    return {"value": vox * n / el, "unit": "voxels/s", "cores": cores, "kind": "port",
+    tail = None
+    try:
+        tail = cpu_stencil_tail(sres, cores)
+    except Exception as e:
+        tail = {"error": repr(e)[:200]}
+    return {"value": vox * n / el, "unit": "voxels/s", "cores": cores, "kind": "port", "stencil_tail": tail,
             "sample": "PyTorch-CPU fp32 restatement of the reference graph (TF 1.15 unavailable): %d full train step(s) after one "
                       "warm-up step (%.1f s), batch 1, FULL grid %dx%dx%d, filters %d, %d threads, %.1f s timed" % (
                           n, warm, sres[0], sres[1], sres[2], filters, cores, el),
             "ms_per_step": el / n * 1e3, "cpu": model}
+
+
+def cpu_stencil_tail(res, cores, batch=2):
+    """SURVEY 8(d) CPU baseline part (i): the stencil / loss tail of the reference graph (jacobian3 on the ground truth, curl3 of psi,
+    jacobian3 of u, two L1 means: 240 B/voxel of algorithmic traffic) on the host, (a) oracle/df_oracle.c with OpenMP on `cores`
+    threads, (b) the oracle's NumPy restatement in the style of the reference's own jacobian_np3 (ops.py:344-374), single thread."""
+    import ctypes
+    import numpy as np
+    import df_oracle as orc
+    Z, Y, X = res
+    rng = np.random.RandomState(5)
+    psi = rng.uniform(-1, 1, (batch, Z, Y, X, 3)).astype(np.float32)
+    x = rng.uniform(-1, 1, (batch, Z, Y, X, 3)).astype(np.float32)
+    nv = float(batch * Z * Y * X)
+    out = {"batch": batch, "algorithmic_bytes_per_voxel": 240}
+    so = os.path.join(ROOT, "oracle", "libdf_oracle.so")
+    if os.path.exists(so):
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        h = ctypes.CDLL(so)
+        I64 = ctypes.c_int64
+        u = np.empty_like(psi); ju = np.empty((batch, Z, Y, X, 9), np.float32); jx = np.empty_like(ju)
+        l1 = ctypes.c_double(); jl1 = ctypes.c_double()
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        args = (ptr(psi), ptr(x), ptr(u), ptr(ju), ptr(jx), ctypes.byref(l1), ctypes.byref(jl1), I64(batch), I64(Z), I64(Y), I64(X))
+        h.dfo_velocity_tail3d(*args)
+        n, t0 = 0, time.time()
+        while n < 3 or (time.time() - t0 < 1.0 and n < 50):
+            h.dfo_velocity_tail3d(*args); n += 1
+        el = (time.time() - t0) / n
+        out["c_openmp"] = {"ms": el * 1e3, "voxels_per_s": nv / el, "GBs": 240.0 * nv / el / 1e9, "threads": cores, "l1": l1.value}
+    t0 = time.time()
+    jx_ = orc.jacobian3(x)[0]; u_ = orc.jacobian3(psi)[1]; ju_ = orc.jacobian3(u_)[0]
+    l1n = orc.l1_mean(u_, x); orc.l1_mean(ju_, jx_)
+    el = time.time() - t0
+    out["numpy"] = {"ms": el * 1e3, "voxels_per_s": nv / el, "GBs": 240.0 * nv / el / 1e9, "threads": 1, "l1": float(l1n)}
+    return out
 
 
 def l1_vs_oracle(filters, precision="fp32", is_3d=True):
@@ -210,8 +252,11 @@ def roofline_of(ks, prefix, pmc, with_traffic):
         alg = v["work"] / v["seconds"] / 1e12
         ratio = EXEC_RATIO.get(prefix)
         if ratio is None:                                        # weight gradient: depends on the form conv_wgrad.hip picks
-            dims = k.split(" ")[1].split("x")
-            ratio = wgrad_exec_ratio(int(dims[0]), int(dims[1]), int(dims[2])) if len(dims) == 3 else 1.0
+            f = k.split(" ")
+            dims = [int(t) for t in f[1].split("x")]
+            cc = [int(t) for t in f[2][1:].split("x")]
+            ratio, form = wgrad_exec_ratio(int(f[3][1:]), dims[0], dims[1], dims[2], cc[0], cc[1])
+            out["wgrad_form"] = {3: "winograd-xyz", 2: "winograd-xy", 1: "winograd-x", 0: "direct"}.get(form, str(form))
         ach = alg * ratio
         out.update(achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS,
                    algorithmic_tflops=alg, algorithmic_speedup=1.0 / ratio,
@@ -277,15 +322,28 @@ def stencil_rooflines(B, Z, Y, X):
     return out
 
 
-def timed_steps(tr, x, y, warm, n):
+def timed_steps(tr, x, y, warm, n, rooflines=None):
+    """Mean wall time per step; ``rooflines`` (a dict) additionally receives the live HIP-event rooflines of the dominant conv /
+    weight-gradient kernel families of these steps."""
     import torch
+    from deep_fluids_amd import _lib
     for _ in range(warm):
         tr.train_step(x, y)
+    timer = _lib.KernelTimer(select_kernel) if rooflines is not None else None
     torch.cuda.synchronize(); t0 = time.perf_counter()
+    _lib.TIMER = timer
     for _ in range(n):
         m = tr.train_step(x, y)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n, m
+    el = (time.perf_counter() - t0) / n
+    _lib.TIMER = None
+    if timer is not None:
+        ks = timer.summary()
+        for fam in ("wino3d_kernel", "wgrad_kernel", "conv_mfma_kernel"):
+            r = roofline_of(ks, fam, {}, False)
+            if r is not None:
+                rooflines["roofline_" + fam.split("_")[0]] = r
+    return el, m
 
 
 def extras(out, a, cfg, x, y, vox_per_step, pmc):
@@ -362,13 +420,17 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
             ops.CONV_PRECISION = prec
             ops.reset_variables()
             tr = Trainer(cfg4)
-            el, m = timed_steps(tr, x4, y4, 1, 2)
+            rf = {} if prec == "fp32" else None
+            el, m = timed_steps(tr, x4, y4, 1, 2, rf)
             res[prec] = {"ms_per_step": el * 1e3, "value": B4 * 112 * 160 * 112 / el}
+            if rf:
+                res[prec].update(rf)
             n_params = tr.n_params
             del tr, m
             torch.cuda.empty_cache()
         return {"grid": [112, 160, 112], "batch_per_gpu": B4, "params": n_params, "unit": "voxels/s", "dtype": "f32",
                 "ms_per_step": res["fp32"]["ms_per_step"], "value": res["fp32"]["value"], "bf16x3_mode": res["bf16x3"],
+                "roofline": res["fp32"].get("roofline_wino3d"), "roofline_wgrad": res["fp32"].get("roofline_wgrad"),
                 "note": "BASELINE cfg4's grid and per-GPU batch (32 / 8 GPUs) on ONE GPU: the per-rank work of the 8-GPU batch-DP job; "
                         "parity: tests/test_gpu_fullsize.py::test_cfg4_*"}
 
@@ -380,8 +442,10 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
         y5 = torch.rand((B5, 2, 10), device="cuda", generator=g5) * 2 - 1
         x5 = ops.curl3(torch.rand((B5, R, R, R, 3), device="cuda", generator=g5) * 2 - 1)
         x5 = (x5 / x5.abs().max()).contiguous()
-        el, m = timed_steps(tr, x5, y5, 1, 2)
+        rf = {}
+        el, m = timed_steps(tr, x5, y5, 1, 2, rf)
         return {"grid": [R, R, R], "batch_per_gpu": B5, "filters": 64, "z_num": 16, "params": tr.n_params, "ms_per_step": el * 1e3,
+                "roofline": rf.get("roofline_wino3d"), "roofline_wgrad": rf.get("roofline_wgrad"), "roofline_conv": rf.get("roofline_conv"),
                 "value": B5 * R ** 3 / el, "unit": "voxels/s", "dtype": "f32",
                 "note": "BASELINE cfg5's shape (AE3 encoder + decoder train step, 128^3, F = 64), fp32"}
 
@@ -434,15 +498,31 @@ def main():
     if sync is not None:
         sync.timing(reset=True)
     timer = _lib.KernelTimer(select_kernel)
+    # per-step HIP events on the stream the kernels are launched on (torch's current stream): ev[i] .. ev[i+1] brackets step i
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     sync_all()
     _lib.TIMER = timer
     t0 = time.perf_counter()
     last = None
-    for _ in range(a.steps):
+    ev[0].record()
+    for i in range(a.steps):
         last = tr.train_step(x, y)
+        ev[i + 1].record()
     sync_all()
     elapsed = time.perf_counter() - t0
     _lib.TIMER = None
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
+    pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * (len(step_ms) - 1) + 0.5))]
+    step_stats = {"median_ms": pct(0.5), "p10_ms": pct(0.1), "p90_ms": pct(0.9), "min_ms": step_ms[0], "max_ms": step_ms[-1],
+                  "source": "HIP events on the launch stream, one per step"}
+    # what the job REALLY ran on: ranks counted by an all-reduce of ones over the production backend, physical devices gathered
+    from deep_fluids_amd.dist import verify_world
+    wv = verify_world()
+    # which algorithm every conv / weight-gradient call of a step takes (one extra, untimed step)
+    ops.DISPATCH_COUNTS = {}
+    tr.train_step(x, y)
+    dispatch, ops.DISPATCH_COUNTS = ops.DISPATCH_COUNTS, None
+    torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         if dist.get_backend() == "gloo":
@@ -479,8 +559,11 @@ def main():
                                "step (fwd+curl3+jacobian3+L1 losses+bwd+Adam)" % (Z, Y, X, a.filters, per_gpu),
                    "global_batch": global_batch, "batch_per_gpu": per_gpu, "grid": [Z, Y, X], "params": tr.n_params,
                    "parallelism": "dp%d" % world},
-        "rccl_ranks": world,
-        "dist_backend": (dist.get_backend() if world > 1 else None),
+        "step_ms": step_stats,
+        "value_median": vox_per_step / (step_stats["median_ms"] * 1e-3) if world == 1 else None,
+        "rccl_ranks": wv["ranks"] if wv["backend"] == "nccl" else 0,      # counted by an on-device all-reduce over RCCL; 0 = not an RCCL job
+        "counted_ranks": wv["ranks"], "dist_backend": wv["backend"], "devices": wv["devices"], "distinct_devices": wv["distinct_devices"],
+        "dispatch": dispatch,
         "allreduce": comm,           # per step: bytes, buckets, comm_span_ms, exposed_ms (after backward), hidden_ms (under backward)
         "loss": loss,
         "l1_vs_ref": {"value": rel_l1, "tolerance": 1e-4,

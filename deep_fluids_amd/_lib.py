@@ -96,6 +96,8 @@ SIGNATURES = {
     "df_conv_wgrad": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
     "df_conv_wgrad_algo": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, I32, P]),
     "df_upconv_wgrad_algo": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, I32, P]),
+    "df_conv_wgrad_form": (I32, [I64, I64, I64, I64, I64, I64, I32, I32]),
+    "df_upconv_wgrad_form": (I32, [I64, I64, I64, I64, I64, I64, I32, I32]),
 }
 
 DF_CONV_LRELU, DF_CONV_RESIDUAL, DF_CONV_MASK, DF_CONV_BIAS, DF_CONV_ADDUP, DF_CONV_VALU_ONLY = 1, 2, 4, 8, 16, 32

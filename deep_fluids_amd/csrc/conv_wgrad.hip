@@ -2255,6 +2255,20 @@ int df_conv_wgrad_bf16x3(const float* x, const float* gy, float* gw, float* gb, 
   return conv_wgrad_impl(x, gy, gw, gb, B, D, H, W, Cin, Cout, kz, workspace, workspace_bytes, stream, 1, 0);
 }
 
+// Which kernel family a df_conv_wgrad_algo call with these arguments runs (16-byte aligned operands assumed): the silent size-based
+// choices made visible to the caller.  0 direct MFMA | 1 Winograd in x | 2 Winograd in (x,y) | 3 Winograd in (x,y,z) |
+// 10 thin layer on the matrix cores | 11 thin layer on the vector ALU (general-shape fallback); < 0: invalid arguments.
+int df_conv_wgrad_form(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int algo) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (kz != 1 && kz != 3) || algo < 0 || (algo & 7) > 4) return DF_EINVAL;
+  const int req = algo & 7;
+  const bool swap = Cin <= 4 && Cout >= 64;
+  const int64_t Cw = swap ? Cout : Cin, Ct = swap ? Cin : Cout;
+  if ((swap || small_n_ok(Cin, Cout)) && req != 1 && thin_mfma_ok(B, D, H, W, Cw, Ct, kz) && thin_mfma_inst(W, Cw, Ct, swap)) return 10;
+  if (small_n_ok(Cin, Cout)) return 11;
+  if (Cin % 2 || Cout % 2) return 0;
+  return wgrad_algo(req, B * D * H, D, H, W, Cin, Cout, kz);
+}
+
 static Plan make_up_plan(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
   Plan p = make_plan(B, Dc, Hc, Wc, Cin, Cout, kz);
   p.ndzdy = kz == 3 ? 32 : 8;
@@ -2277,6 +2291,13 @@ static bool up_wxyz_ok(int req, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, i
 // partial ranges of the 27-point (x,y,z) form: 9 workgroup types per range in one launch -- 28 ranges (252 workgroups: one round of
 // the 256 CUs) below 4096 tile-row pairs, 113 (1017: four rounds) above
 static int up_wxyz_ranges(int64_t B, int64_t Dc, int64_t Hc) { return (B * Dc * Hc + 1) / 2 < 4096 ? 28 : 113; }
+
+// The same for df_upconv_wgrad_algo: 3 = the 27-point Winograd-(x,y,z) form on the coarse input, 0 = the three-product parity-class
+// kernel (algo 0 | 2) or the generic direct kernel on class-strided views (algo 1).
+int df_upconv_wgrad_form(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz, int algo) {
+  if (B <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || Cin <= 0 || Cout <= 0 || (kz != 1 && kz != 3) || algo < 0 || algo > 4) return DF_EINVAL;
+  return up_wxyz_ok(algo, B, Dc, Hc, Wc, Cin, Cout, kz) ? 3 : 0;
+}
 
 int64_t df_upconv_wgrad_workspace_bytes(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
   if (B <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || Cin <= 0 || Cout <= 0) return 0;

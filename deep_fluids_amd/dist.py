@@ -37,6 +37,51 @@ def init_from_env(backend=None):
     return rank, local_rank, world
 
 
+def device_identity(index=None):
+    """A string that is the same for two ranks iff they drive the same physical GPU: PCI domain:bus:device (+ the UUID where the
+    runtime reports one)."""
+    if not torch.cuda.is_available():
+        return "cpu"
+    index = torch.cuda.current_device() if index is None else index
+    pr = torch.cuda.get_device_properties(index)
+    parts = ["%s:%s:%s" % (getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", "?"))]
+    uuid = getattr(pr, "uuid", None)
+    if uuid is not None:
+        parts.append(str(uuid))
+    if parts[0] == "?:?:?" and uuid is None:      # nothing physical to go by: fall back to (host, visible index)
+        parts = ["%s/%s/%d" % (os.uname().nodename, os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "")), index)]
+    return "|".join(parts)
+
+
+def verify_world(group=None):
+    """What the job REALLY runs on, asked of the communication backend itself (bench.py's `rccl_ranks`): an on-device all-reduce of
+    ones over the production backend counts the participating ranks, an all-gather of `device_identity()` lists the physical GPUs.
+    Raises when the RCCL ("nccl") backend is asked to run several ranks on ONE device -- such a job would print a multi-GPU line
+    for single-GPU hardware (the sharing configuration exists for the tests only, over gloo with DF_DIST_BACKEND=gloo)."""
+    if not dist.is_initialized():
+        return {"ranks": 1, "backend": None, "devices": [device_identity()], "distinct_devices": 1}
+    backend = dist.get_backend(group)
+    world = dist.get_world_size(group)
+    on_dev = torch.cuda.is_available() and backend != "gloo"
+    one = torch.ones(1, dtype=torch.float32, device="cuda" if on_dev else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
+    counted = int(round(float(one.item())))
+    ids = [None] * world
+    dist.all_gather_object(ids, device_identity(), group=group)
+    return check_world(backend, world, counted, ids)
+
+
+def check_world(backend, world, counted, ids):
+    """The verdict of :func:`verify_world` (separate so that the refusal rules are testable without a multi-GPU node)."""
+    distinct = len(set(ids))
+    if counted != world:
+        raise RuntimeError("all-reduce of ones over %s returned %d, world size is %d" % (backend, counted, world))
+    if backend == "nccl" and distinct != world:
+        raise RuntimeError("RCCL job with %d ranks on %d distinct device(s) %s: one rank per GPU is required (set DF_DIST_BACKEND=gloo "
+                           "for the single-GPU sharing test configuration)" % (world, distinct, sorted(set(ids))))
+    return {"ranks": counted, "backend": backend, "devices": list(ids), "distinct_devices": distinct}
+
+
 class GradSync(object):
     """Bucketed, backward-overlapped all-reduce of a flat gradient slab.
 
@@ -95,21 +140,23 @@ class GradSync(object):
             chunk.copy_(host)
             return
         if self._comm_stream is not None:
+            # ONE schedule for production and profiled runs: the collective is enqueued from the communication stream (RCCL's internal
+            # stream then waits for the gradients through it) and the communication stream is made to wait for the collective at once
+            # (`w.wait()` is a device-side stream dependency, the host does not block).  finish() then only joins the two streams.
+            # profile=True adds event records on the communication stream and nothing else.
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm_stream):
                 if self._cur is not None and self._cur["start"] is None:
                     self._cur["start"] = torch.cuda.Event(enable_timing=True)
                     self._cur["start"].record()
                 w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w.wait()
                 if self._cur is not None:
-                    # RCCL runs the collective on its own internal stream: make the communication stream wait for it so that
-                    # the end event really marks the end of this bucket's all-reduce (device-side wait, the host does not block)
-                    w.wait()
                     e = torch.cuda.Event(enable_timing=True)
                     e.record()
                     self._cur["ends"].append(e)
-        else:
-            w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return
+        w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._works.append(w)
 
     def finish(self):

@@ -13,6 +13,7 @@ follow slim: ``<scope>/<layer>/weights`` ``[k,(k,)k,Cin,Cout]`` / ``[in,out]`` a
 """
 import contextlib
 import math
+import os as _os
 
 import numpy as np
 import torch
@@ -216,7 +217,23 @@ WGRAD_ALGO = 0
 THIN_VALU_ONLY = False
 
 
+# Which algorithm every conv / weight-gradient call took, counted per (op, form, shape) when set to a dict (bench.py `dispatch`, tests):
+# the library chooses by size and row length, and a shape outside the instantiated variants falls back to a slower kernel SILENTLY --
+# this makes it visible.  None (default) = no bookkeeping.
+DISPATCH_COUNTS = None
+_WGRAD_FORMS = {0: "direct-mfma", 1: "winograd-x", 2: "winograd-xy", 3: "winograd-xyz", 10: "thin-mfma", 11: "thin-valu"}
+
+
+def _count(op, form, dims, cin, cout):
+    if DISPATCH_COUNTS is not None:
+        key = "%s %s %s C%d->%d" % (op, form, "x".join(str(int(d)) for d in dims[1:] if int(d) > 1 or len(dims) < 4), cin, cout)
+        DISPATCH_COUNTS[key] = DISPATCH_COUNTS.get(key, 0) + 1
+
+
 def _wgrad(x, dp, gw, gb, B, D, H, W, cin, cout, kz, sfx=""):
+    if DISPATCH_COUNTS is not None:
+        form = "bf16x3" if sfx else _WGRAD_FORMS.get(query("df_conv_wgrad_form", B, D, H, W, cin, cout, kz, int(WGRAD_ALGO)), "?")
+        _count("wgrad", form, (B, D, H, W), cin, cout)
     nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, kz)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     if sfx:
@@ -254,7 +271,6 @@ def _pack(w, taps, cin, cout, mode, dims=None, fp32=False):
 # Sign-bit masks (conv_wino.hip): the forward convs of a fused generator block whose outputs only serve, in the backward pass, as the
 # lrelu mask of the next layer's dgrad also emit that mask as bit words (1/32 of the bytes); the masked dgrad then reads the words
 # instead of the fp32 activation.  Same arithmetic, bit-identical results; only the 3-D Winograd kernels have the path.
-import os as _os
 SIGN_BIT_MASKS = _os.environ.get("DF_SIGN_BIT_MASKS", "1") != "0"
 
 
@@ -264,11 +280,35 @@ def _new_bits(dims, c, like):
     return torch.empty(nbytes // 8, dtype=torch.int64, device=like.device)
 
 
+def sign_bits_to_mask(bits, dims, c):
+    """Decode the sign words of ``df_wino_conv_fwd_bits`` / ``_addup_bits`` / ``df_wino_upconv_fwd_bits`` (conv_wino.hip, kSignBits) into
+    a bool tensor ``[B, D, H, W, c]`` = (activation > 0).  Layout: one byte per (tile block, cout slice, wave = (z-row th, xi_z), cout
+    16-block nb, lane = (kq, tl)); bit s = (dz, dy, dx) of the lane's 2x2x2 outputs at (4 bz + 2 th + dz, 8 by + 2 kq + dy,
+    8 bx + 2 xi_z + dx), channel 32 cs + 16 nb + tl.  The fetch-list counterpart for layers whose fp32 activation is never written."""
+    B, D, H, W = (int(v) for v in dims)
+    nbz, nby, nbx, ncs = -(-D // 4), -(-H // 8), -(-W // 8), c // 32
+    by = bits.view(torch.uint8)[:B * nbz * nby * nbx * ncs * 1024].view(B, nbz, nby, nbx, ncs, 2, 4, 2, 4, 16)
+    sh = torch.arange(8, device=bits.device, dtype=torch.uint8).view(2, 2, 2)
+    m = ((by[..., None, None, None] >> sh) & 1).bool()      # [B, bz, by, bx, cs, th, xz, nb, kq, tl, dz, dy, dx]
+    m = m.permute(0, 1, 5, 10, 2, 8, 11, 3, 6, 12, 4, 7, 9).reshape(B, nbz * 4, nby * 8, nbx * 8, c)
+    return m[:, :D, :H, :W].contiguous()
+
+
+# Fetch of the block-tail sign words (see ACTIVATION_FETCH below): when set to a list, every up-sampling block on the production tail
+# (df_wino_conv_fwd_addup_bits: the last conv's activation is never written) appends ``(bits, fdims, cout)``; tests decode them with
+# sign_bits_to_mask and compare with the activations of the fp32-mask path.
+SIGN_BITS_FETCH = None
+
+
 def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak, sign_bits=None, mask_bits=None):
     """`wp` must come from ``_pack(..., dims)`` with the same dims (the two agree on the algorithm)."""
     B, D, H, W = dims
     y = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
     algo = _use_wino(cin, cout, dims, kz)
+    if DISPATCH_COUNTS is not None:
+        thin = min(cin, cout) <= 4
+        _count("conv", "winograd-f2x2x2" if algo == 3 else "winograd-f2x2" if algo == 2 else
+               ("thin" + ("-valu-forced" if THIN_VALU_ONLY else "")) if thin else ("direct-mfma" + _sfx(cin, cout)), dims, cin, cout)
     if algo == 3:
         if sign_bits is not None or mask_bits is not None:
             call("df_wino_conv_fwd_bits", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_bits), _ptr(y), _ptr(sign_bits), B, D, H, W, cin, cout,
@@ -464,6 +504,8 @@ class _UpGenBlock(torch.autograd.Function):
                     y = torch.empty(fshape, dtype=torch.float32, device=xc.device)
                     call("df_wino_conv_fwd_addup_bits", _ptr(x), _ptr(wp), _ptr(b), _ptr(xc), _ptr(y), _ptr(tail_bits), fdims[0], fdims[1],
                          fdims[2], fdims[3], cin, cout, float(leak), _stream())
+                    if SIGN_BITS_FETCH is not None:
+                        SIGN_BITS_FETCH.append((tail_bits, fdims, cout))
                     x = None
                 elif i == n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3:
                     # (fp32 masks: the activation is a second output)
@@ -525,6 +567,9 @@ class _UpGenBlock(torch.autograd.Function):
                     call("df_upconv_wgrad" + _sfx(C, C), _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
                          cdims[3], C, C, kz, _ptr(wsb), nbytes, _stream())
                 else:
+                    if DISPATCH_COUNTS is not None:
+                        f = query("df_upconv_wgrad_form", cdims[0], cdims[1], cdims[2], cdims[3], C, C, kz, int(WGRAD_ALGO))
+                        _count("upconv-wgrad", "winograd-xyz-27pt" if f == 3 else "parity-class", fdims, C, C)
                     call("df_upconv_wgrad_algo", _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
                          cdims[3], C, C, kz, _ptr(wsb), nbytes, int(WGRAD_ALGO), _stream())
                 if ctx.needs_input_grad[0]:

@@ -220,12 +220,27 @@ class Trainer(object):
 
     # ---- `train_` (trainer.py:228-293): the loop, the scalar log, the NaN guard, the final checkpoint -------------------------
     def _scalars(self, m, ep):
-        """The scalar summaries of trainer.py:190-199 (+ the 'dg' ones, :208-213)."""
-        out = {"loss/g_loss": float(m.g_loss.detach()), "loss/g_loss_l1": float(m.g_loss_l1.detach()),
-               "loss/g_loss_j_l1": float(m.g_loss_j_l1.detach()), "misc/epoch": ep, "misc/g_lr": self.g_lr}
-        for k in ("g_loss_real", "d_loss_real", "d_loss_fake"):
-            if getattr(m, k, None) is not None:
-                out["loss/" + k] = math.sqrt(max(float(getattr(m, k).detach()), 0.0))
+        """The scalar summaries of trainer.py:190-199 (+ the 'dg' ones, :208-213).  Under data parallelism every loss term is a mean
+        over the rank's shard; the logged value is the mean over ranks = the global-batch mean the single-process reference logs
+        (equal shard sizes), so every rank sees the SAME numbers and the NaN guard fires on all ranks together or on none."""
+        keys = ["g_loss", "g_loss_l1", "g_loss_j_l1"] + [k for k in ("g_loss_real", "d_loss_real", "d_loss_fake")
+                                                        if getattr(m, k, None) is not None]
+        vals = torch.stack([getattr(m, k).detach().reshape(()).float() for k in keys])
+        gs = self.grad_sync
+        if gs is not None and gs.enabled and gs.world > 1:
+            import torch.distributed as dist
+            if gs.backend == "gloo" and vals.is_cuda:
+                h = vals.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=gs.group)
+                vals = h / gs.world
+            else:
+                dist.all_reduce(vals, op=dist.ReduceOp.SUM, group=gs.group)
+                vals = vals / gs.world
+        v = dict(zip(keys, vals.tolist()))
+        out = {"loss/g_loss": v["g_loss"], "loss/g_loss_l1": v["g_loss_l1"], "loss/g_loss_j_l1": v["g_loss_j_l1"], "misc/epoch": ep,
+               "misc/g_lr": self.g_lr}
+        for k in keys[3:]:
+            out["loss/" + k] = math.sqrt(max(v[k], 0.0))
         return out
 
     def train(self, batch_manager, max_step=None, model_dir=None, log_step=None, test_step=None, on_log=None):
@@ -418,10 +433,10 @@ class GANTrainer(Trainer):
         self._adam_t_d = 0
         self.grad_sync_d = None
 
-    def enable_data_parallel(self, group=None, profile=False):
+    def enable_data_parallel(self, group=None, profile=False, force=False):
         """Two gradient slabs -> two bucketed exchanges: G's per generator block (as in ``Trainer``), D's as one bucket."""
-        gs = super(GANTrainer, self).enable_data_parallel(group, profile)
-        self.grad_sync_d = GradSync(self.D.g, [(0, self.D.n, list(self.D.vars))], group)
+        gs = super(GANTrainer, self).enable_data_parallel(group, profile, force)
+        self.grad_sync_d = GradSync(self.D.g, [(0, self.D.n, list(self.D.vars))], group, profile=profile, force=force)
         return gs
 
     def train_step(self, x, y):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DF_VERSION 201 /* 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
+#define DF_VERSION 202 /* 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
 
 enum {
   DF_OK = 0,
@@ -339,6 +339,13 @@ int df_conv_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t
 int df_conv_wgrad_algo(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W,
                        int64_t Cin, int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, int algo,
                        df_stream_t stream);
+/* Which kernel family df_conv_wgrad_algo runs for these arguments (16-byte aligned operands assumed) -- the size-based choices made
+ * visible so that a silent fall-back to a slower form shows up in the caller's log (bench.py `dispatch`):
+ *   0 direct MFMA | 1 Winograd in x | 2 Winograd in (x,y) | 3 Winograd in (x,y,z) | 10 thin layer (Cin or Cout <= 4) on the matrix
+ *   cores | 11 thin layer on the vector ALU; negative = invalid arguments.  df_upconv_wgrad_form: 3 = 27-point Winograd-(x,y,z)
+ *   form on the coarse input, 0 = parity-class kernels.  (No reference counterpart: TF picks cuDNN algorithms internally.) */
+int df_conv_wgrad_form(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz, int algo);
+int df_upconv_wgrad_form(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz, int algo);
 
 #ifdef __cplusplus
 }

@@ -72,8 +72,22 @@ void dfo_jacobian3d(const float* x, float* j, float* c, int64_t B, int64_t Z, in
 /* mean |a-b|, reference trainer.py:170-171 (fp64 accumulation) */
 double dfo_l1_mean(const float* a, const float* b, int64_t n) {
   double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
   for (int64_t i = 0; i < n; ++i) s += fabs((double)a[i] - (double)b[i]);
   return s / (double)n;
+}
+
+/* The reference graph's tail for one batch (trainer.py:30, trainer3.py:18,24,49-51), op by op like the TF graph:
+ *   jx = jacobian3(x)[0];  u = jacobian3(psi)[1];  ju = jacobian3(u)[0];  l1 = mean|u - x|;  jl1 = mean|ju - jx|.
+ * `ju`, `jx` are caller-provided scratch [B,Z,Y,X,9].  Used by bench.py's cpu_baseline leg (host-side stencil baseline). */
+void dfo_velocity_tail3d(const float* psi, const float* x, float* u, float* ju, float* jx, double* l1, double* jl1, int64_t B,
+                         int64_t Z, int64_t Y, int64_t X) {
+  const int64_t n = B * Z * Y * X;
+  dfo_jacobian3d(x, jx, (float*)0, B, Z, Y, X);
+  dfo_jacobian3d(psi, (float*)0, u, B, Z, Y, X);
+  dfo_jacobian3d(u, ju, (float*)0, B, Z, Y, X);
+  *l1 = dfo_l1_mean(u, x, n * 3);
+  *jl1 = dfo_l1_mean(ju, jx, n * 9);
 }
 
 /* slim.conv3d / conv2d, k = 3, stride 1, SAME, channels-last, TF weights [kz,ky,kx,Cin,Cout] (kz = 1: 2-D);

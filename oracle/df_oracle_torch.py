@@ -77,8 +77,10 @@ class _LreluMasked(torch.autograd.Function):
         return torch.where(mask, g, g * ctx.leak), None, None
 
 
-def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, leak=0.2, masks=None, skip_concat=False):
-    """model.py:5-87 (skip_concat=False).  ``masks``: optional {layer number: bool tensor} for :class:`_LreluMasked`."""
+def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, leak=0.2, masks=None, skip_concat=False,
+                  own_masks=None):
+    """model.py:5-87 (skip_concat=False).  ``masks``: optional {layer number: bool tensor} for :class:`_LreluMasked`;
+    ``own_masks``: optional dict that receives {layer number: (this oracle's own pre-activation > 0)}."""
     spatial = list(output_shape[:-1])
     repeat_num = int(np.log2(np.max(spatial))) - 2 if repeat == 0 else repeat
     f = 2 ** (repeat_num - 1)
@@ -89,6 +91,8 @@ def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, l
     for idx in range(repeat_num):
         for _ in range(num_conv):
             pre = conv_same(x, p["%s/%d_conv/weights" % (name, ln)], p["%s/%d_conv/biases" % (name, ln)])
+            if own_masks is not None:
+                own_masks[ln] = (pre > 0).detach()
             x = F.leaky_relu(pre, leak) if masks is None else _LreluMasked.apply(pre, masks[ln], leak)
             ln += 1
         if skip_concat:                              # model.py:30-33 / :72-75
@@ -101,6 +105,43 @@ def generator_fwd(z, p, output_shape, filters, name="G", num_conv=4, repeat=0, l
             x = upscale_nn(x)
             x0 = x
     return conv_same(x, p["%s/%d_conv/weights" % (name, ln)], p["%s/%d_conv/biases" % (name, ln)])
+
+
+def conv_same_s2(x, w, b):
+    """k=3, stride 2, TF 'SAME' on even extents: pad 0 before / 1 after per axis -- NOT torch's padding=1."""
+    nd = x.dim() - 2
+    if nd == 3:
+        xp = F.pad(x.permute(0, 4, 1, 2, 3), (0, 1, 0, 1, 0, 1))
+        return F.conv3d(xp, w.permute(4, 3, 0, 1, 2).contiguous(), b, stride=2).permute(0, 2, 3, 4, 1)
+    xp = F.pad(x.permute(0, 3, 1, 2), (0, 1, 0, 1))
+    return F.conv2d(xp, w.permute(3, 2, 0, 1).contiguous(), b, stride=2).permute(0, 2, 3, 1)
+
+
+def encoder_fwd(x, p, filters, z_num, name="enc", num_conv=3, repeat=0, leak=0.2):
+    """EncoderBE / EncoderBE3 (model.py:118-188): conv, [num_conv convs, concat skip, stride-2 conv] x repeat_num, flatten, FC."""
+    spatial = list(x.shape[1:-1])
+    repeat_num = int(np.log2(np.max(spatial))) - 2 if repeat == 0 else repeat
+    W = lambda n, kind: p["%s/%d_%s/weights" % (name, n, kind)]
+    Bv = lambda n, kind: p["%s/%d_%s/biases" % (name, n, kind)]
+    x = F.leaky_relu(conv_same(x, W(0, "conv"), Bv(0, "conv")), leak)
+    x0 = x
+    ln = 1
+    for idx in range(repeat_num):
+        for _ in range(num_conv):
+            x = F.leaky_relu(conv_same(x, W(ln, "conv"), Bv(ln, "conv")), leak); ln += 1
+        x = torch.cat([x, x0], dim=-1)                      # model.py:138 / :174
+        if idx < repeat_num - 1:
+            x = F.leaky_relu(conv_same_s2(x, W(ln, "conv"), Bv(ln, "conv")), leak); ln += 1      # model.py:141-143
+            x0 = x
+    flat = x.reshape(x.shape[0], -1)
+    return F.linear(flat, W(ln, "fc").t(), Bv(ln, "fc"))
+
+
+def ae_fwd(x, p, filters, z_num, name="AE", num_conv=4, repeat=0):
+    """AE / AE3 (model.py:190-216), use_sparse=False: returns (out, z)."""
+    z = encoder_fwd(x, p, filters, z_num, name + "/enc", num_conv - 1, repeat)
+    out = generator_fwd(z, p, list(x.shape[1:]), filters, name + "/dec", num_conv, repeat)
+    return out, z
 
 
 def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, sign_u=None):
@@ -124,14 +165,18 @@ def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, sign_u=None):
 
 
 def train_step(z, x, p, opt, output_shape, filters, is_3d, num_conv=4, repeat=0, w1=1.0, w2=1.0, beta1=0.5,
-               beta2=0.999, eps=1e-8, masks=None, sign_u=None):
-    """One step with TF1 Adam, in place on ``p`` (dict of leaf tensors) and ``opt`` (m, v, t, lr)."""
+               beta2=0.999, eps=1e-8, masks=None, sign_u=None, own_masks=None, update=True):
+    """One step with TF1 Adam, in place on ``p`` (dict of leaf tensors) and ``opt`` (m, v, t, lr); ``update=False`` stops after the
+    gradients (parity runs that evaluate the same weights twice)."""
     for v in p.values():
         v.requires_grad_(True)
         v.grad = None
-    psi = generator_fwd(z, p, output_shape, filters, num_conv=num_conv, repeat=repeat, masks=masks)
+    psi = generator_fwd(z, p, output_shape, filters, num_conv=num_conv, repeat=repeat, masks=masks, own_masks=own_masks)
     loss, l1, jl1, u = velocity_loss(psi, x, is_3d, w1, w2, sign_u=sign_u)
     loss.backward()
+    if not update:
+        return {"loss": float(loss.detach()), "l1": float(l1.detach()), "j_l1": float(jl1.detach()), "u": u.detach(),
+                "psi": psi.detach(), "grads": {k: v.grad for k, v in p.items()}}
     opt["t"] += 1
     t = opt["t"]
     lr_t = opt["lr"] * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)

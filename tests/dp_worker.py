@@ -65,7 +65,12 @@ def run(case, world, rank, force_sync=False):
     if name == "GANTrainer":
         out["pd"] = tr.D.p.cpu().numpy()
     out["loss"] = np.float64(float(m.g_loss.detach()))
+    out["logged_loss"] = np.float64(tr._scalars(m, 0.0)["loss/g_loss"])      # what Trainer.train logs: the global-batch mean on EVERY rank
     out["g_lr"] = np.float64(tr.g_lr)
+    if dist.is_initialized():
+        from deep_fluids_amd.dist import verify_world
+        w = verify_world()
+        out["counted_ranks"] = np.int64(w["ranks"]); out["distinct_devices"] = np.int64(w["distinct_devices"])
     if force_sync:
         t = tr.grad_sync.timing()
         out["comm_span_ms"] = np.float64(t["comm_span_ms"]); out["exposed_ms"] = np.float64(t["exposed_ms"])

@@ -43,10 +43,10 @@ def test_kernel_selector_and_roofline_object():
     assert key == "jacobian3d_fwd_kernel<j,c>" and work == 60.0 * B * D * H * W                                    # 60 B/voxel
     assert b.select_kernel("df_jacobian3d_fwd", (1, None, 3, B, D, H, W, None)) is None
     key, work = b.select_kernel("df_conv_wgrad_algo", (1, 2, 3, 4, B, D, H, W, C, C, 3, 5, 6, 0, None))
-    assert key == "wgrad_kernel 64x96x64 C128x128"
+    assert key == "wgrad_kernel 64x96x64 C128x128 B16"
     ks = {"wino3d_kernel fwd/dgrad 64x96x64 C128->128": {"launches": 10, "seconds": 0.170, "work": 10 * 5.566277615616e12},
           "wino3d_kernel fwd/dgrad 8x12x8 C128->128": {"launches": 10, "seconds": 0.001, "work": 10 * 1.0872e10},
-          "wgrad_kernel 64x96x64 C128x128": {"launches": 5, "seconds": 0.075, "work": 5 * 5.566277615616e12}}
+          "wgrad_kernel 64x96x64 C128x128 B16": {"launches": 5, "seconds": 0.075, "work": 5 * 5.566277615616e12}}
     r = b.roofline_of(ks, "wino3d_kernel", {"wino3d_kernel": {"traffic_bytes": 3.2e10}}, True)
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r)
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and r["kernel"].startswith("wino3d_kernel fwd/dgrad 64x96x64")
@@ -54,6 +54,10 @@ def test_kernel_selector_and_roofline_object():
     assert abs(r["achieved"] - r["algorithmic_tflops"] * 8 / 27) < 1e-9 and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / 157.3) < 1e-12
     assert r["traffic"] == 3.2e10 and r["traffic_source"]
     w = b.roofline_of(ks, "wgrad_kernel", {}, False)
-    assert abs(w["algorithmic_speedup"] - 3.375) < 1e-12 and w["traffic"] is None and w["frac"] <= 1.0
-    assert b.wgrad_exec_ratio(1, 128, 96) == 4.0 / 9.0 and b.wgrad_exec_ratio(64, 96, 64) == 8.0 / 27.0 and b.wgrad_exec_ratio(7, 10, 7) == 1.0
+    assert abs(w["algorithmic_speedup"] - 3.375) < 1e-12 and w["traffic"] is None and w["frac"] <= 1.0 and w["wgrad_form"] == "winograd-xyz"
+    # the executed / algorithmic ratio follows the LIBRARY's own choice (df_conv_wgrad_form == conv_wgrad.hip::wgrad_algo), incl. its
+    # size and channel-count conditions: (x,y,z) needs 128 -> 128 and >= 4096 image rows, below that (x,y) | x | direct
+    assert b.wgrad_exec_ratio(64, 1, 128, 96, 128, 128) == (4.0 / 9.0, 2) and b.wgrad_exec_ratio(16, 64, 96, 64, 128, 128) == (8.0 / 27.0, 3)
+    assert b.wgrad_exec_ratio(16, 7, 10, 7, 128, 128) == (1.0, 0)
+    assert b.wgrad_exec_ratio(2, 8, 12, 8, 128, 128)[1] in (0, 1) and b.wgrad_exec_ratio(16, 64, 96, 64, 64, 64) == (4.0 / 9.0, 2)
     json.dumps(r)      # the object must be JSON-serialisable as is

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from deep_fluids_amd.dist import GradSync, shard_batch
+from deep_fluids_amd.dist import GradSync, shard_batch, verify_world, check_world
 
 
 def _free_port():
@@ -57,6 +57,7 @@ def _worker(rank, world, port, out):
         _loss(ps, X[lo:lo + n], Y[lo:lo + n]).backward()
         scale = sync.finish()
     out[rank] = (flat_g * scale).clone().numpy()
+    out["world%d" % rank] = verify_world()
     dist.destroy_process_group()
 
 
@@ -72,6 +73,8 @@ def test_bucketed_allreduce_matches_full_batch():
     ref = flat_g.numpy()
     np.testing.assert_allclose(out[0], ref, rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(out[1], out[0], rtol=0, atol=0)      # every rank holds identical reduced gradients
+    for r in range(world):      # bench.py's `rccl_ranks`: counted by an all-reduce over the backend, not read from the environment
+        assert out["world%d" % r]["ranks"] == 2 and out["world%d" % r]["backend"] == "gloo" and len(out["world%d" % r]["devices"]) == 2
 
 
 def test_shard_batch_and_single_process_passthrough():
@@ -81,3 +84,14 @@ def test_shard_batch_and_single_process_passthrough():
     ps, flat_g, buckets = _model_and_slabs()
     sync = GradSync(flat_g, buckets)           # no process group: disabled, scale 1
     assert not sync.enabled and sync.finish() == 1.0
+
+
+def test_check_world_refuses_rccl_on_shared_devices():
+    ok = check_world("nccl", 2, 2, ["0:5:0", "0:6:0"])
+    assert ok == {"ranks": 2, "backend": "nccl", "devices": ["0:5:0", "0:6:0"], "distinct_devices": 2}
+    with pytest.raises(RuntimeError, match="one rank per GPU"):
+        check_world("nccl", 2, 2, ["0:5:0", "0:5:0"])          # two RCCL ranks on one physical GPU: not a 2-GPU measurement
+    assert check_world("gloo", 2, 2, ["0:5:0", "0:5:0"])["distinct_devices"] == 1      # the single-GPU sharing TEST configuration
+    with pytest.raises(RuntimeError, match="returned 1"):
+        check_world("nccl", 2, 1, ["a", "b"])
+    assert verify_world() == {"ranks": 1, "backend": None, "devices": [verify_world()["devices"][0]], "distinct_devices": 1}

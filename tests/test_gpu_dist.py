@@ -62,9 +62,14 @@ def test_two_rank_trainer_matches_global_batch_run(tmp_path, case):
     order = list(dp["launch_order"])
     assert sorted(order) == list(range(int(dp["n_buckets"]))) and order[-1] == 0 and order[0] == int(dp["n_buckets"]) - 1, order
     assert abs(dp["loss"] - ref["loss"]) < 1e-4 * abs(ref["loss"])      # mean of the shard losses (step 2) vs the global-batch loss
+    # Trainer._scalars all-reduces the logged losses: rank 0's logged value IS the global-batch loss (and the NaN guard sees the same
+    # number on every rank); the backend itself counted two ranks
+    assert abs(dp["logged_loss"] - ref["loss"]) < 1e-4 * abs(ref["loss"])
+    assert int(dp["counted_ranks"]) == 2
 
 
-def test_one_rank_rccl_exchange_is_the_identity(tmp_path):
+@pytest.mark.parametrize("case", ["de3_cfg4geom", "dg2"])
+def test_one_rank_rccl_exchange_is_the_identity(tmp_path, case):
     """The production backend: ONE rank over RCCL ("nccl") with the exchange forced on (world_size 1: the all-reduce is the
     identity, 1/world = 1) -- side stream, post-accumulate hooks, async all-reduce on the communication stream, the HIP-event
     profile and the hand-back to the compute stream all run as they do on an 8-GPU node.  Parameters after two steps must be
@@ -74,17 +79,19 @@ def test_one_rank_rccl_exchange_is_the_identity(tmp_path):
     env = dict(os.environ)
     env.update({"HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
                 "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), "de3_cfg4geom", out, "rccl1"], env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), case, out, "rccl1"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-4000:]
     dp = dict(np.load(out))
-    ref = dp_worker.run("de3_cfg4geom", 1, 0)
+    ref = dp_worker.run(case, 1, 0)
     from deep_fluids_amd import ops
     ops.reset_variables()
-    assert str(dp["backend"]) == "nccl"
+    assert str(dp["backend"]) == "nccl" and int(dp["counted_ranks"]) == 1 and int(dp["distinct_devices"]) == 1
     np.testing.assert_array_equal(dp["p_init"], ref["p_init"])
     np.testing.assert_array_equal(dp["g0"], ref["g0"])
     np.testing.assert_array_equal(dp["p"], ref["p"])
+    if "pd" in ref:      # GANTrainer.enable_data_parallel(profile, force) reaches the discriminator's exchange too
+        np.testing.assert_array_equal(dp["gd0"], ref["gd0"]); np.testing.assert_array_equal(dp["pd"], ref["pd"])
     order = list(dp["launch_order"])
     assert sorted(order) == list(range(int(dp["n_buckets"]))) and order[-1] == 0
     assert int(dp["timed_steps"]) == 2 and dp["comm_span_ms"] > 0.0 and dp["exposed_ms"] >= 0.0

@@ -43,20 +43,29 @@ def _worst(errs, n=4):
     return sorted(rel.items(), key=lambda kv: -kv[1])[:n]
 
 
-def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True):
-    """One default-dispatch train step (or, backward=False, the inference graph) on the GPU and on the PyTorch-CPU oracle."""
+def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteered=False):
+    """One default-dispatch train step (or, backward=False, the inference graph) on the GPU and on the PyTorch-CPU oracle.
+
+    3-D, backward: the step is run TWICE on the same weights -- once with ``ops.ACTIVATION_FETCH`` (the fp32 activations are fetched
+    for the oracle's lrelu slopes, which puts the block tails on df_wino_conv_fwd_addup + df_lrelu_bwd_pool2x) and once exactly as
+    bench.py runs it (df_wino_conv_fwd_addup_bits + df_lrelu_bits_bwd_pool2x: the tail activation is never written, only its sign
+    words).  The second run must reproduce velocity, loss and EVERY gradient of the first bit for bit, and its sign words must decode
+    to the first run's activation signs -- so the oracle comparison below covers the dispatch the benchmark measures.
+    ``unsteered``: additionally back-propagate the oracle on ITS OWN linear pieces and report that error + the fraction of lrelu /
+    |.| sign decisions on which GPU and oracle disagree (the reason the steered comparison exists)."""
     from deep_fluids_amd import ops
     from deep_fluids_amd.trainer import Trainer, default_config
     ops.reset_variables()
+    is_3d = len(spatial) == 3
     rng = np.random.RandomState(seed)
-    oshape = list(spatial) + [3]
+    oshape = list(spatial) + [3 if is_3d else 1]
     p = orc.generator_init(rng, 3, oshape, filters)
     for k in p:
         if k.endswith("biases"):
             p[k] = rng.uniform(-0.05, 0.05, p[k].shape).astype(np.float32)
     x, y = orc.synthetic_batch(rng, batch, spatial)
-    cfg = default_config(is_3d=True, res_x=spatial[2], res_y=spatial[1], res_z=spatial[0], filters=filters, batch_size=batch,
-                         num_samples=1000)
+    cfg = default_config(is_3d=is_3d, res_x=spatial[-1], res_y=spatial[-2], res_z=spatial[0] if is_3d else 1, filters=filters,
+                         batch_size=batch, num_samples=1000)
     tr = Trainer(cfg)
     tr.load_variables(p)
     torch.set_num_threads(max(1, min(len(__import__("os").sched_getaffinity(0)), 64)))
@@ -66,7 +75,7 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True):
         u = host(tr.generate(dev(y)))
         with torch.no_grad():
             psi = ort.generator_fwd(torch.from_numpy(y), pt, oshape, filters)
-            ref = ort.jacobian3(psi)[1].numpy()
+            ref = (ort.jacobian3(psi)[1] if is_3d else ort.curl(psi)).numpy()
         out["velocity_rel_l1"] = rel_l1(u, ref)
         ops.reset_variables()
         return out
@@ -77,10 +86,50 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True):
     finally:
         ops.ACTIVATION_FETCH = None
     gr = tr.grads_numpy()
+    flat_g = tr.flat_g.clone()
+    u_t = m.G_.detach().clone()
     u, loss = host(m.G_), float(m.g_loss.detach())
     del m
-    info = ort.train_step(torch.from_numpy(y), torch.from_numpy(x), pt, ort.new_opt(pt), oshape, filters, True, masks=masks,
-                          sign_u=torch.from_numpy(u))
+    if is_3d:
+        # ---- the dispatch bench.py runs: same weights, no activation fetch -> sign-word block tails ----
+        tr.load_variables(p)
+        ops.SIGN_BITS_FETCH = []
+        try:
+            m2 = tr.train_step(dev(x), dev(y))
+            tails = list(ops.SIGN_BITS_FETCH)
+        finally:
+            ops.SIGN_BITS_FETCH = None
+        out["n_bits_tails"] = len(tails)
+        out["prod_velocity_identical"] = bool(torch.equal(m2.G_.detach(), u_t))
+        out["prod_loss_identical"] = float(m2.g_loss.detach()) == loss
+        out["prod_grads_identical"] = bool(torch.equal(tr.flat_g, flat_g))
+        out["prod_grads_maxdiff"] = float((tr.flat_g - flat_g).abs().max())
+        # tail k is the last conv of up-sampling block k: layer 4 (k + 2) with num_conv = 4
+        bad = 0
+        for k, (bits, fdims, cout) in enumerate(tails):
+            ln = len(masks) - 4 * (len(tails) - 1 - k)
+            mk = ops.sign_bits_to_mask(bits, fdims, cout).cpu()
+            bad += int((mk != masks[ln]).sum())
+        out["bits_tail_mask_mismatches"] = bad
+        del m2, tails
+    del flat_g, u_t
+    zt, xt = torch.from_numpy(y), torch.from_numpy(x)
+    if unsteered:
+        own = {}
+        raw = ort.train_step(zt, xt, pt, None, oshape, filters, is_3d, own_masks=own, update=False)
+        e0 = _grad_errs(gr, raw["grads"])
+        out["unsteered_grad_rel_linf"] = _worst(e0)[0][1]
+        nel = sum(int(v.numel()) for v in own.values())
+        out["lrelu_sign_disagree_frac"] = sum(int((own[k] != masks[k]).sum()) for k in own) / float(nel)
+        uo = raw["u"]
+        su = torch.sign(torch.from_numpy(u) - xt) != torch.sign(uo - xt)
+        out["l1_sign_disagree_frac"] = float(su.float().mean())
+        print("UN-steered oracle (its own lrelu / |.| pieces) %s F=%d B=%d: worst gradient rel-Linf %.2e; lrelu sign decisions that differ "
+              "from the GPU's: %.3e of %d; sign(u - x) decisions that differ: %.3e" % (
+                  "x".join(map(str, spatial)), filters, batch, out["unsteered_grad_rel_linf"], out["lrelu_sign_disagree_frac"], nel,
+                  out["l1_sign_disagree_frac"]))
+        del raw, own, uo, su
+    info = ort.train_step(zt, xt, pt, ort.new_opt(pt), oshape, filters, is_3d, masks=masks, sign_u=torch.from_numpy(u))
     out["velocity_rel_l1"] = rel_l1(u, info["u"].numpy())
     out["loss_rel"] = abs(loss - info["loss"]) / abs(info["loss"])
     errs = _grad_errs(gr, info["grads"])
@@ -94,11 +143,20 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True):
     return out
 
 
+def _assert_production_dispatch_identical(r, n_tails):
+    assert r["n_bits_tails"] == n_tails, r                  # the sign-word tail really ran (one per up-sampling block)
+    assert r["prod_velocity_identical"] and r["prod_loss_identical"], r
+    assert r["prod_grads_identical"], r                     # every gradient of the bench's dispatch == the fetched run's, bitwise
+    assert r["bits_tail_mask_mismatches"] == 0, r
+
+
 def test_cfg3_default_dispatch_train_step_vs_torch_oracle_b2():
     """BASELINE cfg3 (64x96x64, F = 128, 4 levels), batch 2: Winograd forward / dgrad (+ fused skip add), up-sampling-aware
     27-point forms, Winograd-(x,y,z) weight gradients (W = 64 | 32 | 16 row variants), matrix-core thin layer."""
-    r = _step_vs_torch_oracle((64, 96, 64), 128, 2, seed=11)
+    r = _step_vs_torch_oracle((64, 96, 64), 128, 2, seed=11, unsteered=True)
     assert r["n_layers_fetched"] == 16, r
+    _assert_production_dispatch_identical(r, 3)
+    assert r["lrelu_sign_disagree_frac"] < 1e-3 and r["l1_sign_disagree_frac"] < 1e-3, r      # measured: see the printed line
     assert r["velocity_rel_l1"] <= 1e-4, r           # north-star tolerance (measured ~2e-6: fp32 vs fp32)
     assert r["loss_rel"] < 1e-5, r
     assert r["grad_rel_linf"] < 2e-4, r              # measured 1.4e-5 (on the GPU's linear piece; 2-4e-3 with the oracle's own signs)
@@ -120,6 +178,7 @@ def test_cfg4_full_grid_train_step_vs_torch_oracle():
     assert r["velocity_rel_l1"] <= 1e-4, r
     if backward:
         assert r["n_layers_fetched"] == 20, r
+        _assert_production_dispatch_identical(r, 4)
         assert r["loss_rel"] < 1e-5, r
         assert r["grad_rel_linf"] < 2e-4, r          # measured 2.5e-5
         assert r["last_bias_abs"] < 1e-3, r
@@ -380,7 +439,28 @@ def test_batch16_first_and_last_element_bit_identical_to_batch1():
     call("df_wino_conv_fwd_addup", _ptr(x1), _ptr(ww[0]), _ptr(bias), _ptr(xc1), _ptr(o1), _ptr(y21), 1, D, H, W, C, C, 0.2, s)
     call("df_wino_conv_fwd_addup", _ptr(xB), _ptr(ww[0]), _ptr(bias), _ptr(xcB), _ptr(oB), _ptr(y2B), B, D, H, W, C, C, 0.2, s)
     assert torch.equal(oB[B - 1], o1[0]) and torch.equal(y2B[B - 1], y21[0]) and torch.equal(y2B[0], y21[0])
-    del o1, oB, y21, y2B
+    # the production block tail (what bench.py runs): df_wino_conv_fwd_addup_bits writes y2 + sign words only; df_lrelu_bits_bwd_pool2x
+    # consumes the words.  Slots 0 / 15 vs batch 1, the words decoded against the fp32 activation, and the backward tail against the
+    # fp32-mask kernel (df_lrelu_bwd_pool2x on the activation) -- bitwise.
+    from deep_fluids_amd import ops as _ops
+    nw1 = query("df_wino_signbits_bytes", 1, D, H, W, C) // 8; nwB = query("df_wino_signbits_bytes", B, D, H, W, C) // 8
+    sb1 = torch.zeros(nw1, dtype=torch.int64, device="cuda"); sbB = torch.zeros(nwB, dtype=torch.int64, device="cuda")
+    z21 = torch.full(shp(1), float("nan"), device="cuda"); z2B = torch.full(shp(B), float("nan"), device="cuda")
+    call("df_wino_conv_fwd_addup_bits", _ptr(x1), _ptr(ww[0]), _ptr(bias), _ptr(xc1), _ptr(z21), _ptr(sb1), 1, D, H, W, C, C, 0.2, s)
+    call("df_wino_conv_fwd_addup_bits", _ptr(xB), _ptr(ww[0]), _ptr(bias), _ptr(xcB), _ptr(z2B), _ptr(sbB), B, D, H, W, C, C, 0.2, s)
+    assert torch.equal(z21, y21) and torch.equal(z2B, y2B)
+    assert torch.equal(sbB[:nw1], sb1) and torch.equal(sbB[nwB - nw1:], sb1)
+    assert torch.equal(_ops.sign_bits_to_mask(sb1, (1, D, H, W), C), o1 > 0)
+    for sl in (0, B - 1):
+        assert torch.equal(_ops.sign_bits_to_mask(sbB[sl * nw1:(sl + 1) * nw1], (1, D, H, W), C), oB[sl:sl + 1] > 0), sl
+    del z21, z2B, y21, y2B
+    gxa = torch.full(shp(B), float("nan"), device="cuda"); gpa = torch.full((B, Dc, Hc, Wc, C), float("nan"), device="cuda")
+    gxb = torch.full(shp(B), float("nan"), device="cuda"); gpb = torch.full((B, Dc, Hc, Wc, C), float("nan"), device="cuda")
+    call("df_lrelu_bwd_pool2x", _ptr(mB), _ptr(oB), _ptr(gxa), _ptr(gpa), 0.2, B, Dc, Hc, Wc, C, 1, s)
+    call("df_lrelu_bits_bwd_pool2x", _ptr(mB), _ptr(sbB), _ptr(gxb), _ptr(gpb), 0.2, B, Dc, Hc, Wc, C, s)
+    assert torch.equal(gxa, gxb) and torch.equal(gpa, gpb)
+    assert torch.equal(gxb[0], gxb[B - 1]) and torch.equal(gpb[0], gpb[B - 1])
+    del o1, oB, gxa, gxb, gpa, gpb, sb1, sbB
     a1 = torch.zeros_like(xc1); aB = torch.zeros_like(xcB)
     call("df_wino_upconv_dgrad", _ptr(x1), _ptr(ww[1]), _ptr(a1), 1, Dc, Hc, Wc, C, C, s)
     call("df_wino_upconv_dgrad", _ptr(xB), _ptr(ww[1]), _ptr(aB), B, Dc, Hc, Wc, C, C, s)
@@ -441,3 +521,77 @@ def test_batch16_generator_outputs_identical_across_batch_cfg3():
     for b in (0, 7, 15):
         assert torch.equal(u16[b], u1[0]), b
     ops.reset_variables()
+
+
+def test_cfg2_train_step_128x96_vs_torch_oracle_and_batch64_identity():
+    """BASELINE cfg2's own shape (2-D 128x96, F = 128, 5 levels): one default-dispatch train step at batch 2 against the PyTorch-CPU
+    oracle (Winograd F(2x2,3x3) forward / dgrad, the 9-of-16-point up-sampling forms, Winograd-(x,y) weight gradients with the
+    W = 96 | 48 | 24 | 12 row variants, thin 128 -> 1 layer), then cfg2's batch (64): 64 identical parameter rows must give 64
+    bit-identical velocity fields equal to the batch-1 result."""
+    r = _step_vs_torch_oracle((128, 96), 128, 2, seed=21, unsteered=True)
+    assert r["n_layers_fetched"] == 20, r
+    assert r["velocity_rel_l1"] <= 1e-4, r
+    assert r["loss_rel"] < 1e-5, r
+    assert r["grad_rel_linf"] < 2e-4, r
+    assert r["last_bias_abs"] < 1e-3, r
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import Trainer, default_config
+    ops.reset_variables()
+    cfg = default_config(is_3d=False, res_x=96, res_y=128, filters=128, batch_size=64, num_samples=21000)
+    tr = Trainer(cfg)
+    z1 = torch.tensor([[0.3, -0.7, 0.1]], device="cuda")
+    u1 = tr.generate(z1)
+    u64 = tr.generate(z1.repeat(64, 1).contiguous())
+    for b in (0, 31, 63):
+        assert torch.equal(u64[b], u1[0]), b
+    # a full train step at batch 64 with identical samples: loss == the batch-1 loss to rounding, gradients == batch-1 gradients
+    rng = np.random.RandomState(22)
+    x1, y1 = orc.synthetic_batch(rng, 1, (128, 96))
+    g = {}
+    for bsz in (1, 64):
+        tr.flat_m.zero_(); tr.flat_v.zero_(); tr._adam_t = 0
+        params = tr.variables_numpy() if bsz == 1 else params
+        tr.load_variables(params)
+        m = tr.train_step(dev(np.repeat(x1, bsz, 0)), dev(np.repeat(y1, bsz, 0)))
+        g[bsz] = (float(m.g_loss.detach()), tr.flat_g.clone())
+        del m
+    assert abs(g[64][0] - g[1][0]) <= 2e-6 * abs(g[1][0]), g
+    scale = g[1][1].abs().max()
+    assert ((g[64][1] - g[1][1]).abs().max() / scale).item() < 2e-5
+    ops.reset_variables()
+
+
+def test_cfg5_ae3_128cube_forward_vs_torch_oracle():
+    """BASELINE cfg5's shape: AE3 (EncoderBE3 + GeneratorBE3, F = 64, z_num = 16) at 128^3, one sample, inference graph: code z and the
+    decoder output against the PyTorch-CPU oracle (stride-2 TF-SAME convs 128->128 ... 320->320 with Cin != Cout concat skips,
+    the 196,608 -> 16 FC, W = 128-row conv variants, 3 -> 64 / 64 -> 3 thin layers)."""
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.model import AE3
+    ops.reset_variables()
+    rng = np.random.RandomState(31)
+    R, filters, z_num = 128, 64, 16
+    xshape = [R, R, R, 3]
+    p = orc.ae_init(rng, xshape, filters, z_num)
+    for k in p:
+        if k.endswith("biases"):
+            p[k] = rng.uniform(-0.05, 0.05, p[k].shape).astype(np.float32)
+    x, _ = orc.synthetic_batch(rng, 1, (R, R, R))
+    for k, v in p.items():
+        ops.set_variable(k, v)
+    with torch.no_grad():
+        out, z, variables = AE3(dev(x), filters, z_num, reuse=True)
+    assert len(variables) == len(p)
+    torch.set_num_threads(max(1, min(len(__import__("os").sched_getaffinity(0)), 64)))
+    with torch.no_grad():
+        oref, zref = ort.ae_fwd(torch.from_numpy(x), ort.to_torch(p), filters, z_num)
+    ez = rel_linf(host(z), zref.numpy()); eo = rel_l1(host(out), oref.numpy()); eoi = rel_linf(host(out), oref.numpy())
+    print("AE3 128^3 F=64 forward vs torch oracle: z rel-Linf %.2e, out rel-L1 %.2e rel-Linf %.2e" % (ez, eo, eoi))
+    assert ez < 1e-4 and eo < 1e-4 and eoi < 1e-3
+    ops.reset_variables()
+
+
+def test_cfg5_ae3_train_step_w128_rows_vs_fp64_oracle():
+    """cfg5's row length at a reduced grid: AE3 F = 64 on 16x32x128 (5 levels down to 1x2x8; W = 128 | 64 | 32 | 16 | 8 row variants
+    of every conv / weight-gradient kernel, stride-2 adjoints), full train step at batch 2 against the fp64 NumPy oracle."""
+    from test_gpu_ae import _ae_step_case
+    _ae_step_case(True, (16, 32, 128), 64, False)

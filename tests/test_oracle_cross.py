@@ -57,3 +57,23 @@ def test_kl_bernoulli_gradient_numeric():
         zm = z.copy(); zm[b, j] -= 1e-6
         num = (orc.kl_bernoulli(zp, n, rho) - orc.kl_bernoulli(zm, n, rho)) / 2e-6
         assert abs(num - g[b, j]) < 1e-6 * max(1.0, abs(num))
+
+
+@pytest.mark.parametrize("xshape,filters", [([8, 16, 8, 3], 8), ([16, 16, 2], 8)])
+def test_ae_forward_numpy_vs_torch_fp64(xshape, filters):
+    """Encoder (stride-2 TF-SAME convs: pad 0 before / 1 after, concat skips, flatten + FC) + decoder: NumPy tap-shift restatement vs
+    F.pad + F.conv*(stride=2).  The torch version is the full-size (128^3) checker of tests/test_gpu_fullsize.py."""
+    rng = np.random.RandomState(1)
+    p = orc.ae_init(rng, xshape, filters, 8)
+    for k in p:
+        if k.endswith("biases"):
+            p[k] = rng.uniform(-0.05, 0.05, p[k].shape).astype(np.float32)
+    x, _ = orc.synthetic_batch(rng, 2, xshape[:-1])
+    x = x[..., :xshape[-1]].astype(np.float64)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    z = orc.encoder_fwd(x, p64, filters, 8, "AE/enc", 3)
+    out = orc.generator_fwd(z, p64, xshape, filters, "AE/dec", 4)
+    with torch.no_grad():
+        o2, z2 = ort.ae_fwd(torch.from_numpy(x), ort.to_torch(p, torch.float64), filters, 8)
+    np.testing.assert_allclose(z2.numpy(), z, atol=1e-12)
+    np.testing.assert_allclose(o2.numpy(), out, atol=1e-12)
