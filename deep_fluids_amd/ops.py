@@ -347,6 +347,8 @@ class _ConvSame3(torch.autograd.Function):
         flags = DF_CONV_BIAS | (DF_CONV_LRELU if leak is not None else 0)
         y = _conv_raw(x, wp, b, None, None, dims, cin, cout, kz, flags, leak if leak is not None else 0.0)
         y = y.view(x.shape[:-1] + (cout,))
+        if ACTIVATION_FETCH is not None and leak is not None:
+            ACTIVATION_FETCH.append(y)
         ctx.save_for_backward(x, w, y if leak is not None else None)
         ctx.leak = leak
         ctx.geom = (dims, cin, cout, kz, taps)
@@ -471,6 +473,9 @@ class _UpGenBlock(torch.autograd.Function):
                 raise ValueError("up_gen_block: weights %s do not match %d channels" % (tuple(w.shape), C))
             sb = _new_bits(fdims, cout, xc) if (SIGN_BIT_MASKS and i < n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3) else None
             bits.append(sb)
+            if DISPATCH_COUNTS is not None and i == 0:
+                _count("upconv", "winograd-27pt" if (is3d and _use_wino(cin, cout, fdims, kz) == 3) else
+                       "winograd2d-9pt" if (not is3d and _use_wino(cin, cout, fdims, kz) == 2) else "parity-class" + _sfx(cin, cout), fdims, cin, cout)
             if i == 0 and is3d and _use_wino(cin, cout, fdims, kz) == 3:
                 # 27-point up-sampling-aware Winograd form (conv_wino.hip, UP variant): same packed operand as a plain conv
                 wp = _pack(w, taps, cin, cout, 0, fdims)
@@ -500,6 +505,7 @@ class _UpGenBlock(torch.autograd.Function):
                 if i == n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3 and SIGN_BIT_MASKS and ACTIVATION_FETCH is None:
                     # block-end skip add fused into the last conv's epilogue, and of the conv's own activation only the sign bits are
                     # kept (all the backward tail needs of it): y = lrelu(conv(x)) + upscale(xc), tail_bits = (lrelu(conv(x)) > 0)
+                    _count("conv", "winograd-f2x2x2+addup+signwords", fdims, cin, cout)
                     tail_bits = _new_bits(fdims, cout, xc)
                     y = torch.empty(fshape, dtype=torch.float32, device=xc.device)
                     call("df_wino_conv_fwd_addup_bits", _ptr(x), _ptr(wp), _ptr(b), _ptr(xc), _ptr(y), _ptr(tail_bits), fdims[0], fdims[1],
@@ -509,6 +515,7 @@ class _UpGenBlock(torch.autograd.Function):
                     x = None
                 elif i == n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3:
                     # (fp32 masks: the activation is a second output)
+                    _count("conv", "winograd-f2x2x2+addup", fdims, cin, cout)
                     x_in, x = x, torch.empty(fshape, dtype=torch.float32, device=xc.device)
                     y = torch.empty(fshape, dtype=torch.float32, device=xc.device)
                     call("df_wino_conv_fwd_addup", _ptr(x_in), _ptr(wp), _ptr(b), _ptr(xc), _ptr(x), _ptr(y), fdims[0], fdims[1],
@@ -573,6 +580,9 @@ class _UpGenBlock(torch.autograd.Function):
                     call("df_upconv_wgrad_algo", _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
                          cdims[3], C, C, kz, _ptr(wsb), nbytes, int(WGRAD_ALGO), _stream())
                 if ctx.needs_input_grad[0]:
+                    if DISPATCH_COUNTS is not None:
+                        _count("upconv-dgrad", "winograd-27pt-pooled" if (is3d and _use_wino(C, C, fdims, kz) == 3) else
+                               "winograd2d-9pt-pooled" if (not is3d and _use_wino(C, C, fdims, kz) == 2) else "parity-class" + _sfx(C, C), fdims, C, C)
                     # dxc holds the skip path's sum-pool of dy (df_lrelu_bwd_pool2x above); += the conv path per parity class
                     if is3d and _use_wino(C, C, fdims, kz) == 3:
                         # pooled-output Winograd form (conv_wino.hip, POOL variant): 27 of the 64 products, coarse stores
@@ -618,6 +628,8 @@ class _ConvSame3S2(torch.autograd.Function):
         call("df_conv_s2_fwd", _ptr(x), _ptr(wp), _ptr(b), _ptr(y), odims[0], odims[1], odims[2], odims[3], cin, cout, kz,
              flags, float(leak if leak is not None else 0.0), _stream())
         y = y.view((x.shape[0],) + tuple(int(d) // 2 for d in x.shape[1:-1]) + (cout,))
+        if ACTIVATION_FETCH is not None and leak is not None:
+            ACTIVATION_FETCH.append(y)
         ctx.save_for_backward(x, w, y if leak is not None else None)
         ctx.leak = leak
         ctx.geom = (idims, odims, cin, cout, kz, taps)
@@ -993,7 +1005,7 @@ def mse_mean(a, b):
 FUSED_BLOCKS = True     # GeneratorBE(3) uses one fused autograd node per block (same kernels, fused backward epilogues)
 
 # Fetch of intermediate tensors (the counterpart of adding a tensor to ``sess.run``'s fetch list): when set to a list, every
-# fused generator block appends its post-lrelu conv outputs (layer order) to it.  Used by the full-size parity tests to hand the
+# fused generator block and every layer-by-layer conv with an lrelu appends its post-lrelu conv outputs (execution order) to it.  Used by the full-size parity tests to hand the
 # oracle the lrelu sign pattern the GPU actually took.  None (default) = no fetch, no cost.
 ACTIVATION_FETCH = None
 

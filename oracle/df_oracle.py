@@ -447,8 +447,9 @@ def encoder_fwd(x, p, filters, z_num, name="enc", num_conv=3, repeat=0, leak=0.2
     return (z, cache) if keep else z
 
 
-def encoder_bwd(dz, cache, p, name="enc", leak=0.2):
-    """Reverse pass of :func:`encoder_fwd` (gradient w.r.t. the input is not needed: x is data)."""
+def encoder_bwd(dz, cache, p, name="enc", leak=0.2, masks=None):
+    """Reverse pass of :func:`encoder_fwd` (gradient w.r.t. the input is not needed: x is data).  ``masks`` ({layer number: bool
+    array}, optional): the lrelu sign pattern of the implementation under test (see :func:`generator_bwd`)."""
     g = {}
     ln = cache["fc_ln"]
     g["%s/%d_fc/weights" % (name, ln)] = cache["flat"].T @ dz
@@ -469,7 +470,7 @@ def encoder_bwd(dz, cache, p, name="enc", leak=0.2):
             if l == 0 and dx0 is not None:              # x0 = output of the first conv
                 dx = dx + dx0
                 dx0 = None
-            dpre = dx * np.where(y > 0, 1.0, leak).astype(dx.dtype)
+            dpre = dx * np.where((y > 0) if masks is None else masks[l], 1.0, leak).astype(dx.dtype)
             dx, dw, db = conv_same_bwd(xin, p["%s/%d_conv/weights" % (name, l)], dpre, stride, need_dx=(l != 0))
             g["%s/%d_conv/weights" % (name, l)] = dw; g["%s/%d_conv/biases" % (name, l)] = db
     return g
@@ -498,35 +499,37 @@ def kl_bernoulli_bwd(z, n, rho, scale=1.0):
 
 
 def ae_train_step(x, y_last, p, opt, filters, z_num, p_num, is_3d, num_conv=4, repeat=0, use_curl=True, w1=1.0, w2=1.0,
-                  w4=1.0, name="AE", use_sparse=False, sparsity=0.01, w5=1.0):
+                  w4=1.0, name="AE", use_sparse=False, sparsity=0.01, w5=1.0, enc_masks=None, dec_masks=None, sign_u=None):
     """build_model_ae + one optimizer step (trainer.py:357-423 / trainer3.py:240-279).
     ``y_last`` = y[:, :, -1]  [B, p_num];  loss = w1*L1 + w2*J-L1 + w4*mean((y_last - z[:, -p_num:])^2)
-    (+ w5 * Bernoulli-KL of the sigmoid code's first z_num - p_num columns when use_sparse, model.py:196,210)."""
+    (+ w5 * Bernoulli-KL of the sigmoid code's first z_num - p_num columns when use_sparse, model.py:196,210).
+    ``enc_masks`` / ``dec_masks`` / ``sign_u``: back-propagate on the linear pieces (lrelu slopes per layer, signs of the |.| terms) the
+    implementation under test is on; forward values and the loss stay this oracle's own."""
     oshape = list(x.shape[1:])                           # model.py:197,211: the decoder emits x's own shape
     zpre, ecache = encoder_fwd(x, p, filters, z_num, name + "/enc", num_conv - 1, repeat, keep=True)
     z = 1.0 / (1.0 + np.exp(-zpre)) if use_sparse else zpre
     s, dcache = generator_fwd(z, p, oshape, filters, name + "/dec", num_conv, repeat, keep=True)
     if use_curl:
         if is_3d:
-            res = velocity_loss(s, x, True, w1, w2)
+            res = velocity_loss(s, x, True, w1, w2, sign_u=sign_u)
             ds = res["dpsi"]
         else:                                            # curl reads channel 0 only (ops.py:267-268)
-            res = velocity_loss(s[..., :1], x, False, w1, w2)
+            res = velocity_loss(s[..., :1], x, False, w1, w2, sign_u=sign_u)
             ds = np.zeros_like(s); ds[..., :1] = res["dpsi"]
     else:
         raise NotImplementedError("oracle: AE without curl (liquid scenes) not restated")
     zp = z[:, -p_num:]
     loss_p = ((y_last - zp) ** 2).mean()
     dzp = -2.0 * (y_last - zp) / zp.size * w4
-    grads = generator_bwd(ds, dcache, p, name + "/dec")
-    dz = _generator_dz(ds, dcache, p, name + "/dec").copy()      # dL/dz through the decoder (z is the encoder's output)
+    grads = generator_bwd(ds, dcache, p, name + "/dec", masks=dec_masks)
+    dz = _generator_dz(ds, dcache, p, name + "/dec", masks=dec_masks).copy()      # dL/dz through the decoder (z is the encoder's output)
     dz[:, -p_num:] += dzp
     loss_kl = 0.0
     if use_sparse:
         loss_kl = kl_bernoulli(z, z_num - p_num, sparsity)
         dz = dz + kl_bernoulli_bwd(z, z_num - p_num, sparsity, w5)
         dz = dz * z * (1.0 - z)                                   # through the sigmoid
-    grads.update(encoder_bwd(dz, ecache, p, name + "/enc"))
+    grads.update(encoder_bwd(dz, ecache, p, name + "/enc", masks=enc_masks))
     t = opt["t"] + 1
     new_p, new_m, new_v = {}, {}, {}
     for k in p:
@@ -536,7 +539,7 @@ def ae_train_step(x, y_last, p, opt, filters, z_num, p_num, is_3d, num_conv=4, r
     return new_p, {"m": new_m, "v": new_v, "t": t, "lr": opt["lr"]}, info
 
 
-def _generator_dz(dout, cache, p, name, leak=0.2):
+def _generator_dz(dout, cache, p, name, leak=0.2, masks=None):
     """dL/dz of the generator input (needed when z comes from an encoder): the reverse pass of generator_fwd down
     to the FC layer's input."""
     ln = cache["last_ln"]
@@ -546,7 +549,7 @@ def _generator_dz(dout, cache, p, name, leak=0.2):
             dx = upscale_nn_bwd(dx, 2)
         dy = dx
         for xin, xout, l in zip(reversed(blk["ins"]), reversed(blk["outs"]), reversed(blk["ln"])):
-            dpre = dx * np.where(xout > 0, 1.0, leak).astype(dx.dtype)
+            dpre = dx * np.where((xout > 0) if masks is None else masks[l], 1.0, leak).astype(dx.dtype)
             dx, _, _ = conv_same_bwd(xin, p["%s/%d_conv/weights" % (name, l)], dpre)
         dx = dx + dy
     return dx.reshape(dx.shape[0], -1) @ p["%s/0_fc/weights" % name].T

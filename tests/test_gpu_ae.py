@@ -164,7 +164,10 @@ def test_ae_train_step_use_sparse_vs_oracle(is_3d, spatial, filters):
     _ae_step_case(is_3d, spatial, filters, True)
 
 
-def _ae_step_case(is_3d, spatial, filters, use_sparse):
+def _ae_step_case(is_3d, spatial, filters, use_sparse, steer=False, grad_tol=1e-3):
+    """``steer``: back-propagate the oracle on the linear pieces the GPU is on (lrelu slopes from the fetched GPU activations, the
+    signs of the |.| terms from the GPU's velocity) -- needed from ~1e5 voxels x 64 channels on, where a handful of pre-activations
+    within rounding error of zero moves the cancelling gradient sums at the 1e-2 level (tests/test_gpu_fullsize.py)."""
     from deep_fluids_amd import ops
     from deep_fluids_amd.trainer import AETrainer, default_config
     ops.reset_variables()
@@ -187,9 +190,23 @@ def _ae_step_case(is_3d, spatial, filters, use_sparse):
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     opt = {"m": {k: np.zeros_like(v) for k, v in p64.items()}, "v": {k: np.zeros_like(v) for k, v in p64.items()},
            "t": 0, "lr": cfg.lr_max}
-    m = tr.train_step(dev(x), dev(y))
+    kw = {}
+    if steer:
+        ops.ACTIVATION_FETCH = []
+        try:
+            m = tr.train_step(dev(x), dev(y))
+            acts = [host(t) > 0 for t in ops.ACTIVATION_FETCH]
+        finally:
+            ops.ACTIVATION_FETCH = None
+        n_enc = sum(1 for k in p if "/enc/" in k and k.endswith("conv/weights"))
+        n_dec = sum(1 for k in p if "/dec/" in k and k.endswith("conv/weights")) - 1           # the last decoder conv has no lrelu
+        assert len(acts) == n_enc + n_dec, (len(acts), n_enc, n_dec)
+        kw = dict(enc_masks={i: a for i, a in enumerate(acts[:n_enc])}, dec_masks={i + 1: a for i, a in enumerate(acts[n_enc:])},
+                  sign_u=host(m.G_))
+    else:
+        m = tr.train_step(dev(x), dev(y))
     _, _, info = orc.ae_train_step(x.astype(np.float64), y[:, :, -1].astype(np.float64), p64, opt, filters, z_num, p_num, is_3d,
-                                   use_sparse=use_sparse, sparsity=0.05, w5=0.7)
+                                   use_sparse=use_sparse, sparsity=0.05, w5=0.7, **kw)
     if use_sparse:
         assert abs(float(m.loss_kl.detach()) - info["loss_kl"]) < 1e-5 * abs(info["loss_kl"])
     assert rel_l1(host(m.G_), info["u"]) <= 1e-4
@@ -197,8 +214,11 @@ def _ae_step_case(is_3d, spatial, filters, use_sparse):
     assert abs(float(m.loss_p.detach()) - info["loss_p"]) < 1e-5 * abs(info["loss_p"]) + 1e-8
     gr = tr.grads_numpy()
     gmax = max(np.abs(v).max() for v in info["grads"].values())
-    worst = max(float(np.abs(gr[k] - info["grads"][k]).max() / max(np.abs(info["grads"][k]).max(), 1e-3 * gmax)) for k in gr)
-    assert worst < 1e-3, worst
+    errs = {k: float(np.abs(gr[k] - info["grads"][k]).max() / max(np.abs(info["grads"][k]).max(), 1e-3 * gmax)) for k in gr}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print("AE step %s F=%d%s: velocity rel-L1 %.2e, worst gradients %s" % ("x".join(map(str, spatial)), filters, " (steered)" if steer else "",
+                                                                       rel_l1(host(m.G_), info["u"]), worst))
+    assert worst[0][1] < grad_tol, worst
     ops.reset_variables()
 
 

@@ -16,7 +16,7 @@ import torch
 
 import df_oracle as orc
 import df_oracle_torch as ort
-from gpu_util import dev, host, rel_l1
+from gpu_util import dev, host, rel_l1, rel_linf
 
 pytestmark = pytest.mark.gpu
 
@@ -594,4 +594,4 @@ def test_cfg5_ae3_train_step_w128_rows_vs_fp64_oracle():
     """cfg5's row length at a reduced grid: AE3 F = 64 on 16x32x128 (5 levels down to 1x2x8; W = 128 | 64 | 32 | 16 | 8 row variants
     of every conv / weight-gradient kernel, stride-2 adjoints), full train step at batch 2 against the fp64 NumPy oracle."""
     from test_gpu_ae import _ae_step_case
-    _ae_step_case(True, (16, 32, 128), 64, False)
+    _ae_step_case(True, (16, 32, 128), 64, False, steer=True, grad_tol=2e-4)
