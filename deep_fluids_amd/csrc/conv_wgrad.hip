@@ -1228,9 +1228,12 @@ inline bool wxyz_ok(int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, 
 // returns 0 direct | 1 Winograd in x | 2 Winograd in (x,y) | 3 Winograd in (x,y,z)
 inline int wgrad_algo(int req, int64_t rows, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
   if (req == 1) return 0;
-  if ((req == 0 || req == 4) && wxyz_ok(D, H, W, Cin, Cout, kz) && (rows >= 4096 || req == 4)) return 3;
-  // (x,y) and (x,y,z) pay a larger partial buffer: worth it from ~4096 image rows (measured at batch 16, 128 -> 128:
-  //  16x24x16: x 0.68, xy 0.52, xyz 0.51 ms; 32x48x32: 3.72, 2.54, 2.00 ms; 64x96x64: 26.7, 18.9, 15.1 ms)
+  // (x,y,z) wherever it is instantiated, whatever the size: since its 16 workgroup types run as ONE launch (16 partial ranges fill the
+  // chip) it wins at every level and batch -- [r3] batch 2 | 4 | 16, ms: 16x24x16 x 0.155 | 0.220 | 0.645, xy 0.143 | 0.189 | 0.492,
+  // xyz 0.077 | 0.102 | 0.276;  32x48x32 x 0.64 | 1.20 | 3.70, xy 0.49 | 0.87 | 2.54, xyz 0.27 | 0.49 | 1.83 (the round-1 threshold of 4096
+  // image rows sent the per-GPU batches of the strong-scaling runs, 16 / 8 GPUs = 2, to the x form: 1.4 ms of a 30 ms step)
+  if ((req == 0 || req == 4) && wxyz_ok(D, H, W, Cin, Cout, kz)) return 3;
+  // (x,y) pays a larger partial buffer than x: worth it from ~4096 image rows where (x,y,z) does not exist (2-D; Cin | Cout != 128)
   if (req != 2 && wxy_ok(H, W, Cin, Cout) && (rows >= 4096 || req >= 3)) return 2;
   return wx_ok(W, Cin, Cout) ? 1 : 0;
 }
@@ -2285,7 +2288,10 @@ static Plan make_up_plan(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t 
 
 // the 27-point Winograd-(x,y,z) form of the up-sampling-aware weight gradient (fine extents 2Dc x 2Hc x 2Wc)
 static bool up_wxyz_ok(int req, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
-  return wxyz_ok(2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz) && (B * Dc * Hc >= 2048 || req == 4) && req != 1 && req != 2 && req != 3;
+  // at every size ([r3] batch 2 | 4 | 16, fine 16x24x16: parity-class 0.216 | 0.315 | 0.443 ms, 27-point 0.048 | 0.058 | 0.132; fine 32x48x32:
+  // 0.442 | 0.597 | 1.484 vs 0.129 | 0.222 | 0.787): the parity-class form pays a fixed-cost reduce of its 32-combo partials
+  (void)B;
+  return wxyz_ok(2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz) && req != 1 && req != 2 && req != 3;
 }
 
 // partial ranges of the 27-point (x,y,z) form: 9 workgroup types per range in one launch -- 28 ranges (252 workgroups: one round of

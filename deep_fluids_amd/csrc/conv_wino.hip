@@ -360,6 +360,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
   f32x4 acc[2][16];
   const int nchunk = a.Cin / CKW;
+  if ((DBG & 131072) && wave >= 4) __builtin_amdgcn_s_setprio(1);      // (experiment: static priority for the later-dispatched half)
 
   // ---- prologue: first block's chunk 0 -> buffer 0 ------------------------------------------------------------------------------
   BlockInfo cur = decode(seq(0));
@@ -783,6 +784,8 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case (18 << 11): hipLaunchKernelGGL((wino3d_kernel<(18 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 16384: hipLaunchKernelGGL((wino3d_kernel<16384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 65536: hipLaunchKernelGGL((wino3d_kernel<65536, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 131072: hipLaunchKernelGGL((wino3d_kernel<131072, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 100: hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // production kernel, compile-time flags (baseline of the experiments)
     case (17 << 11): hipLaunchKernelGGL((wino3d_kernel<(17 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
 #endif
     default: return df::fail(DF_EINVAL, "df_wino_conv_fwd: unknown debug variant");
