@@ -943,7 +943,7 @@ __device__ __forceinline__ void wgrad_wxyz_body(const WxyzArgs& aa, int range, i
   struct Row { const float* x[2][2]; const float* g[2][2]; };      // [plane a|b][row a|b]
   auto row_setup = [&](int pair) -> Row {
     Row rw;
-    const int trow = 2 * pair + half;
+    const int trow = (DBG & 8) ? 2 * (pair & 3) + half : 2 * pair + half;      // (tuning library, DBG 8: every range reads the same 8 tile rows -- an L2-resident working set)
     const bool ok = pair < p1 && trow < aa.ntrows;
     const int yt = trow % aa.Ht;
     const int t = trow / aa.Ht;
@@ -2161,6 +2161,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     else if (W == 64 && g_wgrad_dbg == 3) DF_WXYZ_DBG(3); else if (W == 64 && g_wgrad_dbg == 6) DF_WXYZ_DBG(6);
     else if (W == 64 && g_wgrad_dbg == 7) DF_WXYZ_DBG(7); else if (W == 64 && g_wgrad_dbg == 8) DF_WXYZ_DBG(0);
     else if (W == 64 && g_wgrad_dbg == 9) hipLaunchKernelGGL((wgrad_wxyz_fused_kernel<8, 128, 1>), gridf, dim3(kThreads), 0, s, aa);
+    else if (W == 64 && g_wgrad_dbg == 10) hipLaunchKernelGGL((wgrad_wxyz_fused_kernel<8, 128, 8>), gridf, dim3(kThreads), 0, s, aa);
     else
 #undef DF_WXYZ_DBG
 #endif

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where the time of the (x,y,z) Winograd weight gradient goes (tuning library, results wrong by construction for dbg != 0):
-dbg 0 = production (one fused launch), 8 = four launches by (GZ, GY) class (the round-1 form), 9 = fused + cached loads;
+dbg 0 = production (one fused launch), 8 = four launches by (GZ, GY) class (the round-1 form), 9 = fused + cached loads (L1 hits),
+10 = fused + every range reads the same 8 tile rows (L2-resident working set, L1 misses as in production: the bound of any L2 prefetch);
 for the four-launch form: bit 1 = every operand load reads a cached zero row (no memory latency / bandwidth), 2 = no (z, y) operand combinations,
 4 = no x transform either (MFMAs + loads only); W = 64 rows only."""
 import ctypes, os, sys
@@ -14,7 +15,7 @@ from deep_fluids_amd.ops import _ptr, _stream  # noqa: E402
 from tools.gpu_probe import timeit  # noqa: E402
 
 s = _stream()
-for (B, D, H, W) in ((16, 64, 96, 64), (4, 64, 96, 64)):
+for (B, D, H, W) in ((16, 64, 96, 64),) if os.environ.get('DBGS') else ((16, 64, 96, 64), (4, 64, 96, 64)):
     C = 128
     x = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
     g = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
@@ -22,7 +23,7 @@ for (B, D, H, W) in ((16, 64, 96, 64), (4, 64, 96, 64)):
     ws = torch.empty((nb + 3) // 4, device="cuda")
     gw = torch.empty((27, C, C), device="cuda"); gb = torch.empty(C, device="cuda")
     fl = 2.0 * 27 * C * C * B * D * H * W / 3.375
-    for dbg in (0, 8, 9, 1, 3, 7):
+    for dbg in [int(v) for v in os.environ.get('DBGS', '0,8,9,1,3,7').split(',')]:
         lib().df_debug_set_wgrad(ctypes.c_int(dbg))
         f = lambda: call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, 4, s)
         f(); torch.cuda.synchronize()
@@ -33,6 +34,7 @@ for (B, D, H, W) in ((16, 64, 96, 64), (4, 64, 96, 64)):
         lib().df_debug_set_wgrad(ctypes.c_int(dbg))
         call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, 4, s)
         res[dbg] = (gw.clone(), gb.clone())
-    print("  one fused launch (0) vs four launches (8): gw equal %s, gb equal %s" % (torch.equal(res[0][0], res[8][0]), torch.equal(res[0][1], res[8][1])))
+    o = 8
+    print("  one fused launch (0) vs variant %d: gw equal %s, gb equal %s" % (o, torch.equal(res[0][0], res[o][0]), torch.equal(res[0][1], res[o][1])))
     lib().df_debug_set_wgrad(ctypes.c_int(0))
     del x, g, ws
