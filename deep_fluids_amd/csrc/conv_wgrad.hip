@@ -262,6 +262,156 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
+// ---- weight gradient of the STRIDE-2 conv (TF 'SAME' on even extents: pad 0 before / 1 after; model.py:141-143, 177-179) ----------
+//   gW[tz][ty][tx][ci][co] = sum_{b, o} x[b][2 o_z + tz][2 o_y + ty][2 o_x + tx][ci] * g[b][o][co]        (o over the OUTPUT grid)
+// Same decomposition as wgrad_kernel: a workgroup owns one (tz, ty) and the three tx taps for a range of OUTPUT rows, a wave a 64x64
+// (ci, co) quadrant, both operands straight from L1/L2 into MFMA operand registers.  The gradient ring walks the coarse row, the
+// input ring the FINE row two positions per step (16-deep, 12 positions ahead): output position o multiplies X[2o], X[2o+1], X[2o+2]
+// with G[o] -- 12 MFMAs for 3 loads.  The only padding is the position past the end of a fine row / plane (2 o + 2 = 2 W).
+// The stride-1 kernels on the zero-inserted gradient (round 2) did 8x (3-D) the products of this form -- 2.4x after their Winograd
+// saving -- and read a gradient tensor that is 7/8 zeros.  a.D/H/W = OUTPUT extents; partial layout and reduce as wgrad_kernel.
+template <int WP8>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_s2_kernel(const WgradArgs a) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nq = a.nqi * a.nqj;
+  const int qi = (wave % nq) / a.nqj, qj = (wave % nq) % a.nqj, sub = wave / nq;
+  constexpr int Wc = WP8 * 8;                 // OUTPUT row length; the input row has 2 * Wc positions
+  const int half = lane >> 5, r = lane & 31;
+  const int nwg = a.nranges * a.ndzdy;
+  int wg;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, rem = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int range = wg / a.ndzdy, dzdy = wg % a.ndzdy;
+  const bool is3d = a.ndzdy == 9;
+  const int tz = is3d ? dzdy / 3 : 0, ty = is3d ? dzdy % 3 : dzdy;
+  const int Dx = is3d ? 2 * a.D : 1, Hx = 2 * a.H;
+  const int ci0 = blockIdx.y * 128 + qi * 64, co0 = blockIdx.z * 128 + qj * 64;
+  if (ci0 >= a.Cin || co0 >= a.Cout) return;
+
+  const int ppe = (a.pairs_per_range + a.nsub - 1) / a.nsub;
+  const int p0 = range * a.pairs_per_range + sub * ppe;
+  int p1 = p0 + ppe;
+  if (p1 > (range + 1) * a.pairs_per_range) p1 = (range + 1) * a.pairs_per_range;
+  if (p1 > a.npairs) p1 = a.npairs;
+  const int erange = range * a.nsub + sub;
+  const int cia = ci0 + 2 * r, coa = co0 + 2 * r;
+  const bool ci_ok0 = cia < a.Cin, co_ok0 = coa < a.Cout;
+  const float* zb = a.zeros;
+  struct Row { const float* xb; const float* gb; };
+  auto row_setup = [&](int pair) -> Row {
+    Row rw;
+    const int row = 2 * pair + half;
+    const bool ok = pair < p1 && row < a.nrows;
+    const int y = row % a.H;
+    const int t = row / a.H;
+    const int z = t % a.D;
+    const int b = t / a.D;
+    const int zs = is3d ? 2 * z + tz : 0, ys = 2 * y + ty;
+    const bool xv = ok && zs < Dx && ys < Hx;
+    rw.gb = (ok && co_ok0) ? a.g + (static_cast<int64_t>(row) * Wc) * a.Cout + coa : zb;
+    rw.xb = (xv && ci_ok0) ? a.x + (((static_cast<int64_t>(b) * Dx + zs) * Hx + ys) * (2 * Wc)) * a.Cin + cia : zb;
+    return rw;
+  };
+  auto load_x = [&](const Row& rw, int pos) -> f32x2 { return *reinterpret_cast<const f32x2*>(rw.xb + static_cast<int64_t>(pos) * a.Cin); };
+  auto load_g = [&](const Row& rw, int pos) -> f32x2 { return *reinterpret_cast<const f32x2*>(rw.gb + static_cast<int64_t>(pos) * a.Cout); };
+
+  f32x16 acc[3][2][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][s][t][e] = 0.f;
+  f32x2 bsum = {0.f, 0.f};
+  const bool do_bias = a.want_bias && dzdy == a.ndzdy / 2 && blockIdx.y == 0 && qi == 0;
+
+  // X ring by (fine position) % 16, G ring by (coarse position) % 8: both continuous across rows (2 Wc % 16 == 0, Wc % 8 == 0)
+  f32x2 xr[16], gr[8];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) xr[i] = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gr[i] = f32x2{0.f, 0.f};
+  Row cur = row_setup(p0);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) xr[i] = load_x(cur, i);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) gr[i] = load_g(cur, i);
+
+  auto step = [&](int u, int o) {
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x2 a0 = xr[(2 * u) & 15], a1 = xr[(2 * u + 1) & 15];
+    f32x2 a2 = xr[(2 * u + 2) & 15];
+    const f32x2 b = gr[u];
+    if (o == Wc - 1) a2 = f32x2{0.f, 0.f};      // fine position 2 Wc: the one padded position (the ring slot holds the next row's head)
+    bsum[0] += b[0]; bsum[1] += b[1];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[0][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b[t], acc[0][s][t], 0, 0, 0);
+        acc[1][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b[t], acc[1][s][t], 0, 0, 0);
+        acc[2][s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], b[t], acc[2][s][t], 0, 0, 0);
+      }
+  };
+
+  for (int pair = p0; pair < p1; ++pair) {
+    const Row nxt = row_setup(pair + 1);
+#pragma unroll
+    for (int x0 = 0; x0 < (WP8 - 1) * 8; x0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        xr[(2 * u + 12) & 15] = load_x(cur, 2 * (x0 + u) + 12);
+        xr[(2 * u + 13) & 15] = load_x(cur, 2 * (x0 + u) + 13);
+        gr[(u + 5) & 7] = load_g(cur, x0 + u + 5);
+        step(u, x0 + u);
+      }
+    }
+    {   // last 8 output positions of the row: the prefetch cursors cross into the next row pair
+      constexpr int x0 = Wc - 8;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        xr[(2 * u + 12) & 15] = u < 2 ? load_x(cur, 2 * (x0 + u) + 12) : load_x(nxt, 2 * u - 4);
+        xr[(2 * u + 13) & 15] = u < 2 ? load_x(cur, 2 * (x0 + u) + 13) : load_x(nxt, 2 * u - 3);
+        gr[(u + 5) & 7] = u < 3 ? load_g(cur, x0 + u + 5) : load_g(nxt, u - 3);
+        step(u, x0 + u);
+      }
+    }
+    cur = nxt;
+  }
+
+  const int taps = a.ndzdy * 3;
+  float* P = a.partial + static_cast<int64_t>(erange) * taps * a.Cinp * a.Coutp;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int tap = dzdy * 3 + d;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int ci = ci0 + 2 * i + s, co = co0 + 2 * r + t;
+          P[(static_cast<int64_t>(tap) * a.Cinp + ci) * a.Coutp + co] = acc[d][s][t][e];
+        }
+  }
+  if (do_bias) {
+    bsum[0] += __shfl_xor(bsum[0], 32, 64);
+    bsum[1] += __shfl_xor(bsum[1], 32, 64);
+    if (half == 0) {
+      float* pb = a.bpartial + static_cast<int64_t>(erange) * a.Coutp + co0 + 2 * r;
+      pb[0] = bsum[0]; pb[1] = bsum[1];
+    }
+  }
+}
+
 __device__ __forceinline__ f32x2 wpk_add(f32x2 a, f32x2 b) {
   f32x2 d;
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -1219,9 +1369,13 @@ inline bool wx_ok(int64_t W, int64_t Cin, int64_t Cout) {
   return (W == 16 || W == 32 || W == 64 || W == 56 || W == 112 || W == 128 || W == 96 || W == 48) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
 }
 inline bool wxy_ok(int64_t H, int64_t W, int64_t Cin, int64_t Cout) { return wx_ok(W, Cin, Cout) && H % 2 == 0 && H >= 4; }
-// (x,y,z): instantiated for the 128 -> 128 layers at W = 64 | 32 | 16 (cfg3) and 112 | 56 (cfg4)
+// (x,y,z): instantiated for the 128 -> 128 layers at W = 64 | 32 | 16 (cfg3), 112 | 56 (cfg4), 128, and for the 64 -> 64 layers of the
+// auto-encoder (cfg5, F = 64) at W = 128 | 64 | 32 | 16
 inline bool wxyz_ok(int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
-  return kz == 3 && wxy_ok(H, W, Cin, Cout) && D % 2 == 0 && D >= 4 && Cin == 128 && Cout == 128 && (W == 64 || W == 32 || W == 16 || W == 112 || W == 56 || W == 128);
+  if (!(kz == 3 && wxy_ok(H, W, Cin, Cout) && D % 2 == 0 && D >= 4)) return false;
+  if (Cin == 128 && Cout == 128) return W == 64 || W == 32 || W == 16 || W == 112 || W == 56 || W == 128;
+  if (Cin == 64 && Cout == 64) return W == 128 || W == 64 || W == 32 || W == 16;
+  return false;
 }
 // `req` = the caller's algorithm request (the `algo` argument of df_conv_wgrad_algo, low 3 bits): 0: best available,
 // 1: always the direct kernel, 2: at most Winograd-in-x, 3: (x,y) wherever it exists, 4: (x,y,z) wherever it exists.
@@ -1978,14 +2132,17 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   // ((x,y,z), one launch of 16 types: 16 ranges = one whole round below 4096 row pairs -- 0.45 -> 0.30 ms at 16 x 16x24x16)
   int heur = p.npairs < 4096 ? (algo == 3 ? 16 : 64) : (algo >= 2 ? 128 : kMaxRanges);
   if (algo >= 2 && heur < fill) heur = fill <= kMaxRanges ? fill : kMaxRanges;      // (the direct / x kernels measured slower with more ranges)
-  const int maxr = (ranges > 0 && ranges <= kMaxRanges) ? ranges : heur;
-  int nr = p.npairs >= maxr ? maxr : p.npairs;
-  p.ppr = (p.npairs + nr - 1) / nr;
-  p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
   p.Cinp = (int)(ceil_div(Cin, 64) * 64);
   p.Coutp = (int)(ceil_div(Cout, 64) * 64);
   p.nqi = Cin <= 64 ? 1 : 2; p.nqj = Cout <= 64 ? 1 : 2;
   p.nsub = 4 / (p.nqi * p.nqj);
+  // 64 -> 64 layers ((x,y,z) form, cfg5): the four waves of a workgroup split its voxel range, i.e. write nsub = 4 partials per range -- 128
+  // ranges were 512 partials = 537 MB for the fixed-order reduce (0.38 ms per layer, 9.5 ms per AE step); 32 x 16 types still fill the chip twice
+  if (algo == 3 && p.nsub > 1 && heur > 128 / p.nsub) heur = 128 / p.nsub < fill ? fill : 128 / p.nsub;
+  const int maxr = (ranges > 0 && ranges <= kMaxRanges) ? ranges : heur;
+  int nr = p.npairs >= maxr ? maxr : p.npairs;
+  p.ppr = (p.npairs + nr - 1) / nr;
+  p.nranges = (p.npairs + p.ppr - 1) / p.ppr;
   const int slots = algo == 0 ? p.taps : p.ndzdy * 4;             // the Winograd kernels write 4 xi_x slots per group
   p.partial_elems = static_cast<int64_t>(p.nranges) * p.nsub * slots * p.Cinp * p.Coutp;
   p.bpartial_elems = static_cast<int64_t>(p.nranges) * p.nsub * p.Coutp;
@@ -2165,8 +2322,12 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     else
 #undef DF_WXYZ_DBG
 #endif
+#define DF_WXYZ64(WP) hipLaunchKernelGGL((wgrad_wxyz_fused_kernel<WP, 64>), gridf, dim3(kThreads), 0, s, aa)
+    if (Cin == 64) { if (W == 128) DF_WXYZ64(16); else if (W == 64) DF_WXYZ64(8); else if (W == 32) DF_WXYZ64(4); else DF_WXYZ64(2); }
+    else
     if (W == 64) DF_WXYZ(8); else if (W == 32) DF_WXYZ(4); else if (W == 16) DF_WXYZ(2); else if (W == 112) DF_WXYZ(14); else if (W == 128) DF_WXYZ(16); else DF_WXYZ(7);
 #undef DF_WXYZ
+#undef DF_WXYZ64
     const int64_t rgx = ceil_div(Cin * Cout, 32);
     hipLaunchKernelGGL(wgrad_wxyz_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
                        p.nranges * p.nsub, (int)Cin, (int)Cout, p.Cinp, p.Coutp, 0);
@@ -2259,6 +2420,56 @@ int df_conv_wgrad_bf16x3(const float* x, const float* gy, float* gw, float* gb, 
   return conv_wgrad_impl(x, gy, gw, gb, B, D, H, W, Cin, Cout, kz, workspace, workspace_bytes, stream, 1, 0);
 }
 
+// ---- stride-2 weight gradient (see wgrad_s2_kernel) ---------------------------------------------------------------------------------
+static bool s2_wgrad_ok(int64_t Wo, int64_t Cin, int64_t Cout) {
+  return (Wo == 8 || Wo == 16 || Wo == 32 || Wo == 64) && Cin % 2 == 0 && Cout % 2 == 0 && Cin >= 32 && Cout >= 32;
+}
+int64_t df_conv_s2_wgrad_workspace_bytes(int64_t B, int64_t Do, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout, int kz) {
+  if (B <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || !s2_wgrad_ok(Wo, Cin, Cout)) return 0;
+  const Plan p = make_plan(B, Do, Ho, Wo, Cin, Cout, kz);
+  return (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(2 * Wo, Cin, Cout);
+}
+int df_conv_s2_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t Do, int64_t Ho, int64_t Wo, int64_t Cin,
+                     int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream) {
+  DF_REQUIRE(x && gy && gw && workspace, DF_EINVAL, "df_conv_s2_wgrad: null pointer");
+  DF_REQUIRE(B > 0 && Do > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_conv_s2_wgrad: non-positive extent");
+  DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_conv_s2_wgrad: kz must be 1 (2-D) or 3 (3-D)");
+  DF_REQUIRE(kz == 3 || Do == 1, DF_ESHAPE, "df_conv_s2_wgrad: Do must be 1 when kz == 1");
+  DF_REQUIRE(s2_wgrad_ok(Wo, Cin, Cout), DF_ESHAPE,
+             "df_conv_s2_wgrad: output rows of 8 | 16 | 32 | 64 voxels and even channel counts >= 32 only (other shapes: df_dilate2_odd + df_conv_wgrad)");
+  DF_REQUIRE(B * Do * Ho < (1LL << 30) && 8 * B * Do * Ho * Wo * Cin < (1LL << 40), DF_ESHAPE, "df_conv_s2_wgrad: tensor too large");
+  DF_REQUIRE(df::aligned16(workspace) && (reinterpret_cast<uintptr_t>(x) & 7u) == 0 && (reinterpret_cast<uintptr_t>(gy) & 7u) == 0, DF_EALIGN,
+             "df_conv_s2_wgrad: workspace must be 16-byte, x and gy 8-byte aligned");
+  DF_REQUIRE(workspace_bytes >= df_conv_s2_wgrad_workspace_bytes(B, Do, Ho, Wo, Cin, Cout, kz), DF_EWORKSPACE, "df_conv_s2_wgrad: workspace too small");
+  const Plan p = make_plan(B, Do, Ho, Wo, Cin, Cout, kz);
+  WgradArgs a;
+  a.x = x; a.g = gy;
+  a.partial = static_cast<float*>(workspace);
+  a.bpartial = a.partial + p.partial_elems;
+  float* zeros = a.bpartial + p.bpartial_elems;
+  a.zeros = zeros;
+  a.B = (int)B; a.D = (int)Do; a.H = (int)Ho; a.W = (int)Wo; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.Cinp = p.Cinp; a.Coutp = p.Coutp;
+  a.Wp = (int)Wo;
+  a.nrows = p.nrows; a.npairs = p.npairs; a.nranges = p.nranges; a.pairs_per_range = p.ppr;
+  a.ndzdy = p.ndzdy; a.want_bias = gb != nullptr;
+  a.nqi = p.nqi; a.nqj = p.nqj; a.nsub = p.nsub;
+  a.up = 0; a.gD = a.D; a.gH = a.H; a.gW = a.W;
+  hipStream_t s = df::as_stream(stream);
+  if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(2 * Wo, Cin, Cout), s)) return df::fail((int)e, "df_conv_s2_wgrad: memset: %s", hipGetErrorString(e));
+  dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)ceil_div(Cin, 128), (unsigned)ceil_div(Cout, 128));
+  if (Wo == 64) hipLaunchKernelGGL((wgrad_s2_kernel<8>), grid, dim3(kThreads), 0, s, a);
+  else if (Wo == 32) hipLaunchKernelGGL((wgrad_s2_kernel<4>), grid, dim3(kThreads), 0, s, a);
+  else if (Wo == 16) hipLaunchKernelGGL((wgrad_s2_kernel<2>), grid, dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((wgrad_s2_kernel<1>), grid, dim3(kThreads), 0, s, a);
+  const int64_t total = static_cast<int64_t>(p.taps) * Cin * Cout;
+  int64_t rg = ceil_div(total, kThreads);
+  if (rg > 2048) rg = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
+                     p.nranges * p.nsub, p.taps, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
+  return df::launched("df_conv_s2_wgrad");
+}
+
 // Which kernel family a df_conv_wgrad_algo call with these arguments runs (16-byte aligned operands assumed): the silent size-based
 // choices made visible to the caller.  0 direct MFMA | 1 Winograd in x | 2 Winograd in (x,y) | 3 Winograd in (x,y,z) |
 // 10 thin layer on the matrix cores | 11 thin layer on the vector ALU (general-shape fallback); < 0: invalid arguments.
@@ -2297,7 +2508,10 @@ static bool up_wxyz_ok(int req, int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, i
 
 // partial ranges of the 27-point (x,y,z) form: 9 workgroup types per range in one launch -- 28 ranges (252 workgroups: one round of
 // the 256 CUs) below 4096 tile-row pairs, 113 (1017: four rounds) above
-static int up_wxyz_ranges(int64_t B, int64_t Dc, int64_t Hc) { return (B * Dc * Hc + 1) / 2 < 4096 ? 28 : 113; }
+// (64 -> 64: the spare waves split each range four ways -- 28 ranges are already 112 partials)
+static int up_wxyz_ranges(int64_t B, int64_t Dc, int64_t Hc, int64_t Cin = 128, int64_t Cout = 128) {
+  return ((B * Dc * Hc + 1) / 2 < 4096 || (Cin <= 64 && Cout <= 64)) ? 28 : 113;
+}
 
 // The same for df_upconv_wgrad_algo: 3 = the 27-point Winograd-(x,y,z) form on the coarse input, 0 = the three-product parity-class
 // kernel (algo 0 | 2) or the generic direct kernel on class-strided views (algo 1).
@@ -2309,7 +2523,7 @@ int df_upconv_wgrad_form(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t 
 int64_t df_upconv_wgrad_workspace_bytes(int64_t B, int64_t Dc, int64_t Hc, int64_t Wc, int64_t Cin, int64_t Cout, int kz) {
   if (B <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || Cin <= 0 || Cout <= 0) return 0;
   if (wxyz_ok(2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz)) {      // sized for either form (the choice depends on a debug switch)
-    const Plan q = make_plan(B, 2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz, 3, up_wxyz_ranges(B, Dc, Hc));
+    const Plan q = make_plan(B, 2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, kz, 3, up_wxyz_ranges(B, Dc, Hc, Cin, Cout));
     const Plan p = make_up_plan(B, Dc, Hc, Wc, Cin, Cout, kz);
     const int64_t nq = (q.partial_elems + q.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(2 * Wc, Cin, Cout);
     const int64_t np = (p.partial_elems + p.bpartial_elems) * static_cast<int64_t>(sizeof(float)) + zero_row_bytes(Wc, Cin, Cout);
@@ -2333,7 +2547,7 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
              "df_upconv_wgrad: workspace too small");
   if ((prec == 0 || !wgrad_bf16x3_ok(Wc, Cin, Cout)) && up_wxyz_ok(req, B, Dc, Hc, Wc, Cin, Cout, kz) && df::aligned16(xc) && df::aligned16(gy)) {
     const int64_t D = 2 * Dc, H = 2 * Hc, W = 2 * Wc;
-    const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, 3, up_wxyz_ranges(B, Dc, Hc));
+    const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, 3, up_wxyz_ranges(B, Dc, Hc, Cin, Cout));
     WxyzArgs aa;
     WgradArgs& a = aa.w;
     a.x = xc; a.g = gy;
@@ -2354,8 +2568,12 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
     const unsigned gy_ = (unsigned)ceil_div(Cin, 128), gz_ = (unsigned)ceil_div(Cout, 128);
     const dim3 gridu((unsigned)(p.nranges * 9), gy_, gz_);          // all 9 live (xi_z, xi_y) types of a range, adjacent
 #define DF_UWXYZ(WP) hipLaunchKernelGGL((wgrad_wxyz_up_fused_kernel<WP, 128>), gridu, dim3(kThreads), 0, s, aa)
+#define DF_UWXYZ64(WP) hipLaunchKernelGGL((wgrad_wxyz_up_fused_kernel<WP, 64>), gridu, dim3(kThreads), 0, s, aa)
+    if (Cin == 64) { if (W == 128) DF_UWXYZ64(16); else if (W == 64) DF_UWXYZ64(8); else if (W == 32) DF_UWXYZ64(4); else DF_UWXYZ64(2); }
+    else
     if (W == 64) DF_UWXYZ(8); else if (W == 32) DF_UWXYZ(4); else if (W == 16) DF_UWXYZ(2); else if (W == 112) DF_UWXYZ(14); else if (W == 128) DF_UWXYZ(16); else DF_UWXYZ(7);
 #undef DF_UWXYZ
+#undef DF_UWXYZ64
     const int64_t rgx = ceil_div(Cin * Cout, 32);
     hipLaunchKernelGGL(wgrad_wxyz_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
                        p.nranges * p.nsub, (int)Cin, (int)Cout, p.Cinp, p.Coutp, 1);

@@ -646,11 +646,21 @@ class _ConvSame3S2(torch.autograd.Function):
             call("df_lrelu_bwd", _ptr(gy), _ptr(y), _ptr(dp), float(ctx.leak), gy.numel(), _stream())
         else:
             dp = gy
-        up = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
-        call("df_dilate2_odd", _ptr(dp), _ptr(up), odims[0], odims[1], odims[2], odims[3], cout, int(kz == 3), _stream())
         gw = torch.empty_like(w)
         gb = torch.empty(cout, dtype=torch.float32, device=x.device)
-        _wgrad(x, up, gw, gb, B, D, H, W, cin, cout, kz)
+        up = None
+        nbytes = query("df_conv_s2_wgrad_workspace_bytes", odims[0], odims[1], odims[2], odims[3], cin, cout, kz)
+        if nbytes > 0 and WGRAD_ALGO == 0:
+            # native form on the output grid: x[2o + t] * g[o] (conv_wgrad.hip::wgrad_s2_kernel) -- no zero-inserted gradient
+            _count("wgrad-s2", "native-direct-mfma", odims, cin, cout)
+            ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+            call("df_conv_s2_wgrad", _ptr(x), _ptr(dp), _ptr(gw), _ptr(gb), odims[0], odims[1], odims[2], odims[3], cin, cout, kz, _ptr(ws),
+                 nbytes, _stream())
+        else:
+            # shapes the native kernel is not instantiated for: the stride-1 kernels on the zero-inserted gradient (out[2o+1] = g[o])
+            up = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
+            call("df_dilate2_odd", _ptr(dp), _ptr(up), odims[0], odims[1], odims[2], odims[3], cout, int(kz == 3), _stream())
+            _wgrad(x, up, gw, gb, B, D, H, W, cin, cout, kz)
         gx = None
         if ctx.needs_input_grad[0]:
             if cin > 4 and cout > 4:
@@ -664,6 +674,9 @@ class _ConvSame3S2(torch.autograd.Function):
                      _stream())
                 gx = gx.view(x.shape)
             else:
+                if up is None:
+                    up = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
+                    call("df_dilate2_odd", _ptr(dp), _ptr(up), odims[0], odims[1], odims[2], odims[3], cout, int(kz == 3), _stream())
                 wpd = _pack(w, taps, cin, cout, 1, idims)
                 gx = _conv_raw(up, wpd, None, None, None, idims, cout, cin, kz, 0, 0.0).view(x.shape)
         return gx, gw, gb, None

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DF_VERSION 202 /* 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
+#define DF_VERSION 203 /* 0.2.3: + df_conv_s2_wgrad; 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
 
 enum {
   DF_OK = 0,
@@ -200,6 +200,13 @@ int df_conv_fwd(const float* x, const float* wp, const float* bias, const float*
  * flags: DF_CONV_BIAS | DF_CONV_LRELU only. */
 int df_conv_s2_fwd(const float* x, const float* wp, const float* bias, float* y, int64_t B, int64_t Do, int64_t Ho,
                    int64_t Wo, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream);
+/* Weight (and bias) gradient of that stride-2 conv: gw[tz][ty][tx][ci][co] = sum_{b,o} x[b][2o + t][ci] gy[b][o][co] (TF autodiff of
+ * slim.conv3d(stride=2); model.py:141-143, 177-179) computed natively on the OUTPUT grid -- no zero-inserted gradient tensor.
+ * x [B,2Do|1,2Ho,2Wo,Cin], gy [B,Do,Ho,Wo,Cout]; gw TF layout [kz,3,3,Cin,Cout]; gb may be NULL.  Instantiated for Wo in {8,16,32,64},
+ * even Cin, Cout >= 32 (df_conv_s2_wgrad_workspace_bytes returns 0 otherwise: use df_dilate2_odd + df_conv_wgrad). */
+int64_t df_conv_s2_wgrad_workspace_bytes(int64_t B, int64_t Do, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout, int kz);
+int df_conv_s2_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t Do, int64_t Ho, int64_t Wo, int64_t Cin,
+                     int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream);
 /* ---- up-sampling-aware first conv of a generator block --------------------------------------------------------------
  * model.py:36-37 / 78-79 feed `upscale(x, 2)` into the next block's first conv.  conv(nearest_up2x(xc), w) is computed
  * WITHOUT materialising the up-sampled tensor as 8 (3-D) / 4 (2-D) parity-class convs with 2x2x2 / 2x2 pre-summed taps

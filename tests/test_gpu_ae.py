@@ -17,9 +17,15 @@ TOL = 2e-5
 
 @pytest.mark.parametrize("shape,cin,cout,leak", [
     ((1, 4, 8, 32), 16, 128, 0.2), ((2, 8, 8, 8), 32, 64, 0.2), ((1, 6, 10, 14), 64, 192, None),
-    ((2, 16, 32), 16, 128, 0.2), ((1, 8, 8), 128, 128, None), ((1, 2, 2, 2), 16, 32, 0.2)])
+    ((2, 16, 32), 16, 128, 0.2), ((1, 8, 8), 128, 128, None), ((1, 2, 2, 2), 16, 32, 0.2),
+    # output rows of 8 | 16 | 32 | 64 voxels, even channels >= 32: the NATIVE stride-2 weight gradient (df_conv_s2_wgrad), incl. channel
+    # counts that are not multiples of the 128-wide workgroup tile (192 = 128 + 64) and a single-plane output (Do = 1)
+    ((1, 4, 4, 16), 32, 64, 0.2), ((2, 4, 8, 32), 64, 32, 0.2), ((1, 2, 4, 64), 32, 32, None), ((1, 2, 2, 128), 32, 64, 0.2),
+    ((1, 4, 4, 16), 192, 192, 0.2), ((2, 8, 64), 64, 64, 0.2), ((1, 6, 4, 32), 128, 128, 0.2)])
 def test_conv_stride2_fwd_bwd(shape, cin, cout, leak):
+    from deep_fluids_amd import ops
     from deep_fluids_amd.ops import _ConvSame3S2
+    ops.DISPATCH_COUNTS = {}
     rng = np.random.RandomState(cin + cout + sum(shape))
     nd = len(shape) - 1
     x = rng.uniform(-1, 1, shape + (cin,)).astype(np.float32)
@@ -35,9 +41,12 @@ def test_conv_stride2_fwd_bwd(shape, cin, cout, leak):
     ref = orc.lrelu(pre, leak) if leak is not None else pre
     dpre = go * (np.where(ref > 0, 1.0, leak) if leak is not None else 1.0)
     dx, dw, db = orc.conv_same_bwd(x64, w64, dpre, stride=2)
+    counts, ops.DISPATCH_COUNTS = ops.DISPATCH_COUNTS, None
     errs = {"y": rel_linf(host(y), ref), "dx": rel_linf(host(xt.grad), dx), "dw": rel_linf(host(wt.grad), dw),
             "db": rel_linf(host(bt.grad), db)}
     assert max(errs.values()) < TOL, errs
+    native = shape[-1] // 2 in (8, 16, 32, 64) and cin >= 32 and cout >= 32
+    assert any(k.startswith("wgrad-s2 native") for k in counts) == native, counts
 
 
 @pytest.mark.parametrize("shape,cin,cout", [((1, 4, 8, 32), 16, 128), ((2, 16, 32), 32, 64), ((1, 4, 4, 16), 16, 20)])

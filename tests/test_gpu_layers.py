@@ -103,6 +103,17 @@ def test_conv_wgrad_winograd_xyz(ops, shape, leak):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("shape,leak", [((1, 4, 4, 16), 0.2), ((2, 6, 4, 32), None), ((1, 4, 6, 64), 0.2), ((1, 4, 4, 128), 0.2), ((3, 4, 6, 32), 0.2)])
+def test_conv_wgrad_winograd_xyz_64_channels(ops, shape, leak):
+    """The (x,y,z) form for the auto-encoder's 64 -> 64 layers (cfg5: F = 64; one 64x64 quadrant, the spare waves split the voxel range),
+    the default there since round 3, against the fp64 oracle."""
+    from deep_fluids_amd._lib import query
+    B, D, H, W = shape
+    assert query("df_conv_wgrad_form", B, D, H, W, 64, 64, 3, 0) == 3
+    errs = _conv_case(ops, shape, 64, 64, leak, seed=sum(shape) + 1, mask_from_gpu=True)
+    assert max(errs.values()) < TOL, errs
+
+
 WINO_CASES = [
     ((1, 4, 8, 8), 32, 32, 0.2),        # exactly one tile block
     ((2, 8, 16, 8), 64, 32, 0.2),       # Cin != Cout (forward and dgrad swap them)
@@ -271,7 +282,7 @@ def test_colsum(ops):
 
 @pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 16), ((2, 4, 6, 8), 32), ((1, 3, 5, 7), 128), ((2, 8, 16), 16),
                                       ((1, 5, 9), 128), ((1, 2, 2, 32), 64), ((1, 2, 2, 32), 128), ((2, 1, 3, 16), 64),
-                                      ((1, 3, 24), 128), ((1, 2, 48), 128), ((1, 8, 12), 32), ((2, 9, 20), 64)])
+                                      ((1, 3, 24), 128), ((1, 2, 48), 128), ((1, 8, 12), 32), ((2, 9, 20), 64), ((1, 2, 3, 8), 64), ((1, 2, 2, 64), 64)])
 def test_upconv_block_vs_materialised_upsample(ops, cshape, C):
     """The up-sampling-aware fused block (parity-class convs on the coarse grid) == upscale + conv + ... + add of the
     oracle, forward and every gradient (input, 27-tap weights, biases)."""
