@@ -56,8 +56,10 @@ def test_kernel_selector_and_roofline_object():
     w = b.roofline_of(ks, "wgrad_kernel", {}, False)
     assert abs(w["algorithmic_speedup"] - 3.375) < 1e-12 and w["traffic"] is None and w["frac"] <= 1.0 and w["wgrad_form"] == "winograd-xyz"
     # the executed / algorithmic ratio follows the LIBRARY's own choice (df_conv_wgrad_form == conv_wgrad.hip::wgrad_algo), incl. its
-    # size and channel-count conditions: (x,y,z) needs 128 -> 128 and >= 4096 image rows, below that (x,y) | x | direct
+    # row-length and channel-count conditions: (x,y,z) exists for 128 -> 128 and 64 -> 64 at the instantiated row lengths (any batch since
+    # round 3), elsewhere (x,y) from 4096 image rows | x | direct
     assert b.wgrad_exec_ratio(64, 1, 128, 96, 128, 128) == (4.0 / 9.0, 2) and b.wgrad_exec_ratio(16, 64, 96, 64, 128, 128) == (8.0 / 27.0, 3)
-    assert b.wgrad_exec_ratio(16, 7, 10, 7, 128, 128) == (1.0, 0)
-    assert b.wgrad_exec_ratio(2, 8, 12, 8, 128, 128)[1] in (0, 1) and b.wgrad_exec_ratio(16, 64, 96, 64, 64, 64) == (4.0 / 9.0, 2)
+    assert b.wgrad_exec_ratio(16, 7, 10, 7, 128, 128) == (1.0, 0) and b.wgrad_exec_ratio(2, 32, 48, 32, 128, 128) == (8.0 / 27.0, 3)
+    assert b.wgrad_exec_ratio(2, 8, 12, 8, 128, 128)[1] in (0, 1) and b.wgrad_exec_ratio(16, 64, 96, 64, 64, 64) == (8.0 / 27.0, 3)
+    assert b.wgrad_exec_ratio(16, 64, 96, 64, 96, 96) == (4.0 / 9.0, 2) and b.wgrad_exec_ratio(1, 8, 8, 16, 96, 96) == (2.0 / 3.0, 1)
     json.dumps(r)      # the object must be JSON-serialisable as is
