@@ -42,6 +42,9 @@ __device__ __forceinline__ void block_sum2(double& a, double& b) {
   }
   __syncthreads();
 }
+// Barrier that orders LDS traffic only.  __syncthreads() is a full fence: its s_waitcnt vmcnt(0) would also wait for every global load
+// in flight (the next tile's boxes, requested on purpose a whole tile ahead) and for the acknowledgement of every store of u.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float sgn(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
 
 // adjoint of D along an axis of extent n at position k, given a loader g(i) of the incoming gradient (as stencil.hip)
@@ -222,6 +225,184 @@ __global__ __launch_bounds__(kThreads) void velocity_jl1_3d_vec_kernel(const flo
       }
       s1 += a1; s9 += a9;
     }
+  }
+  block_sum2(s1, s9);
+  if (tid == 0) { partial[2 * blockIdx.x] = s1; partial[2 * blockIdx.x + 1] = s9; }
+}
+
+// ================================ 3-D, ONE kernel: persistent LDS-tiled forward (psi, x) -> (u, l1, j_l1) [r3] =========================
+// The two-launch fast path above moves 48 B/voxel (u is written, then read back) and its strided 16-byte-per-lane loads are bound by the
+// cache-line traffic of the texture path; the one-kernel form further up needs psi at ten offsets per voxel from L1.  Here a persistent
+// workgroup walks tiles of TZ x TY rows x X voxels (X = 4 XQ: whole image rows, so every global access is a run of whole rows):
+//   1. the (TZ+2) x (TY+2) rows of psi and the (TZ+1) x (TY+1) rows of x a tile needs (forward halos: SURVEY A.1) arrive in REGISTERS as
+//      lane-consecutive 16-byte loads -- requested one tile ahead, i.e. in flight during the whole compute phase of the previous tile --
+//      and are written to LDS in the same order (contiguous ds_write_b128);
+//   2. u = curl3(psi) on the (TZ+1) x (TY+1) rows (tile + the forward neighbours the Jacobian of u needs) into LDS, same arithmetic
+//      as stencil.hip (bit-identical u);
+//   3. per quad of 4 voxels: |u - x| and |J(u) - J(x)| from LDS, fp32 per thread and tile, fp64 across tiles; u leaves as 16-byte stores.
+// HBM sees psi, x and u once each (36 B/voxel: the halo rows are re-reads of rows another workgroup of the same XCD fetched).
+// Needs Z % TZ == 0, Y % TY == 0 (the last row / plane of the tensor is then never the first of a tile: its backward difference
+// stays inside the tile) and X in {64, 112, 128}.
+// [r3] cfg3 shape, B = 16: 50 us (+ 7 us for the final fixed-order reduce launch) against 29 + 40 us for the two launches it replaces.
+// Measured alternatives: one workgroup per CU 65 us, 2 x 4-row tiles (three workgroups per CU) 59 us, non-temporal u stores +-0;
+// the boxes fed by LDS-DMA into two input buffers (buffer_load ... lds: no staging registers, no ds_write; one 512-thread workgroup per
+// CU, loads and stores on different waves so that no wave waits for a store acknowledgement) 58 us -- a tile's compute phases last
+// ~1.1 us, less than the ~2.4 us a CU needs to take in the 51 KB of the next tile's boxes (halo rows included: 2.1x the tile's own
+// bytes), so a SECOND workgroup's tile in flight matters more than freeing the registers.  What bounds all of them is the fabric
+// traffic of the forward halos (psi: 40 rows per 16); marching along z with a ring of planes would fetch every plane once.
+constexpr int kTileZ = 2, kTileY = 8;      // default tile: 2 planes x 8 rows x X voxels
+
+struct TileGeo {
+  int B, Z, Y;
+  int ntz, nty, ntiles;
+  unsigned bytes;      // of psi (== of x, of u)
+};
+
+template <int XQ, int kTZ, int kTY, bool NT>
+__global__ __launch_bounds__(kThreads) void velocity_loss3d_tile_kernel(const float* __restrict__ psi, const float* __restrict__ x,
+                                                                        float* __restrict__ u, double* __restrict__ partial, TileGeo g) {
+  constexpr int kPsiRows = (kTZ + 2) * (kTY + 2), kURows = (kTZ + 1) * (kTY + 1);
+  constexpr int X = 4 * XQ, RF4 = 3 * XQ;                      // voxels / float4 per image row
+  // LDS (float4): [psi box: 40 rows, padded to whole 256-thread passes][x box: 27 rows][u box: 27 rows].  The padding makes the psi / x
+  // boundary a pass boundary, so a pass loads from ONE tensor (one wave-uniform buffer descriptor).
+  constexpr int KPSI = (kPsiRows * RF4 + kThreads - 1) / kThreads, KX = (kURows * RF4 + kThreads - 1) / kThreads, NLD = KPSI + KX;
+  extern __shared__ f32x4 smem[];
+  f32x4* sPsi = smem;
+  f32x4* sX = smem + KPSI * kThreads;
+  f32x4* sU = sX + KX * kThreads;
+  const int tid = threadIdx.x;
+  const int64_t rowf4 = RF4;
+  (void)X;
+
+  auto tile_origin = [&](int t, int& b, int& z0, int& y0) {
+    const int yt = t % g.nty;
+    const int t2 = t / g.nty;
+    const int zt = t2 % g.ntz;
+    b = t2 / g.ntz; z0 = zt * kTZ; y0 = yt * kTY;
+  };
+  // Per-thread byte offsets of its pieces relative to the tile's first row -- the same for every tile.  A tile adds its origin; rows
+  // past the last row / plane of a batch element alias rows of the next one (never read back: the backward rule), and pieces past the
+  // END of the tensor are answered with zeros by the buffer load's range check -- no per-tile clamping arithmetic at all.
+  const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(psi), 0, g.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, g.bytes, 0x00020000);
+  unsigned koff[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const bool isx = k >= KPSI;
+    int i = (isx ? k - KPSI : k) * kThreads + tid;
+    const int nrow = isx ? kURows : kPsiRows, ncol = isx ? kTY + 1 : kTY + 2;
+    if (i > nrow * RF4 - 1) i = nrow * RF4 - 1;                // (tail threads of a box's last pass re-load its last piece)
+    const int row = i / RF4, c4 = i - row * RF4;
+    const int dz = row / ncol, dy = row - dz * ncol;
+    koff[k] = static_cast<unsigned>((dz * g.Y + dy) * RF4 + c4) * 16u;
+  }
+  f32x4 pre[NLD];
+  auto issue = [&](int t) {
+    int b, z0, y0;
+    tile_origin(t, b, z0, y0);
+    const unsigned base = static_cast<unsigned>(((b * g.Z + z0) * g.Y + y0) * RF4) * 16u;      // wave-uniform
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      // (the range check of a raw buffer covers the VGPR offset only, so the tile origin goes there and not into the scalar offset)
+      pre[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k >= KPSI ? xsrd : psrd, koff[k] + base, 0, 0));
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) smem[k * kThreads + tid] = pre[k];      // (a box's padded tail slots receive copies of its last piece)
+  };
+  // a quad's 12 floats + the record after it (x+1 neighbour of its last voxel; not read at the end of a row)
+  auto quad = [&](const f32x4* rowp, int q, float (&o)[16]) {
+    const f32x4 a0 = rowp[3 * q], a1 = rowp[3 * q + 1], a2 = rowp[3 * q + 2];
+    const f32x4 a3 = rowp[q + 1 < XQ ? 3 * q + 3 : 3 * q + 2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a0[e]; o[4 + e] = a1[e]; o[8 + e] = a2[e]; }
+    o[12] = a3[0]; o[13] = a3[1]; o[14] = a3[2]; o[15] = 0.f;
+  };
+
+  double s1 = 0.0, s9 = 0.0;
+  int t = dfst::xcd_block(blockIdx.x, gridDim.x, 0) < g.ntiles ? static_cast<int>(dfst::xcd_block(blockIdx.x, gridDim.x, 0)) : -1;
+  // persistent walk: workgroup w (XCD-contiguous numbering) takes tiles w, w + G, ...: at any time the G workgroups cover G consecutive
+  // tiles, neighbours in y on the same XCD
+  const int G = gridDim.x;
+  if (t >= 0) issue(t);
+  while (t >= 0) {
+    int b, z0, y0;
+    tile_origin(t, b, z0, y0);
+    commit();
+    lds_barrier();
+    const int tn = t + G < g.ntiles ? t + G : -1;
+    if (tn >= 0) issue(tn);                                    // in flight during both compute phases
+    // ---- u = curl3(psi) on the (TZ+1) x (TY+1) rows --------------------------------------------------------------------------------
+    for (int it = tid; it < kURows * XQ; it += kThreads) {
+      const int r = it / XQ, q = it - r * XQ;
+      const int dz = r / (kTY + 1), dy = r - dz * (kTY + 1);
+      const int z = z0 + dz, y = y0 + dy;
+      if (z < g.Z && y < g.Y) {
+        const bool ly = y == g.Y - 1, lz = z == g.Z - 1;
+        float po[16], py[16], pz[16];
+        quad(sPsi + (dz * (kTY + 2) + dy) * RF4, q, po);
+        quad(sPsi + (dz * (kTY + 2) + (ly ? dy - 1 : dy + 1)) * RF4, q, py);
+        quad(sPsi + ((lz ? dz - 1 : dz + 1) * (kTY + 2) + dy) * RF4, q, pz);
+        float uo[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool lx = q == XQ - 1 && i == 3;
+          const float o0 = po[i * 3], o1 = po[i * 3 + 1], o2 = po[i * 3 + 2];
+          const float x1 = lx ? po[(i - 1) * 3 + 1] : po[(i + 1) * 3 + 1], x2 = lx ? po[(i - 1) * 3 + 2] : po[(i + 1) * 3 + 2];
+          const float dx1 = lx ? o1 - x1 : x1 - o1, dx2 = lx ? o2 - x2 : x2 - o2;
+          const float dy0 = ly ? o0 - py[i * 3] : py[i * 3] - o0, dy2 = ly ? o2 - py[i * 3 + 2] : py[i * 3 + 2] - o2;
+          const float dz0 = lz ? o0 - pz[i * 3] : pz[i * 3] - o0, dz1 = lz ? o1 - pz[i * 3 + 1] : pz[i * 3 + 1] - o1;
+          uo[i * 3] = dy2 - dz1; uo[i * 3 + 1] = dz0 - dx2; uo[i * 3 + 2] = dx1 - dy0;
+        }
+        f32x4* d = sU + r * RF4 + 3 * q;
+        d[0] = f32x4{uo[0], uo[1], uo[2], uo[3]}; d[1] = f32x4{uo[4], uo[5], uo[6], uo[7]}; d[2] = f32x4{uo[8], uo[9], uo[10], uo[11]};
+      }
+    }
+    lds_barrier();
+    // ---- losses of the TZ x TY rows + the store of u ---------------------------------------------------------------------------------
+    // |J(u) - J(x)| per axis: the backward difference of the last row / plane is the NEGATED forward expression of both terms, and
+    // |-(a - b)| == |a - b| bit for bit, so no operand select is needed for y and z; along x the last voxel's difference is the
+    // previous voxel's (ops.py:214-217 replicates the DIFFERENCE): its three terms are voxel 2's, counted twice.
+    float a1s = 0.f, a9s = 0.f;
+    for (int it = tid; it < kTZ * kTY * XQ; it += kThreads) {
+      const int r = it / XQ, q = it - r * XQ;
+      const int dz = r / kTY, dy = r - dz * kTY;
+      const int z = z0 + dz, y = y0 + dy;
+      const bool ly = y == g.Y - 1, lz = z == g.Z - 1;
+      const int ro = dz * (kTY + 1) + dy, ry = dz * (kTY + 1) + (ly ? dy - 1 : dy + 1), rz = (lz ? dz - 1 : dz + 1) * (kTY + 1) + dy;
+      float uo[16], xo[16], uy[16], xy[16], uz[16], xz[16];
+      quad(sU + ro * RF4, q, uo); quad(sX + ro * RF4, q, xo);
+      quad(sU + ry * RF4, q, uy); quad(sX + ry * RF4, q, xy);
+      quad(sU + rz * RF4, q, uz); quad(sX + rz * RF4, q, xz);
+      const bool lxq = q == XQ - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a1 = (fabsf(uo[i * 3] - xo[i * 3]) + fabsf(uo[i * 3 + 1] - xo[i * 3 + 1])) + fabsf(uo[i * 3 + 2] - xo[i * 3 + 2]);
+        float a9 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float fu = uo[i * 3 + c], fx = xo[i * 3 + c];
+          // x: the difference towards the next record (voxel 3 of a row's last quad: voxel 2's difference again)
+          const int ia = i == 3 ? 2 : i;
+          const float tx3 = fabsf((uo[(ia + 1) * 3 + c] - uo[ia * 3 + c]) - (xo[(ia + 1) * 3 + c] - xo[ia * 3 + c]));
+          const float txn = fabsf((uo[(i + 1) * 3 + c] - fu) - (xo[(i + 1) * 3 + c] - fx));
+          a9 += (i == 3 && lxq) ? tx3 : txn;
+          a9 += fabsf((uy[i * 3 + c] - fu) - (xy[i * 3 + c] - fx));
+          a9 += fabsf((uz[i * 3 + c] - fu) - (xz[i * 3 + c] - fx));
+        }
+        a1s += a1; a9s += a9;
+      }
+      f32x4* dst = reinterpret_cast<f32x4*>(u) + ((static_cast<int64_t>(b) * g.Z + z) * g.Y + y) * rowf4 + 3 * q;
+      if (NT) {
+        __builtin_nontemporal_store(f32x4{uo[0], uo[1], uo[2], uo[3]}, dst); __builtin_nontemporal_store(f32x4{uo[4], uo[5], uo[6], uo[7]}, dst + 1);
+        __builtin_nontemporal_store(f32x4{uo[8], uo[9], uo[10], uo[11]}, dst + 2);
+      } else {
+        dst[0] = f32x4{uo[0], uo[1], uo[2], uo[3]}; dst[1] = f32x4{uo[4], uo[5], uo[6], uo[7]}; dst[2] = f32x4{uo[8], uo[9], uo[10], uo[11]};
+      }
+    }
+    s1 += a1s; s9 += a9s;
+    lds_barrier();                                              // everyone is done with the boxes before the next tile overwrites them
+    t = tn;
   }
   block_sum2(s1, s9);
   if (tid == 0) { partial[2 * blockIdx.x] = s1; partial[2 * blockIdx.x + 1] = s9; }
@@ -512,6 +693,38 @@ int df_velocity_loss3d_fwd(const float* psi, const float* x, float* u, float* l1
     if (int e = df_jacobian3d_fwd(psi, nullptr, u, B, Z, Y, X, stream)) return e;
     hipLaunchKernelGGL(velocity_jl1_3d_kernel, dim3((unsigned)nb), dim3(kThreads), 0, s, u, x, part, g);
     hipLaunchKernelGGL(velocity_loss_final_kernel, dim3(1), dim3(kThreads), 0, s, part, (int)nb, 1.0 / (3.0 * static_cast<double>(g.nvox)),
+                       1.0 / (9.0 * static_cast<double>(g.nvox)), l1, jl1);
+    return df::launched("df_velocity_loss3d_fwd");
+  }
+  // tile shape: 2 x 8 rows (two workgroups per CU at X = 64); (tuning library: df_debug_set_tail 3 = one workgroup per CU, 4 = 2 x 4 rows,
+  // 5 = non-temporal u stores)
+  const int tzv = kTileZ, tyv = g_tail_variant == 4 ? 4 : kTileY;
+  const bool tile_mode = g_tail_variant == 0 || g_tail_variant >= 3;
+  const int64_t ntl = (Z / tzv) * (Y / tyv) * B;
+  const int64_t rf4 = 3 * (X / 4), prow = (tzv + 2) * (tyv + 2), urow = (tzv + 1) * (tyv + 1);
+  const size_t tile_lds = static_cast<size_t>((ceil_div(prow * rf4, kThreads) + ceil_div(urow * rf4, kThreads)) * kThreads + urow * rf4) * sizeof(f32x4);
+  int64_t tile_grid = (g_tail_variant == 3 || tile_lds == 0 ? 1 : static_cast<int64_t>(160 * 1024 / tile_lds)) * df::kCUs;      // workgroups resident at once
+  if (tile_grid > 8 * df::kCUs) tile_grid = 8 * df::kCUs;
+  if (tile_grid > ntl) tile_grid = ntl;
+  if (u && tile_mode && (X == 64 || X == 112 || X == 128) && Z % tzv == 0 && Y % tyv == 0 && df::aligned16(psi) && df::aligned16(x) &&
+      df::aligned16(u) && ntl < (1LL << 30) && tile_grid <= nb && tile_grid > 0 && g.nvox * 12 < (1LL << 32)) {
+    // one persistent LDS-tiled kernel: psi, x -> u, l1, j_l1 (36 B/voxel of HBM traffic, nothing read back); grid = the workgroups that
+    // are resident at once
+    TileGeo tg{(int)B, (int)Z, (int)Y, (int)(Z / tzv), (int)(Y / tyv), (int)ntl, (unsigned)(g.nvox * 12)};
+#define DF_TILE(XQV, TYV, NTV)                                                                                                             \
+  do {                                                                                                                                     \
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&velocity_loss3d_tile_kernel<XQV, kTileZ, TYV, NTV>),             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds))                                     \
+      return df::fail((int)e, "df_velocity_loss3d_fwd: dynamic LDS opt-in: %s", hipGetErrorString(e));                                     \
+    hipLaunchKernelGGL((velocity_loss3d_tile_kernel<XQV, kTileZ, TYV, NTV>), dim3((unsigned)tile_grid), dim3(kThreads), tile_lds, s, psi,  \
+                       x, u, part, tg);                                                                                                    \
+  } while (0)
+#ifdef DF_TUNING
+    if (g_tail_variant == 4 && X == 64) DF_TILE(16, 4, false); else if (g_tail_variant == 5 && X == 64) DF_TILE(16, kTileY, true); else
+#endif
+    if (X == 64) DF_TILE(16, kTileY, false); else if (X == 112) DF_TILE(28, kTileY, false); else DF_TILE(32, kTileY, false);
+#undef DF_TILE
+    hipLaunchKernelGGL(velocity_loss_final_kernel, dim3(1), dim3(kThreads), 0, s, part, (int)tile_grid, 1.0 / (3.0 * static_cast<double>(g.nvox)),
                        1.0 / (9.0 * static_cast<double>(g.nvox)), l1, jl1);
     return df::launched("df_velocity_loss3d_fwd");
   }

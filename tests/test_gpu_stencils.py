@@ -118,7 +118,11 @@ def test_2d_vs_oracle_fwd_bwd(ops, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 7, 9), (1, 2, 2, 2), (2, 16, 24, 16), (1, 3, 4, 1031), (2, 33, 2, 5), (1, 2, 3, 4), (2, 8, 6), (1, 2, 2),
-                                   (3, 128, 96), (1, 3, 1029), (2, 37, 2)])
+                                   (3, 128, 96), (1, 3, 1029), (2, 37, 2),
+                                   # the persistent LDS-tiled forward (X in {64, 112, 128}, Z even, Y % 8 == 0): one tile, several tiles per
+                                   # axis, more tiles than resident workgroups' first pass (3 x 2 x 24 x 64 = 18 tiles is still one pass:
+                                   # the 600-tile case below walks two)
+                                   (3, 2, 8, 64), (2, 4, 16, 64), (1, 2, 8, 112), (1, 6, 24, 128), (5, 16, 120, 64)])
 def test_fused_velocity_loss_vs_oracle_and_unfused_path(ops, shape):
     """ops.velocity_loss (velocity_loss.hip: curl + both Jacobians + both L1 means in one kernel; the adjoint rebuilt from (u, x))
     against the oracle's restatement of the reference graph (trainer.py:140-146,170-172 / trainer3.py:18-24,49-51) and against the

@@ -26,7 +26,7 @@ ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device="cuda")
 l1 = torch.empty((), device="cuda"); jl1 = torch.empty((), device="cuda")
 one = torch.ones((), device="cuda")
 ref = None
-for var in (1, 2):
+for var in (1, 0, 2):
     lib().df_debug_set_tail(ctypes.c_int(var))
     k = [0]
     def fwd():
@@ -38,9 +38,10 @@ for var in (1, 2):
     tf = timeit(fwd, 20, 3); tb = timeit(bwd, 20, 3)
     call("df_velocity_loss3d_fwd", _ptr(psis[0]), _ptr(xs[0]), _ptr(us[0]), _ptr(l1), _ptr(jl1), B, Z, Y, X, _ptr(ws), nb, s)
     call("df_velocity_loss3d_bwd", _ptr(us[0]), _ptr(xs[0]), _ptr(one), _ptr(one), _ptr(gp), B, Z, Y, X, _ptr(ws), nb, s)
-    res = (float(l1), float(jl1), gp.clone())
+    res = (float(l1), float(jl1), gp.clone(), us[0].clone())
     if ref is None:
         ref = res
-    print("variant %d: fwd %.1f us  bwd %.1f us   l1 %.8f jl1 %.8f  dpsi max diff vs variant 1: %.2e" % (
-        var, tf * 1e6, tb * 1e6, res[0], res[1], (res[2] - ref[2]).abs().max().item()), flush=True)
+    print("variant %d (%s): fwd %.1f us  bwd %.1f us   l1 %.8f jl1 %.8f  dpsi max diff vs variant 1: %.2e  u identical: %s" % (
+        var, {0: "default: persistent LDS-tiled forward", 1: "curl3 + 16-byte quad reduction", 2: "record-per-lane kernels", 3: "tiled, one workgroup per CU", 4: "tiled, 2 x 4-row tiles", 5: "tiled, non-temporal u stores"}[var], tf * 1e6, tb * 1e6,
+        res[0], res[1], (res[2] - ref[2]).abs().max().item(), torch.equal(res[3], ref[3])), flush=True)
 lib().df_debug_set_tail(ctypes.c_int(0))
