@@ -11,15 +11,16 @@ import re
 import sys
 
 FAMILIES = [  # (key, regex on the kernel name, algorithmic read bytes, algorithmic write bytes) at B=16 64x96x64 F=128
-    ("jacobian3d_fwd_kernel<j,c>", r"jacobian3d_fwd_vec_kernel<true, true", 75497472, 301989888),
+    ("jacobian3d_fwd_kernel", r"jacobian3d_fwd_vec_kernel<true, true", 75497472, 301989888),
     ("jacobian3d_fwd_kernel<c>", r"jacobian3d_fwd_vec_kernel<false, true", 75497472, 75497472),
     ("jacobian3d_bwd_kernel<j>", r"jacobian3d_bwd_(vec_kernel<true, false|lds_kernel<9)", 226492416, 75497472),
     ("jacobian3d_bwd_kernel<c>", r"jacobian3d_bwd_(vec_kernel<false, true|lds_kernel<3)", 75497472, 75497472),
     ("velocity_jl1_3d (tail forward, after curl3)", r"velocity_jl1_3d_vec_kernel", 150994944, 0),
+    ("velocity_loss3d_tile_kernel (one-kernel tail forward [r3])", r"velocity_loss3d_tile_kernel", 150994944, 75497472),
     ("velocity_du3d (tail backward, before the curl3 adjoint)", r"velocity_du3d_vec_kernel", 150994944, 75497472),
-    ("wino3d_kernel<fwd>", r"wino3d_kernel<0, 9, 0>", 3221225472, 3221225472),
-    ("wino3d_kernel<dgrad+mask>", r"wino3d_kernel<0, 4, 0>", 6442450944, 3221225472),
-    ("wgrad_wxyz_kernel(16 types)", r"wgrad_wxyz_(fused_)?kernel<8, 128", 6442450944, 1769472),
+    ("wino3d_kernel", r"wino3d_kernel<0, 9, 0>", 3221225472, 3221225472),
+    ("wino3d_kernel_dgrad_mask", r"wino3d_kernel<0, 4, 0>", 6442450944, 3221225472),
+    ("wgrad_kernel", r"wgrad_wxyz_(fused_)?kernel<8, 128", 6442450944, 1769472),
     ("wgrad_wxyz_reduce_kernel", r"wgrad_wxyz_reduce_kernel", 0, 1769472),
 ]
 
