@@ -2130,7 +2130,9 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   const int per_launch = algo == 3 ? 16 : algo == 2 ? p.ndzdy / 2 : p.ndzdy;
   const int fill = (256 + per_launch - 1) / per_launch;
   // ((x,y,z), one launch of 16 types: 16 ranges = one whole round below 4096 row pairs -- 0.45 -> 0.30 ms at 16 x 16x24x16)
-  int heur = p.npairs < 4096 ? (algo == 3 ? 16 : 64) : (algo >= 2 ? 128 : kMaxRanges);
+  // ((x,y,z) above 4096 tile-row pairs [r3], top level B = 16: 32 ranges 14.96 ms, 64 14.47, 128 14.66, 256 14.96 -- and half the partial
+  //  buffer / reduce of 128)
+  int heur = p.npairs < 4096 ? (algo == 3 ? 16 : 64) : (algo == 3 ? 64 : algo == 2 ? 128 : kMaxRanges);
   if (algo >= 2 && heur < fill) heur = fill <= kMaxRanges ? fill : kMaxRanges;      // (the direct / x kernels measured slower with more ranges)
   p.Cinp = (int)(ceil_div(Cin, 64) * 64);
   p.Coutp = (int)(ceil_div(Cout, 64) * 64);
