@@ -53,3 +53,28 @@ def test_python_surface_fails_loudly_without_gpu():
         ops.curl3(torch.zeros((1, 4, 4, 4, 3)))
     with pytest.raises(_lib.DeepFluidsHipError):
         ops.l1_mean(torch.zeros(8), torch.zeros(8))
+
+
+def test_sign_word_layout_decoder_roundtrip():
+    """ops.sign_bits_to_mask documents the sign-word layout of conv_wino.hip (kSignBits): encode a random mask with an index-form restatement
+    of the kernel's epilogue addressing (byte = (tile block, cout slice, wave = (th, xi_z), cout 16-block, lane = (kq, tl)), bit s =
+    (dz, dy, dx)) and decode it back -- ragged extents included (bits of outputs outside the tensor are don't-care)."""
+    import numpy as np
+    import torch
+    from deep_fluids_amd import ops
+    rng = np.random.RandomState(0)
+    for (B, D, H, W, C) in ((1, 4, 8, 8, 32), (2, 6, 10, 12, 64), (1, 5, 7, 9, 32)):
+        m = rng.rand(B, D, H, W, C) > 0.5
+        nbz, nby, nbx, ncs = -(-D // 4), -(-H // 8), -(-W // 8), C // 32
+        by = np.zeros(B * nbz * nby * nbx * ncs * 1024, np.uint8)
+        for b, z, y, x, c in zip(*np.nonzero(m)):
+            bz, by_, bx = z // 4, y // 8, x // 8
+            th, kq, xz = (z % 4) // 2, (y % 8) // 2, (x % 8) // 2
+            s = (z % 2) * 4 + (y % 2) * 2 + (x % 2)
+            cs, nb, tl = c // 32, (c // 16) % 2, c % 16
+            blk = ((b * nbz + bz) * nby + by_) * nbx + bx
+            by[(blk * ncs + cs) * 1024 + (th * 4 + xz) * 128 + nb * 64 + kq * 16 + tl] |= 1 << s
+        pad = (-by.size) % 8
+        words = torch.from_numpy(np.concatenate([by, np.zeros(pad, np.uint8)])).view(torch.int64)
+        got = ops.sign_bits_to_mask(words, (B, D, H, W), C).numpy()
+        np.testing.assert_array_equal(got, m)
