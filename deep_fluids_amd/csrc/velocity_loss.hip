@@ -408,6 +408,175 @@ __global__ __launch_bounds__(kThreads) void velocity_loss3d_tile_kernel(const fl
   if (tid == 0) { partial[2 * blockIdx.x] = s1; partial[2 * blockIdx.x + 1] = s9; }
 }
 
+#ifdef DF_TUNING
+// ================================ 3-D, ONE kernel, marching along z [r3; tuning library only] ==========================================
+// MEASURED (cfg3, 16x64x96x64): 58.4 us per forward against 57.5 us for the tile kernel above (both incl. the 1-block final reduction), so
+// the tiles stay the production path and this kernel is kept under DF_TUNING (df_debug_set_tail(8), tools/tail_probe.py) as the record of
+// the experiment: fetching every plane once does not pay because the halo re-reads of the tiles are L2 hits, not HBM traffic.
+// The tiles above load (TZ+2)(TY+2) rows of psi per TZ x TY rows of output: 2.5x at 2 x 8.  Here a workgroup owns a COLUMN of TY rows x X
+// voxels of one batch element and marches through all Z planes: every plane of psi and x is fetched once (+ the forward halo rows of the
+// column: (TY+2)/TY, (TY+1)/TY), by LDS-DMA (`buffer_load_dwordx4 ... lds`: the planes are verbatim runs of image rows) into rings of 8
+// planes, SEVEN z-steps ahead of their use -- the memory latency is covered by ring depth, not by occupancy.  6 waves:
+//   waves 0-1  issue the DMA of plane s+7 (3 + 3 instructions each), wait for plane s+3 with `s_waitcnt vmcnt(18)` (loads only: these waves
+//              never store), and compute u(s+2) = curl3(psi) from psi(s+2), psi(s+3) into a ring of 4 u planes;
+//   waves 2-5  take |u - x| and |J(u) - J(x)| of plane s from u(s), u(s+1), x(s), x(s+1) (two threads per quad: x, y terms + l1 | z terms)
+//              and store u(s) -- they never wait for a load.
+// ONE LDS-only barrier per z-step.  Same arithmetic as the tile kernel (u bit-identical to df_jacobian3d_fwd).  X = 64, Y % TY == 0, Z >= 4.
+constexpr int kMarchT = 384, kMarchP = 7;
+
+struct MarchGeo {
+  int B, Z, Y, ncol;       // ncol = Y / TY columns per batch element
+  unsigned bytes;
+};
+
+template <int XQ, int TY>
+__global__ __launch_bounds__(kMarchT) void velocity_loss3d_march_kernel(const float* __restrict__ psi, const float* __restrict__ x,
+                                                                         float* __restrict__ u, double* __restrict__ partial, MarchGeo g) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  constexpr int RF4 = 3 * XQ;                       // float4 per image row
+  constexpr int PR = TY + 2;                        // rows per ring plane (psi needs TY + 2, x and u TY + 1)
+  constexpr int PL = PR * RF4;                      // float4 per ring plane; == 6 DMA instructions of 64 pieces for XQ = 16, TY = 6
+  constexpr int NDMA = (PL + 127) / 128;            // DMA instructions per loader wave, plane and tensor
+  static_assert(PL % 64 == 0, "plane must be whole 64-piece DMA instructions");
+  extern __shared__ f32x4 smem[];                   // [psi ring 8][x ring 8][u ring 4] planes of PL float4
+  f32x4* sPsi = smem;
+  f32x4* sX = smem + 8 * PL;
+  f32x4* sU = smem + 16 * PL;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave < 2;
+  const int col = blockIdx.x % g.ncol, b = blockIdx.x / g.ncol;
+  const int y0 = col * TY;
+  const int64_t rowf4 = RF4;
+
+  const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(psi), 0, g.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, g.bytes, 0x00020000);
+  // loader lane: piece (wave & 1) * 64 + lane of every 128-piece group of a plane; byte offset within the plane's run of rows
+  unsigned koff[NDMA];
+#pragma unroll
+  for (int k = 0; k < NDMA; ++k) koff[k] = static_cast<unsigned>(k * 128 + (wave & 1) * 64 + lane) * 16u;
+  const unsigned colbase = static_cast<unsigned>((b * g.Z * g.Y + y0) * RF4) * 16u;      // row (b, z = 0, y0)
+  const unsigned planeb = static_cast<unsigned>(g.Y * RF4) * 16u;
+  auto dma_plane = [&](int z) {      // psi and x rows y0 .. y0 + TY + 1 of plane z -> ring slot z & 7 (rows past the column's needs are never read)
+    const unsigned base = colbase + static_cast<unsigned>(z) * planeb;
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) {
+      if (k * 128 + (wave & 1) * 64 < PL) {
+        lds_ptr dp = (lds_ptr)(sPsi + (z & 7) * PL + k * 128 + (wave & 1) * 64);
+        const unsigned vo = koff[k] + base;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(psrd, dp, 16, vo, 0u, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) {
+      if (k * 128 + (wave & 1) * 64 < PL) {
+        lds_ptr dx = (lds_ptr)(sX + (z & 7) * PL + k * 128 + (wave & 1) * 64);
+        const unsigned vo = koff[k] + base;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, dx, 16, vo, 0u, 0, 0);
+      }
+    }
+  };
+  auto quad = [&](const f32x4* rowp, int q, float (&o)[16]) {
+    const f32x4 a0 = rowp[3 * q], a1 = rowp[3 * q + 1], a2 = rowp[3 * q + 2];
+    const f32x4 a3 = rowp[q + 1 < XQ ? 3 * q + 3 : 3 * q + 2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a0[e]; o[4 + e] = a1[e]; o[8 + e] = a2[e]; }
+    o[12] = a3[0]; o[13] = a3[1]; o[14] = a3[2]; o[15] = 0.f;
+  };
+
+  // prologue: planes 0 .. P-3 (step s issues plane s + P; the first step is s = -2)
+  if (loader) {
+    for (int z = 0; z < kMarchP - 2 && z < g.Z; ++z) dma_plane(z);
+  }
+  double s1 = 0.0, s9 = 0.0;
+  for (int s = -2; s < g.Z; ++s) {
+    if (loader) {
+      // plane s + 3 (the newest one this step reads) has landed: at most the 3 planes issued after it may still be in flight
+      if (s + kMarchP - 1 < g.Z) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * 2 * ((PL / 64 + 1) / 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();
+    if (loader) {
+      if (s + kMarchP < g.Z) dma_plane(s + kMarchP);
+      // ---- u(s+2) = curl3(psi) on rows 0 .. TY of the column ---------------------------------------------------------------------
+      const int zu = s + 2;
+      const int it = tid;                                      // 128 loader threads >= (TY + 1) * XQ items
+      if (zu < g.Z && it < (TY + 1) * XQ) {
+        const int r = it / XQ, q = it - r * XQ;
+        const int y = y0 + r;
+        if (y < g.Y) {
+          const bool ly = y == g.Y - 1, lz = zu == g.Z - 1;
+          float po[16], py[16], pz[16];
+          quad(sPsi + (zu & 7) * PL + r * RF4, q, po);
+          quad(sPsi + (zu & 7) * PL + (ly ? r - 1 : r + 1) * RF4, q, py);
+          quad(sPsi + ((lz ? zu - 1 : zu + 1) & 7) * PL + r * RF4, q, pz);
+          float uo[12];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool lx = q == XQ - 1 && i == 3;
+            const float o0 = po[i * 3], o1 = po[i * 3 + 1], o2 = po[i * 3 + 2];
+            const float x1 = lx ? po[(i - 1) * 3 + 1] : po[(i + 1) * 3 + 1], x2 = lx ? po[(i - 1) * 3 + 2] : po[(i + 1) * 3 + 2];
+            const float dx1 = lx ? o1 - x1 : x1 - o1, dx2 = lx ? o2 - x2 : x2 - o2;
+            const float dy0 = ly ? o0 - py[i * 3] : py[i * 3] - o0, dy2 = ly ? o2 - py[i * 3 + 2] : py[i * 3 + 2] - o2;
+            const float dz0 = lz ? o0 - pz[i * 3] : pz[i * 3] - o0, dz1 = lz ? o1 - pz[i * 3 + 1] : pz[i * 3 + 1] - o1;
+            uo[i * 3] = dy2 - dz1; uo[i * 3 + 1] = dz0 - dx2; uo[i * 3 + 2] = dx1 - dy0;
+          }
+          f32x4* d = sU + (zu & 3) * PL + r * RF4 + 3 * q;
+          d[0] = f32x4{uo[0], uo[1], uo[2], uo[3]}; d[1] = f32x4{uo[4], uo[5], uo[6], uo[7]}; d[2] = f32x4{uo[8], uo[9], uo[10], uo[11]};
+        }
+      }
+    } else if (s >= 0) {
+      // ---- losses of plane s: every quad of the TY rows by two threads ----------------------------------------------------------------
+      const int it = tid - 128;                                // 0 .. 255 >= 2 * TY * XQ
+      if (it < 2 * TY * XQ) {
+        const int role = it / (TY * XQ), iq = it - role * (TY * XQ);
+        const int r = iq / XQ, q = iq - r * XQ;
+        const int y = y0 + r;
+        const bool ly = y == g.Y - 1, lz = s == g.Z - 1;
+        const int zn = role == 0 ? s : (lz ? s - 1 : s + 1), rn = role == 0 ? (ly ? r - 1 : r + 1) : r;
+        float uo[16], xo[16], un[16], xn[16];
+        quad(sU + (s & 3) * PL + r * RF4, q, uo); quad(sX + (s & 7) * PL + r * RF4, q, xo);
+        quad(sU + (zn & 3) * PL + rn * RF4, q, un); quad(sX + (zn & 7) * PL + rn * RF4, q, xn);
+        const bool lxq = q == XQ - 1;
+        float a1 = 0.f, a9 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float fu = uo[i * 3 + c], fx = xo[i * 3 + c];
+            a9 += fabsf((un[i * 3 + c] - fu) - (xn[i * 3 + c] - fx));
+            if (role == 0) {
+              const int ia = i == 3 ? 2 : i;
+              const float tx3 = fabsf((uo[(ia + 1) * 3 + c] - uo[ia * 3 + c]) - (xo[(ia + 1) * 3 + c] - xo[ia * 3 + c]));
+              const float txn = fabsf((uo[(i + 1) * 3 + c] - fu) - (xo[(i + 1) * 3 + c] - fx));
+              a9 += (i == 3 && lxq) ? tx3 : txn;
+              a1 += fabsf(fu - fx);
+            }
+          }
+        }
+        s1 += a1; s9 += a9;
+        if (role == 1) {
+          f32x4* dst = reinterpret_cast<f32x4*>(u) + ((static_cast<int64_t>(b) * g.Z + s) * g.Y + y) * rowf4 + 3 * q;
+          dst[0] = f32x4{uo[0], uo[1], uo[2], uo[3]}; dst[1] = f32x4{uo[4], uo[5], uo[6], uo[7]}; dst[2] = f32x4{uo[8], uo[9], uo[10], uo[11]};
+        }
+      }
+    }
+  }
+  // block sums over the 6 waves (the loaders contribute zeros), fixed order
+  __syncthreads();
+  double* red = reinterpret_cast<double*>(smem);
+  s1 = wave_sum(s1); s9 = wave_sum(s9);
+  if (lane == 0) { red[wave] = s1; red[8 + wave] = s9; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0, c = 0.0;
+    for (int w = 0; w < kMarchT / 64; ++w) { a += red[w]; c += red[8 + w]; }
+    partial[2 * blockIdx.x] = a; partial[2 * blockIdx.x + 1] = c;
+  }
+}
+#endif  // DF_TUNING
+
 // du of 4 consecutive voxels per thread: the adjoint of D along an axis at position k needs f = (u, x) at k-1, k, k+1 only
 // (on the last two positions the replicated difference folds back onto the same three values), i.e. the quads one
 // row / slice before and after and the two records left / right of the quad.  Same operation order as velocity_loss3d_bwd_kernel.
@@ -696,10 +865,25 @@ int df_velocity_loss3d_fwd(const float* psi, const float* x, float* u, float* l1
                        1.0 / (9.0 * static_cast<double>(g.nvox)), l1, jl1);
     return df::launched("df_velocity_loss3d_fwd");
   }
+#ifdef DF_TUNING      // z-marching columns (one workgroup per column of 6 rows: 256 columns at cfg3)
+  if (u && g_tail_variant == 8 && X == 64 && Y % 6 == 0 && Z >= 4 && df::aligned16(psi) && df::aligned16(x) &&
+      df::aligned16(u) && B * (Y / 6) >= 192 && B * (Y / 6) <= nb && g.nvox * 12 < (1LL << 32)) {
+    MarchGeo mg{(int)B, (int)Z, (int)Y, (int)(Y / 6), (unsigned)(g.nvox * 12)};
+    const int64_t mgrid = B * (Y / 6);
+    const size_t mlds = static_cast<size_t>(20) * (6 + 2) * 3 * 16 * sizeof(f32x4);      // 8 + 8 + 4 ring planes of 8 rows
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&velocity_loss3d_march_kernel<16, 6>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds))
+      return df::fail((int)e, "df_velocity_loss3d_fwd: dynamic LDS opt-in: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((velocity_loss3d_march_kernel<16, 6>), dim3((unsigned)mgrid), dim3(kMarchT), mlds, s, psi, x, u, part, mg);
+    hipLaunchKernelGGL(velocity_loss_final_kernel, dim3(1), dim3(kThreads), 0, s, part, (int)mgrid, 1.0 / (3.0 * static_cast<double>(g.nvox)),
+                       1.0 / (9.0 * static_cast<double>(g.nvox)), l1, jl1);
+    return df::launched("df_velocity_loss3d_fwd");
+  }
+#endif
   // tile shape: 2 x 8 rows (two workgroups per CU at X = 64); (tuning library: df_debug_set_tail 3 = one workgroup per CU, 4 = 2 x 4 rows,
   // 5 = non-temporal u stores)
   const int tzv = kTileZ, tyv = g_tail_variant == 4 ? 4 : kTileY;
-  const bool tile_mode = g_tail_variant == 0 || g_tail_variant >= 3;
+  const bool tile_mode = g_tail_variant == 0 || (g_tail_variant >= 3 && g_tail_variant != 8);
   const int64_t ntl = (Z / tzv) * (Y / tyv) * B;
   const int64_t rf4 = 3 * (X / 4), prow = (tzv + 2) * (tyv + 2), urow = (tzv + 1) * (tyv + 1);
   const size_t tile_lds = static_cast<size_t>((ceil_div(prow * rf4, kThreads) + ceil_div(urow * rf4, kThreads)) * kThreads + urow * rf4) * sizeof(f32x4);

@@ -117,12 +117,25 @@ def test_2d_vs_oracle_fwd_bwd(ops, shape):
     np.testing.assert_array_equal(host(vt.grad), orc.jacobian_bwd(gj, gw))
 
 
+def _assert_close_up_to_sign_ties(got, ref, tol, quantum):
+    """The loss gradients are sums of sign(a - b) * const: where the fp32 difference a - b rounds across zero (|a - b| below ~1e-7: about
+    one term in 1e7, i.e. expected once the field has a million voxels) the fp32 kernel and the fp64 oracle legitimately pick different
+    signs.  One flipped term moves du at two voxels by `quantum`, which the curl adjoint spreads over at most 4 entries of dpsi each: allow
+    a handful of such entries, each off by a few quanta, and nothing else."""
+    err = np.abs(got - ref)
+    bad = err > tol
+    assert int(bad.sum()) <= 32 and float(err.max()) <= tol + 4.0 * quantum, (int(bad.sum()), float(err.max()), tol, quantum)
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 7, 9), (1, 2, 2, 2), (2, 16, 24, 16), (1, 3, 4, 1031), (2, 33, 2, 5), (1, 2, 3, 4), (2, 8, 6), (1, 2, 2),
                                    (3, 128, 96), (1, 3, 1029), (2, 37, 2),
                                    # the persistent LDS-tiled forward (X in {64, 112, 128}, Z even, Y % 8 == 0): one tile, several tiles per
                                    # axis, more tiles than resident workgroups' first pass (3 x 2 x 24 x 64 = 18 tiles is still one pass:
                                    # the 600-tile case below walks two)
-                                   (3, 2, 8, 64), (2, 4, 16, 64), (1, 2, 8, 112), (1, 6, 24, 128), (5, 16, 120, 64)])
+                                   (3, 2, 8, 64), (2, 4, 16, 64), (1, 2, 8, 112), (1, 6, 24, 128), (5, 16, 120, 64),
+                                   # X = 64 shapes the tiles do not take (odd depth, Y % 8 != 0: the curl3 + quad-reduction path) next to one they do;
+                                   # the last one has 1.4 M voxels: see _assert_close_up_to_sign_ties
+                                   (16, 4, 72, 64), (32, 5, 36, 64), (16, 19, 72, 64)])
 def test_fused_velocity_loss_vs_oracle_and_unfused_path(ops, shape):
     """ops.velocity_loss (velocity_loss.hip: curl + both Jacobians + both L1 means in one kernel; the adjoint rebuilt from (u, x))
     against the oracle's restatement of the reference graph (trainer.py:140-146,170-172 / trainer3.py:18-24,49-51) and against the
@@ -139,7 +152,8 @@ def test_fused_velocity_loss_vs_oracle_and_unfused_path(ops, shape):
     np.testing.assert_array_equal(host(u), orc.curl3(psi) if is_3d else orc.curl(psi))          # bit-exact velocity
     assert abs(float(l1) - ref["l1"]) <= 2e-6 * ref["l1"] and abs(float(jl1) - ref["j_l1"]) <= 2e-6 * ref["j_l1"]
     scale = np.abs(ref["dpsi"]).max()
-    assert np.abs(host(pt.grad) - ref["dpsi"]).max() <= 1e-5 * scale
+    nvox = int(np.prod(shape))
+    _assert_close_up_to_sign_ties(host(pt.grad), ref["dpsi"], 1e-5 * scale, 2.0 * max(w1 / 3, w2 / (9 if is_3d else 4)) / nvox)
     # the unfused path: same kernels the GAN / AE graphs use
     pt2 = dev(psi).requires_grad_(True)
     xt = dev(x)
@@ -157,7 +171,7 @@ def test_fused_velocity_loss_vs_oracle_and_unfused_path(ops, shape):
     l1b, _, _ = ops.velocity_loss(pt3, dev(x))
     l1b.backward()
     ref1 = orc.velocity_loss(psi.astype(np.float64), x.astype(np.float64), is_3d, 1.0, 0.0)
-    assert np.abs(host(pt3.grad) - ref1["dpsi"]).max() <= 1e-5 * np.abs(ref1["dpsi"]).max()
+    _assert_close_up_to_sign_ties(host(pt3.grad), ref1["dpsi"], 1e-5 * np.abs(ref1["dpsi"]).max(), 2.0 / (3 if is_3d else 2) / nvox)
 
 
 def test_full_size_properties_cfg3(ops):

@@ -26,7 +26,7 @@ ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device="cuda")
 l1 = torch.empty((), device="cuda"); jl1 = torch.empty((), device="cuda")
 one = torch.ones((), device="cuda")
 ref = None
-for var in (1, 0, 2):
+for var in (1, 0, 8):
     lib().df_debug_set_tail(ctypes.c_int(var))
     k = [0]
     def fwd():
@@ -42,6 +42,6 @@ for var in (1, 0, 2):
     if ref is None:
         ref = res
     print("variant %d (%s): fwd %.1f us  bwd %.1f us   l1 %.8f jl1 %.8f  dpsi max diff vs variant 1: %.2e  u identical: %s" % (
-        var, {0: "default: persistent LDS-tiled forward", 1: "curl3 + 16-byte quad reduction", 2: "record-per-lane kernels", 3: "tiled, one workgroup per CU", 4: "tiled, 2 x 4-row tiles", 5: "tiled, non-temporal u stores"}[var], tf * 1e6, tb * 1e6,
+        var, {0: "default: persistent LDS-tiled forward", 8: "z-marching columns, LDS-DMA rings", 1: "curl3 + 16-byte quad reduction", 2: "record-per-lane kernels", 3: "tiled, one workgroup per CU", 4: "tiled, 2 x 4-row tiles", 5: "tiled, non-temporal u stores"}[var], tf * 1e6, tb * 1e6,
         res[0], res[1], (res[2] - ref[2]).abs().max().item(), torch.equal(res[3], ref[3])), flush=True)
 lib().df_debug_set_tail(ctypes.c_int(0))
