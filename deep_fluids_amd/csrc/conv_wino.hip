@@ -32,6 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kT = 512;                   // 8 waves: (xi_z, tile z-row)
 constexpr int kPackT = 256;
@@ -50,6 +53,13 @@ constexpr int kNoPrimary = 256;            // with DF_CONV_ADDUP + kSignBits: y 
                                            // the backward pass needs of it (df_wino_conv_fwd_addup_bits / df_lrelu_bits_bwd_pool2x)
 constexpr int kBitBytesPerBlock = 1024;    // 8 waves x 2 cout blocks x 64 lanes, per (tile block, cout slice)
 constexpr int kZeroFloats = 1024;         // zeroed tail of the packed weights: SAME padding reads it, one 64-byte step per chunk
+// PREC = 1 ("bf16x3" in the Winograd domain, see wino3d_kernel): LDS holds the z-TRANSFORMED input of a chunk, position-major with the 16
+// channels of a position contiguous: [plane = (z-row, xi_z)][y 0..9][x 0..9 of pitch 12][16 channels + 4 pad floats]
+constexpr int BPOS = 80;                  // bytes per position (16 channels + pad: 5 sixteen-byte slots, odd -> conflict-free ds_read_b128)
+constexpr int BPY = 12;                   // positions per row (pitch)
+constexpr int BPLANE = (9 * BPY + 10) * BPOS;      // bytes per plane (the last row needs 10 positions only)
+constexpr int BBUF = 8 * BPLANE;          // bytes per LDS buffer (75520)
+constexpr int BCOL = 400;                 // staging threads: one (y, x, channel quad) z-column of the halo block each
 
 struct WinoArgs {
   const float* x;
@@ -121,6 +131,56 @@ __global__ __launch_bounds__(kPackT) void wino_pack_kernel(const float* __restri
     wp[total + i] = 0.f;
 }
 
+// "bf16x3" operand: the same transform, every U split into two bf16 words (hi = rne(U), lo = rne(U - hi)) and laid out for
+// v_mfma_f32_16x16x16_bf16: Ub[cs][xz][k16][xy][xx][nb][lane = (k % 16) / 4 * 16 + n % 16][hi(k % 4 = 0..3) | lo(0..3)] -- one 16-byte load per
+// lane gives the B operand (hi and lo) of a (transform point, cout 16-block) for the 16 input channels of a chunk.
+__global__ __launch_bounds__(kPackT) void wino_pack_bf16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int cin, int cout,
+                                                                  int mode, int64_t total) {
+  const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  const int64_t nfil = static_cast<int64_t>(K) * N;
+  for (int64_t f = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; f < nfil; f += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int n = static_cast<int>(f % N), k = static_cast<int>(f / N);
+    double g[27];
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap)
+      g[tap] = static_cast<double>(mode == 0 ? w[(static_cast<int64_t>(tap) * cin + k) * cout + n]
+                                             : w[(static_cast<int64_t>(26 - tap) * cin + n) * cout + k]);
+    double gx[9][4];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const double a = g[r * 3], b = g[r * 3 + 1], c = g[r * 3 + 2];
+      gx[r][0] = a; gx[r][1] = 0.5 * (a + b + c); gx[r][2] = 0.5 * (a - b + c); gx[r][3] = c;
+    }
+    const int cs = n >> 5, nb = (n >> 4) & 1, j = n & 15, k16 = k >> 4, kq = (k >> 2) & 3, e = k & 3;
+#pragma unroll
+    for (int xz = 0; xz < 4; ++xz) {
+      double gz[3][4];
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx) {
+          const double a = gx[ty][xx], b = gx[3 + ty][xx], c = gx[6 + ty][xx];
+          gz[ty][xx] = xz == 0 ? a : xz == 3 ? c : xz == 1 ? 0.5 * (a + b + c) : 0.5 * (a - b + c);
+        }
+#pragma unroll
+      for (int xy = 0; xy < 4; ++xy)
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx) {
+          const double a = gz[0][xx], b = gz[1][xx], c = gz[2][xx];
+          const float u = static_cast<float>(xy == 0 ? a : xy == 3 ? c : xy == 1 ? 0.5 * (a + b + c) : 0.5 * (a - b + c));
+          const __bf16 h = static_cast<__bf16>(u);
+          const __bf16 l = static_cast<__bf16>(u - static_cast<float>(h));
+          const int64_t rec = ((((((static_cast<int64_t>(cs) * 4 + xz) * (K / 16) + k16) * 4 + xy) * 4 + xx) * 2 + nb) * 64 + kq * 16 + j) * 8;
+          wp[rec + e] = h;
+          wp[rec + 4 + e] = l;
+        }
+    }
+  }
+  float* wz = reinterpret_cast<float*>(wp);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < kZeroFloats; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    wz[total + i] = 0.f;
+}
+
 // ---- packed-fp32 helpers (VOP3P): one instruction = two lanes of the separable B^T transform --------------------------------
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
   f32x2 d;
@@ -184,12 +244,28 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // POOL (MODE 2): the adjoint case -- the output is the 2x2x2 sum-pool of the convolution (d/d(xc) of the up-sampling-aware conv: x is
 // the fine gradient, y the COARSE tensor [B, D/2, H/2, W/2, Cout], accumulated into).  The pooled inverse transform is
 // (A^T row 0 + row 1) = (1, 2, 0, -1) per axis, so the same 27 points are the only ones needed and a tile block writes 32 voxels, not 256.
-template <int DBG, int FL = -1, int MODE = 0>
+//
+// PREC = 1 -- "bf16x3" IN THE WINOGRAD DOMAIN (opt-in precision mode, ops.CONV_PRECISION = "bf16x3"; the default stays exact fp32).
+// Same decomposition, staging loads, weights-from-L2 stream and epilogue; the 64 GEMMs run on the bf16 matrix pipe with both operands split
+// into bf16 (hi, lo) words AFTER the fp32 transforms, three v_mfma_f32_16x16x16_bf16 per product block (lo*hi + hi*lo + hi*hi, fp32
+// accumulate; tools/ubench/mfma_bf16_overlap.hip: 16.5 cycles each and -- unlike the fp32 MFMA -- plain VALU work hides beside them):
+//   * the staging threads apply the z part of B^T once per chunk (a thread owns a z-column of the halo block: 6 loads -> the 8 (z-row, xi_z)
+//     planes) and store 16 bytes = 4 channels of a position at a time: LDS = [plane][y][x][16 channels], 75.5 KB per buffer;
+//   * a k-step is (chunk of 16 channels, xi_y): lane = (tile, channel quad) reads 2 rows x 4 positions of its plane as ds_read_b128 (its 4
+//     channels at once), applies the y and x parts (32 plain v_add/v_sub: v_pk_* cost 15 cycles beside a bf16 MFMA) and splits the 4 points
+//     x 4 channels into packed bf16 hi / lo (v_cvt_pk_bf16_f32; 48 ops) = the A operands of 4 points, K = 16;
+//   * weights: U pre-split by wino_pack_bf16x3_kernel, one 16-byte load per lane = (hi, lo) of a (point, cout block): 8 loads per k-step.
+// The fp32 values that are split are bit-identical to the PREC = 0 kernel's operands; per-product error 2^-17 (16 significand bits).
+template <int DBG, int FL = -1, int MODE = 0, int PREC = 0>
 __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   constexpr bool UP = MODE == 1, POOL = MODE == 2, P27 = MODE != 0;
-  __shared__ __attribute__((aligned(16))) float sIn[2 * BUF];
+  constexpr bool BX = PREC == 1;
+  constexpr int BUFF = BX ? BBUF / 4 : BUF;      // floats per LDS buffer
+  __shared__ __attribute__((aligned(16))) float sIn[2 * BUFF];
   __shared__ float sBias[32];        // this worker's cout slice of the bias (the slice is fixed for the worker's whole life)
-  __shared__ float sM[16 * kT];      // lrelu-mask operands of a tile block's outputs, fetched by LDS-DMA loads (no registers)
+  // lrelu-mask operands of a tile block's outputs, fetched by LDS-DMA loads (no registers); PREC = 1: behind the epilogue's exchange area in
+  // the idle input buffer (32 + 32 of its 75.5 KB)
+  __shared__ float sMs[BX ? 4 : 16 * kT];
 
   const int eflags = FL >= 0 ? FL : a.flags;
   const int tid = threadIdx.x;
@@ -291,6 +367,51 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     d[0] = v[0]; d[CP] = v[1]; d[2 * CP] = v[2]; d[3 * CP] = v[3];
   };
 
+  // ---- PREC = 1 staging plan: thread p < 400 owns the z-column (hy, hx, channel quad) of the halo block -------------------------
+  unsigned soz[6];
+  const int colp = tid < BCOL ? tid : BCOL - 1;
+  const int chy = colp / 40, chx = (colp >> 2) % 10, cq4 = colp & 3;
+  const int ldsz = (chy * BPY + chx) * BPOS + cq4 * 16;      // bytes, plane 0 of buffer 0
+  auto set_offs_b = [&](const BlockInfo& bi) {
+    const int gy = bi.y0 - 1 + chy, gx = bi.x0 - 1 + chx;
+    const bool okyx = tid < BCOL && static_cast<unsigned>(gy) < static_cast<unsigned>(a.H) && static_cast<unsigned>(gx) < static_cast<unsigned>(a.W);
+#pragma unroll
+    for (int z = 0; z < 6; ++z) {
+      const int gz = bi.z0 - 1 + z;
+      const bool ok = okyx && static_cast<unsigned>(gz) < static_cast<unsigned>(a.D);
+      if (UP) {
+        const int Hc = a.H >> 1, Wc = a.W >> 1;
+        soz[z] = ok ? static_cast<unsigned>((((gz >> 1) * Hc + (gy >> 1)) * Wc + (gx >> 1)) * a.Cin + cq4 * 4) * 4u : 0x80000000u;
+      } else {
+        soz[z] = ok ? static_cast<unsigned>(bi.hoff + ((z * a.H + chy) * a.W + chx) * a.Cin + cq4 * 4) * 4u : 0x80000000u;
+      }
+    }
+  };
+  auto vsub4 = [](const f32x4& p, const f32x4& q) -> f32x4 {      // plain v_sub_f32 x 4 (hipcc would form v_pk_add_f32)
+    f32x4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { float t; asm("v_sub_f32 %0, %1, %2" : "=v"(t) : "v"(p[e]), "v"(q[e])); d[e] = t; }
+    return d;
+  };
+  auto vadd4 = [](const f32x4& p, const f32x4& q) -> f32x4 {
+    f32x4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { float t; asm("v_add_f32 %0, %1, %2" : "=v"(t) : "v"(p[e]), "v"(q[e])); d[e] = t; }
+    return d;
+  };
+  auto stage_store_b = [&](int bufbytes, const f32x4 (&pl)[6]) {      // z part of B^T (same operations as the PREC = 0 lanes apply) + 8 stores
+    if (tid < BCOL) {
+      char* d = sInB + (bufbytes + ldsz);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        *reinterpret_cast<f32x4*>(d + (t * 4 + 0) * BPLANE) = vsub4(pl[2 * t], pl[2 * t + 2]);
+        *reinterpret_cast<f32x4*>(d + (t * 4 + 1) * BPLANE) = vadd4(pl[2 * t + 1], pl[2 * t + 2]);
+        if (!P27) *reinterpret_cast<f32x4*>(d + (t * 4 + 2) * BPLANE) = vsub4(pl[2 * t + 2], pl[2 * t + 1]);
+        *reinterpret_cast<f32x4*>(d + (t * 4 + 3) * BPLANE) = vsub4(pl[2 * t + 1], pl[2 * t + 3]);
+      }
+    }
+  };
+
   // ---- A operand: this lane's tile, planes (za, zb) of xi_z ---------------------------------------------------------------
   const int tx = tl & 3, ty = tl >> 2;
   // main-loop role (mz = xi_z, mth = tile z-row).  Plain conv: the wave's (xz, th).  27-point modes: only xi_z in {0, 1, 3} is
@@ -358,14 +479,68 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     for (int q = 0; q < 4; ++q) bq[nb][q] = buf_load16(wsrd, laneb + q * 1024u, sb);
   };
 
+  // ---- PREC = 1: A operands of a k-step = (chunk, xi_y = j); B operands ------------------------------------------------------------
+  const int aoffB = (mth * 4 + mz) * BPLANE + ((2 * ty) * BPY + 2 * tx) * BPOS + kq * 16;      // this lane's tile, its plane, its channel quad
+  f32x4 rwa[4], rwb[4];      // the two rows of the y combination: 4 positions x 4 channels each
+  u32x2 Ah[4], Al[4];        // [xi_x]: packed bf16 (hi | lo) of the lane's 4 channels
+  auto raw_read_b = [&](int bufbytes, int j) {
+    const int rA = j == 0 ? 0 : j == 2 ? 2 : 1, rB = j == 0 ? 2 : j == 1 ? 2 : j == 2 ? 1 : 3;      // U = row rA -+ row rB
+    int ia = bufbytes + aoffB;
+    asm volatile("" : "+v"(ia));
+    __builtin_assume((ia & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rwa[i] = *reinterpret_cast<const f32x4*>(sInB + ia + (rA * BPY + i) * BPOS);
+      rwb[i] = *reinterpret_cast<const f32x4*>(sInB + ia + (rB * BPY + i) * BPOS);
+    }
+  };
+  auto split2 = [](float v0, float v1, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+    float l0, l1;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(l0) : "v"(v0), "v"(h0));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(l1) : "v"(v1), "v"(h1));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(l0), "v"(l1));
+  };
+  auto transform_b = [&](int j) {
+    f32x4 Uy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Uy[i] = j == 1 ? vadd4(rwa[i], rwb[i]) : vsub4(rwa[i], rwb[i]);
+#pragma unroll
+    for (int xx = 0; xx < 4; ++xx) {
+      if (P27 && xx == 2) continue;
+      const f32x4 v = xx == 0 ? vsub4(Uy[0], Uy[2]) : xx == 1 ? vadd4(Uy[1], Uy[2]) : xx == 2 ? vsub4(Uy[2], Uy[1]) : vsub4(Uy[1], Uy[3]);
+      unsigned h01, l01, h23, l23;
+      split2(v[0], v[1], h01, l01);
+      split2(v[2], v[3], h23, l23);
+      Ah[xx] = u32x2{h01, h23};
+      Al[xx] = u32x2{l01, l23};
+    }
+  };
+  u32x4 bw[2][4];            // [cout 16-block][xi_x] = (hi k0k1, hi k2k3, lo k0k1, lo k2k3)
+  const unsigned wbaseB = static_cast<unsigned>((cs * 4 + mz) * (a.Cin >> 4)) * 32768u + static_cast<unsigned>(hnb) * 1024u;
+  auto issue_bw = [&](int nb, int k16, int j) {      // record (k16, xi_y = j): 4 xi_x x 2 cout blocks x 1 KB
+    const unsigned sb = wbaseB + static_cast<unsigned>(k16 * 4 + j) * 8192u + nb * 1024u;      // wave-uniform
+#pragma unroll
+    for (int xx = 0; xx < 4; ++xx)
+      if (!(P27 && xx == 2)) bw[nb][xx] = __builtin_bit_cast(u32x4, buf_load16(wsrd, laneb, sb + xx * 2048u));
+  };
+
   f32x4 acc[2][16];
   const int nchunk = a.Cin / CKW;
   if ((DBG & 131072) && wave >= 4) __builtin_amdgcn_s_setprio(1);      // (experiment: static priority for the later-dispatched half)
 
   // ---- prologue: first block's chunk 0 -> buffer 0 ------------------------------------------------------------------------------
   BlockInfo cur = decode(seq(0));
-  set_offs(cur);
-  {
+  if constexpr (BX) {
+    set_offs_b(cur);
+    const __amdgpu_buffer_rsrc_t srd0 = make_srd(cur.xb, vol_bytes);
+    f32x4 stz[6];
+#pragma unroll
+    for (int z = 0; z < 6; ++z) stz[z] = buf_load16(srd0, soz[z], 0u);
+    stage_store_b(0, stz);
+  } else {
+    set_offs(cur);
     const __amdgpu_buffer_rsrc_t srd0 = make_srd(cur.xb, vol_bytes);
     f32x4 stg[NLOAD];
 #pragma unroll
@@ -384,9 +559,15 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // nothing is prefetched across the epilogue (registers): first raw inputs / weights of this block
-    raw_read(pb * BUF * 4);
-    issue_b(0, 0);
-    if (!half) issue_b(1, 0);
+    if constexpr (BX) {
+      raw_read_b(pb * BBUF, 0);
+      issue_bw(0, 0, 0);
+      if (!half) issue_bw(1, 0, 0);
+    } else {
+      raw_read(pb * BUF * 4);
+      issue_b(0, 0);
+      if (!half) issue_b(1, 0);
+    }
 
     const unsigned long long tp1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -400,6 +581,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       const __amdgpu_buffer_rsrc_t msrd = make_srd(a.mask_src + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout,
                                                    static_cast<unsigned>(a.D) * a.H * a.W * a.Cout * 4u);
       const unsigned mv = static_cast<unsigned>(((oz0 * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl) * 4u;
+      float* const sM = BX ? sIn + ((nchunk - 1 + pb) & 1) * BUFF + 8192 : sMs;
 #pragma unroll
       for (int n2 = 0; n2 < 2; ++n2)
 #pragma unroll
@@ -470,13 +652,91 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       }
     }
     };
-    if (half) main_loop(std::true_type{}); else main_loop(std::false_type{});
+    // PREC = 1: k-step = (chunk, xi_y); the 27-point modes skip xi_y = 2 (and the xi_x = 2 products)
+    auto main_loop_b = [&](auto half_c) {
+      constexpr bool HALF = decltype(half_c)::value;
+      constexpr int NST = P27 ? 3 : 4;
+      for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const int bo = ((chunk + pb) & 1) * BBUF, bn = BBUF - bo;
+        const bool lastc = chunk + 1 == nchunk;
+        if (lastc) set_offs_b(nxt);
+        const __amdgpu_buffer_rsrc_t ssrd = make_srd(lastc ? nxt.xb : cur.xb, vol_bytes);
+        const unsigned schunk = static_cast<unsigned>(lastc ? 0 : chunk + 1) * (CKW * 4u);
+        const int cnext = lastc ? 0 : chunk + 1;      // (the weights of the next tile block's first k-step)
+        f32x4 stz[6];
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+          const int j = P27 && st == 2 ? 3 : st;                                   // xi_y of this k-step
+          const int jn = st + 1 < NST ? (P27 && st + 1 == 2 ? 3 : st + 1) : 0;     // ... and of the next one
+          const int kn = st + 1 < NST ? chunk : cnext;
+          if (!(DBG & 1)) transform_b(j);
+          __builtin_amdgcn_sched_barrier(0);
+          constexpr int STS = (DBG & 16) ? NST - 1 : NST - 2;      // (experiment 16: store the staged chunk one k-step later)
+          if (st == STS && !(DBG & 4)) stage_store_b(bn, stz);
+          if (st == NST - 1) __syncthreads();
+          if (!(DBG & 2)) raw_read_b(st + 1 < NST ? bo : bn, jn);
+          __builtin_amdgcn_sched_barrier(0);
+          auto mfma_nb = [&](int nb) {
+            if (DBG & 32) {      // (experiment 32: xi_x-major -- a point's three products back to back, its weight registers reloaded at once)
+#pragma unroll
+              for (int xx = 0; xx < 4; ++xx)
+                if (!(P27 && xx == 2)) {
+#pragma unroll
+                  for (int t = 0; t < 3; ++t) {
+                    const u32x2 av = t == 0 ? Al[xx] : Ah[xx];
+                    const u32x2 bv = t == 1 ? u32x2{bw[nb][xx][2], bw[nb][xx][3]} : u32x2{bw[nb][xx][0], bw[nb][xx][1]};
+                    acc[nb][j * 4 + xx] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, av), __builtin_bit_cast(s16x4, bv),
+                                                                                    acc[nb][j * 4 + xx], 0, 0, 0);
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+                  if (!(DBG & 8)) {
+                    const unsigned sb = wbaseB + static_cast<unsigned>(kn * 4 + jn) * 8192u + nb * 1024u;
+                    bw[nb][xx] = __builtin_bit_cast(u32x4, buf_load16(wsrd, laneb, sb + xx * 2048u));
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+              for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int xx = 0; xx < 4; ++xx)
+                  if (!(P27 && xx == 2)) {
+                    const u32x2 av = t == 0 ? Al[xx] : Ah[xx];
+                    const u32x2 bv = t == 1 ? u32x2{bw[nb][xx][2], bw[nb][xx][3]} : u32x2{bw[nb][xx][0], bw[nb][xx][1]};
+                    acc[nb][j * 4 + xx] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, av), __builtin_bit_cast(s16x4, bv),
+                                                                                    acc[nb][j * 4 + xx], 0, 0, 0);
+                  }
+              __builtin_amdgcn_sched_barrier(0);
+              if (!(DBG & 8)) issue_bw(nb, kn, jn);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          };
+          if (st == 0 && (DBG & 64)) {      // (experiment 64: staging loads ahead of the k-step's MFMAs)
+#pragma unroll
+            for (int z = 0; z < 6; ++z) stz[z] = buf_load16(ssrd, soz[z], schunk);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          mfma_nb(0);
+          if (!HALF) mfma_nb(1);
+          if (st == 0 && !(DBG & 4) && !(DBG & 64)) {      // staging loads of the next chunk, right behind a weight batch (see the PREC = 0 loop)
+#pragma unroll
+            for (int z = 0; z < 6; ++z) stz[z] = buf_load16(ssrd, soz[z], schunk);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    if constexpr (BX) {
+      if (half) main_loop_b(std::true_type{}); else main_loop_b(std::false_type{});
+    } else {
+      if (half) main_loop(std::true_type{}); else main_loop(std::false_type{});
+    }
 
     const unsigned long long tp2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
     // ---- epilogue: inverse transform in x, y per accumulator element; z across the waves through the idle LDS buffer ---------
     // (the buffer of the last chunk is free since that chunk's barrier; the other one holds the next block's chunk 0)
     if constexpr (POOL) {
-      const int lb = ((nchunk - 1 + pb) & 1) * BUF;
+      const int lb = ((nchunk - 1 + pb) & 1) * BUFF;
       float* sP = sIn + lb;      // [xi_z][tz][e][lane]: the (y, x)-pooled value of accumulator element e
       const int Dc = a.D >> 1, Hc = a.H >> 1, Wc = a.W >> 1;
       const int cz = (cur.z0 >> 1) + th, cy = (cur.y0 >> 1) + kq, cx = (cur.x0 >> 1) + xz;      // this wave combines e = xz of its z-row
@@ -504,7 +764,8 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         __syncthreads();
       }
     } else {
-      const int lb = ((nchunk - 1 + pb) & 1) * BUF;
+      const int lb = ((nchunk - 1 + pb) & 1) * BUFF;
+      const float* const sM = BX ? sIn + lb + 8192 : sMs;
       f32x4* sO = reinterpret_cast<f32x4*>(sIn + lb);      // [xi_z][tz][e][lane] float4 = (oy0ox0, oy0ox1, oy1ox0, oy1ox1)
       // this wave combines accumulator element e = xi_z of its own z-row:  tile (ty = lane>>4, tx = e), cout = lane & 15
       const int oz0 = cur.z0 + 2 * th, oy0 = cur.y0 + 2 * kq, ox0 = cur.x0 + 2 * xz;
@@ -674,6 +935,56 @@ void df_debug_set_wino(int v) { g_wino_dbg = v & 0xfffff; g_wino_spx = v >> 20; 
 int df_debug_wino_prof(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_prof), z, sizeof(z)); }
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_prof), 32 * sizeof(unsigned long long));
+}
+#endif
+
+#ifdef DF_TUNING
+// The "bf16x3 in the Winograd domain" experiment (wino3d_kernel PREC = 1), tuning library only: same arguments as df_wino_pack_weights /
+// df_wino_conv_fwd.  df_debug_set_wino: 0 production order | 32 xi_x-major MFMA order | diagnosis variants (results wrong by construction)
+// 1 no transform | 2 no LDS operand reads | 4 no staging | 8 no weight loads and sums | 16 staged chunk stored one k-step later |
+// 64 staging loads ahead of the k-step's MFMAs.
+int df_debug_wino_pack_weights_bf16x3(const float* w, float* wp, int64_t cin, int64_t cout, int mode, df_stream_t stream) {
+  DF_REQUIRE(w && wp, DF_EINVAL, "df_debug_wino_pack_weights_bf16x3: null pointer");
+  DF_REQUIRE(cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 && (mode == 0 || mode == 1), DF_ESHAPE,
+             "df_debug_wino_pack_weights_bf16x3: cin, cout must be multiples of 32; mode 0|1");
+  const int64_t total = 64 * cin * cout;      // in fp32 units: (hi, lo) bf16 = 4 bytes per transformed weight
+  int64_t g = ceil_div(cin * cout, 64);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(wino_pack_bf16x3_kernel, dim3((unsigned)g), dim3(64), 0, df::as_stream(stream), w, reinterpret_cast<__bf16*>(wp), (int)cin,
+                     (int)cout, mode, total);
+  return df::launched("df_debug_wino_pack_weights_bf16x3");
+}
+static int64_t wino_grid(WinoArgs& a, int64_t ntb);
+int df_debug_wino_conv_fwd_bf16x3(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src, float* y,
+                                  int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak,
+                                  df_stream_t stream) {
+  DF_REQUIRE(x && wp && y, DF_EINVAL, "df_debug_wino_conv_fwd_bf16x3: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE,
+             "df_debug_wino_conv_fwd_bf16x3: positive extents, Cin, Cout multiples of 32");
+  DF_REQUIRE(D * H * W * (Cin > Cout ? Cin : Cout) <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
+             "df_debug_wino_conv_fwd_bf16x3: one batch volume must stay below 2 GiB");
+  DF_REQUIRE(!(flags & DF_CONV_ADDUP) && (!(flags & DF_CONV_BIAS) || bias) && (!(flags & DF_CONV_RESIDUAL) || residual) &&
+                 (!(flags & DF_CONV_MASK) || mask_src), DF_EINVAL, "df_debug_wino_conv_fwd_bf16x3: flag without its operand");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x), DF_EALIGN, "df_debug_wino_conv_fwd_bf16x3: x and packed weights must be 16-byte aligned");
+  WinoArgs a;
+  a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
+  a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y; a.y2 = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
+  a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.nbz = (int)ceil_div(D, 4); a.nby = (int)ceil_div(H, 8); a.nbx = (int)ceil_div(W, 8);
+  const int64_t ntb = B * a.nbz * a.nby * a.nbx;
+  a.ncs = (int)(Cout / 32);
+  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_debug_wino_conv_fwd_bf16x3: too many workgroups");
+  a.ntb = (int)ntb;
+  a.flags = flags; a.leak = leak;
+  const int64_t grid = wino_grid(a, ntb);
+#define DF_WB(V) case V: hipLaunchKernelGGL((wino3d_kernel<V, DF_CONV_BIAS | DF_CONV_LRELU, 0, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break
+  switch (g_wino_dbg) {
+    case 0: hipLaunchKernelGGL((wino3d_kernel<0, -1, 0, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    DF_WB(1); DF_WB(2); DF_WB(3); DF_WB(4); DF_WB(8); DF_WB(12); DF_WB(7); DF_WB(15); DF_WB(11); DF_WB(16); DF_WB(32); DF_WB(64);
+    default: return df::fail(DF_EINVAL, "df_debug_wino_conv_fwd_bf16x3: unknown debug variant");
+  }
+#undef DF_WB
+  return df::launched("df_debug_wino_conv_fwd_bf16x3");
 }
 #endif
 

@@ -9,6 +9,8 @@
 #ifndef DEEPFLUIDS_HIP_DEBUG_H
 #define DEEPFLUIDS_HIP_DEBUG_H
 
+#include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -26,6 +28,14 @@ void df_debug_set_tail(int v);
 void df_debug_set_wgrad(int v);            /* wgrad_wxyz_kernel experiments (results wrong by construction): bit 1 = every operand load reads
                                              the cached zero row (no memory latency), 2 = no (z, y) operand combinations, 4 = no x transform; values
                                              1, 2, 3, 6, 7 are instantiated (W = 64 rows) */
+
+/* The "bf16x3 in the Winograd domain" experiment (wino3d_kernel PREC = 1): arguments as df_wino_pack_weights /
+ * df_wino_conv_fwd.  The kernel variant follows the RAW value of df_debug_set_wino: 0 production, 32 xi_x-major MFMA order; timing-only
+ * variants (results wrong by construction) 1 no transform, 2 no LDS operand reads, 4 no staging, 8 no weight loads (+ the sums 3, 7, 11, 12, 15),
+ * 16 staged chunk stored one k-step later, 64 staging loads ahead of the k-step's MFMAs. */
+int df_debug_wino_pack_weights_bf16x3(const float* w, float* wp, int64_t cin, int64_t cout, int mode, void* stream);
+int df_debug_wino_conv_fwd_bf16x3(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src, float* y,
+                                  int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, void* stream);
 
 #ifdef __cplusplus
 }
