@@ -235,7 +235,9 @@ __global__ __launch_bounds__(kThreads) void conv_small_k_kernel(const ConvArgs a
 // wave walks image rows in 32-voxel chunks, and the shifted 3|4-channel input records are gathered from a 9-row LDS tile private to the
 // wave (zero x-halo, zero rows for SAME padding, double-buffered per image row: no workgroup barriers).  Two waves share a row stream,
 // 64 output channels each; N-block j of lane l holds channel 2*(l%32)+j of the wave's half, so every output / residual / mask access is
-// a float2 and a wave instruction covers two voxels' 256-byte half rows.
+// a float2 and a wave instruction covers two voxels' 256-byte half rows.  [r3] CO = 64 (the auto-encoder's 3 -> 64 dgrad: one wave per row
+// stream), rows of any multiple of 8 voxels >= 32 (the last chunk of a row then starts at W - 32: it recomputes up to 24 voxels of the one
+// before and stores the same values again) and rows of up to 448 floats (NP = 2 load passes; LDS opt-in above 64 KB) -- cfg4's W = 112.
 struct ThinKArgs {
   const float* x;
   const f32x4* wp;
@@ -252,14 +254,15 @@ struct ThinKArgs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int CI>
+template <int CI, int CO, int NP>
 __global__ __launch_bounds__(kThreads, 1) void conv_thin_k_mfma_kernel(const ThinKArgs a) {
   constexpr int NK = 27 * CI, KS = (NK + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) float smem_thin_k[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gwave = blockIdx.x * 4 + wave;
-  const int stream = gwave >> 1, half = gwave & 1;      // two waves per row stream: 64 output channels each (the filter bank fits the registers)
+  // CO = 128: two waves per row stream, 64 output channels each (the filter bank fits the registers); CO = 64: one
+  const int stream = CO == 128 ? gwave >> 1 : gwave, half = CO == 128 ? gwave & 1 : 0;
   const int RS = a.RS, W = a.W, WC = W * CI;
   float* sG = smem_thin_k + wave * 19 * RS;          // [2 buffers][9 (dz, dy) rows][RS] + one zero row
   const int r0 = stream * a.rows_per;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_thin_k_mfma_kernel(const Thi
 
   // ---- input rows of image row `row` -> registers -> LDS buffer ----------------------------------------------------------------------
   const int nl4 = WC / 4;
-  f32x4 gq[9];
+  f32x4 gq[NP][9];
   auto load_g = [&](int row) {
     const int y = row % a.H;
     const int t = row / a.H;
@@ -300,23 +303,28 @@ __global__ __launch_bounds__(kThreads, 1) void conv_thin_k_mfma_kernel(const Thi
       const bool ok = zs >= 0 && zs < a.D && ys >= 0 && ys < a.H;      // wave-uniform
       const int zc = ok ? zs : z, yc = ok ? ys : y;
       const float* src = a.x + ((static_cast<int64_t>(b) * a.D + zc) * a.H + yc) * WC;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (lane < nl4) v = *reinterpret_cast<const f32x4*>(src + lane * 4);
-      gq[k] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (lane + 64 * p < nl4) v = *reinterpret_cast<const f32x4*>(src + (lane + 64 * p) * 4);
+        gq[p][k] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
   auto store_g = [&](int buf) {
-    if (lane < nl4) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) *reinterpret_cast<f32x4*>(sG + (buf * 9 + k) * RS + 4 + lane * 4) = gq[k];
-    }
+    for (int p = 0; p < NP; ++p)
+      if (lane + 64 * p < nl4) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) *reinterpret_cast<f32x4*>(sG + (buf * 9 + k) * RS + 4 + (lane + 64 * p) * 4) = gq[p][k];
+      }
   };
 
   // ---- A operand gather: lane (voxel m = l % 32 of the chunk, k = 2s + l / 32) ---------------------------------------------------------
   const char* sGb = reinterpret_cast<const char*>(sG);
   const int lanebase = (lane & 31) * CI * 4;
-  auto gather = [&](int buf, int chunk, float (&av)[KS]) {
-    const int cb = lanebase + chunk * (32 * CI * 4);
+  auto gather = [&](int buf, int x0, float (&av)[KS]) {      // x0: first voxel of the chunk
+    const int cb = lanebase + x0 * (CI * 4);
     const int bb = buf * (9 * RS * 4);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -329,20 +337,21 @@ __global__ __launch_bounds__(kThreads, 1) void conv_thin_k_mfma_kernel(const Thi
 
   load_g(r0);
   store_g(0);
-  const int nchunk = W >> 5;
+  const int nchunk = (W + 31) >> 5;
   int buf = 0;
   for (int row = r0; row < r1; ++row) {
     const bool more = row + 1 < r1;
     if (more) load_g(row + 1);
-    const int64_t obase = static_cast<int64_t>(row) * W * 128 + n4;
+    const int64_t obase = static_cast<int64_t>(row) * W * CO + n4;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
       float av[KS];
-      gather(buf, chunk, av);
-      const int64_t oc = obase + static_cast<int64_t>(chunk) * 32 * 128;
+      const int x0 = chunk * 32 + 32 <= W ? chunk * 32 : W - 32;
+      gather(buf, x0, av);
+      const int64_t oc = obase + static_cast<int64_t>(x0) * CO;
       f32x2 mk[16];
       if (a.flags & DF_CONV_MASK) {      // requested now, used after the chunk's 2*KS MFMAs
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mk[r] = *reinterpret_cast<const f32x2*>(a.mask_src + oc + ((r >> 2) * 8 + kk * 4 + (r & 3)) * 128);
+        for (int r = 0; r < 16; ++r) mk[r] = *reinterpret_cast<const f32x2*>(a.mask_src + oc + ((r >> 2) * 8 + kk * 4 + (r & 3)) * CO);
       }
       f32x16 acc[2];
 #pragma unroll
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_thin_k_mfma_kernel(const Thi
         for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wr[s][j], acc[j], 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t o = oc + ((r >> 2) * 8 + kk * 4 + (r & 3)) * 128;
+        const int64_t o = oc + ((r >> 2) * 8 + kk * 4 + (r & 3)) * CO;
         f32x2 v = f32x2{acc[0][r], acc[1][r]} + bias2;
         if (a.flags & DF_CONV_LRELU) {
 #pragma unroll
@@ -374,9 +383,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv_thin_k_mfma_kernel(const Thi
   }
 }
 
-// (LDS: 4 waves x 19 rows x (W*Cin + 8) floats under the 64 KB a launch gets without opting in)
+// (LDS: 4 waves x 19 rows x (W*Cin + 8) floats: opt-in above the 64 KB a launch gets by default)
 inline bool thin_k_mfma_ok(const ConvArgs& a, int kz) {
-  return kz == 3 && a.Cin <= 4 && a.Cout == 128 && a.W % 32 == 0 && a.W * a.Cin <= 192 && (a.W * a.Cin) % 16 == 0 &&
+  return kz == 3 && a.Cin <= 4 && (a.Cout == 128 || a.Cout == 64) && a.W % 8 == 0 && a.W >= 32 && a.W * a.Cin <= 448 && (a.W * a.Cin) % 16 == 0 &&
          static_cast<int64_t>(a.B) * a.D * a.H >= 4 && a.nclass == 1 && df::aligned16(a.x) && df::aligned16(a.y) &&
          (!(a.flags & DF_CONV_BIAS) || df::aligned16(a.bias)) && (!(a.flags & DF_CONV_RESIDUAL) || df::aligned16(a.residual)) &&
          (!(a.flags & DF_CONV_MASK) || df::aligned16(a.mask_src));
@@ -388,14 +397,28 @@ int launch_thin_k_mfma(const ConvArgs& a, hipStream_t s) {
   t.D = a.D; t.H = a.H; t.W = a.W;
   t.tapstride = (a.Kpad >> 3) * 2 * a.Npad;
   t.nrows = a.B * a.D * a.H;
-  int ns = 2 * df::kCUs;      // row streams (two waves each)
+  t.RS = a.W * a.Cin + 8;
+  const size_t lds = static_cast<size_t>(4) * 19 * t.RS * sizeof(float);
+  const int wps = a.Cout == 128 ? 2 : 1;                       // waves per row stream
+  int ns = 4 / wps * df::kCUs;                                 // row streams: one workgroup (4 waves) per CU
   if (ns > t.nrows) ns = t.nrows / 2 * 2;
   t.rows_per = (t.nrows + ns - 1) / ns;
-  t.RS = a.W * a.Cin + 8;
   t.flags = a.flags; t.leak = a.leak;
-  const size_t lds = static_cast<size_t>(4) * 19 * t.RS * sizeof(float);
-  dim3 grid((unsigned)ceil_div(ceil_div(t.nrows, t.rows_per), 2));
-#define DF_TK(CI) hipLaunchKernelGGL((conv_thin_k_mfma_kernel<CI>), grid, dim3(kThreads), lds, s, t)
+  dim3 grid((unsigned)ceil_div(ceil_div(t.nrows, t.rows_per) * wps, 4));
+  const bool two = a.W * a.Cin > 256;                          // rows of more than 64 float4: two load passes
+#define DF_TK2(CI, COV, NPV)                                                                                                                \
+  do {                                                                                                                                      \
+    if (lds > 64 * 1024)                                                                                                                    \
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_thin_k_mfma_kernel<CI, COV, NPV>),                         \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))                                         \
+        return df::fail((int)e, "df_conv_fwd(thin-K mfma): dynamic LDS opt-in: %s", hipGetErrorString(e));                                  \
+    hipLaunchKernelGGL((conv_thin_k_mfma_kernel<CI, COV, NPV>), grid, dim3(kThreads), lds, s, t);                                           \
+  } while (0)
+#define DF_TK(CI)                                                                                                                           \
+  do {                                                                                                                                      \
+    if (a.Cout == 128) { if (two) DF_TK2(CI, 128, 2); else DF_TK2(CI, 128, 1); }                                                            \
+    else { if (two) DF_TK2(CI, 64, 2); else DF_TK2(CI, 64, 1); }                                                                            \
+  } while (0)
   switch (a.Cin) {
     case 1: DF_TK(1); break;
     case 2: DF_TK(2); break;
@@ -403,6 +426,7 @@ int launch_thin_k_mfma(const ConvArgs& a, hipStream_t s) {
     default: DF_TK(4); break;
   }
 #undef DF_TK
+#undef DF_TK2
   return df::launched("df_conv_fwd(thin-K mfma)");
 }
 
@@ -414,7 +438,10 @@ int launch_thin_k_mfma(const ConvArgs& a, hipStream_t s) {
 // line of x is consumed by four back-to-back loads) feed 192 v_mfma_f32_32x32x2 whose filter operands all stay in registers; the
 // 9-way (dy, dx) shift-add of the product tile goes through a three-row LDS ring private to the wave (ds_add_f32 in program order:
 // deterministic), and a finished output row leaves as 3*W contiguous floats.  x is read by the three waves of neighbouring planes
-// at about the same time (L2 / Infinity Cache), 16 loads in flight per lane.
+// at about the same time (L2 / Infinity Cache), 16 loads in flight per lane.  [r3] CIN = 64 (the auto-encoder's 64 -> 3 layer: K = 3*64, 8
+// loads in flight), rows of any multiple of 8 voxels >= 32 (the last chunk of a row then starts at W - 32 and the lanes of the voxels the
+// chunk before already covered load through an out-of-range offset: zeros, their products add nothing) and output rows of up to 512
+// floats (two store passes) -- cfg4's W = 112.
 struct ThinNArgs {
   const float* x;
   const f32x4* wp;
@@ -427,9 +454,11 @@ struct ThinNArgs {
   float leak;
 };
 
-template <int CO>
+template <int CO, int CIN>
 __global__ __launch_bounds__(kThreads, 1) void conv_thin_n_mfma_kernel(const ThinNArgs a) {
   constexpr int NC = 9 * CO;
+  constexpr int QN = CIN / 8;        // 8-channel items per z tap (lane half kk takes 4 of the 8)
+  constexpr int NIT = 3 * QN;
   extern __shared__ __attribute__((aligned(16))) float smem_thin_n[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -448,46 +477,47 @@ __global__ __launch_bounds__(kThreads, 1) void conv_thin_n_mfma_kernel(const Thi
   const int n = lane & 31, kk = lane >> 5;
 
   // ---- filter bank -> registers: item (dz, q) holds W[dz, dy(n), dx(n)][c = 8q + 4kk + t][co(n)], t = 0..3 ------------------------
-  f32x4 wr[48];
+  f32x4 wr[NIT];
 #pragma unroll
-  for (int it = 0; it < 48; ++it) {
-    const int dz = it >> 4, q = it & 15;
+  for (int it = 0; it < NIT; ++it) {
+    const int dz = it / QN, q = it % QN;
     const int tap = dz * 9 + (n < NC ? n / CO : 0);
     const f32x4 rec = a.wp[((static_cast<int64_t>(tap) * a.K8 + q) * 2 + kk) * a.Npad + (n < NC ? n % CO : 0)];
     wr[it] = n < NC ? rec : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // output-side constants of this lane's column
   const int dy = n / (3 * CO), dx = (n / CO) % 3, co = n % CO;
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (a.flags & DF_CONV_BIAS) {
+  float bias3[CO];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bias4[j] = a.bias[(lane * 4 + j) % CO];
-  }
+  for (int j = 0; j < CO; ++j) bias3[j] = (a.flags & DF_CONV_BIAS) ? a.bias[j] : 0.f;
 
   // ---- x loads: batch volume as a buffer; lane (voxel m = n, half kk) reads channels 8q + 4kk .. +3 ----------------------------------
-  const int64_t vol = static_cast<int64_t>(a.D) * H * W * 128;
+  const int64_t vol = static_cast<int64_t>(a.D) * H * W * CIN;
   const __amdgpu_buffer_rsrc_t xsrd =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + static_cast<int64_t>(b) * vol), 0, static_cast<unsigned>(vol * 4), 0x00020000);
-  const unsigned lanev = static_cast<unsigned>(n) * 512u + static_cast<unsigned>(kk) * 16u;
+  const unsigned lanev = static_cast<unsigned>(n) * (CIN * 4u) + static_cast<unsigned>(kk) * 16u;
+  const int nchunk = (W + 31) >> 5;
+  const int xlast = W - 32;                                                 // first voxel of a row's last chunk (== (nchunk - 1) * 32 when W % 32 == 0)
+  const unsigned lastbit = xlast + n >= (nchunk - 1) * 32 ? 0u : 0x80000000u;      // ... whose already-covered voxels read zeros
   unsigned vplane[3];      // per z tap: lane offset, or an out-of-range offset (reads zeros) when the plane is outside the volume
 #pragma unroll
   for (int dz = 0; dz < 3; ++dz) vplane[dz] = (z + dz - 1 >= 0 && z + dz - 1 < a.D) ? lanev : 0x80000000u;
   auto soff_of = [&](int dz, int row, int chunk) -> unsigned {      // wave-uniform byte offset of (plane, row, chunk); clamped plane
     int zz = z + dz - 1;
     zz = zz < 0 ? 0 : (zz >= a.D ? a.D - 1 : zz);
-    return static_cast<unsigned>(((zz * H + row) * W + chunk * 32) * 512);
+    return static_cast<unsigned>(((zz * H + row) * W + (chunk + 1 == nchunk ? xlast : chunk * 32)) * (CIN * 4));
   };
   auto load_x = [&](unsigned voff, unsigned soff, int q) -> f32x4 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrd, voff + static_cast<unsigned>(q) * 32u, soff, 0));
   };
 
-  const int nchunk = W >> 5;
   const int ra = y0 > 0 ? y0 - 1 : 0, rb = y1 < H ? y1 + 1 : H;      // input rows [ra, rb)
-  f32x4 xr[16];
+  f32x4 xr[QN];
   {
     const unsigned s0 = soff_of(0, ra, 0);
+    const unsigned v0 = vplane[0] | (nchunk == 1 ? lastbit : 0u);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) xr[i] = load_x(vplane[0], s0, i);
+    for (int i = 0; i < QN; ++i) xr[i] = load_x(v0, s0, i);
   }
 
   typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -499,17 +529,19 @@ __global__ __launch_bounds__(kThreads, 1) void conv_thin_n_mfma_kernel(const Thi
       const bool more = nrow < rb;
       const unsigned s1 = soff_of(1, row, chunk), s2 = soff_of(2, row, chunk);
       const unsigned sn = soff_of(0, more ? nrow : row, more ? nchk : chunk);
-      const unsigned vn = more ? vplane[0] : 0x80000000u;
+      const unsigned vn = more ? (vplane[0] | (nchk == nchunk - 1 ? lastbit : 0u)) : 0x80000000u;
+      const unsigned cbit = lastc ? lastbit : 0u;
+      const unsigned v1 = vplane[1] | cbit, v2 = vplane[2] | cbit;
       f32x16 acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
-      for (int it = 0; it < 48; ++it) {
-        const f32x4 xv = xr[it & 15];
-        const int nit = it + 16;      // the item this slot is refilled for
-        if (nit < 32) xr[it & 15] = load_x(vplane[1], s1, nit & 15);
-        else if (nit < 48) xr[it & 15] = load_x(vplane[2], s2, nit & 15);
-        else xr[it & 15] = load_x(vn, sn, nit & 15);
+      for (int it = 0; it < NIT; ++it) {
+        const f32x4 xv = xr[it % QN];
+        const int nit = it + QN;      // the item this slot is refilled for
+        if (nit < 2 * QN) xr[it % QN] = load_x(v1, s1, nit % QN);
+        else if (nit < 3 * QN) xr[it % QN] = load_x(v2, s2, nit % QN);
+        else xr[it % QN] = load_x(vn, sn, nit % QN);
         __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks every load to just before its use: vmcnt(0) per item)
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[0], wr[it][0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[1], wr[it][1], acc1, 0, 0, 0);
@@ -520,7 +552,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_thin_n_mfma_kernel(const Thi
       // ---- shift-add: column (dy, dx, co) of input row `row` belongs to output row row - (dy - 1), position x' - (dx - 1) --------
       const int orow = row + 1 - dy;
       if (n < NC && orow >= y0 && orow < y1) {
-        float* dst = ring + (orow % 3) * RS + 4 + (chunk * 32 + kk * 4 + 1 - dx) * CO + co;
+        float* dst = ring + (orow % 3) * RS + 4 + ((lastc ? xlast : chunk * 32) + kk * 4 + 1 - dx) * CO + co;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           __hip_atomic_fetch_add(dst + ((r >> 2) * 8 + (r & 3)) * CO, acc0[r] + acc1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -533,23 +565,28 @@ __global__ __launch_bounds__(kThreads, 1) void conv_thin_n_mfma_kernel(const Thi
       const bool go = k == 0 ? (fr >= y0 && fr < y1) : (row == H - 1 && fr >= y0 && fr < y1);
       if (!go) continue;
       float* src = ring + (fr % 3) * RS + 4;
-      if (lane * 4 < W * CO) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(src + lane * 4) + bias4;
+      for (int i0 = lane * 4; i0 < W * CO; i0 += 256) {      // one pass up to 64 x 4 floats per row, two above
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + i0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = (i0 + j) % CO;
+          v[j] += CO == 1 ? bias3[0] : c == 0 ? bias3[0] : c == 1 ? bias3[1 % CO] : bias3[2 % CO];
+        }
         if (a.flags & DF_CONV_LRELU) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], a.leak * v[j]);
         }
-        *reinterpret_cast<f32x4*>(a.y + ((static_cast<int64_t>(plane) * H + fr) * W) * CO + lane * 4) = v;
-        *reinterpret_cast<f32x4*>(src + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(a.y + ((static_cast<int64_t>(plane) * H + fr) * W) * CO + i0) = v;
+        *reinterpret_cast<f32x4*>(src + i0) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
 }
 
 inline bool thin_n_mfma_ok(const ConvArgs& a, int kz) {
-  return kz == 3 && a.Cin == 128 && a.Cout <= 3 && a.W % 32 == 0 && a.W * a.Cout <= 256 && a.nclass == 1 &&
-         !(a.flags & (DF_CONV_RESIDUAL | DF_CONV_MASK)) && df::aligned16(a.x) && df::aligned16(a.y) &&
-         static_cast<int64_t>(a.D) * a.H * a.W * 512 < (1LL << 31);
+  return kz == 3 && (a.Cin == 128 || a.Cin == 64) && a.Cout <= 3 && a.W % 8 == 0 && a.W >= 32 && a.W * a.Cout <= 512 && (a.W * a.Cout) % 4 == 0 &&
+         a.nclass == 1 && !(a.flags & (DF_CONV_RESIDUAL | DF_CONV_MASK)) && df::aligned16(a.x) && df::aligned16(a.y) &&
+         static_cast<int64_t>(a.D) * a.H * a.W * a.Cin * 4 < (1LL << 31);
 }
 
 int launch_thin_n_mfma(const ConvArgs& a, hipStream_t s) {
@@ -566,7 +603,11 @@ int launch_thin_n_mfma(const ConvArgs& a, hipStream_t s) {
   t.flags = a.flags; t.leak = a.leak;
   const size_t lds = static_cast<size_t>(4) * 3 * (a.W * a.Cout + 8) * sizeof(float);
   dim3 grid((unsigned)ceil_div(planes * t.nsplit, 4));
-#define DF_TN(CO) hipLaunchKernelGGL((conv_thin_n_mfma_kernel<CO>), grid, dim3(kThreads), lds, s, t)
+#define DF_TN(CO)                                                                                                  \
+  do {                                                                                                             \
+    if (a.Cin == 128) hipLaunchKernelGGL((conv_thin_n_mfma_kernel<CO, 128>), grid, dim3(kThreads), lds, s, t);     \
+    else hipLaunchKernelGGL((conv_thin_n_mfma_kernel<CO, 64>), grid, dim3(kThreads), lds, s, t);                   \
+  } while (0)
   switch (a.Cout) {
     case 1: DF_TN(1); break;
     case 2: DF_TN(2); break;

@@ -416,32 +416,42 @@ def test_thin_wgrad_mfma_and_valu_vs_oracle(ops, shape, cout, algo):
     assert rel_linf(host(gb), db) < TOL
 
 
-@pytest.mark.parametrize("shape,cin,leak", [((1, 3, 5, 32), 3, 0.2), ((2, 2, 3, 64), 3, None), ((1, 4, 2, 32), 1, 0.2), ((1, 2, 3, 32), 4, 0.2),
-                                            ((1, 1, 5, 32), 2, 0.2), ((1, 5, 1, 64), 3, 0.2)])
-def test_thin_k_conv_mfma_vs_oracle(ops, shape, cin, leak):
-    """Cin <= 4 -> 128 conv on the matrix cores (conv_thin_k_mfma_kernel: taps on the GEMM's K side, rows of 32-voxel chunks), forward and
-    all gradients against the fp64 oracle."""
-    errs = _conv_case(ops, shape, cin, 128, leak, seed=cin + sum(shape), mask_from_gpu=True)
+@pytest.mark.parametrize("shape,cin,leak,wide", [((1, 3, 5, 32), 3, 0.2, 128), ((2, 2, 3, 64), 3, None, 128), ((1, 4, 2, 32), 1, 0.2, 128),
+                                                 ((1, 2, 3, 32), 4, 0.2, 128), ((1, 1, 5, 32), 2, 0.2, 128), ((1, 5, 1, 64), 3, 0.2, 128),
+                                                 # [r3] rows that end in a shifted chunk (W % 32 != 0), two load passes (W * Cin > 256: LDS opt-in),
+                                                 # 64 output channels (the auto-encoder's first layer / the dgrad of its last)
+                                                 ((1, 2, 3, 112), 3, 0.2, 128), ((1, 3, 2, 48), 3, None, 64), ((1, 2, 2, 128), 3, 0.2, 64),
+                                                 ((1, 1, 3, 40), 2, 0.2, 128), ((2, 2, 3, 64), 3, 0.2, 64), ((1, 2, 2, 56), 4, None, 64)])
+def test_thin_k_conv_mfma_vs_oracle(ops, shape, cin, leak, wide):
+    """Cin <= 4 -> 128 | 64 conv on the matrix cores (conv_thin_k_mfma_kernel: taps on the GEMM's K side, rows of 32-voxel chunks), forward
+    and all gradients against the fp64 oracle."""
+    errs = _conv_case(ops, shape, cin, wide, leak, seed=cin + sum(shape), mask_from_gpu=True)
     assert max(errs.values()) < TOL, errs
 
 
-@pytest.mark.parametrize("shape,cout,leak", [((1, 3, 5, 32), 3, None), ((2, 2, 4, 64), 3, 0.2), ((1, 4, 9, 32), 1, None), ((1, 2, 3, 32), 2, None),
-                                             ((1, 1, 6, 32), 3, None), ((1, 2, 16, 32), 3, None), ((1, 1, 13, 64), 3, 0.2)])
-def test_thin_n_conv_mfma_vs_oracle(ops, shape, cout, leak):
-    """128 -> Cout <= 3 conv forward on the matrix cores (conv_thin_n_mfma_kernel: z taps on the GEMM's K side, in-plane taps on its N
+@pytest.mark.parametrize("shape,cout,leak,wide", [((1, 3, 5, 32), 3, None, 128), ((2, 2, 4, 64), 3, 0.2, 128), ((1, 4, 9, 32), 1, None, 128),
+                                                  ((1, 2, 3, 32), 2, None, 128), ((1, 1, 6, 32), 3, None, 128), ((1, 2, 16, 32), 3, None, 128),
+                                                  ((1, 1, 13, 64), 3, 0.2, 128),
+                                                  # [r3] shifted last chunk, two store passes (W * Cout > 256), 64 input channels
+                                                  ((1, 2, 3, 112), 3, None, 128), ((1, 3, 5, 48), 3, 0.2, 64), ((1, 2, 2, 128), 3, None, 64),
+                                                  ((1, 1, 4, 40), 2, None, 128), ((2, 2, 4, 64), 3, 0.2, 64), ((1, 2, 9, 112), 1, None, 64)])
+def test_thin_n_conv_mfma_vs_oracle(ops, shape, cout, leak, wide):
+    """128 | 64 -> Cout <= 3 conv forward on the matrix cores (conv_thin_n_mfma_kernel: z taps on the GEMM's K side, in-plane taps on its N
     side, LDS shift-add ring), incl. single-plane volumes, y ranges with halo rows (few planes) and the gradients of the same layer."""
-    errs = _conv_case(ops, shape, 128, cout, leak, seed=cout + sum(shape), mask_from_gpu=True)
+    errs = _conv_case(ops, shape, wide, cout, leak, seed=cout + sum(shape), mask_from_gpu=True)
     assert max(errs.values()) < TOL, errs
 
 
-@pytest.mark.parametrize("flags", [0, 9, 4, 2, 15])
-def test_thin_k_conv_mfma_epilogues_match_valu_kernel(ops, flags):
+@pytest.mark.parametrize("flags,W,N", [(0, 64, 128), (9, 64, 128), (4, 64, 128), (2, 64, 128), (15, 64, 128), (15, 112, 128), (4, 112, 128),
+                                       (15, 48, 64), (6, 128, 64)])
+def test_thin_k_conv_mfma_epilogues_match_valu_kernel(ops, flags, W, N):
     """Every fused epilogue of the thin-K matrix-core kernel (bias, lrelu, residual, lrelu-mask of another tensor: the dgrad of the
-    generator's last layer uses the mask) against the vector-ALU kernel it replaces."""
+    generator's last layer uses the mask) against the vector-ALU kernel it replaces; [r3] incl. rows with a shifted last chunk (the
+    overlapped voxels are computed and stored twice: same values), two load passes and 64 output channels."""
     from deep_fluids_amd._lib import call, query, lib
     from deep_fluids_amd.ops import _ptr, _stream
     torch.manual_seed(flags)
-    B, D, H, W, C, N = 2, 3, 5, 64, 3, 128
+    B, D, H, C = 2, 3, 5, 3
     s = _stream()
     x = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
     w = (torch.rand((3, 3, 3, N, C), device="cuda") * 2 - 1) * 0.2      # weights of the 128 -> 3 layer whose dgrad this is
