@@ -2151,6 +2151,34 @@ Plan make_plan(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t 
   return p;
 }
 
+// ---- row lengths without an (x,y,z) Winograd instantiation (W = 28, 14: levels of cfg4's 112-wide grid) ----------------------------------
+// gW of a SAME conv does not change when both operands get zero columns appended (the added gradient columns are zero, and the added input
+// columns are what SAME padding supplies anyway): copy x and gy into rows of the next instantiated length and run that kernel -- two
+// copies of a low-resolution level against a 2-3x faster weight gradient.  Returns the padded row length, 0 = does not apply.
+inline int64_t wxyz_padded_w(int req, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz) {
+  if (!(req == 0 || req == 4) || kz != 3 || W < 12) return 0;
+  if (wxyz_ok(D, H, W, Cin, Cout, kz)) return 0;
+  static const int64_t kLens[] = {16, 32, 56, 64, 112, 128};
+  for (int64_t L : kLens)
+    if (L > W && 8 * (L - W) <= L + 7 && wxyz_ok(D, H, L, Cin, Cout, kz)) return L;      // at most 1/8 of the row is padding
+  return 0;
+}
+inline int64_t up256(int64_t n) { return (n + 255) / 256 * 256; }
+inline int64_t wxyz_pad_bytes(int64_t B, int64_t D, int64_t H, int64_t Wp, int64_t Cin, int64_t Cout) {
+  return up256(B * D * H * Wp * Cin * 4) + up256(B * D * H * Wp * Cout * 4);
+}
+
+// dst[row][0..Wp) = src[row][0..W) followed by zeros; one float4 of channels per thread
+__global__ __launch_bounds__(kThreads) void pad_rows_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t nrows, int W, int Wp, int C4) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const int64_t per = static_cast<int64_t>(Wp) * C4;
+  if (i >= nrows * per) return;
+  const int64_t row = i / per;
+  const int r = static_cast<int>(i - row * per);
+  const int xx = r / C4;
+  dst[i] = xx < W ? src[(row * W + xx) * C4 + (r - xx * C4)] : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 }  // namespace
 
 extern "C" {
@@ -2170,6 +2198,8 @@ int64_t df_conv_wgrad_workspace_bytes(int64_t B, int64_t D, int64_t H, int64_t W
     }
     return fl * static_cast<int64_t>(sizeof(float)) + kZeroBytes;
   }
+  if (const int64_t Wp = wxyz_padded_w(0, D, H, W, Cin, Cout, kz))      // zero-padded rows + the workspace of the padded shape
+    return df_conv_wgrad_workspace_bytes(B, D, H, Wp, Cin, Cout, kz) + 256 + wxyz_pad_bytes(B, D, H, Wp, Cin, Cout);
   int64_t best = 0;
   if (Cin <= 4 && Cout >= 64 && thin_mfma_ok(B, D, H, W, Cout, Cin, kz))
     best = thin_wgrad_ws_floats(B, D, H, Cout, Cin, true) * static_cast<int64_t>(sizeof(float));
@@ -2271,6 +2301,19 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, sa.partial, sa.bpartial, gw,
                        gb, sp.nstreams, per, sp.CO, (int)Cout);
     return df::launched("df_conv_wgrad(small-N)");
+  }
+  if (const int64_t Wp = prec == 0 && df::aligned16(x) && df::aligned16(gy) ? wxyz_padded_w(req, D, H, W, Cin, Cout, kz) : 0) {
+    const int64_t inner = up256(df_conv_wgrad_workspace_bytes(B, D, H, Wp, Cin, Cout, kz));
+    float* xp = reinterpret_cast<float*>(static_cast<char*>(workspace) + inner);
+    float* gp = reinterpret_cast<float*>(reinterpret_cast<char*>(xp) + up256(B * D * H * Wp * Cin * 4));
+    hipStream_t s = df::as_stream(stream);
+    const int64_t rows = B * D * H;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ceil_div(rows * Wp * (Cin / 4), kThreads)), dim3(kThreads), 0, s,
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(xp), rows, (int)W, (int)Wp, (int)(Cin / 4));
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ceil_div(rows * Wp * (Cout / 4), kThreads)), dim3(kThreads), 0, s,
+                       reinterpret_cast<const f32x4*>(gy), reinterpret_cast<f32x4*>(gp), rows, (int)W, (int)Wp, (int)(Cout / 4));
+    if (int e = df::launched("df_conv_wgrad(pad rows)")) return e;
+    return conv_wgrad_impl(xp, gp, gw, gb, B, D, H, Wp, Cin, Cout, kz, workspace, inner, stream, prec, algo_arg);
   }
   const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
@@ -2483,6 +2526,7 @@ int df_conv_wgrad_form(int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, 
   if ((swap || small_n_ok(Cin, Cout)) && req != 1 && thin_mfma_ok(B, D, H, W, Cw, Ct, kz) && thin_mfma_inst(W, Cw, Ct, swap)) return 10;
   if (small_n_ok(Cin, Cout)) return 11;
   if (Cin % 2 || Cout % 2) return 0;
+  if (wxyz_padded_w(req, D, H, W, Cin, Cout, kz)) return 3;      // (x,y,z) on zero-padded rows
   return wgrad_algo(req, B * D * H, D, H, W, Cin, Cout, kz);
 }
 

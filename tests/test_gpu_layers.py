@@ -114,6 +114,25 @@ def test_conv_wgrad_winograd_xyz_64_channels(ops, shape, leak):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("shape,leak", [((1, 4, 4, 28), 0.2), ((2, 4, 6, 14), None), ((1, 6, 4, 28), None)])
+def test_conv_wgrad_winograd_xyz_on_zero_padded_rows(ops, shape, leak):
+    """Row lengths without an (x,y,z) instantiation (W = 28, 14: levels of cfg4's 112-wide grid) run the W = 32 / 16 kernel on copies with
+    zero columns appended (conv_wgrad.hip::wxyz_padded_w: the weight gradient of a SAME conv is unchanged by that) -- against the fp64
+    oracle, and against the direct kernel the shape took before."""
+    from deep_fluids_amd._lib import query
+    B, D, H, W = shape
+    assert query("df_conv_wgrad_form", B, D, H, W, 128, 128, 3, 0) == 3 and query("df_conv_wgrad_form", B, D, H, W, 128, 128, 3, 1) == 0
+    assert query("df_conv_wgrad_workspace_bytes", B, D, H, W, 128, 128, 3) > query("df_conv_wgrad_workspace_bytes", B, D, H, W + (4 if W == 28 else 2), 128, 128, 3)
+    errs = _conv_case(ops, shape, 128, 128, leak, seed=sum(shape) + 2, mask_from_gpu=True)
+    assert max(errs.values()) < TOL, errs
+    ops.WGRAD_ALGO = 1
+    try:
+        errs1 = _conv_case(ops, shape, 128, 128, leak, seed=sum(shape) + 2, mask_from_gpu=True)
+    finally:
+        ops.WGRAD_ALGO = 0
+    assert max(errs1.values()) < TOL, errs1
+
+
 WINO_CASES = [
     ((1, 4, 8, 8), 32, 32, 0.2),        # exactly one tile block
     ((2, 8, 16, 8), 64, 32, 0.2),       # Cin != Cout (forward and dgrad swap them)
