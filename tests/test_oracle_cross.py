@@ -77,3 +77,32 @@ def test_ae_forward_numpy_vs_torch_fp64(xshape, filters):
         o2, z2 = ort.ae_fwd(torch.from_numpy(x), ort.to_torch(p, torch.float64), filters, 8)
     np.testing.assert_allclose(z2.numpy(), z, atol=1e-12)
     np.testing.assert_allclose(o2.numpy(), out, atol=1e-12)
+
+
+def test_kl_bernoulli_closed_form_equals_definition_and_logit_form():
+    """The one loss term whose reference implementation lives in an absent dependency (tf.distributions.kl_divergence of two Bernoullis,
+    trainer3.py:272-277; TensorFlow 1.15 is not in this image): the oracle's closed form against (a) the definition
+    sum_k P(k) log(P(k) / Q(k)) over the two outcomes in extended precision and (b) the logits / softplus form TensorFlow's
+    `_kl_bernoulli_bernoulli` evaluates (sigmoid(a) (softplus(-b) - softplus(-a)) + sigmoid(-a) (softplus(b) - softplus(a)), restated);
+    and its analytic gradient against central differences.  Still a restatement -- DESIGN.md section 2 keeps the term 'parity unpinned'."""
+    import df_oracle as orc
+    rng = np.random.RandomState(5)
+    z = rng.uniform(0.02, 0.98, (6, 9))
+    n, rho = 7, 0.05
+    got = orc.kl_bernoulli(z, n, rho)
+    q = z[:, :n].mean(axis=0).astype(np.longdouble)
+    p = np.longdouble(rho)
+    definition = sum(float(pk * np.log(pk / qk)) for qj in q for pk, qk in ((p, qj), (1 - p, 1 - qj)))
+    assert abs(got - definition) <= 1e-13 * abs(definition)
+    softplus = lambda t: np.logaddexp(0.0, t)
+    la, lb = np.log(rho) - np.log1p(-rho), np.log(q.astype(np.float64)) - np.log1p(-q.astype(np.float64))
+    sig = lambda t: 1.0 / (1.0 + np.exp(-t))
+    logit_form = float((sig(la) * (softplus(-lb) - softplus(-la)) + sig(-la) * (softplus(lb) - softplus(la))).sum())
+    assert abs(got - logit_form) <= 1e-12 * abs(got)
+    g = orc.kl_bernoulli_bwd(z, n, rho, scale=0.7)
+    assert np.all(g[:, n:] == 0.0)
+    for (b, j) in ((0, 0), (3, 4), (5, 6)):
+        zp, zm = z.copy(), z.copy()
+        zp[b, j] += 1e-6; zm[b, j] -= 1e-6
+        fd = 0.7 * (orc.kl_bernoulli(zp, n, rho) - orc.kl_bernoulli(zm, n, rho)) / 2e-6
+        assert abs(g[b, j] - fd) <= 1e-6 * abs(fd)
