@@ -26,6 +26,9 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        # dmabuf IPC (this driver has no legacy IPC: RCCL's hipIpcGetMemHandle fails without it); effective only if the HIP runtime has not
+        # been initialised yet -- launchers (bench.py, the tests) also export it
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
