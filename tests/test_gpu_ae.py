@@ -163,7 +163,11 @@ def test_ae_vs_reference_model_py(tag):
                                                    # (64 -> 32, 128 -> 64, 192 -> 64), stride-2 dgrad as parity-class convs, W = 32 rows
                                                    (True, (16, 16, 16), 32), (True, (16, 16, 32), 64)])
 def test_ae_train_step_vs_oracle(is_3d, spatial, filters):
-    _ae_step_case(is_3d, spatial, filters, False)
+    # F = 64 at 16x16x32: one pre-activation within rounding of zero already moves an encoder gradient by 3e-3 (measured when the thin
+    # first / last layers moved to the matrix-core kernels: different summation order, same values to 1e-6) -- back-propagate the
+    # oracle on the GPU's linear pieces there (6e-5 then) as the full-size tests do
+    steer = filters >= 64
+    _ae_step_case(is_3d, spatial, filters, False, steer=steer, grad_tol=2e-4 if steer else 1e-3)
 
 
 @pytest.mark.parametrize("is_3d,spatial,filters", [(True, (8, 16, 8), 8), (False, (16, 16), 16)])
