@@ -32,7 +32,7 @@ def dur(d):
             out[(r["Kernel_Name"], int(r["Dispatch_Id"]))] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
     return out
 sq, tcc, du = read("$O/pmc_sq"), read("$O/pmc_tcc"), dur("$O/pmc_sq")
-fam = [("wino3d_kernel<0,9,0> forward 64x96x64 B=16", r"wino3d_kernel<0, 9, 0>"), ("wino3d_kernel<0,4,0> dgrad + lrelu mask", r"wino3d_kernel<0, 4, 0>"),
+fam = [("wino3d_kernel<0,9,0> forward 64x96x64 B=16", r"wino3d_kernel<0, 9, 0[,>]"), ("wino3d_kernel<0,4,0> dgrad + lrelu mask", r"wino3d_kernel<0, 4, 0[,>]"),
        ("wgrad_wxyz_fused_kernel<8,128>", r"wgrad_wxyz_fused_kernel<8, 128"), ("jacobian3d_fwd_vec_kernel<j,c>", r"jacobian3d_fwd_vec_kernel<true, true"),
        ("velocity_loss3d_tile_kernel (one-kernel tail forward)", r"velocity_loss3d_tile_kernel"), ("velocity_du3d_vec_kernel (tail backward)", r"velocity_du3d_vec_kernel")]
 print("| kernel | duration ms | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY | mfma busy cycles / SIMD | of kernel time @2.4 GHz | L2 hit rate |\n|---|---|---|---|---|---|---|---|")
