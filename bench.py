@@ -421,7 +421,7 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
             ops.reset_variables()
             tr = Trainer(cfg4)
             rf = {} if prec == "fp32" else None
-            el, m = timed_steps(tr, x4, y4, 1, 2, rf)
+            el, m = timed_steps(tr, x4, y4, 2, 3, rf)
             res[prec] = {"ms_per_step": el * 1e3, "value": B4 * 112 * 160 * 112 / el}
             if rf:
                 res[prec].update(rf)
@@ -443,7 +443,7 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
         x5 = ops.curl3(torch.rand((B5, R, R, R, 3), device="cuda", generator=g5) * 2 - 1)
         x5 = (x5 / x5.abs().max()).contiguous()
         rf = {}
-        el, m = timed_steps(tr, x5, y5, 1, 2, rf)
+        el, m = timed_steps(tr, x5, y5, 2, 3, rf)
         return {"grid": [R, R, R], "batch_per_gpu": B5, "filters": 64, "z_num": 16, "params": tr.n_params, "ms_per_step": el * 1e3,
                 "roofline": rf.get("roofline_wino3d"), "roofline_wgrad": rf.get("roofline_wgrad"), "roofline_conv": rf.get("roofline_conv"),
                 "value": B5 * R ** 3 / el, "unit": "voxels/s", "dtype": "f32",
