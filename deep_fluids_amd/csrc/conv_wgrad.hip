@@ -2318,7 +2318,10 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   const bool xvec = (Cin % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   const bool gvec = (Cout % 2 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 7u) == 0);
   // bf16x3 mode: rows without a bf16x3 variant (W = 56 | 28 | ... of cfg4) take the fp32 Winograd forms, not the 2.6x slower direct kernel
-  const bool use_bf16x3 = prec == 1 && xvec && gvec && wgrad_bf16x3_ok(W, Cin, Cout);
+  // ... and where the fp32 (x,y,z) Winograd form exists it is FASTER than the split-operand kernel (cfg3 top level 14.2 vs 15.2 ms, one level
+  // down 1.76 vs 2.03) and exact: the opt-in precision mode keeps it
+  const bool use_bf16x3 = prec == 1 && xvec && gvec && wgrad_bf16x3_ok(W, Cin, Cout) &&
+                          !((req == 0 || req == 4) && wxyz_ok(D, H, W, Cin, Cout, kz) && df::aligned16(x) && df::aligned16(gy));
   const int algo = (!use_bf16x3 && xvec && gvec) ? wgrad_algo(req, B * D * H, D, H, W, Cin, Cout, kz) : 0;
   const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, algo, req_ranges);
   // a caller-chosen number of partial ranges may need more room than df_conv_wgrad_workspace_bytes (sized for the defaults) promises
@@ -2591,7 +2594,8 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   DF_REQUIRE(df::aligned16(workspace), DF_EALIGN, "df_upconv_wgrad: workspace must be 16-byte aligned");
   DF_REQUIRE(workspace_bytes >= df_upconv_wgrad_workspace_bytes(B, Dc, Hc, Wc, Cin, Cout, kz), DF_EWORKSPACE,
              "df_upconv_wgrad: workspace too small");
-  if ((prec == 0 || !wgrad_bf16x3_ok(Wc, Cin, Cout)) && up_wxyz_ok(req, B, Dc, Hc, Wc, Cin, Cout, kz) && df::aligned16(xc) && df::aligned16(gy)) {
+  // (the 27-point fp32 form beats the bf16x3 parity-class kernel too -- 5.8 vs 7.0 ms at the cfg3 top level -- so both precision modes take it)
+  if (up_wxyz_ok(req, B, Dc, Hc, Wc, Cin, Cout, kz) && df::aligned16(xc) && df::aligned16(gy)) {
     const int64_t D = 2 * Dc, H = 2 * Hc, W = 2 * Wc;
     const Plan p = make_plan(B, D, H, W, Cin, Cout, kz, 3, up_wxyz_ranges(B, Dc, Hc, Cin, Cout));
     WxyzArgs aa;

@@ -232,7 +232,9 @@ def _count(op, form, dims, cin, cout):
 
 def _wgrad(x, dp, gw, gb, B, D, H, W, cin, cout, kz, sfx=""):
     if DISPATCH_COUNTS is not None:
-        form = "bf16x3" if sfx else _WGRAD_FORMS.get(query("df_conv_wgrad_form", B, D, H, W, cin, cout, kz, int(WGRAD_ALGO)), "?")
+        fid = query("df_conv_wgrad_form", B, D, H, W, cin, cout, kz, int(WGRAD_ALGO))
+        # (bf16x3 mode: the library keeps the fp32 (x,y,z) Winograd form where it exists -- it is faster than the split-operand kernel)
+        form = "bf16x3" if (sfx and fid != 3) else _WGRAD_FORMS.get(fid, "?")
         _count("wgrad", form, (B, D, H, W), cin, cout)
     nbytes = query("df_conv_wgrad_workspace_bytes", B, D, H, W, cin, cout, kz)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
