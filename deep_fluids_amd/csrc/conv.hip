@@ -331,7 +331,15 @@ int launch_n(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
+#ifdef DF_TUNING
+namespace dfconv { void set_bf16_dbg(int v); }
+#endif
+
 extern "C" {
+
+#ifdef DF_TUNING
+void df_debug_set_conv_bf16(int v) { dfconv::set_bf16_dbg(v); }      // timing-only variants of conv_bf16x3_kernel (conv_bf16.hip)
+#endif
 
 int64_t df_conv_packed_elems(int64_t taps, int64_t cin, int64_t cout, int mode) {
   const int64_t K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;

@@ -23,6 +23,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifdef DF_TUNING
+int g_bf16_dbg = 0;
+#endif
 constexpr int CKB = 32;           // input channels per LDS chunk
 constexpr int ROWB = 80;          // bytes per staged voxel and image: 32 ch * 2 B + 16 B pad (5 x 16-byte slots: odd)
 
@@ -105,7 +108,9 @@ __global__ __launch_bounds__(kThreads) void upconv_pack_bf16x3_kernel(const floa
 }
 
 // ---- main kernel (same tiling / arguments as conv_mfma_kernel, stride 1) -----------------------------------------------------
-template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, int KT>
+// DBG (tuning library, results wrong by construction): 1 = staging loads replaced by zeros (the LDS writes stay), 2 = no weight loads,
+// 4 = no LDS operand reads, 8 = no staging at all (one barrier pair per chunk stays)
+template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, int KT, int DBG = 0>
 __global__ __launch_bounds__(kThreads) void conv_bf16x3_kernel(const ConvArgs a_in) {
   static_assert(TZ * TY * TX == 128 && WM * MB * 32 == 128 && WM * WN == 4, "tile shape");
   constexpr int HZ = TZ + KZ - 1, HY = TY + KT - 1, HX = TX + KT - 1, HV = HZ * HY * HX;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16x3_kernel(const ConvArgs a_
       const int gz = tz0 + hz - a.pz, gy = ty0 + hy - a.py, gx = tx0 + hx - a.px;
       const int ch = chunk * CKB + q * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < NPIECE && gz >= 0 && gz < a.Di && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi && ch < a.Cin) {
+      if (!(DBG & 1) && p < NPIECE && gz >= 0 && gz < a.Di && gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi && ch < a.Cin) {
         const int64_t vox = ((static_cast<int64_t>(b) * a.xD + (gz * a.is + a.iz)) * a.xH + (gy * a.is + a.iy)) * a.xW +
                             (gx * a.is + a.ix);
         v = *reinterpret_cast<const float4*>(a.x + vox * a.Cin + ch);
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16x3_kernel(const ConvArgs a_
       }
     };
     __syncthreads();   // every wave has finished reading the previous chunk
+    if (!(DBG & 8))
     for (int it0 = 0; it0 < NLOAD; it0 += LBATCH) {
       float4 stg[LBATCH];
 #pragma unroll
@@ -216,15 +222,15 @@ __global__ __launch_bounds__(kThreads) void conv_bf16x3_kernel(const ConvArgs a_
       const int dz = tap / (KT * KT), dy = (tap / KT) % KT, dx = tap % KT;
       const int toff = ((dz * HY + dy) * HX + dx) * S16 + s * 2;
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) { dh[mb] = sHi8[aidx[mb] + toff]; dl[mb] = sLo8[aidx[mb] + toff]; }
+      for (int mb = 0; mb < MB; ++mb)
+        if (!(DBG & 4)) { dh[mb] = sHi8[aidx[mb] + toff]; dl[mb] = sLo8[aidx[mb] + toff]; }
     };
     auto glb_b = [&](int step, bf16x8 (&dh)[NB], bf16x8 (&dl)[NB]) {
       const int tap = step >> 1, s = step & 1;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const bf16x8* p = bchunk[nb] + tap * tapstride + s * rec;
-        dh[nb] = p[0];
-        dl[nb] = p[a.Npad];
+        if (!(DBG & 2)) { dh[nb] = p[0]; dl[nb] = p[a.Npad]; }
       }
     };
     glb_b(0, bh[0], bl[0]);
@@ -283,6 +289,17 @@ int launch_t(ConvArgs a, hipStream_t s) {
   const unsigned ncls = (unsigned)(a.nclass > 1 ? a.nclass : 1);
   if (a.Npad % 128 == 0) {
     dim3 grid((unsigned)nt, (unsigned)(a.Npad / 128), ncls);
+#ifdef DF_TUNING
+    if (g_bf16_dbg && KZ == 3 && TX == 16 && KT == 3) {
+      switch (g_bf16_dbg) {
+#define DF_CB(V) case V: hipLaunchKernelGGL((conv_bf16x3_kernel<KZ, TZ, TY, TX, 2, 2, 2, 2, KT, V>), grid, dim3(kThreads), 0, s, a); break
+        DF_CB(1); DF_CB(2); DF_CB(3); DF_CB(4); DF_CB(6); DF_CB(8); DF_CB(10); DF_CB(14);
+#undef DF_CB
+        default: return df::fail(DF_EINVAL, "df_conv_fwd(bf16x3): unknown debug variant");
+      }
+      return df::launched("df_conv_fwd(bf16x3)");
+    }
+#endif
     hipLaunchKernelGGL((conv_bf16x3_kernel<KZ, TZ, TY, TX, 2, 2, 2, 2, KT>), grid, dim3(kThreads), 0, s, a);
   } else if (a.Npad % 64 == 0) {
     dim3 grid((unsigned)nt, (unsigned)(a.Npad / 64), ncls);
@@ -310,6 +327,10 @@ int launch_bf16x3(const ConvArgs& a, int kz, int kt, hipStream_t s) {
   if (kz == 3) return a.W >= 12 ? launch_t<2, 2, 4, 16, 2>(a, s) : launch_t<2, 4, 4, 8, 2>(a, s);
   return a.W >= 12 ? launch_t<1, 1, 8, 16, 2>(a, s) : launch_t<1, 1, 16, 8, 2>(a, s);
 }
+
+#ifdef DF_TUNING
+void set_bf16_dbg(int v) { g_bf16_dbg = v; }
+#endif
 
 int upconv_pack_bf16x3(const float* w, void* wp, int kz, int cin, int cout, int Kpad, int Npad, int mode, hipStream_t s) {
   const int64_t total = static_cast<int64_t>(kz == 3 ? 64 : 16) * Kpad * Npad;

@@ -29,6 +29,9 @@ void df_debug_set_wgrad(int v);            /* wgrad_wxyz_kernel experiments (res
                                              the cached zero row (no memory latency), 2 = no (z, y) operand combinations, 4 = no x transform; values
                                              1, 2, 3, 6, 7 are instantiated (W = 64 rows) */
 
+/* conv_bf16x3_kernel (the direct split-operand conv) timing-only variants, results wrong by construction: 1 staging loads replaced by zeros,
+ * 2 no weight loads, 4 no LDS operand reads, 8 no staging at all (+ sums 3, 6, 10, 14); 0 = production */
+void df_debug_set_conv_bf16(int v);
 /* The "bf16x3 in the Winograd domain" experiment (wino3d_kernel PREC = 1): arguments as df_wino_pack_weights /
  * df_wino_conv_fwd.  The kernel variant follows the RAW value of df_debug_set_wino: 0 production, 32 xi_x-major MFMA order; timing-only
  * variants (results wrong by construction) 1 no transform, 2 no LDS operand reads, 4 no staging, 8 no weight loads (+ the sums 3, 7, 11, 12, 15),
