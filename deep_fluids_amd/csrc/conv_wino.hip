@@ -353,11 +353,12 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         so[it] = ok ? static_cast<unsigned>((((gz >> 1) * Hc + (gy >> 1)) * Wc + (gx >> 1)) * a.Cin + q4 * 4) * 4u : 0x80000000u;
       } else {
         so[it] = ok ? static_cast<unsigned>(bi.hoff + roff) * 4u : 0x80000000u;
+        if ((DBG & 384) == 384 && ok) so[it] &= 0xFFFC0u;      // (experiment 384: every staging load inside one 1 MB window -- L2 hits, L1 misses)
       }
     }
   };
   auto stage_load = [&](int it, __amdgpu_buffer_rsrc_t srd, unsigned chunkbytes) -> f32x4 {
-    if (DBG & 256) return buf_load16(wsrd_dbg, static_cast<unsigned>(lane) * 16u, 0u);      // always-cached address (latency experiment)
+    if ((DBG & 384) == 256) return buf_load16(wsrd_dbg, static_cast<unsigned>(lane) * 16u, 0u);      // always-cached address (latency experiment)
     constexpr int SAUX = (DBG >> 11) & 31;      // (experiment: cache policy of the staging loads)
     return buf_load16_aux<SAUX>(srd, so[it], chunkbytes);
   };
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         if (ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
                                          // the first wait that covers them is the one for the NEXT weight batch (1.5 k-steps away)
 #pragma unroll
-          for (int it = 0; it < NLOAD; ++it) stg[it] = (DBG & 128) ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
+          for (int it = 0; it < NLOAD; ++it) stg[it] = (DBG & 384) == 128 ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (DBG & 16) {
@@ -1096,6 +1097,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 16384: hipLaunchKernelGGL((wino3d_kernel<16384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 65536: hipLaunchKernelGGL((wino3d_kernel<65536, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 131072: hipLaunchKernelGGL((wino3d_kernel<131072, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 384: hipLaunchKernelGGL((wino3d_kernel<384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // staging loads confined to a 1 MB window (L2-resident, L1 misses)
     case 100: hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // production kernel, compile-time flags (baseline of the experiments)
     case (17 << 11): hipLaunchKernelGGL((wino3d_kernel<(17 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
 #endif
