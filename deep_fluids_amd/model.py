@@ -99,9 +99,15 @@ def _encoder(x, filters, z_num, name, num_conv, conv_k, repeat, act, reuse, is_3
         x0 = x
         layer_num += 1
         for idx in range(repeat_num):
-            for _ in range(num_conv):
-                x = conv(x, filters, k=conv_k, s=1, act=act, name=str(layer_num) + "_conv")
-                layer_num += 1
+            if ops_mod.FUSED_BLOCKS and act is lrelu and conv_k == 3 and num_conv > 1 and int(filters) >= 8 and int(filters) % 4 == 0:
+                # one autograd node per level's conv stack (same kernels; the reverse chain fuses the lrelu slopes into the dgrads)
+                names = [str(layer_num + i) + "_conv" for i in range(num_conv)]
+                x = ops_mod.conv_chain(x, filters, names, 3 if is_3d else 2)
+                layer_num += num_conv
+            else:
+                for _ in range(num_conv):
+                    x = conv(x, filters, k=conv_k, s=1, act=act, name=str(layer_num) + "_conv")
+                    layer_num += 1
             x = concat([x, x0], axis=-1)                                        # model.py:138 / :174 skip connection
             ch += filters
             if idx < repeat_num - 1:

@@ -446,6 +446,70 @@ class _GenBlock(torch.autograd.Function):
         return (dx0, None) + tuple(grads)
 
 
+class _ConvChain(torch.autograd.Function):
+    """n x [conv k3 s1 + bias + lrelu] in a row as ONE autograd node -- the per-level conv stack of the encoder (model.py:131-136 / 167-172;
+    the first conv may change the channel count).  Same forward kernels as the layer-by-layer path; the reverse chain applies the lrelu
+    slope of the layer below in each dgrad's epilogue (DF_CONV_MASK, sign bits where the 3-D Winograd forward emits them) exactly as
+    _GenBlock does, so only the LAST layer's element-wise lrelu-backward pass remains (its gradient arrives from the concat)."""
+
+    @staticmethod
+    def forward(ctx, x0, leak, *wb):
+        x0 = _prep(x0, "x")
+        n = len(wb) // 2
+        nd = x0.dim() - 2
+        kz = 3 if nd == 3 else 1
+        taps = 27 if nd == 3 else 9
+        dims = (x0.shape[0], x0.shape[1] if nd == 3 else 1, x0.shape[-3], x0.shape[-2])
+        xs = [x0]
+        bits = []
+        x = x0
+        for i in range(n):
+            w = _prep(wb[2 * i], "weights"); b = _prep(wb[2 * i + 1], "biases")
+            cin, cout = w.shape[-2], w.shape[-1]
+            if tuple(w.shape[:-2]) != (3,) * nd or x.shape[-1] != cin:
+                raise ValueError("conv_chain: weights %s do not match input %s" % (tuple(w.shape), tuple(x.shape)))
+            wp = _pack(w, taps, cin, cout, 0, dims)
+            sb = _new_bits(dims, cout, x0) if (SIGN_BIT_MASKS and i < n - 1 and _use_wino(cin, cout, dims, kz) == 3) else None
+            bits.append(sb)
+            x = _conv_raw(x, wp, b, None, None, dims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak, sign_bits=sb).view(
+                x0.shape[:-1] + (cout,))
+            xs.append(x)
+        if ACTIVATION_FETCH is not None:
+            ACTIVATION_FETCH.extend(xs[1:])
+        ctx.save_for_backward(*(xs + [wb[2 * i] for i in range(n)]))
+        ctx.geom = (n, dims, kz, taps, float(leak))
+        ctx.bits = bits
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, dims, kz, taps, leak = ctx.geom
+        saved = ctx.saved_tensors
+        xs, ws = saved[:n + 1], saved[n + 1:]
+        B, D, H, W = dims
+        dy = _prep(dy, "grad")
+        dp = torch.empty_like(dy)
+        call("df_lrelu_bwd", _ptr(dy), _ptr(xs[n]), _ptr(dp), leak, dy.numel(), _stream())
+        grads = [None] * (2 * n)
+        dx0 = None
+        for i in range(n, 0, -1):
+            w = ws[i - 1]
+            cin, cout = w.shape[-2], w.shape[-1]
+            gw = torch.empty_like(w)
+            gb = torch.empty(cout, dtype=torch.float32, device=dy.device)
+            _wgrad(xs[i - 1], dp, gw, gb, B, D, H, W, cin, cout, kz, _sfx(cin, cout))
+            grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
+            if i > 1 or ctx.needs_input_grad[0]:
+                wpd = _pack(w, taps, cin, cout, 1, dims)
+                if i > 1:      # dgrad, times the lrelu slope of the layer below: directly the next dp
+                    mb = ctx.bits[i - 2]
+                    dp = _conv_raw(dp, wpd, None, None, None if mb is not None else xs[i - 1], dims, cout, cin, kz, DF_CONV_MASK, leak,
+                                   mask_bits=mb).view(xs[i - 1].shape)
+                else:
+                    dx0 = _conv_raw(dp, wpd, None, None, None, dims, cout, cin, kz, 0, 0.0).view(xs[0].shape)
+        return (dx0, None) + tuple(grads)
+
+
 class _UpGenBlock(torch.autograd.Function):
     """``x0 = upscale(xc, 2)`` followed by one generator block (model.py:36-40 / 78-82) as a single autograd node that
     never materialises ``x0``: the block's first conv runs as parity-class 2x2(x2)-tap convs on the coarse input
@@ -1034,6 +1098,17 @@ def gen_block(x, filters, names, nd, leak=0.2):
         wb.append(get_variable(name + "/biases", (int(filters),), "zeros", x.device))
         cin = int(filters)
     return _GenBlock.apply(x, leak, *wb)
+
+
+def conv_chain(x, filters, names, nd, leak=0.2):
+    """``len(names)`` x conv(k=3,s=1,act=lrelu) (the encoder's per-level stack, model.py:131-136 / 167-172) as one autograd node."""
+    wb = []
+    cin = int(x.shape[-1])
+    for name in names:
+        wb.append(get_variable(name + "/weights", (3,) * nd + (cin, int(filters)), "xavier", x.device))
+        wb.append(get_variable(name + "/biases", (int(filters),), "zeros", x.device))
+        cin = int(filters)
+    return _ConvChain.apply(x, leak, *wb)
 
 
 def up_gen_block(xc, filters, names, nd, leak=0.2):
