@@ -202,7 +202,7 @@ def _sfx(cin, cout):
 
 # Algorithm of the wide 3-D stride-1 convs (forward and dgrad), fp32 mode only:
 #   "auto"     Winograd F(2x2x2,3x3x3) / F(2x2,3x3) (conv_wino.hip / conv_wino2d.hip: same fp32 arithmetic, 3.4x / 2.25x fewer
-#              matrix FLOPs) where it applies (Cin and Cout multiples of 32; 3-D extents >= 8, 2-D extents >= 16 x 24) and the direct
+#              matrix FLOPs) where it applies (Cin and Cout multiples of 32; 3-D extents >= 6, 2-D extents >= 16 x 24) and the direct
 #              implicit-GEMM kernel everywhere else;
 #   "direct"   always the direct kernel;   "winograd"  Winograd wherever the channel counts allow (tests).
 CONV_ALGO = "auto"
@@ -250,7 +250,9 @@ def _use_wino(cin, cout, dims, kz):
     if CONV_ALGO == "direct" or CONV_PRECISION != "fp32" or cin % 32 or cout % 32:
         return 0
     if kz == 3:
-        return 3 if (CONV_ALGO == "winograd" or min(dims[1], dims[2], dims[3]) >= 8) else 0
+        # (from 6 voxels per axis on: at 7x10x7 -- cfg4's lowest level -- the direct kernel has 24 workgroups of 184 us each, the Winograd
+        #  kernel 64 of a sixth of the work)
+        return 3 if (CONV_ALGO == "winograd" or min(dims[1], dims[2], dims[3]) >= 6) else 0
     return 2 if (CONV_ALGO == "winograd" or (dims[2] >= 16 and dims[3] >= 24)) else 0
 
 
