@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
   f32x4 acc[2][16];
   const int nchunk = a.Cin / CKW;
-  if ((DBG & 131072) && wave >= 4) __builtin_amdgcn_s_setprio(1);      // (experiment: static priority for the later-dispatched half)
+  if ((DBG & 196608) == 131072 && wave >= 4) __builtin_amdgcn_s_setprio(1);      // (experiment: static priority for the later-dispatched half)
 
   // ---- prologue: first block's chunk 0 -> buffer 0 ------------------------------------------------------------------------------
   BlockInfo cur = decode(seq(0));
@@ -624,22 +624,37 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         if (DBG & 16) asm volatile("s_waitcnt vmcnt(4)");
         const unsigned long long q3 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (DBG & 32) __builtin_amdgcn_s_setprio(3);
+        // [r3] a xi_y row's weight registers are reloaded right after its 4 MFMAs, not after the cout block's 16: every weight load is in
+        // flight up to 12 MFMAs longer before the next k-step needs it (16.52 -> 16.27 ms per top-level launch; tuning variant 196608 = the
+        // old order)
+        constexpr bool ROWRELOAD = (DBG & 196608) != 196608;
+        auto reload_row = [&](int nb, int q) {
+          if ((DBG & 8) || (P27 && q == 2)) return;
+          const int k4 = chunk * 4 + ks + 1;
+          const int kl = k4 < nk4 ? k4 : 0;
+          const unsigned sb = wbase_b + static_cast<unsigned>(kl) * 8192u + nb * 4096u;
+          bq[nb][q] = buf_load16(wsrd, laneb + q * 1024u, sb);
+        };
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < 16; ++i) {
           if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
             acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
+          if (ROWRELOAD && (i & 3) == 3) { __builtin_amdgcn_sched_barrier(0); reload_row(0, i >> 2); __builtin_amdgcn_sched_barrier(0); }
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(DBG & 8)) issue_b(0, chunk * 4 + ks + 1);       // weights of the next k-step, as each register block frees up
+        if (!(DBG & 8) && !ROWRELOAD) issue_b(0, chunk * 4 + ks + 1);       // weights of the next k-step, as each register block frees up
         __builtin_amdgcn_sched_barrier(0);
         if (!HALF) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
+          for (int i = 0; i < 16; ++i) {
             if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
               acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
+            if (ROWRELOAD && (i & 3) == 3) { __builtin_amdgcn_sched_barrier(0); reload_row(1, i >> 2); __builtin_amdgcn_sched_barrier(0); }
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         if (DBG & 32) __builtin_amdgcn_s_setprio(0);
-        if (!HALF && !(DBG & 8)) issue_b(1, chunk * 4 + ks + 1);
+        if (!HALF && !(DBG & 8) && !ROWRELOAD) issue_b(1, chunk * 4 + ks + 1);
         if (ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
                                          // the first wait that covers them is the one for the NEXT weight batch (1.5 k-steps away)
 #pragma unroll
@@ -843,7 +858,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
             char* yb = reinterpret_cast<char*>(a.y + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
                                                ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
             if (DBG & 512) asm volatile("" :: "v"(v));      // (experiment: no stores)
-            else if (DBG & 65536) __builtin_nontemporal_store(v, reinterpret_cast<float*>(yb + lane_off));      // (experiment: nt stores)
+            else if ((DBG & 196608) == 65536) __builtin_nontemporal_store(v, reinterpret_cast<float*>(yb + lane_off));      // (experiment: nt stores)
             else if (!NOY) *reinterpret_cast<float*>(yb + lane_off) = v;
             if (eflags & DF_CONV_ADDUP) {
               char* yb2 = reinterpret_cast<char*>(a.y2 + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
@@ -1097,6 +1112,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 16384: hipLaunchKernelGGL((wino3d_kernel<16384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 65536: hipLaunchKernelGGL((wino3d_kernel<65536, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 131072: hipLaunchKernelGGL((wino3d_kernel<131072, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 196608: hipLaunchKernelGGL((wino3d_kernel<196608, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // weights reloaded per cout block (the order before round 3)
     case 384: hipLaunchKernelGGL((wino3d_kernel<384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // staging loads confined to a 1 MB window (L2-resident, L1 misses)
     case 100: hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // production kernel, compile-time flags (baseline of the experiments)
     case (17 << 11): hipLaunchKernelGGL((wino3d_kernel<(17 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
