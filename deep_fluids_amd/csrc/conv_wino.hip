@@ -616,8 +616,10 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 #pragma unroll
           for (int it = 0; it < NLOAD; ++it) asm volatile("" :: "v"(stg[it]));
         }
-        if (ks == 3) __syncthreads();       // next chunk staged by everyone; everyone is done reading the planes it overwrote
-        else if (DBG & 16384) lds_barrier();     // (experiment: lock-step k-steps -- both waves of a SIMD transform, then both multiply)
+        // next chunk staged by everyone; everyone is done reading the planes it overwrote.  [r3] An LDS-only barrier: the staged data was
+        // already waited for at the LDS writes of ks == 2, and __syncthreads()' vmcnt(0) drained the weight loads in flight (this and the
+        // two epilogue barriers: 16.21 -> 16.05 ms per top-level launch; tuning variant 16384 = full barriers)
+        if (ks == 3) { if (DBG & 16384) __syncthreads(); else lds_barrier(); }
         if (!(DBG & 2)) raw_read(ks < 3 ? bo + (ks + 1) * 16 * CP : bn);     // raw inputs of the next k-step
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long q2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
@@ -791,6 +793,8 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       const unsigned lane_off = static_cast<unsigned>(((oz0 * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl) * 4u;      // bytes within the batch volume
       constexpr bool SB = FL >= 0 && (FL & kSignBits) != 0, MB = FL >= 0 && (FL & kMaskBits) != 0, NOY = FL >= 0 && (FL & kNoPrimary) != 0;
       if (full && (eflags & DF_CONV_MASK) && !MB) mask_dma();
+      // the fp32-mask DMA path counts on vmcnt(8) with nothing but its own loads outstanding: keep the draining barriers there
+      const bool full_bar = (DBG & 16384) != 0 || ((eflags & DF_CONV_MASK) && !MB);
       const int64_t wbase = (static_cast<int64_t>(cur.id) * a.ncs + cs) * kBitBytesPerBlock + wave * 128 + lane;
       float rres[2][8];
 #pragma unroll
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
             for (int s = 0; s < 8; ++s)
               rres[n2][s] = a.residual[obase + n2 * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW];
         }
-        __syncthreads();
+        if (full_bar) __syncthreads(); else lds_barrier();      // (the combine below reads LDS only; the residual loads are waited for at their use)
         const unsigned long long e2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         const f32x4 m0 = sO[((0 * 2 + th) * 4 + xz) * 64 + lane], m1 = sO[((1 * 2 + th) * 4 + xz) * 64 + lane];
         const f32x4 m3 = sO[((3 * 2 + th) * 4 + xz) * 64 + lane];
@@ -874,7 +878,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         }
         if (SB) a.bits_out[wbase + nb * 64] = static_cast<unsigned char>(sbyte);
         const unsigned long long e3 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
-        __syncthreads();
+        if (full_bar) __syncthreads(); else lds_barrier();      // (the output stores drain behind the next cout block's exchange / the next tile block)
         if (DBG & 16) {
           const unsigned long long e4 = __builtin_readcyclecounter();
           ph[4 + 0] += e1 - e0; ph[4 + 1] += e2 - e1; ph[4 + 2] += e3 - e2; ph[4 + 3] += e4 - e3;
