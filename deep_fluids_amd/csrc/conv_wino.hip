@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
   f32x4 acc[2][16];
   const int nchunk = a.Cin / CKW;
-  if ((DBG & 196608) == 131072 && wave >= 4) __builtin_amdgcn_s_setprio(1);      // (experiment: static priority for the later-dispatched half)
+  constexpr int STORE_KS = (DBG & 196608) == 131072 ? 3 : 2;      // (experiment 131072: the staged chunk is written to LDS one k-step later)      // (experiment: static priority for the later-dispatched half)
 
   // ---- prologue: first block's chunk 0 -> buffer 0 ------------------------------------------------------------------------------
   BlockInfo cur = decode(seq(0));
@@ -559,15 +559,20 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // nothing is prefetched across the epilogue (registers): first raw inputs / weights of this block
+    // first raw inputs of this block (and, for the worker's first block, the weights of k-step 0)
     if constexpr (BX) {
       raw_read_b(pb * BBUF, 0);
       issue_bw(0, 0, 0);
       if (!half) issue_bw(1, 0, 0);
     } else {
       raw_read(pb * BUF * 4);
-      issue_b(0, 0);
-      if (!half) issue_b(1, 0);
+      // [r3] the weights of k-step 0 are the same for every tile block of the worker and the last k-step of a block has already reloaded
+      // them (issue_b / reload_row wrap around): they stay in their registers across the epilogue (16.13 -> 16.05 ms per top-level
+      // launch; tuning variant 65536 = reloaded at every block start)
+      if (it == 0 || (DBG & 196608) == 65536) {
+        issue_b(0, 0);
+        if (!half) issue_b(1, 0);
+      }
     }
 
     const unsigned long long tp1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         const unsigned long long q1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (!(DBG & 1)) transform();
         __builtin_amdgcn_sched_barrier(0);
-        if (ks == 2 && !(DBG & 4) && !(DBG & 64)) {
+        if (ks == STORE_KS && !(DBG & 4) && !(DBG & 64)) {
 #pragma unroll
           for (int it = 0; it < NLOAD; ++it) stage_store(it, bn, stg[it]);
         }
@@ -775,11 +780,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         };
         if (!half) emit(acc[nb]);
         else if (nb == hnb) emit(acc[0]);
-        __syncthreads();
+        if (DBG & 16384) __syncthreads(); else lds_barrier();
         const float m0 = sP[((0 * 2 + th) * 4 + xz) * 64 + lane], m1 = sP[((1 * 2 + th) * 4 + xz) * 64 + lane];
         const float m3 = sP[((3 * 2 + th) * 4 + xz) * 64 + lane];
         if (inb) yo[nb * 16] = prev + (m0 + 2.f * m1 - m3);
-        __syncthreads();
+        if (DBG & 16384) __syncthreads(); else lds_barrier();
       }
     } else {
       const int lb = ((nchunk - 1 + pb) & 1) * BUFF;
@@ -862,7 +867,6 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
             char* yb = reinterpret_cast<char*>(a.y + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
                                                ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
             if (DBG & 512) asm volatile("" :: "v"(v));      // (experiment: no stores)
-            else if ((DBG & 196608) == 65536) __builtin_nontemporal_store(v, reinterpret_cast<float*>(yb + lane_off));      // (experiment: nt stores)
             else if (!NOY) *reinterpret_cast<float*>(yb + lane_off) = v;
             if (eflags & DF_CONV_ADDUP) {
               char* yb2 = reinterpret_cast<char*>(a.y2 + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
