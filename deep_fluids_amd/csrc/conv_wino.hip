@@ -529,7 +529,8 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
   f32x4 acc[2][16];
   const int nchunk = a.Cin / CKW;
-  constexpr int STORE_KS = (DBG & 196608) == 131072 ? 3 : 2;      // (experiment 131072: the staged chunk is written to LDS one k-step later)      // (experiment: static priority for the later-dispatched half)
+  constexpr bool SPLITSTG = (DBG & 196608) == 131072;      // (experiment 131072: staging in two batches -- 3 pieces loaded behind k-step 0 and
+                                                            //  written in k-step 2, 2 pieces loaded behind k-step 1 and written in k-step 3)      // (experiment: static priority for the later-dispatched half)
 
   // ---- prologue: first block's chunk 0 -> buffer 0 ------------------------------------------------------------------------------
   BlockInfo cur = decode(seq(0));
@@ -613,9 +614,13 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         const unsigned long long q1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (!(DBG & 1)) transform();
         __builtin_amdgcn_sched_barrier(0);
-        if (ks == STORE_KS && !(DBG & 4) && !(DBG & 64)) {
+        if (ks == 2 && !(DBG & 4) && !(DBG & 64)) {
 #pragma unroll
-          for (int it = 0; it < NLOAD; ++it) stage_store(it, bn, stg[it]);
+          for (int it = 0; it < (SPLITSTG ? 3 : NLOAD); ++it) stage_store(it, bn, stg[it]);
+        }
+        if (SPLITSTG && ks == 3) {
+#pragma unroll
+          for (int it = 3; it < NLOAD; ++it) stage_store(it, bn, stg[it]);
         }
         if (ks == 2 && (DBG & 64)) {       // keep the loads alive without the LDS writes
 #pragma unroll
@@ -665,7 +670,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         if (ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
                                          // the first wait that covers them is the one for the NEXT weight batch (1.5 k-steps away)
 #pragma unroll
-          for (int it = 0; it < NLOAD; ++it) stg[it] = (DBG & 384) == 128 ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
+          for (int it = 0; it < (SPLITSTG ? 3 : NLOAD); ++it) stg[it] = (DBG & 384) == 128 ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
+        }
+        if (SPLITSTG && ks == 1) {
+#pragma unroll
+          for (int it = 3; it < NLOAD; ++it) stg[it] = stage_load(it, ssrd, schunk);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (DBG & 16) {
