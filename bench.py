@@ -47,6 +47,13 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra measurements appended at N=1 (bf16x3 mode, 2-D, cfg4, AE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--init-timeout", type=float, default=120.0,
+                    help="N > 1: seconds the rendezvous / the RCCL communicator creation + first all-reduce may take before the watchdog "
+                         "prints a diagnostic JSON line (rccl_ranks 0) and exits non-zero")
+    ap.add_argument("--no-other-leg", action="store_true", help="N > 1: skip the short leg in the other scaling mode")
+    ap.add_argument("--other-steps", type=int, default=5)
+    ap.add_argument("--sidecar", default=None, help="where the full record goes (default gpurun_out/bench_full_n<N>.json)")
+    ap.add_argument("--full-line", action="store_true", help="print the full record instead of the compact line")
     return ap.parse_args()
 
 
@@ -62,12 +69,16 @@ def self_launch(a):
 
 
 def make_inputs(batch, res, seed, ops):
-    """y ~ U(-1,1) [B,3]; x = curl3(psi_gt) rescaled to max|x| = 1 (divergence-free, in [-1,1])."""
+    """np.random.RandomState(seed) (123 + rank), never a framework RNG: y ~ U(-1,1) [B,3]; x = curl3(psi_gt) with
+    psi_gt ~ U(-1,1), rescaled to max|x| = 1 (divergence-free, in [-1,1] like the reference's normalised data, data.py:87-88,329)."""
+    import numpy as np
     import torch
-    g = torch.Generator(device="cuda").manual_seed(seed)
-    y = torch.rand((batch, 3), device="cuda", generator=g) * 2 - 1
-    psi = torch.rand((batch, res[0], res[1], res[2], 3), device="cuda", generator=g) * 2 - 1
-    x = ops.curl3(psi)
+    rng = np.random.RandomState(seed)
+    y = torch.from_numpy(rng.uniform(-1, 1, (batch, 3)).astype(np.float32)).cuda()
+    psi = torch.empty([batch] + list(res) + [3], dtype=torch.float32, device="cuda")
+    for b in range(batch):
+        psi[b].copy_(torch.from_numpy(rng.uniform(-1, 1, list(res) + [3]).astype(np.float32)))
+    x = ops.curl3(psi) if len(res) == 3 else ops.curl(psi[..., :1].contiguous())
     x = x / x.abs().max()
     return x.contiguous(), y.contiguous()
 
@@ -116,10 +127,11 @@ def wgrad_exec_ratio(B, D, H, W, cin, cout):
     return {3: 8.0 / 27.0, 2: 4.0 / 9.0, 1: 2.0 / 3.0}.get(form, 1.0), form
 
 
-def cpu_baseline(res, filters, budget_s):
+def cpu_baseline(res, filters, budget_s, fullsize_parity=None):
     """The oracle's PyTorch-CPU restatement of the SAME train step, timed on this node's host cores at the FULL grid of the
     workload, batch 1 (a bounded sample: one warm-up step + as many timed steps as fit the budget, at least one).  A reported
-    baseline, not the optimisation target."""
+    baseline, not the optimisation target.  ``fullsize_parity`` (a dict): the warm-up step's velocity field and loss -- the oracle's
+    own, at the benchmarked grid -- are compared with one GPU train step on the same weights / inputs and the figures stored in it."""
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -134,13 +146,20 @@ def cpu_baseline(res, filters, budget_s):
     sres = list(res)
     rng = np.random.RandomState(123)
     oshape = sres + [3]
-    p = ort.to_torch(orc.generator_init(rng, 3, oshape, filters))
+    p0 = orc.generator_init(rng, 3, oshape, filters)
+    p = ort.to_torch(p0)
     opt = ort.new_opt(p)
     x, y = orc.synthetic_batch(rng, 1, sres)
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
     t0 = time.time()
-    ort.train_step(yt, xt, p, opt, oshape, filters, True)           # warm-up (thread pools, oneDNN primitives, page faults)
+    first = ort.train_step(yt, xt, p, opt, oshape, filters, True)   # warm-up (thread pools, oneDNN primitives, page faults)
     warm = time.time() - t0
+    if fullsize_parity is not None:
+        try:
+            fullsize_parity.update(gpu_vs_oracle_fullsize(sres, filters, p0, x, y, first["u"].numpy(), first["loss"]))
+        except Exception as e:
+            fullsize_parity.update(error=repr(e)[:300])
+    del first
     n, t0, el = 0, time.time(), 0.0
     while True:
         ort.train_step(yt, xt, p, opt, oshape, filters, True)
@@ -184,8 +203,9 @@ def cpu_stencil_tail(res, cores, batch=2):
     out = {"batch": batch, "algorithmic_bytes_per_voxel": 240}
     so = os.path.join(ROOT, "oracle", "libdf_oracle.so")
     if os.path.exists(so):
-        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
         h = ctypes.CDLL(so)
+        h.dfo_set_threads(int(cores))           # through the OpenMP runtime itself: OMP_NUM_THREADS is read once, at ITS initialisation
+        threads = int(h.dfo_max_threads())
         I64 = ctypes.c_int64
         u = np.empty_like(psi); ju = np.empty((batch, Z, Y, X, 9), np.float32); jx = np.empty_like(ju)
         l1 = ctypes.c_double(); jl1 = ctypes.c_double()
@@ -196,13 +216,37 @@ def cpu_stencil_tail(res, cores, batch=2):
         while n < 3 or (time.time() - t0 < 1.0 and n < 50):
             h.dfo_velocity_tail3d(*args); n += 1
         el = (time.time() - t0) / n
-        out["c_openmp"] = {"ms": el * 1e3, "voxels_per_s": nv / el, "GBs": 240.0 * nv / el / 1e9, "threads": cores, "l1": l1.value}
+        out["c_openmp"] = {"ms": el * 1e3, "voxels_per_s": nv / el, "GBs": 240.0 * nv / el / 1e9, "threads": threads, "l1": l1.value}
     t0 = time.time()
     jx_ = orc.jacobian3(x)[0]; u_ = orc.jacobian3(psi)[1]; ju_ = orc.jacobian3(u_)[0]
     l1n = orc.l1_mean(u_, x); orc.l1_mean(ju_, jx_)
     el = time.time() - t0
     out["numpy"] = {"ms": el * 1e3, "voxels_per_s": nv / el, "GBs": 240.0 * nv / el / 1e9, "threads": 1, "l1": float(l1n)}
     return out
+
+
+def gpu_vs_oracle_fullsize(res, filters, p0, x, y, u_ref, loss_ref):
+    """One default-dispatch GPU train step at the BENCHMARKED grid (batch 1) on the weights / inputs the CPU baseline's first step
+    used: relative L1 of the velocity field (north-star tolerance 1e-4) and relative loss difference vs the PyTorch-CPU oracle."""
+    import numpy as np
+    import torch
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import Trainer, default_config
+    ops.reset_variables()
+    cfg = default_config(is_3d=True, res_x=res[2], res_y=res[1], res_z=res[0], filters=filters, batch_size=1, num_samples=6600)
+    tr = Trainer(cfg)
+    tr.load_variables(p0)
+    m = tr.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    u = m.G_.detach().cpu().numpy().astype(np.float64)
+    loss = float(m.g_loss.detach())
+    del m, tr
+    ops.reset_variables()
+    torch.cuda.empty_cache()
+    ref = np.asarray(u_ref, np.float64)
+    return {"velocity_rel_l1": float(np.abs(u - ref).sum() / np.abs(ref).sum()), "loss_rel": abs(loss - loss_ref) / abs(loss_ref),
+            "loss_gpu": loss, "loss_oracle": float(loss_ref), "tolerance": 1e-4,
+            "case": "one train step at the benchmarked grid %dx%dx%d, filters %d, batch 1, same weights / inputs on the GPU (default "
+                    "dispatch) and the PyTorch-CPU fp32 oracle" % (res[0], res[1], res[2], filters)}
 
 
 def l1_vs_oracle(filters, precision="fp32", is_3d=True):
@@ -213,7 +257,6 @@ def l1_vs_oracle(filters, precision="fp32", is_3d=True):
     import df_oracle as orc
     from deep_fluids_amd import ops
     from deep_fluids_amd.trainer import Trainer, default_config
-    ops.CONV_PRECISION = precision
     ops.reset_variables()
     rng = np.random.RandomState(123)
     spatial = (16, 24, 16) if is_3d else (32, 24)
@@ -222,13 +265,13 @@ def l1_vs_oracle(filters, precision="fp32", is_3d=True):
     x, y = orc.synthetic_batch(rng, 1, spatial)
     cfg = default_config(is_3d=is_3d, res_x=spatial[-1], res_y=spatial[-2], res_z=spatial[0] if is_3d else 1, filters=filters,
                          batch_size=1, num_samples=100)
-    tr = Trainer(cfg)
-    tr.load_variables(p)
-    u = tr.generate(torch.from_numpy(y).cuda()).cpu().numpy().astype(np.float64)
+    with ops.options(conv_precision=precision):
+        tr = Trainer(cfg)
+        tr.load_variables(p)
+        u = tr.generate(torch.from_numpy(y).cuda()).cpu().numpy().astype(np.float64)
     psi = orc.generator_fwd(y.astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()}, oshape, filters)
     ref = orc.curl3(psi) if is_3d else orc.curl(psi)
     ops.reset_variables()
-    ops.CONV_PRECISION = "fp32"
     return float(np.abs(u - ref).sum() / np.abs(ref).sum())
 
 
@@ -335,24 +378,28 @@ def stencil_rooflines(B, Z, Y, X):
     return out
 
 
-def timed_steps(tr, x, y, warm, n, rooflines=None):
+def timed_steps(tr, x, y, warm, n, rooflines=None, families=("wino3d_kernel", "wgrad_kernel", "conv_mfma_kernel")):
     """Mean wall time per step; ``rooflines`` (a dict) additionally receives the live HIP-event rooflines of the dominant conv /
     weight-gradient kernel families of these steps."""
     import torch
     from deep_fluids_amd import _lib
     for _ in range(warm):
         tr.train_step(x, y)
-    timer = _lib.KernelTimer(select_kernel) if rooflines is not None else None
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    _lib.TIMER = timer
     for _ in range(n):
         m = tr.train_step(x, y)
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / n
-    _lib.TIMER = None
-    if timer is not None:
+    if rooflines is not None:                 # a separate, untimed pass: the per-launch event records stay out of ms_per_step
+        timer = _lib.KernelTimer(select_kernel)
+        _lib.TIMER = timer
+        try:
+            for _ in range(2):
+                m = tr.train_step(x, y)
+        finally:
+            _lib.TIMER = None
         ks = timer.summary()
-        for fam in ("wino3d_kernel", "wgrad_kernel", "conv_mfma_kernel"):
+        for fam in families:
             r = roofline_of(ks, fam, {}, False)
             if r is not None:
                 rooflines["roofline_" + fam.split("_")[0]] = r
@@ -361,7 +408,7 @@ def timed_steps(tr, x, y, warm, n, rooflines=None):
 
 def extras(out, a, cfg, x, y, vox_per_step, pmc):
     """Appended at N = 1, clearly separate from `value`: the other BASELINE shapes / the opt-in bf16x3 mode.  An extra must never
-    take the metric line down with it."""
+    take the metric line down with it.  Precision modes are entered through ``ops.options`` (restored whatever happens)."""
     import torch
     from deep_fluids_amd import _lib, ops
     from deep_fluids_amd.trainer import Trainer, AETrainer, default_config
@@ -371,49 +418,36 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
             out[key] = fn()
         except Exception as e:
             out[key] = {"error": repr(e)[:300]}
-        ops.CONV_PRECISION = "fp32"
         _lib.TIMER = None
         ops.reset_variables()
         torch.cuda.empty_cache()
 
     def alt_bf16x3():
         rel_alt = l1_vs_oracle(a.filters, "bf16x3")
-        ops.CONV_PRECISION = "bf16x3"
-        ops.reset_variables()
-        el, _ = timed_steps(Trainer(cfg), x, y, 2, 3)
+        with ops.options(conv_precision="bf16x3"):
+            ops.reset_variables()
+            el, _ = timed_steps(Trainer(cfg), x, y, 2, 3)
         return {"ms_per_step": el * 1e3, "value": vox_per_step / el, "unit": "voxels/s", "l1_vs_ref": rel_alt,
                 "note": "opt-in precision mode, not the BASELINE cfg3 dtype: conv operands split into bf16 hi/lo words, 3 bf16 MFMAs per "
                         "product, fp32 accumulation"}
 
     def two_d():
         res = {}
-        g2 = torch.Generator(device="cuda").manual_seed(1)
-        y2 = torch.rand((64, 3), device="cuda", generator=g2) * 2 - 1
-        x2 = ops.curl(torch.rand((64, 128, 96, 1), device="cuda", generator=g2) * 2 - 1)
-        x2 = (x2 / x2.abs().max()).contiguous()
+        x2, y2 = make_inputs(64, [128, 96], 1, ops)
         cfg2 = default_config(is_3d=False, res_x=96, res_y=128, filters=a.filters, batch_size=64, num_samples=21000)
         for prec in ("fp32", "bf16x3"):
             rel = l1_vs_oracle(a.filters, prec, is_3d=False)
-            ops.CONV_PRECISION = prec
-            ops.reset_variables()
-            tr = Trainer(cfg2)
-            for _ in range(3):
-                tr.train_step(x2, y2)
-            timer = _lib.KernelTimer(select_kernel)
-            torch.cuda.synchronize()
-            _lib.TIMER = timer
-            t2 = time.perf_counter()
-            for _ in range(10):
-                tr.train_step(x2, y2)
-            torch.cuda.synchronize(); el = (time.perf_counter() - t2) / 10
-            _lib.TIMER = None
+            with ops.options(conv_precision=prec):
+                ops.reset_variables()
+                tr = Trainer(cfg2)
+                rf = {} if prec == "fp32" else None
+                el, _ = timed_steps(tr, x2, y2, 3, 10, rf, families=("wino2d_kernel", "wgrad_kernel", "jacobian2d_fwd_kernel"))
             r = {"ms_per_step": el * 1e3, "value": 64 * 128 * 96 / el, "unit": "pixels/s", "batch": 64, "l1_vs_ref": rel,
                  "conv_tflops_reference_equivalent": 3.71e12 / el / 1e12}
-            if prec == "fp32":
-                ks = timer.summary()
-                r["roofline"] = roofline_of(ks, "wino2d_kernel", {}, False)
-                r["roofline_wgrad"] = roofline_of(ks, "wgrad_kernel", {}, False)
-                r["roofline_stencil"] = roofline_of(ks, "jacobian2d_fwd_kernel", {}, False)
+            if rf:
+                r["roofline"] = rf.get("roofline_wino2d")
+                r["roofline_wgrad"] = rf.get("roofline_wgrad")
+                r["roofline_stencil"] = rf.get("roofline_jacobian2d")
             res[prec] = r
             del tr
         f = res["fp32"]
@@ -430,11 +464,11 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
         x4, y4 = make_inputs(B4, [112, 160, 112], 7, ops)
         res = {}
         for prec in ("fp32", "bf16x3"):
-            ops.CONV_PRECISION = prec
-            ops.reset_variables()
-            tr = Trainer(cfg4)
-            rf = {} if prec == "fp32" else None
-            el, m = timed_steps(tr, x4, y4, 2, 3, rf)
+            with ops.options(conv_precision=prec):
+                ops.reset_variables()
+                tr = Trainer(cfg4)
+                rf = {} if prec == "fp32" else None
+                el, m = timed_steps(tr, x4, y4, 2, 3, rf)
             res[prec] = {"ms_per_step": el * 1e3, "value": B4 * 112 * 160 * 112 / el}
             if rf:
                 res[prec].update(rf)
@@ -448,24 +482,128 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
                         "parity: tests/test_gpu_fullsize.py::test_cfg4_*"}
 
     def ae_cfg5():
+        import numpy as np
         B5, R = 4, 128
         cfg5 = default_config(is_3d=True, res_x=R, res_y=R, res_z=R, filters=64, batch_size=B5, num_samples=5000, z_num=16, p_num=2)
         tr = AETrainer(cfg5)
-        g5 = torch.Generator(device="cuda").manual_seed(1)
-        y5 = torch.rand((B5, 2, 10), device="cuda", generator=g5) * 2 - 1
-        x5 = ops.curl3(torch.rand((B5, R, R, R, 3), device="cuda", generator=g5) * 2 - 1)
-        x5 = (x5 / x5.abs().max()).contiguous()
+        x5, _ = make_inputs(B5, [R, R, R], 1, ops)
+        y5 = torch.from_numpy(np.random.RandomState(2).uniform(-1, 1, (B5, 2, 10)).astype(np.float32)).cuda()
         rf = {}
         el, m = timed_steps(tr, x5, y5, 2, 3, rf)
         return {"grid": [R, R, R], "batch_per_gpu": B5, "filters": 64, "z_num": 16, "params": tr.n_params, "ms_per_step": el * 1e3,
                 "roofline": rf.get("roofline_wino3d"), "roofline_wgrad": rf.get("roofline_wgrad"), "roofline_conv": rf.get("roofline_conv"),
                 "value": B5 * R ** 3 / el, "unit": "voxels/s", "dtype": "f32",
-                "note": "BASELINE cfg5's shape (AE3 encoder + decoder train step, 128^3, F = 64), fp32"}
+                "note": "BASELINE cfg5's shape (AE3 encoder + decoder train step, 128^3, F = 64), fp32; parity at this shape: "
+                        "tests/test_gpu_fullsize.py::test_cfg5_*"}
 
     guarded("alt_bf16x3_mode", alt_bf16x3)
     guarded("extra_2d_128x96", two_d)
     guarded("extra_cfg4_slice", cfg4_slice)
     guarded("extra_ae_cfg5", ae_cfg5)
+
+
+class Watchdog(object):
+    """A hung RCCL bring-up must not hang the lease: if `stage` is not disarmed within `seconds`, rank 0's line is a diagnostic JSON
+    object (`rccl_ranks: 0`, the stage that hung) and every rank exits non-zero (os._exit: the main thread may sit inside a collective)."""
+
+    def __init__(self, rank, world):
+        import threading
+        self.rank, self.world = rank, world
+        self._lock = threading.Lock()
+        self._deadline, self._stage = None, None
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def arm(self, stage, seconds):
+        with self._lock:
+            self._stage, self._deadline = stage, time.time() + seconds
+
+    def disarm(self):
+        with self._lock:
+            self._stage, self._deadline = None, None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self._lock:
+                stage, dl = self._stage, self._deadline
+            if dl is not None and time.time() > dl:
+                msg = {"metric": "velocity-field voxels/sec (3D train step), whole job", "value": None, "unit": "voxels/s",
+                       "n_gpus": self.world, "rccl_ranks": 0, "error": "watchdog: stage %r did not complete in time" % stage,
+                       "rank": self.rank, "env": {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "LOCAL_RANK",
+                                                                               "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")}}
+                stream = sys.stdout if self.rank == 0 else sys.stderr
+                print(json.dumps(msg), file=stream, flush=True)
+                os._exit(3)
+
+
+def run_leg(tr, sync, x, y, warmup, steps, world, dist, torch, timer=None):
+    """warmup + `steps` timed train steps bracketed by barrier + device sync on both sides; MAX over ranks; all-reduce timing of the
+    timed steps only.  Returns (elapsed seconds, per-step HIP-event times in ms, last step's graph, all-reduce timing)."""
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        tr.train_step(x, y)
+    if sync is not None:
+        sync.timing(reset=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    from deep_fluids_amd import _lib
+    sync_all()
+    _lib.TIMER = timer            # live HIP-event rooflines of exactly the timed steps (the contract's `roofline.achieved`)
+    t0 = time.perf_counter()
+    last = None
+    try:
+        ev[0].record()
+        for i in range(steps):
+            last = tr.train_step(x, y)
+            ev[i + 1].record()
+        sync_all()
+    finally:
+        _lib.TIMER = None
+    elapsed = time.perf_counter() - t0
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        if dist.get_backend() == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    comm = sync.timing() if sync is not None else None
+    return elapsed, step_ms, last, comm
+
+
+def compact(out):
+    """The printed line: headline objects first, bulky diagnostics (per-kernel table, dispatch log, standalone stencil table, the
+    extras' nested rooflines, long notes) only in the sidecar file."""
+    def slim(r, keep=("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_copy_rate", "traffic", "avg_launch_ms", "avg_launch_us",
+                      "launches", "algorithmic_tflops", "algorithmic_speedup", "wgrad_form", "algorithmic_bytes_per_voxel")):
+        return None if not isinstance(r, dict) else ({k: r[k] for k in keep if k in r} if "error" not in r else r)
+    head = ["metric", "value", "unit", "per_gpu", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config"]
+    line = {k: out[k] for k in head}
+    for k in ("roofline", "roofline_stencil", "roofline_wgrad", "roofline_tail_fwd", "roofline_tail_bwd"):
+        line[k] = slim(out.get(k))
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = None if not isinstance(cb, dict) else {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "ms_per_step", "cpu", "error") if k in cb}
+    line["l1_vs_ref"] = out.get("l1_vs_ref")
+    line["l1_vs_ref_fullsize"] = out.get("l1_vs_ref_fullsize")
+    for k in ("step_ms", "value_median", "rccl_ranks", "counted_ranks", "dist_backend", "distinct_devices", "allreduce", "other_scaling_leg", "loss"):
+        line[k] = out.get(k)
+    for k in ("alt_bf16x3_mode", "extra_2d_128x96", "extra_cfg4_slice", "extra_ae_cfg5"):
+        e = out.get(k)
+        if isinstance(e, dict) and "error" not in e:
+            c = {q: e[q] for q in ("ms_per_step", "value", "unit", "l1_vs_ref", "batch", "batch_per_gpu", "grid") if q in e}
+            if isinstance(e.get("bf16x3_mode"), dict):
+                c["bf16x3_ms_per_step"] = e["bf16x3_mode"].get("ms_per_step")
+            for q in ("roofline", "roofline_wgrad"):
+                if isinstance(e.get(q), dict):
+                    c[q + "_frac"] = e[q].get("frac")
+            e = c
+        line[k] = e
+    line["sidecar"] = out.get("sidecar")
+    return line
 
 
 def main():
@@ -476,13 +614,24 @@ def main():
     import torch
     import torch.distributed as dist
     from deep_fluids_amd import _lib, ops
-    from deep_fluids_amd.dist import init_from_env
+    from deep_fluids_amd.dist import init_from_env, verify_world
     from deep_fluids_amd.trainer import Trainer, default_config
 
+    env_rank, env_world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dog = Watchdog(env_rank, env_world) if env_world > 1 else None
+    if dog:
+        dog.arm("torch.distributed rendezvous (init_process_group)", a.init_timeout)
     rank, local_rank, world = init_from_env()
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    # what the job REALLY runs on, asked before anything is timed: ranks counted by an on-device all-reduce of ones over the production
+    # backend (for RCCL this is also the communicator creation), physical devices gathered
+    if dog:
+        dog.arm("RCCL communicator creation + first all-reduce (verify_world)", a.init_timeout)
+    wv = verify_world()
+    if dog:
+        dog.disarm()
 
     if a.scaling == "strong":
         if a.batch % world:
@@ -491,60 +640,51 @@ def main():
     else:
         per_gpu, global_batch = a.batch, a.batch * world
 
-    rel_l1 = l1_vs_oracle(a.filters, a.precision) if rank == 0 else None
-    ops.CONV_PRECISION = a.precision
-
     Z, Y, X = a.res
-    cfg = default_config(is_3d=True, res_x=X, res_y=Y, res_z=Z, filters=a.filters, batch_size=global_batch,
-                         num_samples=6600, random_seed=123)     # smoke3_obs_buo: 11*4*150 samples
-    tr = Trainer(cfg)                                           # same seed on every rank -> identical init
-    sync = tr.enable_data_parallel(profile=True) if world > 1 else None
-    x, y = make_inputs(per_gpu, a.res, 123 + rank, ops)
+    with ops.options(conv_precision=a.precision):
+        rel_l1 = l1_vs_oracle(a.filters, a.precision) if rank == 0 else None
+        cfg = default_config(is_3d=True, res_x=X, res_y=Y, res_z=Z, filters=a.filters, batch_size=global_batch,
+                             num_samples=6600, random_seed=123)     # smoke3_obs_buo: 11*4*150 samples
+        tr = Trainer(cfg)                                           # same seed on every rank -> identical init
+        sync = tr.enable_data_parallel(profile=True) if world > 1 else None
+        x, y = make_inputs(a.batch if world > 1 else per_gpu, a.res, 123 + rank, ops)     # N > 1: enough samples for either leg
+        xm, ym = x[:per_gpu].contiguous(), y[:per_gpu].contiguous()
 
-    def sync_all():
-        if world > 1:
-            dist.barrier()
+        if dog:
+            dog.arm("warm-up steps (first gradient all-reduces)", a.init_timeout + 60.0 * a.warmup)
+        for _ in range(min(a.warmup, 1)):
+            tr.train_step(xm, ym)
         torch.cuda.synchronize()
+        if dog:
+            dog.disarm()
+        timer = _lib.KernelTimer(select_kernel)
+        elapsed, step_ms, last, comm = run_leg(tr, sync, xm, ym, max(a.warmup - 1, 0), a.steps, world, dist, torch, timer)
+        ks = timer.summary()
+        pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * (len(step_ms) - 1) + 0.5))]
+        step_stats = {"median_ms": pct(0.5), "p10_ms": pct(0.1), "p90_ms": pct(0.9), "min_ms": step_ms[0], "max_ms": step_ms[-1],
+                      "source": "HIP events on the launch stream, one per step"}
+        loss = float(last.g_loss.detach())
+        assert loss == loss, "Model diverged with loss = NaN"        # trainer.py:275
 
-    for _ in range(a.warmup):
-        tr.train_step(x, y)
-    if sync is not None:
-        sync.timing(reset=True)
-    timer = _lib.KernelTimer(select_kernel)
-    # per-step HIP events on the stream the kernels are launched on (torch's current stream): ev[i] .. ev[i+1] brackets step i
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-    sync_all()
-    _lib.TIMER = timer
-    t0 = time.perf_counter()
-    last = None
-    ev[0].record()
-    for i in range(a.steps):
-        last = tr.train_step(x, y)
-        ev[i + 1].record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    _lib.TIMER = None
-    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
-    pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * (len(step_ms) - 1) + 0.5))]
-    step_stats = {"median_ms": pct(0.5), "p10_ms": pct(0.1), "p90_ms": pct(0.9), "min_ms": step_ms[0], "max_ms": step_ms[-1],
-                  "source": "HIP events on the launch stream, one per step"}
-    # what the job REALLY ran on: ranks counted by an all-reduce of ones over the production backend, physical devices gathered
-    from deep_fluids_amd.dist import verify_world
-    wv = verify_world()
-    # which algorithm every conv / weight-gradient call of a step takes (one extra, untimed step)
-    ops.DISPATCH_COUNTS = {}
-    tr.train_step(x, y)
-    dispatch, ops.DISPATCH_COUNTS = ops.DISPATCH_COUNTS, None
-    torch.cuda.synchronize()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        if dist.get_backend() == "gloo":
-            t = t.cpu()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss = float(last.g_loss.detach())
-    assert loss == loss, "Model diverged with loss = NaN"        # trainer.py:275
-    comm = sync.timing() if sync is not None else None
+        # N > 1: the OTHER scaling mode as a short second leg of the same job, so that one driver invocation yields both curves
+        other = None
+        if world > 1 and not a.no_other_leg:
+            o_mode = "strong" if a.scaling == "weak" else "weak"
+            o_per = (a.batch // world) if o_mode == "strong" else a.batch
+            if o_per >= 1 and (o_mode == "weak" or a.batch % world == 0):
+                xo, yo = x[:o_per].contiguous(), y[:o_per].contiguous()
+                o_el, o_ms, o_last, o_comm = run_leg(tr, sync, xo, yo, 2, a.other_steps, world, dist, torch)
+                o_glob = o_per * world
+                other = {"scaling": o_mode, "global_batch": o_glob, "batch_per_gpu": o_per, "steps": a.other_steps, "warmup": 2,
+                         "ms_per_step": o_el / a.other_steps * 1e3, "value": o_glob * Z * Y * X * a.other_steps / o_el, "unit": "voxels/s",
+                         "allreduce": o_comm, "loss": float(o_last.g_loss.detach())}
+                del o_last, xo, yo
+
+        # which algorithm every conv / weight-gradient call of a step takes (one extra, untimed step)
+        dispatch = {}
+        with ops.options(dispatch_counts=dispatch):
+            tr.train_step(xm, ym)
+        torch.cuda.synchronize()
 
     if rank != 0:
         if world > 1:
@@ -553,7 +693,6 @@ def main():
         return
     vox_per_step = global_batch * Z * Y * X
     value = vox_per_step * a.steps / elapsed
-    ks = timer.summary()
 
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
@@ -572,24 +711,26 @@ def main():
                                "step (fwd+curl3+jacobian3+L1 losses+bwd+Adam)" % (Z, Y, X, a.filters, per_gpu),
                    "global_batch": global_batch, "batch_per_gpu": per_gpu, "grid": [Z, Y, X], "params": tr.n_params,
                    "parallelism": "dp%d" % world},
+        "roofline": None,            # filled below: the kernel family with the largest share of the step
+        "roofline_stencil": None,    # the standalone jacobian3 kernel (the >= 70 % target); the step itself runs the fused tail
+        "cpu_baseline": None,
+        "l1_vs_ref": {"value": rel_l1, "tolerance": 1e-4,
+                      "case": "relative L1 of the velocity field vs the fp64 oracle, grid 16x24x16, filters %d" % a.filters},
+        "l1_vs_ref_fullsize": None,
         "step_ms": step_stats,
         "value_median": vox_per_step / (step_stats["median_ms"] * 1e-3) if world == 1 else None,
         "rccl_ranks": wv["ranks"] if wv["backend"] == "nccl" else 0,      # counted by an on-device all-reduce over RCCL; 0 = not an RCCL job
         "counted_ranks": wv["ranks"], "dist_backend": wv["backend"], "devices": wv["devices"], "distinct_devices": wv["distinct_devices"],
-        "dispatch": dispatch,
         "allreduce": comm,           # per step: bytes, buckets, comm_span_ms, exposed_ms (after backward), hidden_ms (under backward)
+        "other_scaling_leg": other,
         "loss": loss,
-        "l1_vs_ref": {"value": rel_l1, "tolerance": 1e-4,
-                      "case": "relative L1 of the velocity field vs the fp64 oracle, grid 16x24x16, filters %d" % a.filters},
-        "roofline": None,            # filled below: the kernel family with the largest share of the step
         "roofline_wgrad": roofline_of(ks, "wgrad_kernel", pmc, default_shape),
         "roofline_conv": roofline_of(ks, "conv_mfma_kernel", pmc, default_shape),
         "roofline_wino": roofline_of(ks, "wino3d_kernel", pmc, default_shape),
-        # in-step stencil work = the fused tail (velocity_loss.hip); the standalone kernels are timed below (stencils_standalone)
-        "roofline_stencil": None,
         "roofline_tail_fwd": roofline_of(ks, "velocity_loss3d_fwd_kernel", {}, False),
         "roofline_tail_bwd": roofline_of(ks, "velocity_loss3d_bwd_kernel", {}, False),
         "stencils_standalone": None,
+        "dispatch": dispatch,
         "kernels": {k: {"launches": v["launches"], "ms_total": v["seconds"] * 1e3} for k, v in sorted(ks.items())},
     }
     fam = {}
@@ -608,18 +749,33 @@ def main():
                                            traffic_source="profiles/pmc_latest.json" if default_shape else None,
                                            note="standalone launches over rotating buffers (cold HBM); the train step itself runs the fused "
                                                 "tail (roofline_tail_fwd / _bwd)")
+            copy_gbs = out["stencils_standalone"]["copy_rate"]["achieved"]
+            for k in ("roofline_tail_fwd", "roofline_tail_bwd"):       # the in-step fused tail beside the copy rate of the same run
+                if out[k]:
+                    out[k]["frac_of_copy_rate"] = out[k]["achieved"] / copy_gbs
+                    out[k]["avg_launch_us"] = out[k]["avg_launch_ms"] * 1e3
         except Exception as e:
             out["stencils_standalone"] = {"error": repr(e)[:300]}
     if world == 1 and not a.no_alt and a.precision == "fp32":
         del tr, last
-        extras(out, a, cfg, x, y, vox_per_step, pmc)
-    out["cpu_baseline"] = None
+        extras(out, a, cfg, xm, ym, vox_per_step, pmc)
     try:
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.res, a.filters, a.cpu_seconds)
+            par = {} if (a.precision == "fp32" and len(a.res) == 3) else None
+            out["cpu_baseline"] = cpu_baseline(a.res, a.filters, a.cpu_seconds, par)
+            out["l1_vs_ref_fullsize"] = par
     except Exception as e:      # an extra must never take the metric line down with it
         out["cpu_baseline"] = {"error": repr(e)[:300]}
-    print(json.dumps(out))
+    # the full record goes to a sidecar file, the printed line stays short (headline objects first)
+    try:
+        side = a.sidecar or os.path.join(ROOT, "gpurun_out", "bench_full_n%d.json" % world)
+        os.makedirs(os.path.dirname(side), exist_ok=True)
+        out["sidecar"] = os.path.relpath(side, ROOT)
+        with open(side, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:
+        out["sidecar"] = "not written: %r" % (e,)
+    print(json.dumps(out if a.full_line else compact(out)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

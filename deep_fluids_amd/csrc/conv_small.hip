@@ -388,7 +388,8 @@ inline bool thin_k_mfma_ok(const ConvArgs& a, int kz) {
   return kz == 3 && a.Cin <= 4 && (a.Cout == 128 || a.Cout == 64) && a.W % 8 == 0 && a.W >= 32 && a.W * a.Cin <= 448 && (a.W * a.Cin) % 16 == 0 &&
          static_cast<int64_t>(a.B) * a.D * a.H >= 4 && a.nclass == 1 && df::aligned16(a.x) && df::aligned16(a.y) &&
          (!(a.flags & DF_CONV_BIAS) || df::aligned16(a.bias)) && (!(a.flags & DF_CONV_RESIDUAL) || df::aligned16(a.residual)) &&
-         (!(a.flags & DF_CONV_MASK) || df::aligned16(a.mask_src));
+         (!(a.flags & DF_CONV_MASK) || df::aligned16(a.mask_src)) &&
+         static_cast<int64_t>(4) * 19 * (a.W * a.Cin + 8) * 4 <= df::lds_optin_bytes();      // else: the vector-ALU kernel
 }
 
 int launch_thin_k_mfma(const ConvArgs& a, hipStream_t s) {

@@ -2228,6 +2228,7 @@ static int launch_thin_wgrad(const float* wide, const float* thin, float* gw, fl
   const uint64_t xb = static_cast<uint64_t>(B * D * H * W) * static_cast<uint64_t>(Cw) * 4u;
   ta.x_bytes_lo = static_cast<unsigned>(xb & 0xffffffffu); ta.x_bytes_hi = static_cast<unsigned>(xb >> 32);
   if (!(static_cast<int64_t>(ta.rows_per) * W * Cw * 4 < (1LL << 32) && ns >= 4)) return kThinNotApplicable;
+  if (static_cast<int64_t>(4) * 19 * ta.RS * 4 > df::lds_optin_bytes()) return kThinNotApplicable;      // LDS opt-in not available: generic path
   hipStream_t s = df::as_stream(stream);
   const size_t lds = static_cast<size_t>(4) * 19 * ta.RS * sizeof(float);
   const dim3 grid((unsigned)(ns / 4));
@@ -2302,7 +2303,9 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
                        gb, sp.nstreams, per, sp.CO, (int)Cout);
     return df::launched("df_conv_wgrad(small-N)");
   }
-  if (const int64_t Wp = prec == 0 && df::aligned16(x) && df::aligned16(gy) ? wxyz_padded_w(req, D, H, W, Cin, Cout, kz) : 0) {
+  // (both precision modes: where the (x,y,z) form exists the bf16x3 mode keeps it -- see use_bf16x3 below -- so rows that reach an
+  //  instantiated length by zero padding take it too instead of the direct kernel; df_conv_wgrad_form reports 3 for them in both modes)
+  if (const int64_t Wp = df::aligned16(x) && df::aligned16(gy) ? wxyz_padded_w(req, D, H, W, Cin, Cout, kz) : 0) {
     const int64_t inner = up256(df_conv_wgrad_workspace_bytes(B, D, H, Wp, Cin, Cout, kz));
     float* xp = reinterpret_cast<float*>(static_cast<char*>(workspace) + inner);
     float* gp = reinterpret_cast<float*>(reinterpret_cast<char*>(xp) + up256(B * D * H * Wp * Cin * 4));

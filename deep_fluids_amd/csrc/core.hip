@@ -16,6 +16,21 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+int64_t lds_optin_bytes() {
+  static const int64_t bytes = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess || v <= 0) {
+      (void)hipGetLastError();
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) {
+        (void)hipGetLastError();
+        v = 64 * 1024;
+      }
+    }
+    return static_cast<int64_t>(v);
+  }();
+  return bytes;
+}
+
 }  // namespace df
 
 extern "C" {

@@ -24,6 +24,10 @@ inline int launched(const char* what) {
   return DF_OK;
 }
 
+// LDS a single workgroup may opt in to on the current device (hipDeviceAttributeSharedMemPerBlockOptin; 160 KiB on an unpartitioned
+// MI355X), queried once per process.  Kernels that size themselves for it fall back to their smaller-footprint path when it is less.
+int64_t lds_optin_bytes();
+
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kCUs = 256;          // MI355X
 

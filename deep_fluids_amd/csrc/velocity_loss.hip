@@ -887,30 +887,38 @@ int df_velocity_loss3d_fwd(const float* psi, const float* x, float* u, float* l1
   const int64_t ntl = (Z / tzv) * (Y / tyv) * B;
   const int64_t rf4 = 3 * (X / 4), prow = (tzv + 2) * (tyv + 2), urow = (tzv + 1) * (tyv + 1);
   const size_t tile_lds = static_cast<size_t>((ceil_div(prow * rf4, kThreads) + ceil_div(urow * rf4, kThreads)) * kThreads + urow * rf4) * sizeof(f32x4);
-  int64_t tile_grid = (g_tail_variant == 3 || tile_lds == 0 ? 1 : static_cast<int64_t>(160 * 1024 / tile_lds)) * df::kCUs;      // workgroups resident at once
+  const int64_t lds_cap = df::lds_optin_bytes();          // 160 KiB per CU on an unpartitioned MI355X
+  int64_t tile_grid = (g_tail_variant == 3 || tile_lds == 0 ? 1 : static_cast<int64_t>(lds_cap / static_cast<int64_t>(tile_lds))) * df::kCUs;      // workgroups resident at once
   if (tile_grid > 8 * df::kCUs) tile_grid = 8 * df::kCUs;
   if (tile_grid > ntl) tile_grid = ntl;
   if (u && tile_mode && (X == 64 || X == 112 || X == 128) && Z % tzv == 0 && Y % tyv == 0 && df::aligned16(psi) && df::aligned16(x) &&
-      df::aligned16(u) && ntl < (1LL << 30) && tile_grid <= nb && tile_grid > 0 && g.nvox * 12 < (1LL << 32)) {
+      df::aligned16(u) && ntl < (1LL << 30) && tile_grid <= nb && tile_grid > 0 && g.nvox * 12 < (1LL << 32) &&
+      static_cast<int64_t>(tile_lds) <= lds_cap) {
     // one persistent LDS-tiled kernel: psi, x -> u, l1, j_l1 (36 B/voxel of HBM traffic, nothing read back); grid = the workgroups that
     // are resident at once
     TileGeo tg{(int)B, (int)Z, (int)Y, (int)(Z / tzv), (int)(Y / tyv), (int)ntl, (unsigned)(g.nvox * 12)};
+    bool tile_ok = true;      // a refused LDS opt-in (partitioned device) falls through to the two-launch path below instead of failing
 #define DF_TILE(XQV, TYV, NTV)                                                                                                             \
   do {                                                                                                                                     \
-    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&velocity_loss3d_tile_kernel<XQV, kTileZ, TYV, NTV>),             \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds))                                     \
-      return df::fail((int)e, "df_velocity_loss3d_fwd: dynamic LDS opt-in: %s", hipGetErrorString(e));                                     \
-    hipLaunchKernelGGL((velocity_loss3d_tile_kernel<XQV, kTileZ, TYV, NTV>), dim3((unsigned)tile_grid), dim3(kThreads), tile_lds, s, psi,  \
-                       x, u, part, tg);                                                                                                    \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&velocity_loss3d_tile_kernel<XQV, kTileZ, TYV, NTV>),                            \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds) != hipSuccess) {                                    \
+      (void)hipGetLastError();                                                                                                             \
+      tile_ok = false;                                                                                                                     \
+    } else {                                                                                                                               \
+      hipLaunchKernelGGL((velocity_loss3d_tile_kernel<XQV, kTileZ, TYV, NTV>), dim3((unsigned)tile_grid), dim3(kThreads), tile_lds, s,     \
+                         psi, x, u, part, tg);                                                                                             \
+    }                                                                                                                                      \
   } while (0)
 #ifdef DF_TUNING
     if (g_tail_variant == 4 && X == 64) DF_TILE(16, 4, false); else if (g_tail_variant == 5 && X == 64) DF_TILE(16, kTileY, true); else
 #endif
     if (X == 64) DF_TILE(16, kTileY, false); else if (X == 112) DF_TILE(28, kTileY, false); else DF_TILE(32, kTileY, false);
 #undef DF_TILE
-    hipLaunchKernelGGL(velocity_loss_final_kernel, dim3(1), dim3(kThreads), 0, s, part, (int)tile_grid, 1.0 / (3.0 * static_cast<double>(g.nvox)),
-                       1.0 / (9.0 * static_cast<double>(g.nvox)), l1, jl1);
-    return df::launched("df_velocity_loss3d_fwd");
+    if (tile_ok) {
+      hipLaunchKernelGGL(velocity_loss_final_kernel, dim3(1), dim3(kThreads), 0, s, part, (int)tile_grid, 1.0 / (3.0 * static_cast<double>(g.nvox)),
+                         1.0 / (9.0 * static_cast<double>(g.nvox)), l1, jl1);
+      return df::launched("df_velocity_loss3d_fwd");
+    }
   }
   if (u && X % 4 == 0 && df::aligned16(psi) && df::aligned16(x) && df::aligned16(u)) {
     // fast path: u = curl3(psi) with the 16-byte-load stencil kernel, then one reduction pass over (u, x)

@@ -41,17 +41,19 @@ def init_from_env(backend=None):
 
 
 def device_identity(index=None):
-    """A string that is the same for two ranks iff they drive the same physical GPU: PCI domain:bus:device (+ the UUID where the
-    runtime reports one)."""
+    """A string that is the same for two ranks iff they drive the same physical GPU: host name + PCI domain:bus:device (+ the UUID
+    where the runtime reports one).  The host name keeps two nodes of a multi-node job apart on runtimes without UUIDs (identical PCI
+    ids on every node)."""
     if not torch.cuda.is_available():
         return "cpu"
     index = torch.cuda.current_device() if index is None else index
     pr = torch.cuda.get_device_properties(index)
-    parts = ["%s:%s:%s" % (getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", "?"))]
+    parts = ["%s/%s:%s:%s" % (os.uname().nodename, getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"),
+                              getattr(pr, "pci_device_id", "?"))]
     uuid = getattr(pr, "uuid", None)
     if uuid is not None:
         parts.append(str(uuid))
-    if parts[0] == "?:?:?" and uuid is None:      # nothing physical to go by: fall back to (host, visible index)
+    if parts[0].endswith("/?:?:?") and uuid is None:      # nothing physical to go by: fall back to (host, visible index)
         parts = ["%s/%s/%d" % (os.uname().nodename, os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "")), index)]
     return "|".join(parts)
 

@@ -12,8 +12,10 @@ name-keyed registry: ``variable_scope(name, reuse)`` + ``get_variables(scope)``;
 follow slim: ``<scope>/<layer>/weights`` ``[k,(k,)k,Cin,Cout]`` / ``[in,out]`` and ``.../biases``.
 """
 import contextlib
+import contextlib as _contextlib
 import math
 import os as _os
+import threading as _threading
 
 import numpy as np
 import torch
@@ -1089,6 +1091,39 @@ FUSED_BLOCKS = True     # GeneratorBE(3) uses one fused autograd node per block 
 # fused generator block and every layer-by-layer conv with an lrelu appends its post-lrelu conv outputs (execution order) to it.  Used by the full-size parity tests to hand the
 # oracle the lrelu sign pattern the GPU actually took.  None (default) = no fetch, no cost.
 ACTIVATION_FETCH = None
+
+
+# The switches above are process-wide module attributes (like the reference's single global `config`).  `options` is the one supported way
+# to change them temporarily: it sets them, restores the previous values on exit -- also when the body raises, so a failing test cannot
+# leak its mode into the next one -- and holds a re-entrant lock for the duration of the block, so two threads cannot interleave
+# different option sets (a second thread entering `options` waits until the first leaves).
+_OPTION_ATTRS = {"conv_precision": "CONV_PRECISION", "conv_algo": "CONV_ALGO", "wgrad_algo": "WGRAD_ALGO",
+                 "thin_valu_only": "THIN_VALU_ONLY", "sign_bit_masks": "SIGN_BIT_MASKS", "fused_blocks": "FUSED_BLOCKS",
+                 "dispatch_counts": "DISPATCH_COUNTS", "activation_fetch": "ACTIVATION_FETCH", "sign_bits_fetch": "SIGN_BITS_FETCH"}
+_OPTION_CHOICES = {"conv_precision": ("fp32", "bf16x3"), "conv_algo": ("auto", "direct", "winograd"), "wgrad_algo": (0, 1, 2, 3, 4)}
+_OPTION_LOCK = _threading.RLock()
+
+
+@_contextlib.contextmanager
+def options(**kw):
+    """``with ops.options(conv_precision="bf16x3", conv_algo="direct", wgrad_algo=1, activation_fetch=[]): ...``
+    Keys: conv_precision, conv_algo, wgrad_algo, thin_valu_only, sign_bit_masks, fused_blocks, dispatch_counts (a dict to count into),
+    activation_fetch / sign_bits_fetch (a list to append to).  Unknown keys and out-of-range values raise before anything changes."""
+    for k, v in kw.items():
+        if k not in _OPTION_ATTRS:
+            raise TypeError("ops.options: unknown option %r (known: %s)" % (k, ", ".join(sorted(_OPTION_ATTRS))))
+        if k in _OPTION_CHOICES and v not in _OPTION_CHOICES[k]:
+            raise ValueError("ops.options: %s=%r not in %r" % (k, v, _OPTION_CHOICES[k]))
+    g = globals()
+    with _OPTION_LOCK:
+        old = {k: g[_OPTION_ATTRS[k]] for k in kw}
+        try:
+            for k, v in kw.items():
+                g[_OPTION_ATTRS[k]] = v
+            yield
+        finally:
+            for k, v in old.items():
+                g[_OPTION_ATTRS[k]] = v
 
 
 def gen_block(x, filters, names, nd, leak=0.2):

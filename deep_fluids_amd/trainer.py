@@ -16,6 +16,7 @@ each live in one flat slab (one fused optimizer launch, bucketed all-reduce for 
 import json
 import math
 import os
+import re
 import time
 from types import SimpleNamespace
 
@@ -36,13 +37,29 @@ def default_config(**over):
              optimizer="adam", beta1=0.5, beta2=0.999, lr_update="decay", lr_update_step=120000,
              start_step=0, random_seed=123, num_samples=21000, c_num=3, use_curl3_alias=True,
              z_num=16, use_sparse=False, sparsity=0.01, w4=1.0, w5=1.0, p_num=2, x_channels=None, w3=0.005,
-             log_step=500, test_step=1000, test_batch_size=100, model_dir=None,            # config.py:62-68
+             log_step=500, test_step=1000, test_batch_size=100, model_dir=None, load_path="", save_sec=3600,   # config.py:62-68
              fused_tail=True)
     c.update(over)
     return SimpleNamespace(**c)
 
 
+_CKPT_RE = re.compile(r"^model\.ckpt-(\d+)\.npz$")
+
+
+def latest_checkpoint(model_dir):
+    """``tf.train.latest_checkpoint``: the ``model.ckpt-<global step>.npz`` with the largest step in ``model_dir`` (None if there is none)."""
+    best = None
+    if model_dir and os.path.isdir(model_dir):
+        for f in os.listdir(model_dir):
+            m = _CKPT_RE.match(f)
+            if m and (best is None or int(m.group(1)) > best[0]):
+                best = (int(m.group(1)), os.path.join(model_dir, f))
+    return None if best is None else best[1]
+
+
 class Trainer(object):
+    _restore_in_base = True          # subclasses that add variables after Trainer.__init__ (GANTrainer's D slab) restore at THEIR end
+
     def __init__(self, config, device="cuda", name="G"):
         self.config = config
         self.device = torch.device(device)
@@ -68,6 +85,9 @@ class Trainer(object):
         ops.set_random_seed(config.random_seed)
         self._build_variables()
         self.grad_sync = None
+        self.save_sec = getattr(config, "save_sec", 3600)      # config.py:68 -> Supervisor(save_model_secs=...), trainer.py:110-117
+        if self._restore_in_base:
+            self._auto_restore()
 
     # ---- variables: created by one shape-only pass through the generator, then moved into flat slabs ----
     def _create_variables(self):
@@ -119,25 +139,51 @@ class Trainer(object):
         return 0 if layer == 0 else 1 + (layer - 1) // self.num_conv
 
     # ---- checkpoint / resume (SURVEY 8(f)-3; reference: tf.train.Saver + Supervisor, trainer.py:107-123,291-292) ----
+    def _ckpt_slabs(self):
+        """[(name -> (offset, numel), params, adam m, adam v)] of every variable slab a checkpoint holds."""
+        return [(self.var_slices, self.flat_p, self.flat_m, self.flat_v)]
+
     def save(self, path):
         """Own format (.npz): variables under their slim names (G/0_fc/weights ...), Adam slots as
-        '<name>/Adam' and '<name>/Adam_1' (TF's slot names), 'step', 'g_lr', 'beta_power_t'."""
+        '<name>/Adam' and '<name>/Adam_1' (TF's slot names), 'step', 'g_lr', 'beta_power_t'.  Written to a temporary file and
+        renamed, so an interrupted save never leaves a truncated ``model.ckpt-*.npz`` for the next start to restore."""
         out = {}
-        for k, (o, n) in self.var_slices.items():
-            shp = ops._VARS[k].shape
-            out[k] = self.flat_p[o:o + n].view(shp).cpu().numpy()
-            out[k + "/Adam"] = self.flat_m[o:o + n].view(shp).cpu().numpy()
-            out[k + "/Adam_1"] = self.flat_v[o:o + n].view(shp).cpu().numpy()
+        for slices, fp, fm, fv in self._ckpt_slabs():
+            for k, (o, n) in slices.items():
+                shp = ops._VARS[k].shape
+                out[k] = fp[o:o + n].view(shp).cpu().numpy()
+                out[k + "/Adam"] = fm[o:o + n].view(shp).cpu().numpy()
+                out[k + "/Adam_1"] = fv[o:o + n].view(shp).cpu().numpy()
         out["step"] = np.int64(self.step); out["g_lr"] = np.float64(self.g_lr); out["beta_power_t"] = np.int64(self._adam_t)
-        np.savez(path, **out)
+        out.update(self._ckpt_extra())
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, **out)
+        os.replace(tmp, path if path.endswith(".npz") else path + ".npz")
+
+    def _ckpt_extra(self):
+        return {}
+
+    def _ckpt_load_extra(self, d):
+        pass
 
     def load(self, path):
         with np.load(path) as d:
-            for k, (o, n) in self.var_slices.items():
-                self.flat_p[o:o + n].copy_(torch.from_numpy(d[k].reshape(-1)))
-                self.flat_m[o:o + n].copy_(torch.from_numpy(d[k + "/Adam"].reshape(-1)))
-                self.flat_v[o:o + n].copy_(torch.from_numpy(d[k + "/Adam_1"].reshape(-1)))
+            for slices, fp, fm, fv in self._ckpt_slabs():
+                for k, (o, n) in slices.items():
+                    fp[o:o + n].copy_(torch.from_numpy(d[k].reshape(-1)))
+                    fm[o:o + n].copy_(torch.from_numpy(d[k + "/Adam"].reshape(-1)))
+                    fv[o:o + n].copy_(torch.from_numpy(d[k + "/Adam_1"].reshape(-1)))
             self.step = int(d["step"]); self.g_lr = float(d["g_lr"]); self._adam_t = int(d["beta_power_t"])
+            self._ckpt_load_extra(d)
+
+    def _auto_restore(self):
+        """``sv.prepare_or_wait_for_session`` (trainer.py:107-123): a trainer started on a ``model_dir`` (= ``--load_path`` when given,
+        util.py:37-38) that already holds checkpoints continues from the latest one -- variables, Adam slots, global step, g_lr."""
+        d = getattr(self.config, "load_path", "") or getattr(self.config, "model_dir", None)
+        self.restored_from = latest_checkpoint(d)
+        if self.restored_from is not None:
+            self.load(self.restored_from)
+            print("[*] restored %s (step %d)" % (self.restored_from, self.step))
 
     def enable_data_parallel(self, group=None, profile=False, force=False):
         """Bucket the flat gradient slab per generator block (fc | 4 convs | ... | last conv)."""
@@ -244,7 +290,9 @@ class Trainer(object):
         return out
 
     def train(self, batch_manager, max_step=None, model_dir=None, log_step=None, test_step=None, on_log=None):
-        """``Trainer.train_``: steps ``start_step .. max_step-1`` on batches dequeued from ``batch_manager``.  Every ``log_step``
+        """``Trainer.train_``: steps ``start_step .. max_step-1`` (from the restored global step when the trainer was started on a
+        ``model_dir`` with checkpoints) on batches dequeued from ``batch_manager``; a checkpoint ``model.ckpt-<global step>.npz`` every
+        ``config.save_sec`` seconds of wall time (config.py:68; the Supervisor's timed saver).  Every ``log_step``
         steps (and at the last) the scalars of the reference's summary op are appended as one JSON line to
         ``<model_dir>/scalars.jsonl`` (the counterpart of the TensorBoard event file) and the loss is checked for NaN
         (trainer.py:271-276); every ``test_step`` steps the fixed parameter sweeps are generated (trainer.py:230-241, 281-282;
@@ -265,9 +313,14 @@ class Trainer(object):
             z_samples.append(zi)
         records = []
         t0 = time.time()
+        last_save = time.time()
         for step in range(self.step, max_step):
             x, y = batch_manager.batch()
             m = self.train_step(x, y)
+            if model_dir and rank0 and self.save_sec is not None and time.time() - last_save >= self.save_sec:
+                # the Supervisor's timed saver (save_model_secs = config.save_sec, trainer.py:110-117): model.ckpt-<global step>
+                self.save(os.path.join(model_dir, "model.ckpt-%d.npz" % self.step))
+                last_save = time.time()
             if step % log_step == 0 or step == max_step - 1:
                 ep = step * batch_manager.epochs_per_step
                 rec = self._scalars(m, ep)
@@ -419,6 +472,8 @@ class GANTrainer(Trainer):
     """arch='dg' (SURVEY 8(f)-4): generator + PatchGAN discriminator with LSGAN terms, both updated from the same
     forward pass like ``sess.run([g_optim, d_optim])`` (trainer.py:149-156, 174-184, 265-267; trainer3.py:26-33,53-63)."""
 
+    _restore_in_base = False
+
     def __init__(self, config, device="cuda", name="G"):
         self.w3 = config.w3
         super(GANTrainer, self).__init__(config, device, name)
@@ -432,6 +487,16 @@ class GANTrainer(Trainer):
         self.D = _Slab([k for k in ops.all_variables() if k.startswith("D/")], self.device)
         self._adam_t_d = 0
         self.grad_sync_d = None
+        self._auto_restore()
+
+    def _ckpt_slabs(self):
+        return super(GANTrainer, self)._ckpt_slabs() + [(self.D.slices, self.D.p, self.D.m, self.D.v)]
+
+    def _ckpt_extra(self):
+        return {"beta_power_t_d": np.int64(self._adam_t_d)}
+
+    def _ckpt_load_extra(self, d):
+        self._adam_t_d = int(d["beta_power_t_d"])
 
     def enable_data_parallel(self, group=None, profile=False, force=False):
         """Two gradient slabs -> two bucketed exchanges: G's per generator block (as in ``Trainer``), D's as one bucket."""

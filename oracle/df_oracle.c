@@ -11,6 +11,26 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Thread count of the OpenMP loops below, set / read through the runtime itself (an OMP_NUM_THREADS exported after the host process
+ * has already initialised an OpenMP runtime -- PyTorch's -- is ignored): bench.py's cpu_baseline reports what dfo_max_threads() says. */
+void dfo_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+int dfo_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 
 /* D_a f[i] = f[i+1]-f[i] (i <= n-2), D_a f[n-1] = D_a f[n-2]  -- reference ops.py:214-217, 243-253, 269-270 */
 static inline float fdiff(const float* f, int64_t i, int64_t n, int64_t stride) {

@@ -516,8 +516,9 @@ def ae_train_step(x, y_last, p, opt, filters, z_num, p_num, is_3d, num_conv=4, r
         else:                                            # curl reads channel 0 only (ops.py:267-268)
             res = velocity_loss(s[..., :1], x, False, w1, w2, sign_u=sign_u)
             ds = np.zeros_like(s); ds[..., :1] = res["dpsi"]
-    else:
-        raise NotImplementedError("oracle: AE without curl (liquid scenes) not restated")
+    else:                                                # trainer.py:362-364 / trainer3.py:245-247: x_ = the decoder's own output
+        res = velocity_loss(s, x, is_3d, w1, w2, sign_u=sign_u, use_curl=False)
+        ds = res["dpsi"]
     zp = z[:, -p_num:]
     loss_p = ((y_last - zp) ** 2).mean()
     dzp = -2.0 * (y_last - zp) / zp.size * w4
@@ -630,15 +631,18 @@ def gan_losses_and_grads(z, x, pG, pD, output_shape, filters, is_3d, w1=1.0, w2=
 # Train step (trainer.py:136-184, trainer3.py:14-63) + TF1 Adam + LR schedule
 # ----------------------------------------------------------------------------------------
 
-def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, need_grad=True, sign_u=None):
-    """G_ = curl(psi) | jacobian3(psi)[1];  loss = w1*mean|G_-x| + w2*mean|J(G_)-J(x)|.
+def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, need_grad=True, sign_u=None, use_curl=True):
+    """G_ = curl(psi) | jacobian3(psi)[1]  (use_curl=False, trainer.py:141-143 / trainer3.py:19-21: G_ = the generator's own
+    2- | 3-channel output, every liquid scene of run.bat);  loss = w1*mean|G_-x| + w2*mean|J(G_)-J(x)|.
     Returns dict(loss, l1, j_l1, u, dpsi).  ``sign_u`` (optional): take the sign pattern of the two |.| terms in the reverse
     pass from this velocity field (the one the implementation under test produced) -- |.| is piecewise linear and values within
     rounding error of zero may sit on either piece, which moves the heavily cancelling parameter gradients at the 1e-3 level."""
     if is_3d:
-        u = curl3(psi); ju, _ = jacobian3(u); jx, _ = jacobian3(x)
+        u = curl3(psi) if use_curl else psi
+        ju, _ = jacobian3(u); jx, _ = jacobian3(x)
     else:
-        u = curl(psi); ju, _ = jacobian(u); jx, _ = jacobian(x)
+        u = curl(psi) if use_curl else psi
+        ju, _ = jacobian(u); jx, _ = jacobian(x)
     l1 = l1_mean(u, x); jl1 = l1_mean(ju, jx)
     res = {"loss": w1 * l1 + w2 * jl1, "l1": l1, "j_l1": jl1, "u": u, "ju": ju, "jx": jx}
     if need_grad:
@@ -648,10 +652,10 @@ def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, need_grad=True, sign_u=None):
         dj = l1_mean_bwd(js, jx, w2)
         if is_3d:
             du = du + jacobian3_bwd(gj=dj)
-            res["dpsi"] = jacobian3_bwd(gc=du)
+            res["dpsi"] = jacobian3_bwd(gc=du) if use_curl else du
         else:
             du = du + jacobian_bwd(dj)
-            res["dpsi"] = curl_bwd(du)
+            res["dpsi"] = curl_bwd(du) if use_curl else du
     return res
 
 
@@ -665,21 +669,31 @@ def adam_tf1(p, g, m, v, t, lr, beta1=0.5, beta2=0.999, eps=1e-8):
     return p, m, v
 
 
+def lr_step(lr, step, lr_update_step, lr_min=2.5e-6):
+    """lr_update='step' (trainer.py:77-78, 285-286): after loop iteration ``step`` (0-based) the rate is halved, floored at lr_min,
+    when ``step % lr_update_step == lr_update_step - 1``."""
+    return max(lr * 0.5, lr_min) if step % lr_update_step == lr_update_step - 1 else lr
+
+
 def lr_cosine(step, max_step, lr_max=1e-4, lr_min=2.5e-6):
     """trainer.py:74-75: assigned AFTER each step with the already-incremented step."""
     return lr_min + 0.5 * (lr_max - lr_min) * (math.cos(step * math.pi / max_step) + 1.0)
 
 
 def train_step(z, x, p, opt, output_shape, filters, is_3d, num_conv=4, repeat=0, w1=1.0, w2=1.0,
-               name="G", masks=None, sign_u=None):
+               name="G", masks=None, sign_u=None, use_curl=True, optimizer="adam"):
     """One full step: G fwd -> curl -> Jacobian -> L1 losses -> bwd -> TF1 Adam (in place on
-    copies).  ``opt`` = dict(m, v, t, lr).  Returns (new_p, new_opt, info)."""
+    copies).  ``opt`` = dict(m, v, t, lr).  Returns (new_p, new_opt, info).  ``use_curl=False``: ``output_shape`` carries the
+    velocity's own 2 | 3 channels (trainer.py:48-55).  ``optimizer='gd'``: tf.train.GradientDescentOptimizer (trainer.py:163-165)."""
     psi, cache = generator_fwd(z, p, output_shape, filters, name, num_conv, repeat, keep=True)
-    res = velocity_loss(psi, x, is_3d, w1, w2, sign_u=sign_u)
+    res = velocity_loss(psi, x, is_3d, w1, w2, sign_u=sign_u, use_curl=use_curl)
     grads = generator_bwd(res["dpsi"], cache, p, name, masks=masks)
     t = opt["t"] + 1
     new_p, new_m, new_v = {}, {}, {}
     for k in p:
+        if optimizer == "gd":
+            new_p[k], new_m[k], new_v[k] = p[k] - opt["lr"] * grads[k], opt["m"][k], opt["v"][k]
+            continue
         new_p[k], new_m[k], new_v[k] = adam_tf1(p[k], grads[k], opt["m"][k], opt["v"][k], t, opt["lr"])
     info = {k: res[k] for k in ("loss", "l1", "j_l1", "u")}
     info["psi"] = psi; info["grads"] = grads

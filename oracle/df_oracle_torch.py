@@ -117,42 +117,69 @@ def conv_same_s2(x, w, b):
     return F.conv2d(xp, w.permute(3, 2, 0, 1).contiguous(), b, stride=2).permute(0, 2, 3, 1)
 
 
-def encoder_fwd(x, p, filters, z_num, name="enc", num_conv=3, repeat=0, leak=0.2):
-    """EncoderBE / EncoderBE3 (model.py:118-188): conv, [num_conv convs, concat skip, stride-2 conv] x repeat_num, flatten, FC."""
+def encoder_fwd(x, p, filters, z_num, name="enc", num_conv=3, repeat=0, leak=0.2, masks=None, own_masks=None):
+    """EncoderBE / EncoderBE3 (model.py:118-188): conv, [num_conv convs, concat skip, stride-2 conv] x repeat_num, flatten, FC.
+    ``masks`` / ``own_masks``: as in :func:`generator_fwd`, keyed by the encoder's layer number (0 = the first conv)."""
     spatial = list(x.shape[1:-1])
     repeat_num = int(np.log2(np.max(spatial))) - 2 if repeat == 0 else repeat
     W = lambda n, kind: p["%s/%d_%s/weights" % (name, n, kind)]
     Bv = lambda n, kind: p["%s/%d_%s/biases" % (name, n, kind)]
-    x = F.leaky_relu(conv_same(x, W(0, "conv"), Bv(0, "conv")), leak)
+
+    def act(pre, ln):
+        if own_masks is not None:
+            own_masks[ln] = (pre > 0).detach()
+        return F.leaky_relu(pre, leak) if masks is None else _LreluMasked.apply(pre, masks[ln], leak)
+
+    x = act(conv_same(x, W(0, "conv"), Bv(0, "conv")), 0)
     x0 = x
     ln = 1
     for idx in range(repeat_num):
         for _ in range(num_conv):
-            x = F.leaky_relu(conv_same(x, W(ln, "conv"), Bv(ln, "conv")), leak); ln += 1
+            x = act(conv_same(x, W(ln, "conv"), Bv(ln, "conv")), ln); ln += 1
         x = torch.cat([x, x0], dim=-1)                      # model.py:138 / :174
         if idx < repeat_num - 1:
-            x = F.leaky_relu(conv_same_s2(x, W(ln, "conv"), Bv(ln, "conv")), leak); ln += 1      # model.py:141-143
+            x = act(conv_same_s2(x, W(ln, "conv"), Bv(ln, "conv")), ln); ln += 1      # model.py:141-143
             x0 = x
     flat = x.reshape(x.shape[0], -1)
     return F.linear(flat, W(ln, "fc").t(), Bv(ln, "fc"))
 
 
-def ae_fwd(x, p, filters, z_num, name="AE", num_conv=4, repeat=0):
+def ae_fwd(x, p, filters, z_num, name="AE", num_conv=4, repeat=0, enc_masks=None, dec_masks=None, own_enc=None, own_dec=None):
     """AE / AE3 (model.py:190-216), use_sparse=False: returns (out, z)."""
-    z = encoder_fwd(x, p, filters, z_num, name + "/enc", num_conv - 1, repeat)
-    out = generator_fwd(z, p, list(x.shape[1:]), filters, name + "/dec", num_conv, repeat)
+    z = encoder_fwd(x, p, filters, z_num, name + "/enc", num_conv - 1, repeat, masks=enc_masks, own_masks=own_enc)
+    out = generator_fwd(z, p, list(x.shape[1:]), filters, name + "/dec", num_conv, repeat, masks=dec_masks, own_masks=own_dec)
     return out, z
 
 
-def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, sign_u=None):
+def ae_grads(x, y_last, p, filters, z_num, p_num, is_3d, num_conv=4, repeat=0, use_curl=True, w1=1.0, w2=1.0, w4=1.0,
+             enc_masks=None, dec_masks=None, sign_u=None, own_enc=None, own_dec=None):
+    """build_model_ae (trainer.py:357-423 / trainer3.py:240-279, use_sparse=False) through autograd: loss = w1*L1 + w2*J-L1 +
+    w4*mean((y_last - z[:, -p_num:])^2); returns losses, the velocity field, the code and d loss / d every variable."""
+    for v in p.values():
+        v.requires_grad_(True)
+        v.grad = None
+    s, z = ae_fwd(x, p, filters, z_num, num_conv=num_conv, repeat=repeat, enc_masks=enc_masks, dec_masks=dec_masks,
+                  own_enc=own_enc, own_dec=own_dec)
+    psi = s if (is_3d or not use_curl) else s[..., :1]      # 2-D curl reads channel 0 only (ops.py:267-268)
+    loss_v, l1, jl1, u = velocity_loss(psi, x, is_3d, w1, w2, sign_u=sign_u, use_curl=use_curl)
+    loss_p = ((y_last - z[:, -p_num:]) ** 2).mean()
+    loss = loss_v + w4 * loss_p
+    loss.backward()
+    return {"loss": float(loss.detach()), "l1": float(l1.detach()), "j_l1": float(jl1.detach()), "loss_p": float(loss_p.detach()),
+            "u": u.detach(), "z": z.detach(), "grads": {k: v.grad for k, v in p.items()}}
+
+
+def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, sign_u=None, use_curl=True):
     """``sign_u`` (optional): the velocity field of the implementation under test.  |.| is piecewise linear: where u - x or
     J(u) - J(x) lies within rounding error of zero two correct implementations may sit on different linear pieces, and the
     parameter gradients -- sums of ~1e7 sign terms with heavy cancellation -- then differ at the 1e-3 level for reasons that say
     nothing about the kernels.  With ``sign_u`` the returned loss keeps its value but back-propagates on the pieces ``sign_u`` is on."""
     if is_3d:
-        u = jacobian3(psi)[1]; ju = jacobian3(u)[0]; jx = jacobian3(x)[0]
+        u = jacobian3(psi)[1] if use_curl else psi         # use_curl=False: trainer3.py:19-21
+        ju = jacobian3(u)[0]; jx = jacobian3(x)[0]
     else:
-        u = curl(psi); ju = jacobian(u)[0]; jx = jacobian(x)[0]
+        u = curl(psi) if use_curl else psi                 # trainer.py:141-143
+        ju = jacobian(u)[0]; jx = jacobian(x)[0]
     l1 = (u - x).abs().mean(); jl1 = (ju - jx).abs().mean()
     loss = l1 * w1 + jl1 * w2
     if sign_u is not None:
@@ -165,14 +192,14 @@ def velocity_loss(psi, x, is_3d, w1=1.0, w2=1.0, sign_u=None):
 
 
 def train_step(z, x, p, opt, output_shape, filters, is_3d, num_conv=4, repeat=0, w1=1.0, w2=1.0, beta1=0.5,
-               beta2=0.999, eps=1e-8, masks=None, sign_u=None, own_masks=None, update=True):
+               beta2=0.999, eps=1e-8, masks=None, sign_u=None, own_masks=None, update=True, use_curl=True):
     """One step with TF1 Adam, in place on ``p`` (dict of leaf tensors) and ``opt`` (m, v, t, lr); ``update=False`` stops after the
     gradients (parity runs that evaluate the same weights twice)."""
     for v in p.values():
         v.requires_grad_(True)
         v.grad = None
     psi = generator_fwd(z, p, output_shape, filters, num_conv=num_conv, repeat=repeat, masks=masks, own_masks=own_masks)
-    loss, l1, jl1, u = velocity_loss(psi, x, is_3d, w1, w2, sign_u=sign_u)
+    loss, l1, jl1, u = velocity_loss(psi, x, is_3d, w1, w2, sign_u=sign_u, use_curl=use_curl)
     loss.backward()
     if not update:
         return {"loss": float(loss.detach()), "l1": float(l1.detach()), "j_l1": float(jl1.detach()), "u": u.detach(),

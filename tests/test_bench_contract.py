@@ -63,3 +63,46 @@ def test_kernel_selector_and_roofline_object():
     assert b.wgrad_exec_ratio(2, 8, 12, 8, 128, 128)[1] in (0, 1) and b.wgrad_exec_ratio(16, 64, 96, 64, 64, 64) == (8.0 / 27.0, 3)
     assert b.wgrad_exec_ratio(16, 64, 96, 64, 96, 96) == (4.0 / 9.0, 2) and b.wgrad_exec_ratio(1, 8, 8, 16, 96, 96) == (2.0 / 3.0, 1)
     json.dumps(r)      # the object must be JSON-serialisable as is
+
+
+def test_compact_line_puts_headline_objects_first_and_drops_bulk():
+    b = _bench()
+    rf = {"kernel": "wino3d_kernel fwd/dgrad 64x96x64 C128->128", "bound": "mfma", "achieved": 99.0, "peak": 157.3, "unit": "TFLOP/s",
+          "frac": 0.63, "traffic": 3.0e10, "note": "x" * 500, "work_per_launch": 1.0, "avg_launch_ms": 16.6, "launches": 3}
+    out = {"metric": "m", "value": 1.0, "unit": "voxels/s", "per_gpu": 1.0, "n_gpus": 1, "steps": 2, "warmup": 1, "ms_per_step": 198.0,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "cfg3"},
+           "roofline": rf, "roofline_stencil": dict(rf, bound="hbm"), "roofline_wgrad": rf, "roofline_tail_fwd": None, "roofline_tail_bwd": None,
+           "cpu_baseline": {"value": 1.2e5, "unit": "voxels/s", "cores": 64, "kind": "port", "sample": "s", "stencil_tail": {"big": "x" * 900}},
+           "l1_vs_ref": {"value": 1e-6}, "l1_vs_ref_fullsize": {"velocity_rel_l1": 2e-6, "loss_rel": 1e-7},
+           "kernels": {"k%d" % i: {"launches": 1, "ms_total": 1.0} for i in range(60)}, "dispatch": {"d%d" % i: 1 for i in range(60)},
+           "stencils_standalone": {"x": "y" * 2000}, "extra_cfg4_slice": {"ms_per_step": 258.0, "value": 3e7, "roofline": rf, "note": "n" * 400,
+                                                                           "bf16x3_mode": {"ms_per_step": 238.0}},
+           "extra_ae_cfg5": {"error": "boom"}, "sidecar": "gpurun_out/bench_full_n1.json", "loss": 0.5}
+    line = b.compact(out)
+    keys = list(line)
+    assert keys[:14] == ["metric", "value", "unit", "per_gpu", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                         "vs_baseline", "dtype", "data", "config"]
+    assert keys.index("roofline") < keys.index("cpu_baseline") < keys.index("l1_vs_ref") < keys.index("l1_vs_ref_fullsize") < keys.index("step_ms")
+    assert "kernels" not in line and "dispatch" not in line and "stencils_standalone" not in line
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"]) and "note" not in line["roofline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"]) and "stencil_tail" not in line["cpu_baseline"]
+    assert line["extra_cfg4_slice"] == {"ms_per_step": 258.0, "value": 3e7, "bf16x3_ms_per_step": 238.0, "roofline_frac": 0.63}
+    assert line["extra_ae_cfg5"] == {"error": "boom"}
+    assert len(json.dumps(line)) < 3000
+
+
+def test_watchdog_prints_a_diagnostic_line_and_exits_nonzero(tmp_path):
+    """N > 1 bring-up that hangs (rendezvous / RCCL communicator / first all-reduce): one JSON line with rccl_ranks 0 on rank 0's stdout,
+    exit code 3 -- never a hung lease."""
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r); import importlib.util as u; s = u.spec_from_file_location('b', %r); "
+            "m = u.module_from_spec(s); s.loader.exec_module(m); d = m.Watchdog(0, 8); d.arm('first all-reduce', 0.6); time.sleep(30)"
+            % (ROOT, os.path.join(ROOT, "bench.py")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3
+    msg = json.loads(r.stdout.strip().splitlines()[-1])
+    assert msg["rccl_ranks"] == 0 and msg["value"] is None and msg["n_gpus"] == 8 and "first all-reduce" in msg["error"]
+    # disarmed in time: nothing happens
+    code2 = code.replace("time.sleep(30)", "d.disarm(); time.sleep(1.5); print('alive')")
+    r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=60)
+    assert r2.returncode == 0 and r2.stdout.strip().endswith("alive")

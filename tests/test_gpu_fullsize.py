@@ -79,12 +79,9 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteere
         out["velocity_rel_l1"] = rel_l1(u, ref)
         ops.reset_variables()
         return out
-    ops.ACTIVATION_FETCH = []
-    try:
+    with ops.options(activation_fetch=[]):
         m = tr.train_step(dev(x), dev(y))
         masks = {i + 1: (t > 0).cpu() for i, t in enumerate(ops.ACTIVATION_FETCH)}
-    finally:
-        ops.ACTIVATION_FETCH = None
     gr = tr.grads_numpy()
     flat_g = tr.flat_g.clone()
     u_t = m.G_.detach().clone()
@@ -93,12 +90,9 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteere
     if is_3d:
         # ---- the dispatch bench.py runs: same weights, no activation fetch -> sign-word block tails ----
         tr.load_variables(p)
-        ops.SIGN_BITS_FETCH = []
-        try:
+        with ops.options(sign_bits_fetch=[]):
             m2 = tr.train_step(dev(x), dev(y))
             tails = list(ops.SIGN_BITS_FETCH)
-        finally:
-            ops.SIGN_BITS_FETCH = None
         out["n_bits_tails"] = len(tails)
         out["prod_velocity_identical"] = bool(torch.equal(m2.G_.detach(), u_t))
         out["prod_loss_identical"] = float(m2.g_loss.detach()) == loss
@@ -160,28 +154,45 @@ def test_cfg3_default_dispatch_train_step_vs_torch_oracle_b2():
     assert r["velocity_rel_l1"] <= 1e-4, r           # north-star tolerance (measured ~2e-6: fp32 vs fp32)
     assert r["loss_rel"] < 1e-5, r
     assert r["grad_rel_linf"] < 2e-4, r              # measured 1.4e-5 (on the GPU's linear piece; 2-4e-3 with the oracle's own signs)
+    # and WITHOUT steering (the oracle on its own linear pieces): a handful of pre-activations within rounding error of zero moves the
+    # cancelling gradient sums by 1.6e-2 (measured, round 3); a kernel that flipped even 1e-4 of the masks consistently in forward and
+    # backward would pass the steered check above and fail this bound (and the sign-disagreement bound) by an order of magnitude
+    assert r["unsteered_grad_rel_linf"] < 5e-2, r
     assert r["last_bias_abs"] < 1e-3, r
 
 
-def test_cfg4_full_grid_train_step_vs_torch_oracle():
-    """BASELINE cfg4's grid (112x160x112, 5 levels, x0 = 7x10x7, W = 112 | 56 | 28 | 14 | 7 rows), one sample: forward
-    velocity and -- when the host has the memory for the oracle's autograd tape -- every gradient."""
-    free_gb = 0.0
+def _host_mem_available_gb():
     try:
         for line in open("/proc/meminfo"):
             if line.startswith("MemAvailable"):
-                free_gb = float(line.split()[1]) / 1e6
+                return float(line.split()[1]) / 1e6
     except OSError:
         pass
-    backward = free_gb >= 160.0
-    r = _step_vs_torch_oracle((112, 160, 112), 128, 1, seed=12, backward=backward)
+    return 0.0
+
+
+def test_cfg4_full_grid_inference_vs_torch_oracle():
+    """BASELINE cfg4's grid (112x160x112, 5 levels, x0 = 7x10x7, W = 112 | 56 | 28 | 14 | 7 rows), one sample: the inference graph's
+    velocity field (needs ~10 GB of host memory: always runs)."""
+    r = _step_vs_torch_oracle((112, 160, 112), 128, 1, seed=12, backward=False)
     assert r["velocity_rel_l1"] <= 1e-4, r
-    if backward:
-        assert r["n_layers_fetched"] == 20, r
-        _assert_production_dispatch_identical(r, 4)
-        assert r["loss_rel"] < 1e-5, r
-        assert r["grad_rel_linf"] < 2e-4, r          # measured 2.5e-5
-        assert r["last_bias_abs"] < 1e-3, r
+
+
+def test_cfg4_full_grid_train_step_vs_torch_oracle():
+    """The same grid, full train step: loss and every gradient.  The oracle's autograd tape at this size is ~60 GB on the host
+    (20 layers x (1 GB input + 1 GB pre-activation) + oneDNN workspaces); a box without it is reported as SKIPPED with the reason,
+    never as a pass (the 28x40x28 fp64 test below covers the geometry everywhere)."""
+    free_gb = _host_mem_available_gb()
+    if free_gb < 100.0:
+        pytest.skip("host MemAvailable %.0f GB < 100 GB: the PyTorch-CPU oracle's autograd tape for 112x160x112 F=128 does not fit" % free_gb)
+    r = _step_vs_torch_oracle((112, 160, 112), 128, 1, seed=12, backward=True, unsteered=False)
+    print("cfg4 full-grid backward parity ran (host MemAvailable %.0f GB)" % free_gb)
+    assert r["velocity_rel_l1"] <= 1e-4, r
+    assert r["n_layers_fetched"] == 20, r
+    _assert_production_dispatch_identical(r, 4)
+    assert r["loss_rel"] < 1e-5, r
+    assert r["grad_rel_linf"] < 2e-4, r          # measured 2.5e-5
+    assert r["last_bias_abs"] < 1e-3, r
 
 
 def test_cfg4_geometry_reduced_train_step_vs_fp64_oracle():
@@ -203,12 +214,9 @@ def test_cfg4_geometry_reduced_train_step_vs_fp64_oracle():
     opt = {"m": {k: np.zeros_like(v) for k, v in p64.items()}, "v": {k: np.zeros_like(v) for k, v in p64.items()}, "t": 0,
            "lr": cfg.lr_max}
     for s in range(2):
-        ops.ACTIVATION_FETCH = []
-        try:
+        with ops.options(activation_fetch=[]):
             m = tr.train_step(dev(x), dev(y))
             masks = {i + 1: host(t) > 0 for i, t in enumerate(ops.ACTIVATION_FETCH)}
-        finally:
-            ops.ACTIVATION_FETCH = None
         p64, opt, info = orc.train_step(y.astype(np.float64), x.astype(np.float64), p64, opt, oshape, filters, True, masks=masks,
                                         sign_u=host(m.G_))
         opt["lr"] = orc.lr_cosine(s + 1, tr.max_step)
@@ -533,6 +541,7 @@ def test_cfg2_train_step_128x96_vs_torch_oracle_and_batch64_identity():
     assert r["velocity_rel_l1"] <= 1e-4, r
     assert r["loss_rel"] < 1e-5, r
     assert r["grad_rel_linf"] < 2e-4, r
+    assert r["unsteered_grad_rel_linf"] < 5e-2 and r["lrelu_sign_disagree_frac"] < 1e-3, r      # see the cfg3 test
     assert r["last_bias_abs"] < 1e-3, r
     from deep_fluids_amd import ops
     from deep_fluids_amd.trainer import Trainer, default_config
@@ -595,3 +604,66 @@ def test_cfg5_ae3_train_step_w128_rows_vs_fp64_oracle():
     of every conv / weight-gradient kernel, stride-2 adjoints), full train step at batch 2 against the fp64 NumPy oracle."""
     from test_gpu_ae import _ae_step_case
     _ae_step_case(True, (16, 32, 128), 64, False, steer=True, grad_tol=2e-4)
+
+
+def test_cfg5_ae3_full_train_step_vs_torch_oracle():
+    """BASELINE cfg5's OWN shape -- AE3 (F = 64, z_num = 16) at 128^3, one sample -- as a full train step (build_model_ae,
+    trainer3.py:240-279): velocity, code, loss terms and every gradient (stride-2 native weight gradients at Wo = 64 ... 8, the
+    320 -> 320 layer, the 196,608 -> 16 FC, 64 -> 64 Winograd forms at W = 128) against the PyTorch-CPU oracle's autograd, steered
+    on the GPU's linear pieces and -- bounded -- on the oracle's own.  Falls back to 64^3 (printed) when the host has < 100 GB free."""
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import AETrainer, default_config
+    ops.reset_variables()
+    free_gb = _host_mem_available_gb()
+    R = 128 if free_gb >= 100.0 else 64
+    filters, z_num, p_num = 64, 16, 2
+    rng = np.random.RandomState(41)
+    xshape = [R, R, R, 3]
+    p = orc.ae_init(rng, xshape, filters, z_num)
+    for k in p:
+        if k.endswith("biases"):
+            p[k] = rng.uniform(-0.05, 0.05, p[k].shape).astype(np.float32)
+    x, _ = orc.synthetic_batch(rng, 1, (R, R, R))
+    y = rng.uniform(-1, 1, (1, p_num, 5)).astype(np.float32)
+    cfg = default_config(is_3d=True, res_x=R, res_y=R, res_z=R, filters=filters, batch_size=1, num_samples=1000, z_num=z_num, p_num=p_num)
+    tr = AETrainer(cfg)
+    assert sorted(tr.var_names) == sorted(p)
+    tr.load_variables(p)
+    with ops.options(activation_fetch=[]):
+        m = tr.train_step(dev(x), dev(y))
+        acts = [(t > 0).cpu() for t in ops.ACTIVATION_FETCH]
+    n_enc = sum(1 for k in p if "/enc/" in k and k.endswith("conv/weights"))
+    n_dec = sum(1 for k in p if "/dec/" in k and k.endswith("conv/weights")) - 1
+    assert len(acts) == n_enc + n_dec, (len(acts), n_enc, n_dec)
+    enc_masks = {i: a for i, a in enumerate(acts[:n_enc])}
+    dec_masks = {i + 1: a for i, a in enumerate(acts[n_enc:])}
+    gr = tr.grads_numpy()
+    u, zc = host(m.G_), host(m.z)
+    loss, loss_p = float(m.g_loss.detach()), float(m.loss_p.detach())
+    del m
+    torch.cuda.empty_cache()
+    torch.set_num_threads(max(1, min(len(__import__("os").sched_getaffinity(0)), 64)))
+    pt = ort.to_torch(p)
+    xt, yl = torch.from_numpy(x), torch.from_numpy(y[:, :, -1].copy())
+    info = ort.ae_grads(xt, yl, pt, filters, z_num, p_num, True, enc_masks=enc_masks, dec_masks=dec_masks, sign_u=torch.from_numpy(u))
+
+    def errs_of(ref):
+        ref = {k: v.numpy().astype(np.float64) for k, v in ref.items()}
+        gmax = max(np.abs(v).max() for v in ref.values())
+        e = {k: float(np.abs(gr[k] - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-3 * gmax)) for k in gr}
+        return sorted(e.items(), key=lambda kv: -kv[1])[:4]
+    worst = errs_of(info["grads"])
+    ev, ez = rel_l1(u, info["u"].numpy()), rel_linf(zc, info["z"].numpy())
+    own_e, own_d = {}, {}
+    raw = ort.ae_grads(xt, yl, pt, filters, z_num, p_num, True, own_enc=own_e, own_dec=own_d)
+    worst_raw = errs_of(raw["grads"])
+    nel = sum(int(v.numel()) for v in list(own_e.values()) + list(own_d.values()))
+    dis = (sum(int((own_e[k] != enc_masks[k]).sum()) for k in own_e) + sum(int((own_d[k] != dec_masks[k]).sum()) for k in own_d)) / float(nel)
+    print("AE3 %d^3 F=64 B=1 train step vs torch oracle (host MemAvailable %.0f GB): velocity rel-L1 %.2e, z rel-Linf %.2e, loss rel %.1e, "
+          "worst gradients steered %s / un-steered %s, lrelu sign decisions that differ %.2e of %d" % (
+              R, free_gb, ev, ez, abs(loss - info["loss"]) / abs(info["loss"]), worst, worst_raw[:2], dis, nel))
+    assert ev <= 1e-4 and ez < 1e-4
+    assert abs(loss - info["loss"]) < 1e-5 * abs(info["loss"]) and abs(loss_p - info["loss_p"]) < 1e-4 * abs(info["loss_p"]) + 1e-8
+    assert worst[0][1] < 2e-4, worst
+    assert worst_raw[0][1] < 5e-2 and dis < 1e-3, (worst_raw, dis)
+    ops.reset_variables()

@@ -83,11 +83,8 @@ CASES_2D = [
 def test_conv_wgrad_algorithms(ops, shape, cin, cout, leak, algo):
     """df_conv_wgrad forced to the direct kernel (1), Winograd in x (2) and Winograd in (x,y) (3) -- the default picks by size --
     against the fp64 oracle; the last case is 2-D (kz = 1)."""
-    ops.WGRAD_ALGO = algo
-    try:
+    with ops.options(wgrad_algo=algo):
         errs = _conv_case(ops, shape, cin, cout, leak, seed=algo + cin + cout)
-    finally:
-        ops.WGRAD_ALGO = 0
     assert max(errs.values()) < TOL, errs
 
 
@@ -95,11 +92,8 @@ def test_conv_wgrad_algorithms(ops, shape, cin, cout, leak, algo):
 def test_conv_wgrad_winograd_xyz(ops, shape, leak):
     """df_conv_wgrad forced to the Winograd F(2x2x2,3x3x3) form (algo 4: 64 transform-domain products per 2x2x2 positions, four launches of
     (xi_z, xi_y) workgroup types, z/y/x G^T in the reduce) against the fp64 oracle; odd tile-row counts, several batches."""
-    ops.WGRAD_ALGO = 4
-    try:
+    with ops.options(wgrad_algo=4):
         errs = _conv_case(ops, shape, 128, 128, leak, seed=sum(shape), mask_from_gpu=True)
-    finally:
-        ops.WGRAD_ALGO = 0
     assert max(errs.values()) < TOL, errs
 
 
@@ -125,11 +119,8 @@ def test_conv_wgrad_winograd_xyz_on_zero_padded_rows(ops, shape, leak):
     assert query("df_conv_wgrad_workspace_bytes", B, D, H, W, 128, 128, 3) > query("df_conv_wgrad_workspace_bytes", B, D, H, W + (4 if W == 28 else 2), 128, 128, 3)
     errs = _conv_case(ops, shape, 128, 128, leak, seed=sum(shape) + 2, mask_from_gpu=True)
     assert max(errs.values()) < TOL, errs
-    ops.WGRAD_ALGO = 1
-    try:
+    with ops.options(wgrad_algo=1):
         errs1 = _conv_case(ops, shape, 128, 128, leak, seed=sum(shape) + 2, mask_from_gpu=True)
-    finally:
-        ops.WGRAD_ALGO = 0
     assert max(errs1.values()) < TOL, errs1
 
 
@@ -156,12 +147,8 @@ WINO2D_CASES = [
 @pytest.mark.parametrize("shape,cin,cout,leak", WINO2D_CASES)
 def test_conv2d_winograd_fwd_bwd(ops, shape, cin, cout, leak):
     """conv_wino2d.hip (forward and dgrad through _ConvSame3) against the fp64 oracle, same tolerance as the direct kernel."""
-    old = ops.CONV_ALGO
-    ops.CONV_ALGO = "winograd"
-    try:
+    with ops.options(conv_algo="winograd"):
         errs = _conv_case(ops, shape, cin, cout, leak, seed=cin * 3 + cout + sum(shape), mask_from_gpu=True)
-    finally:
-        ops.CONV_ALGO = old
     assert max(errs.values()) < TOL, errs
 
 
@@ -169,12 +156,8 @@ def test_conv2d_winograd_fwd_bwd(ops, shape, cin, cout, leak):
 def test_conv3d_winograd_fwd_bwd(ops, shape, cin, cout, leak):
     """conv_wino.hip (forward and dgrad through _ConvSame3; the wgrad stays direct) against the fp64 oracle, same tolerance
     as the direct kernel."""
-    old = ops.CONV_ALGO
-    ops.CONV_ALGO = "winograd"
-    try:
+    with ops.options(conv_algo="winograd"):
         errs = _conv_case(ops, shape, cin, cout, leak, seed=cin * 3 + cout + sum(shape), mask_from_gpu=True)
-    finally:
-        ops.CONV_ALGO = old
     assert max(errs.values()) < TOL, errs
 
 
@@ -389,11 +372,8 @@ def test_wino_upconv_dgrad_vs_oracle(ops, cshape, cin, cout):
 def test_upconv_block_wgrad_winograd_xyz_27point(ops, cshape):
     """The up-sampling-aware weight gradient in its 27-point Winograd-(x,y,z) form (wgrad_wxyz_kernel<.., UP>: coarse operand reads,
     9 workgroup types, xi_x = 2 skipped), forced on small grids; whole fused block against the oracle."""
-    ops.WGRAD_ALGO = 4
-    try:
+    with ops.options(wgrad_algo=4):
         test_upconv_block_vs_materialised_upsample(ops, cshape, 128)
-    finally:
-        ops.WGRAD_ALGO = 0
 
 
 @pytest.mark.parametrize("cshape,C", [((1, 2, 4, 16), 32), ((1, 3, 5, 7), 128), ((1, 2, 2, 32), 64), ((1, 5, 9), 128), ((2, 8, 16), 32),
@@ -401,12 +381,8 @@ def test_upconv_block_wgrad_winograd_xyz_27point(ops, cshape):
 def test_upconv_block_winograd_forced(ops, cshape, C):
     """The fused up-sampling block with the Winograd kernels forced on small/ragged grids (forward through df_wino_upconv_fwd, adjoint
     through df_wino_upconv_dgrad; 2-D: df_wino2d_upconv_fwd / _dgrad, 9 of 16 products)."""
-    old = ops.CONV_ALGO
-    ops.CONV_ALGO = "winograd"
-    try:
+    with ops.options(conv_algo="winograd"):
         test_upconv_block_vs_materialised_upsample(ops, cshape, C)
-    finally:
-        ops.CONV_ALGO = old
 
 
 @pytest.mark.parametrize("algo", [0, 1])
@@ -514,9 +490,8 @@ def test_thin_wgrad_mfma_orientations_vs_oracle(ops, shape, cin, cout):
 
 @pytest.fixture
 def bf16x3(ops):
-    ops.CONV_PRECISION = "bf16x3"
-    yield
-    ops.CONV_PRECISION = "fp32"
+    with ops.options(conv_precision="bf16x3"):
+        yield
 
 
 @pytest.mark.parametrize("shape,cin,cout,leak", [((1, 4, 8, 16), 32, 128, 0.2), ((2, 8, 12, 8), 64, 128, 0.2),
@@ -595,12 +570,9 @@ def test_sign_bit_masks_are_bit_identical_to_activation_masks(ops, shape, C, up)
     bs = [rng.uniform(-0.3, 0.3, C).astype(np.float32) for _ in range(n)]
     fshape = tuple(shape[:1]) + tuple(2 * d for d in shape[1:]) if up else shape
     go = rng.uniform(-1, 1, fshape + (C,)).astype(np.float32)
-    old_algo, old_bits = ops.CONV_ALGO, ops.SIGN_BIT_MASKS
-    ops.CONV_ALGO = "winograd"
     res = []
-    try:
-        for use_bits in (True, False):
-            ops.SIGN_BIT_MASKS = use_bits
+    for use_bits in (True, False):
+        with ops.options(conv_algo="winograd", sign_bit_masks=use_bits):
             xt = dev(x).requires_grad_(True)
             args = []
             for w, b in zip(ws, bs):
@@ -608,8 +580,6 @@ def test_sign_bit_masks_are_bit_identical_to_activation_masks(ops, shape, C, up)
             y = (_UpGenBlock if up else _GenBlock).apply(xt, 0.2, *args)
             (y * dev(go)).sum().backward()
             res.append([host(y), host(xt.grad)] + [host(a.grad) for a in args])
-    finally:
-        ops.CONV_ALGO, ops.SIGN_BIT_MASKS = old_algo, old_bits
     for a, b in zip(*res):
         np.testing.assert_array_equal(a, b)
 

@@ -43,13 +43,10 @@ def _velocity_errors(is_3d, spatial, filters=128):
         return rel_l1(u, ref)
 
     out["fp32"] = run()
-    ops.CONV_PRECISION = "bf16x3"
-    try:
+    with ops.options(conv_precision="bf16x3"):
         out["bf16x3"] = run()
-    finally:
-        ops.CONV_PRECISION = "fp32"
     # plain bf16 operands: layer-by-layer path with both conv operands rounded to bf16 before the exact-fp32 kernels
-    pack0, raw0, fused0 = ops._pack, ops._conv_raw, ops.FUSED_BLOCKS
+    pack0, raw0 = ops._pack, ops._conv_raw
     rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
 
     def pack_bf16(w, taps, cin, cout, mode, dims=None, fp32=False):
@@ -58,11 +55,12 @@ def _velocity_errors(is_3d, spatial, filters=128):
     def raw_bf16(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak):
         return raw0(rb(x) if min(cin, cout) >= 16 else x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak)
 
-    ops._pack, ops._conv_raw, ops.FUSED_BLOCKS = pack_bf16, raw_bf16, False
+    ops._pack, ops._conv_raw = pack_bf16, raw_bf16          # (monkey-patched kernels' inputs, not an option of the package)
     try:
-        out["bf16"] = run()
+        with ops.options(fused_blocks=False):
+            out["bf16"] = run()
     finally:
-        ops._pack, ops._conv_raw, ops.FUSED_BLOCKS = pack0, raw0, fused0
+        ops._pack, ops._conv_raw = pack0, raw0
     return out
 
 

@@ -117,13 +117,17 @@ def test_2d_vs_oracle_fwd_bwd(ops, shape):
     np.testing.assert_array_equal(host(vt.grad), orc.jacobian_bwd(gj, gw))
 
 
-def _assert_close_up_to_sign_ties(got, ref, tol, quantum):
+def _assert_close_up_to_sign_ties(got, ref, tol, quantum, nvox):
     """The loss gradients are sums of sign(a - b) * const: where the fp32 difference a - b rounds across zero (|a - b| below ~1e-7: about
     one term in 1e7, i.e. expected once the field has a million voxels) the fp32 kernel and the fp64 oracle legitimately pick different
     signs.  One flipped term moves du at two voxels by `quantum`, which the curl adjoint spreads over at most 4 entries of dpsi each: allow
-    a handful of such entries, each off by a few quanta, and nothing else."""
+    a handful of such entries, each off by a few quanta, and nothing else -- and ONLY for fields large enough to expect a tie at all:
+    below 1e5 voxels the bound is strict (a boundary-row or last-plane bug that touches a few voxels must not hide behind the allowance)."""
     err = np.abs(got - ref)
     bad = err > tol
+    if nvox < 100000:
+        assert not bad.any(), (int(bad.sum()), float(err.max()), tol, nvox)
+        return
     assert int(bad.sum()) <= 32 and float(err.max()) <= tol + 4.0 * quantum, (int(bad.sum()), float(err.max()), tol, quantum)
 
 
@@ -153,7 +157,7 @@ def test_fused_velocity_loss_vs_oracle_and_unfused_path(ops, shape):
     assert abs(float(l1) - ref["l1"]) <= 2e-6 * ref["l1"] and abs(float(jl1) - ref["j_l1"]) <= 2e-6 * ref["j_l1"]
     scale = np.abs(ref["dpsi"]).max()
     nvox = int(np.prod(shape))
-    _assert_close_up_to_sign_ties(host(pt.grad), ref["dpsi"], 1e-5 * scale, 2.0 * max(w1 / 3, w2 / (9 if is_3d else 4)) / nvox)
+    _assert_close_up_to_sign_ties(host(pt.grad), ref["dpsi"], 1e-5 * scale, 2.0 * max(w1 / 3, w2 / (9 if is_3d else 4)) / nvox, nvox)
     # the unfused path: same kernels the GAN / AE graphs use
     pt2 = dev(psi).requires_grad_(True)
     xt = dev(x)
@@ -171,7 +175,7 @@ def test_fused_velocity_loss_vs_oracle_and_unfused_path(ops, shape):
     l1b, _, _ = ops.velocity_loss(pt3, dev(x))
     l1b.backward()
     ref1 = orc.velocity_loss(psi.astype(np.float64), x.astype(np.float64), is_3d, 1.0, 0.0)
-    _assert_close_up_to_sign_ties(host(pt3.grad), ref1["dpsi"], 1e-5 * np.abs(ref1["dpsi"]).max(), 2.0 / (3 if is_3d else 2) / nvox)
+    _assert_close_up_to_sign_ties(host(pt3.grad), ref1["dpsi"], 1e-5 * np.abs(ref1["dpsi"]).max(), 2.0 / (3 if is_3d else 2) / nvox, nvox)
 
 
 def test_full_size_properties_cfg3(ops):

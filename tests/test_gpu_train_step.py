@@ -63,39 +63,41 @@ def test_generator_skip_concat_gradients_vs_torch_oracle():
     ops.reset_variables()
 
 
-def _run_step_case(is_3d, spatial, filters, batch, steps=2):
+def _run_step_case(is_3d, spatial, filters, batch, steps=2, use_curl=True, optimizer="adam", lr_update="decay", lr_update_step=2,
+                   lr_max=1e-4):
     from deep_fluids_amd import ops
     from deep_fluids_amd.trainer import Trainer, default_config
     ops.reset_variables()
     rng = np.random.RandomState(123)
-    oshape = list(spatial) + [3 if is_3d else 1]
+    oshape = list(spatial) + [(3 if is_3d else 1) if use_curl else (3 if is_3d else 2)]      # trainer.py:48-55
     p = orc.generator_init(rng, 3, oshape, filters)
     for k in p:
         if k.endswith("biases"):
             p[k] = rng.uniform(-0.05, 0.05, p[k].shape).astype(np.float32)
     x, y = orc.synthetic_batch(rng, batch, spatial)
     cfg = default_config(is_3d=is_3d, res_x=spatial[-1], res_y=spatial[-2], res_z=spatial[0] if is_3d else 1,
-                         filters=filters, batch_size=batch, num_samples=1000)
+                         filters=filters, batch_size=batch, num_samples=1000, use_curl=use_curl, optimizer=optimizer,
+                         lr_update=lr_update, lr_update_step=lr_update_step, lr_max=lr_max)
     tr = Trainer(cfg)
+    assert tr.output_shape == oshape
     tr.load_variables(p)
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     opt = {"m": {k: np.zeros_like(v) for k, v in p64.items()}, "v": {k: np.zeros_like(v) for k, v in p64.items()},
            "t": 0, "lr": cfg.lr_max}
-    out = {}
+    out = {"lrs": []}
     for s in range(steps):
         # the oracle's reverse pass uses the lrelu sign pattern the GPU took (fetched from the fused blocks; the layer-by-layer
         # path of thin models keeps the oracle's own): the network is piecewise linear and a pre-activation within rounding
         # error of zero may pick either slope -- an O(1) change of one dp element that says nothing about the kernels
-        ops.ACTIVATION_FETCH = []
-        try:
+        with ops.options(activation_fetch=[]):
             m = tr.train_step(dev(x), dev(y))
             fetched = list(ops.ACTIVATION_FETCH)
-        finally:
-            ops.ACTIVATION_FETCH = None
         masks = {i + 1: host(t) > 0 for i, t in enumerate(fetched)} if fetched else None
         p64, opt, info = orc.train_step(y.astype(np.float64), x.astype(np.float64), p64, opt, oshape, filters, is_3d, masks=masks,
-                                        sign_u=host(m.G_))
-        opt["lr"] = orc.lr_cosine(s + 1, tr.max_step)
+                                        sign_u=host(m.G_), use_curl=use_curl, optimizer=optimizer)
+        opt["lr"] = orc.lr_cosine(s + 1, tr.max_step) if lr_update == "decay" else orc.lr_step(opt["lr"], s, lr_update_step, cfg.lr_min)
+        out["lrs"].append(tr.g_lr)
+        assert abs(tr.g_lr - opt["lr"]) < 1e-12, (s, tr.g_lr, opt["lr"])
         out["velocity_rel_l1_step%d" % s] = rel_l1(host(m.G_), info["u"])
         out["loss_rel_step%d" % s] = abs(float(m.g_loss) - info["loss"]) / abs(info["loss"])
         if s == 0:
@@ -114,7 +116,6 @@ def _run_step_case(is_3d, spatial, filters, batch, steps=2):
     num = sum(np.abs((newp[k] - p[k]) - (p64[k] - p[k])).sum() for k in p if k != last_bias)
     den = sum(np.abs(p64[k] - p[k]).sum() for k in p if k != last_bias)
     out["param_delta_rel_l1"] = float(num / den)
-    assert abs(tr.g_lr - opt["lr"]) < 1e-12
     ops.reset_variables()
     return out
 
@@ -124,6 +125,34 @@ def test_train_step_3d_vs_oracle():
     assert r["velocity_rel_l1_step0"] <= 1e-4 and r["velocity_rel_l1_step1"] <= 1e-4, r
     assert r["loss_rel_step0"] < 1e-5 and r["loss_rel_step1"] < 1e-4, r
     assert r["grad_rel_linf"] < 1e-3, r          # sign(a-b) gradients flip on fp32-vs-fp64 ties; see DESIGN.md
+    assert r["param_delta_rel_l1"] < 1e-2, r
+
+
+@pytest.mark.parametrize("is_3d,spatial,filters,batch", [(False, (16, 8), 16, 3), (True, (8, 16, 8), 16, 2), (True, (16, 24, 16), 128, 1)])
+def test_train_step_without_curl_vs_oracle(is_3d, spatial, filters, batch):
+    """use_curl=False (trainer.py:48-55,141-143 / trainer3.py:19-21; run.bat's liquid scenes): the generator's last conv emits the
+    2- | 3-channel velocity itself, the Jacobian / L1 tail runs op by op (no stream function, no curl).  F = 128 at 16x24x16 puts the
+    Winograd forward / dgrad, the Winograd weight gradients and the matrix-core thin 128 -> 3 layer under it."""
+    r = _run_step_case(is_3d, spatial, filters, batch, steps=2 if filters < 128 else 1, use_curl=False)
+    assert r["velocity_rel_l1_step0"] <= 1e-4, r
+    assert r["loss_rel_step0"] < 1e-5, r
+    assert r["grad_rel_linf"] < 1e-3, r
+    if filters < 128:
+        assert r["velocity_rel_l1_step1"] <= 1e-4 and r["param_delta_rel_l1"] < 1e-2, r
+
+
+@pytest.mark.parametrize("is_3d,spatial", [(False, (16, 8)), (True, (8, 16, 8))])
+def test_lr_update_step_and_gd_optimizer_vs_oracle(is_3d, spatial):
+    """`--lr_update step` (trainer.py:77-78, 285-286: g_lr halved after iterations lr_update_step-1, 2*lr_update_step-1, ..., floored at
+    lr_min) and `--optimizer gd` (tf.train.GradientDescentOptimizer, trainer.py:163-165): five steps against the fp64 oracle."""
+    r = _run_step_case(is_3d, spatial, 16, 2, steps=5, optimizer="gd", lr_update="step", lr_update_step=2, lr_max=1e-2)
+    assert r["lrs"] == [1e-2, 5e-3, 5e-3, 2.5e-3, 2.5e-3], r["lrs"]
+    for s in range(5):
+        assert r["velocity_rel_l1_step%d" % s] <= 1e-4, r
+    assert r["grad_rel_linf"] < 1e-3 and r["param_delta_rel_l1"] < 1e-3, r
+    # the schedule alone, down to the floor, with Adam
+    r = _run_step_case(is_3d, spatial, 16, 2, steps=4, lr_update="step", lr_update_step=1, lr_max=8e-6)
+    assert r["lrs"] == [4e-6, 2.5e-6, 2.5e-6, 2.5e-6], r["lrs"]
     assert r["param_delta_rel_l1"] < 1e-2, r
 
 
@@ -140,12 +169,8 @@ def test_train_step_cfg3_geometry_filters128(algo):
     """One real-width (F=128) 3-D step at a reduced grid (16x24x16: same 4-level geometry as 64x96x64 / 4), with the direct
     MFMA convs and with the default dispatch (Winograd forward / dgrad at the 8x12x8 and 16x24x16 levels)."""
     from deep_fluids_amd import ops
-    old = ops.CONV_ALGO
-    ops.CONV_ALGO = algo
-    try:
+    with ops.options(conv_algo=algo):
         r = _run_step_case(True, (16, 24, 16), 128, 1, steps=1)
-    finally:
-        ops.CONV_ALGO = old
     assert r["velocity_rel_l1_step0"] <= 1e-4, r
     assert r["loss_rel_step0"] < 1e-5, r
     # (lrelu sign pattern taken from the GPU, see _run_step_case: both algorithms are pinned at the same 1e-3)
@@ -266,4 +291,74 @@ def test_train_loop_scalars_nan_guard_and_test_sweep(tmp_path):
             np.testing.assert_array_equal(d["x"], ref[i])
     with pytest.raises(ValueError):
         tr.test_(bm3, p1=1, p2=1, test_b_num=3)
+    ops.reset_variables()
+
+
+class _FixedBatches(object):
+    """A deterministic batch source (the reference's queue threads draw at random, data.py:124-144): batch i is a function of i."""
+
+    def __init__(self, xs, ys, start, epochs_per_step):
+        self.xs, self.ys, self.i, self.epochs_per_step = xs, ys, start, epochs_per_step
+
+    def batch(self):
+        i = self.i
+        self.i += 1
+        return self.xs[i], self.ys[i]
+
+
+@pytest.mark.parametrize("arch", ["de", "dg"])
+def test_periodic_checkpoint_and_auto_restore_resume_is_bit_identical(tmp_path, arch):
+    """SURVEY 8(f)-3 (trainer.py:107-123: Supervisor(save_model_secs=save_sec) + prepare_or_wait_for_session): a 6-step run interrupted
+    after step 3 and restarted on the same model_dir -- which auto-restores the latest model.ckpt-<step>.npz: variables, Adam slots,
+    global step, g_lr (and the discriminator's slab for arch='dg') -- ends bit-identical to the uninterrupted run."""
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import Trainer, GANTrainer, default_config, latest_checkpoint
+    cls = GANTrainer if arch == "dg" else Trainer
+    rng = np.random.RandomState(3)
+    xs, ys = [], []
+    for _ in range(6):
+        x, y = orc.synthetic_batch(rng, 2, (16, 16))
+        xs.append(dev(x)); ys.append(dev(y))
+
+    def cfg(d, **kw):
+        return default_config(is_3d=False, res_x=16, res_y=16, filters=16, batch_size=2, num_samples=40, model_dir=d, log_step=100,
+                              test_step=100, arch=arch, **kw)
+
+    def final_state(tr):
+        st = {"p": tr.flat_p.clone(), "m": tr.flat_m.clone(), "v": tr.flat_v.clone()}
+        if arch == "dg":
+            st.update(pd=tr.D.p.clone(), md=tr.D.m.clone(), vd=tr.D.v.clone())
+        return st, (tr.step, tr.g_lr, tr._adam_t)
+
+    dir_a, dir_b = str(tmp_path / "a"), str(tmp_path / "b")
+    ops.reset_variables()
+    tr = cls(cfg(dir_a, save_sec=None))
+    assert tr.restored_from is None
+    init = tr.flat_p.clone(); init_d = tr.D.p.clone() if arch == "dg" else None
+    tr.train(_FixedBatches(xs, ys, 0, 2 / 40.0), max_step=6)
+    ref, ref_meta = final_state(tr)
+    assert sorted(f for f in os.listdir(dir_a) if f.startswith("model.ckpt")) == ["model.ckpt-6.npz"]      # save_sec=None: only the last one
+    # interrupted run: a checkpoint after every step (save_sec = 0), stopped after 3 steps
+    ops.reset_variables()
+    tr = cls(cfg(dir_b, save_sec=0))
+    tr.flat_p.copy_(init)
+    if arch == "dg":
+        tr.D.p.copy_(init_d)
+    tr.train(_FixedBatches(xs, ys, 0, 2 / 40.0), max_step=3)
+    assert sorted(f for f in os.listdir(dir_b) if f.startswith("model.ckpt")) == ["model.ckpt-1.npz", "model.ckpt-2.npz", "model.ckpt-3.npz"]
+    assert latest_checkpoint(dir_b).endswith("model.ckpt-3.npz")
+    del tr
+    # restart on the same model_dir (or with --load_path pointing at it): continues from step 3
+    ops.reset_variables()
+    tr = cls(cfg(str(tmp_path / "elsewhere"), load_path=dir_b) if arch == "de" else cfg(dir_b))
+    assert tr.restored_from.endswith("model.ckpt-3.npz") and tr.step == 3 and tr._adam_t == 3
+    tr.train(_FixedBatches(xs, ys, 3, 2 / 40.0), max_step=6, model_dir=dir_b)
+    got, got_meta = final_state(tr)
+    assert got_meta == ref_meta, (got_meta, ref_meta)
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
+    with np.load(os.path.join(dir_a, "model.ckpt-6.npz")) as da, np.load(os.path.join(dir_b, "model.ckpt-6.npz")) as db:
+        assert sorted(da.files) == sorted(db.files) and ("D/Conv/weights/Adam_1" in da.files) == (arch == "dg")
+        for k in da.files:
+            np.testing.assert_array_equal(da[k], db[k])
     ops.reset_variables()

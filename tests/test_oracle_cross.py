@@ -106,3 +106,57 @@ def test_kl_bernoulli_closed_form_equals_definition_and_logit_form():
         zp[b, j] += 1e-6; zm[b, j] -= 1e-6
         fd = 0.7 * (orc.kl_bernoulli(zp, n, rho) - orc.kl_bernoulli(zm, n, rho)) / 2e-6
         assert abs(g[b, j] - fd) <= 1e-6 * abs(fd)
+
+
+@pytest.mark.parametrize("is_3d,spatial,filters", [(True, (4, 8, 4), 4), (False, (16, 8), 8)])
+def test_train_step_without_curl_numpy_vs_torch_fp64(is_3d, spatial, filters):
+    """use_curl=False (trainer.py:141-143 / trainer3.py:19-21; every liquid scene of run.bat): the generator emits the velocity
+    itself (2 | 3 channels); hand-written reverse pass vs autograd, and the 'gd' optimizer (trainer.py:163-165)."""
+    rng = np.random.RandomState(9)
+    oshape = list(spatial) + [3 if is_3d else 2]
+    p = {k: v.astype(np.float64) for k, v in orc.generator_init(rng, 3, oshape, filters).items()}
+    x, y = orc.synthetic_batch(rng, 2, spatial)
+    x = x.astype(np.float64); y = y.astype(np.float64)
+    opt = {"m": {k: np.zeros_like(v) for k, v in p.items()}, "v": {k: np.zeros_like(v) for k, v in p.items()}, "t": 0, "lr": 1e-2}
+    pt = ort.to_torch(p, torch.float64)
+    it = ort.train_step(torch.tensor(y), torch.tensor(x), pt, None, oshape, filters, is_3d, update=False, use_curl=False)
+    newp, _, info = orc.train_step(y, x, p, opt, oshape, filters, is_3d, use_curl=False, optimizer="gd")
+    assert info["u"].shape[-1] == oshape[-1] and np.array_equal(info["u"], info["psi"])
+    assert abs(info["loss"] - it["loss"]) < 1e-12
+    for k in p:
+        np.testing.assert_allclose(info["grads"][k], it["grads"][k].numpy(), atol=1e-12, err_msg=k)
+        np.testing.assert_allclose(newp[k], p[k] - 1e-2 * info["grads"][k], atol=0, rtol=0)
+
+
+def test_lr_step_schedule_restatement():
+    """lr_update='step' (trainer.py:77-78, 285-286): halved after iterations lr_update_step-1, 2*lr_update_step-1, ..., floored."""
+    lr, seen = 1e-4, []
+    for step in range(10):
+        lr = orc.lr_step(lr, step, 3, lr_min=2e-5)
+        seen.append(lr)
+    assert seen == [1e-4, 1e-4, 5e-5, 5e-5, 5e-5, 2.5e-5, 2.5e-5, 2.5e-5, 2e-5, 2e-5]
+
+
+@pytest.mark.parametrize("xshape,filters,use_curl", [([8, 16, 8, 3], 8, True), ([8, 16, 8, 3], 8, False), ([16, 16, 2], 8, True),
+                                                     ([16, 16, 2], 8, False)])
+def test_ae_gradients_numpy_vs_torch_fp64(xshape, filters, use_curl):
+    """The AE train step's gradients (build_model_ae, trainer3.py:240-279; with and without curl): hand-written reverse pass of
+    df_oracle.ae_train_step vs autograd of df_oracle_torch.ae_grads -- the latter is the full-size (cfg5) checker."""
+    rng = np.random.RandomState(2)
+    z_num, p_num = 8, 2
+    is_3d = len(xshape) == 4
+    p = {k: v.astype(np.float64) for k, v in orc.ae_init(rng, xshape, filters, z_num).items()}
+    for k in p:
+        if k.endswith("biases"):
+            p[k] = rng.uniform(-0.05, 0.05, p[k].shape)
+    x, _ = orc.synthetic_batch(rng, 2, xshape[:-1])
+    x = x.astype(np.float64)
+    y_last = rng.uniform(-1, 1, (2, p_num))
+    opt = {"m": {k: np.zeros_like(v) for k, v in p.items()}, "v": {k: np.zeros_like(v) for k, v in p.items()}, "t": 0, "lr": 1e-4}
+    _, _, info = orc.ae_train_step(x, y_last, p, opt, filters, z_num, p_num, is_3d, use_curl=use_curl)
+    it = ort.ae_grads(torch.tensor(x), torch.tensor(y_last), ort.to_torch(p, torch.float64), filters, z_num, p_num, is_3d,
+                      use_curl=use_curl)
+    assert abs(info["loss"] - it["loss"]) < 1e-12 and abs(info["loss_p"] - it["loss_p"]) < 1e-12
+    np.testing.assert_allclose(info["u"], it["u"].numpy(), atol=1e-12)
+    for k in p:
+        np.testing.assert_allclose(info["grads"][k], it["grads"][k].numpy(), atol=1e-11, err_msg=k)
