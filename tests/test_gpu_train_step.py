@@ -271,7 +271,8 @@ def test_train_loop_scalars_nan_guard_and_test_sweep(tmp_path):
     with np.load(os.path.join(model_dir, "4_G.npz")) as d:
         assert d["G"].shape == (3, 4, 16, 8, 2) and d["z"].shape == (3, 4, 3)
     # NaN guard: poison the parameters -> the next logged step must raise the reference's assertion
-    tr2 = Trainer(cfg, name="G2")
+    cfg_nan = default_config(is_3d=False, res_x=8, res_y=16, filters=16, batch_size=4, num_samples=n, log_step=2, test_step=2)
+    tr2 = Trainer(cfg_nan, name="G2")                   # (no model_dir in ITS config: a trainer auto-restores the model_dir it is given)
     tr2.flat_p.fill_(float("nan"))
     bm2 = BatchManager(dcfg)
     with pytest.raises(AssertionError, match="Model diverged with loss = NaN"):
