@@ -77,6 +77,7 @@ struct WinoArgs {
   int flags;
   float leak;
   int spx;
+  int Wb;              // XS != 0: x-blocks of 4 per row of the x-blocked copy (2 nbx + 1); a.x then points to that copy
 };
 
 // ---- weight transform + packing ------------------------------------------------------------------------------------------
@@ -256,11 +257,28 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //     x 4 channels into packed bf16 hi / lo (v_cvt_pk_bf16_f32; 48 ops) = the A operands of 4 points, K = 16;
 //   * weights: U pre-split by wino_pack_bf16x3_kernel, one 16-byte load per lane = (hi, lo) of a (point, cout block): 8 loads per k-step.
 // The fp32 values that are split are bit-identical to the PREC = 0 kernel's operands; per-product error 2^-17 (16 significand bits).
-template <int DBG, int FL = -1, int MODE = 0, int PREC = 0>
+//
+// XS != 0 -- STAGING BY LDS-DMA FROM AN X-BLOCKED COPY OF THE INPUT (round 4).  a.x = G[b][z][y][xb][c][4], element i of granule (xb, c) =
+// x[b][z][y][4 xb - 1 + i][c] (zero outside the row: the SAME padding in x is part of the layout).  The 10 halo positions x0-1 .. x0+8 of a
+// tile block (x0 = 8 bx) are the first 10 of the 12 floats of granules xb = 2 bx .. 2 bx + 2, and the 16 channels of a chunk of one granule
+// column are 256 contiguous bytes: a halo ROW of a chunk is three such pieces = one `buffer_load_dwordx4 ... lds` of 51 lanes (lane =
+// (piece g, channel c | pad)), global -> LDS with no staging registers, no ds_write, no transpose, two full 128-byte lines per piece
+// instead of a 64-byte piece of every 512-byte voxel record.  LDS = [plane hz][row hy][piece g][17 slots: 16 channels + 1 pad][4 x]:
+// piece pitch 68 dwords, row pitch 204 -- the wave-wide ds_read2_b64 of the A path (lane = (tile, channel); the two x pairs of a tile row
+// sit in one or two pieces) stay bank-conflict free.  The row's address is scalar (SALU); a row outside the tensor reads through a
+// zero-length descriptor (zeros = SAME padding in y, z).  60 DMA instructions per chunk.
+// XS & 2: only waves 4-7 (one per SIMD) issue them -- the other wave of every SIMD never has a staging load in its in-order vmcnt queue and
+// keeps the matrix pipe busy while its partner waits for HBM.  XS & 4: issued in front of k-step 0's MFMAs instead of behind them.
+template <int DBG, int FL = -1, int MODE = 0, int PREC = 0, int XS = 0>
 __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   constexpr bool UP = MODE == 1, POOL = MODE == 2, P27 = MODE != 0;
   constexpr bool BX = PREC == 1;
-  constexpr int BUFF = BX ? BBUF / 4 : BUF;      // floats per LDS buffer
+  constexpr bool XB = XS != 0, XASYM = (XS & 2) != 0;
+  static_assert(!XB || (!UP && !BX), "x-blocked staging: plain / pooled fp32 modes only");
+  constexpr int PZk = PZ, CPk = CP;
+  constexpr int XROWB = 51 * 16, XROWS = 60;        // XS: bytes per LDS row (3 pieces x 17 slots x 16 B), halo rows per chunk (6 planes x 10)
+  constexpr int BUFk = XB ? XROWS * XROWB / 4 : CKW * CPk;
+  constexpr int BUFF = BX ? BBUF / 4 : BUFk;      // floats per LDS buffer
   __shared__ __attribute__((aligned(16))) float sIn[2 * BUFF];
   __shared__ float sBias[32];        // this worker's cout slice of the bias (the slice is fixed for the worker's whole life)
   // lrelu-mask operands of a tile block's outputs, fetched by LDS-DMA loads (no registers); PREC = 1: behind the epilogue's exchange area in
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const int bz = t2 % a.nbz;
     bi.b = t2 / a.nbz;
     bi.z0 = bz * 4; bi.y0 = by * 8; bi.x0 = bx * 8;
-    bi.xb = a.x + static_cast<int64_t>(bi.b) * (UP ? (a.D >> 1) * (a.H >> 1) * (a.W >> 1) : a.D * a.H * a.W) * a.Cin;
+    bi.xb = a.x + static_cast<int64_t>(bi.b) * (XB ? a.D * a.H * a.Wb * 4 : UP ? (a.D >> 1) * (a.H >> 1) * (a.W >> 1) : a.D * a.H * a.W) * a.Cin;
     bi.hoff = (((bi.z0 - 1) * a.H + (bi.y0 - 1)) * a.W + (bi.x0 - 1)) * a.Cin;
     return bi;
   };
@@ -333,9 +351,9 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     if (p > HV * 4 - 1) p = HV * 4 - 1;     // the tail threads of the last pass duplicate the last piece (same data, same slot)
     const int hv = p >> 2, q4 = p & 3;
     const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-    ldst[it] = ((q4 * 4) * CP + hz * PZ + hy * PY + hx) * 4;          // bytes, buffer 0
+    ldst[it] = ((q4 * 4) * CPk + hz * PZk + hy * PY + hx) * 4;        // bytes, buffer 0
   }
-  const unsigned vol_bytes = static_cast<unsigned>(UP ? (a.D >> 1) * (a.H >> 1) * (a.W >> 1) : a.D * a.H * a.W) * a.Cin * 4u;
+  const unsigned vol_bytes = static_cast<unsigned>(XB ? a.D * a.H * a.Wb * 4 : UP ? (a.D >> 1) * (a.H >> 1) * (a.W >> 1) : a.D * a.H * a.W) * a.Cin * 4u;
   auto set_offs = [&](const BlockInfo& bi) {
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
@@ -365,7 +383,46 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   char* sInB = reinterpret_cast<char*>(sIn);
   auto stage_store = [&](int it, int bufbytes, const f32x4& v) {
     float* d = reinterpret_cast<float*>(sInB + (ldst[it] + bufbytes));
-    d[0] = v[0]; d[CP] = v[1]; d[2 * CP] = v[2]; d[3 * CP] = v[3];
+    d[0] = v[0]; d[CPk] = v[1]; d[2 * CPk] = v[2]; d[3 * CPk] = v[3];
+  };
+
+  // ---- XS staging: DMA instruction = halo row r = hz * 10 + hy; lane = (piece g, slot c), 51 of 64 lanes active -------------------------
+  constexpr int NXM = XASYM ? 15 : 8;           // rows per issuing wave
+  const bool xissuer = XB && (!XASYM || wave >= 4);
+  const int xg = lane / 17, xc = lane - xg * 17;
+  const unsigned xvoff = (lane < 51 && xc < 16) ? static_cast<unsigned>((xg * a.Cin + xc) * 16) : 0x80000000u;      // pad slot: zeros
+  auto issue_dma = [&](int bufbytes, const BlockInfo& bi, unsigned chunkbytes) {      // chunkbytes = chunk * 256 (16 channels x 16 B)
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    if (!xissuer) return;
+    const __amdgpu_buffer_rsrc_t dsrd = make_srd(bi.xb, vol_bytes);
+    const int rowb = a.Wb * a.Cin * 16;                                             // bytes per (z, y) row of the copy
+    const int base = (((bi.z0 - 1) * a.H + (bi.y0 - 1)) * a.Wb + (bi.x0 >> 2)) * a.Cin * 16 + static_cast<int>(chunkbytes);
+    // a rolled loop of scalar row arithmetic (nothing of it lives in registers across the main loop); a row outside the tensor reads
+    // through the out-of-range lane offset (zeros = the SAME padding in y, z)
+    auto one_row = [&](int r) {
+      const int hz = r / 10, hy = r - hz * 10;
+      const bool ok = static_cast<unsigned>(bi.z0 - 1 + hz) < static_cast<unsigned>(a.D) &&
+                      static_cast<unsigned>(bi.y0 - 1 + hy) < static_cast<unsigned>(a.H);
+      // branch-free: a row outside the tensor keeps its (meaningless, never dereferenced) scalar offset and gets the out-of-range bit in
+      // the LANE offset -- the range check looks at the lane offset only
+      const unsigned soff = static_cast<unsigned>(base + (hz * a.H + hy) * rowb);
+      const unsigned vo = xvoff | (ok ? 0u : 0x80000000u);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dsrd, (lds_ptr)(sInB + bufbytes + r * XROWB), 16, vo, soff, 0, 0);
+    };
+    if (lane < 51) {
+      if constexpr ((XS & 8) != 0) {      // unrolled: the compiler counts the pieces in its vmcnt waits (a rolled loop makes it assume none were issued)
+        int w0 = XASYM ? wave - 4 : wave;
+#pragma unroll
+        for (int j = 0; j < (XASYM ? 15 : 8); ++j) {
+          asm volatile("" : "+s"(w0));      // opaque: the row arithmetic is redone per piece instead of living in SGPRs across the main loop
+          const int r0 = w0 + (XASYM ? 4 : 8) * j;
+          one_row(r0 < XROWS ? r0 : XROWS - 1);      // (the surplus piece of waves 4-7 repeats row 59: same bytes, same place)
+        }
+      } else {
+#pragma unroll 1
+        for (int r = XASYM ? wave - 4 : wave; r < XROWS; r += XASYM ? 4 : 8) one_row(r);
+      }
+    }
   };
 
   // ---- PREC = 1 staging plan: thread p < 400 owns the z-column (hy, hx, channel quad) of the halo block -------------------------
@@ -426,13 +483,28 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   const int zb = mz == 0 ? 2 : mz == 1 ? 2 : mz == 2 ? 1 : 3;
   const float qs = mz == 1 ? 1.f : -1.f;
   const f32x2 qs2 = {qs, qs};
-  const int abase = kq * CP + (2 * mth) * PZ + (2 * ty) * PY + 2 * tx;
-  const int offA = abase + za * PZ, offB = abase + zb * PZ;
+  const int abase = kq * CPk + (2 * mth) * PZk + (2 * ty) * PY + 2 * tx;
+  const int offA = abase + za * PZk, offB = abase + zb * PZk;
 
   f32x2 ra[8], rb[8];      // raw inputs [y][x pair] of planes za / zb
   f32x2 T[8], U[8];        // after the z / y transform
   f32x2 A2[8];             // A operands of a k-step: A2[xi_y*2 + h] = (xi_x = 2h, 2h+1)
   const int offAb = offA * 4, offBb = offB * 4;      // bytes (multiples of 8)
+  // XS: x pair h of this lane's tile = floats 2 tx + 2 h, + 1 of the row = piece (tx + h) >> 1, element 2 ((tx + h) & 1)
+  const int xrowA = ((2 * mth + za) * 10 + 2 * ty) * XROWB + kq * 16, xrowB = ((2 * mth + zb) * 10 + 2 * ty) * XROWB + kq * 16;
+  const int xp0 = (tx >> 1) * (17 * 16) + (tx & 1) * 8, xp1 = ((tx + 1) >> 1) * (17 * 16) + ((tx + 1) & 1) * 8;
+  auto raw_read_x = [&](int idxbytes) {   // idxbytes: buffer + 64 ks (the k-step's 4 channels are slots 4 ks .. 4 ks + 3)
+    int ia0 = idxbytes + xrowA + xp0, ia1 = idxbytes + xrowA + xp1, ib0 = idxbytes + xrowB + xp0, ib1 = idxbytes + xrowB + xp1;
+    asm volatile("" : "+v"(ia0), "+v"(ia1), "+v"(ib0), "+v"(ib1));
+    __builtin_assume((ia0 & 7) == 0); __builtin_assume((ia1 & 7) == 0); __builtin_assume((ib0 & 7) == 0); __builtin_assume((ib1 & 7) == 0);
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      ra[y * 2 + 0] = *reinterpret_cast<const f32x2*>(sInB + ia0 + y * XROWB);
+      ra[y * 2 + 1] = *reinterpret_cast<const f32x2*>(sInB + ia1 + y * XROWB);
+      rb[y * 2 + 0] = *reinterpret_cast<const f32x2*>(sInB + ib0 + y * XROWB);
+      rb[y * 2 + 1] = *reinterpret_cast<const f32x2*>(sInB + ib1 + y * XROWB);
+    }
+  };
   auto raw_read = [&](int idxbytes) {   // idxbytes: LDS byte offset of plane 4 ks (+ buffer), without this lane's offset
     int ia = idxbytes + offAb, ib = idxbytes + offBb;
     asm volatile("" : "+v"(ia), "+v"(ib));     // opaque: the 16 row reads become 8 ds_read2_b64 with small immediate offsets
@@ -465,9 +537,15 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
   // ---- B operand ------------------------------------------------------------------------------------------------------------
   const int nk4 = a.Cin >> 2;
-  f32x4 bq[2][4];          // [cout 16-block][xi_y] = (xi_x 0..3)
+  // XS & 32: TWO weight register sets (even / odd k-steps): a row is reloaded right behind its MFMAs with the weights of k-step + 2, i.e.
+  // every weight load has two k-steps (~3000 cycles) to come back instead of one -- the staging pieces' HBM misses sit in front of the
+  // weight loads in the CU's in-order vector-memory return path (the DMA staging freed the registers for it)
+  constexpr int NBQ = (XS & 32) ? 2 : 1;
+  f32x4 bq[NBQ][2][4];     // [k-step parity][cout 16-block][xi_y] = (xi_x 0..3)
   const unsigned laneb = static_cast<unsigned>(lane) * 16u;
-  const __amdgpu_buffer_rsrc_t wsrd = make_srd(a.wp, static_cast<unsigned>(a.Cin) * a.Cout * 256u);
+  // (experiments 262144 / 524288, timing only: the weight loads of the tile z-row 1 waves / of every wave go through a zero-length descriptor
+  //  -- same instructions, no cache traffic: what the DUPLICATE weight stream of the two z-row waves costs the CU's vector-memory path)
+  const __amdgpu_buffer_rsrc_t wsrd = make_srd(a.wp, ((DBG & 524288) || ((DBG & 262144) && th == 1)) ? 0u : static_cast<unsigned>(a.Cin) * a.Cout * 256u);
   const unsigned wbase_b = static_cast<unsigned>((cs * 4 + mz) * nk4) * 8192u + static_cast<unsigned>(hnb) * 4096u;
   // (experiment, DBG & 1024) odd cout slices walk the 16-channel chunks pairwise swapped (1,0,3,2,...): the two slices that share an XCD
   // then request the two 64-byte halves of each 128-byte line of the input at the same time
@@ -477,7 +555,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const int k2 = (((kl >> 2) ^ cperm) << 2) | (kl & 3);
     const unsigned sb = wbase_b + static_cast<unsigned>(k2) * 8192u + nb * 4096u;      // wave-uniform
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bq[nb][q] = buf_load16(wsrd, laneb + q * 1024u, sb);
+    for (int q = 0; q < 4; ++q) bq[0][nb][q] = buf_load16(wsrd, laneb + q * 1024u, sb);
+  };
+  auto issue_b1 = [&](int nb) {      // NBQ == 2: k-step 1 into the odd set
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[NBQ - 1][nb][q] = buf_load16(wsrd, laneb + q * 1024u, wbase_b + 8192u + nb * 4096u);
   };
 
   // ---- PREC = 1: A operands of a k-step = (chunk, xi_y = j); B operands ------------------------------------------------------------
@@ -541,6 +623,9 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 #pragma unroll
     for (int z = 0; z < 6; ++z) stz[z] = buf_load16(srd0, soz[z], 0u);
     stage_store_b(0, stz);
+  } else if constexpr (XB) {
+    issue_dma(0, cur, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     set_offs(cur);
     const __amdgpu_buffer_rsrc_t srd0 = make_srd(cur.xb, vol_bytes);
@@ -566,13 +651,14 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       issue_bw(0, 0, 0);
       if (!half) issue_bw(1, 0, 0);
     } else {
-      raw_read(pb * BUF * 4);
+      if constexpr (XB) raw_read_x(pb * BUFk * 4); else raw_read(pb * BUFk * 4);
       // [r3] the weights of k-step 0 are the same for every tile block of the worker and the last k-step of a block has already reloaded
       // them (issue_b / reload_row wrap around): they stay in their registers across the epilogue (16.13 -> 16.05 ms per top-level
       // launch; tuning variant 65536 = reloaded at every block start)
       if (it == 0 || (DBG & 196608) == 65536) {
         issue_b(0, 0);
         if (!half) issue_b(1, 0);
+        if (NBQ == 2) { issue_b1(0); if (!half) issue_b1(1); }
       }
     }
 
@@ -600,23 +686,35 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     auto main_loop = [&](auto half_c) {
     constexpr bool HALF = decltype(half_c)::value;      // this wave owns one 16-cout block only (acc[0], weights of block hnb)
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-      const int bo = ((chunk + pb) & 1) * BUF * 4, bn = BUF * 4 - bo;        // byte offsets of this / the other buffer
+      const int bo = ((chunk + pb) & 1) * BUFk * 4, bn = BUFk * 4 - bo;      // byte offsets of this / the other buffer
       const bool lastc = chunk + 1 == nchunk;
-      if (lastc) set_offs(nxt);                      // the last chunk stages the next tile block's first chunk
+      if constexpr (!XB) {
+        if (lastc) set_offs(nxt);                    // the last chunk stages the next tile block's first chunk
+      }
       const __amdgpu_buffer_rsrc_t ssrd = make_srd(lastc ? nxt.xb : cur.xb, vol_bytes);
-      const unsigned schunk = static_cast<unsigned>((lastc ? 0 : chunk + 1) ^ cperm) * (CKW * 4u);
-      f32x4 stg[NLOAD];
+      const unsigned schunk = XB ? static_cast<unsigned>(lastc ? 0 : chunk + 1) * 256u : static_cast<unsigned>((lastc ? 0 : chunk + 1) ^ cperm) * (CKW * 4u);
+      f32x4 stg[XB ? 1 : NLOAD];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         // -- A operands of this k-step (its raw inputs were requested during the previous one) --
         const unsigned long long q0 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (DBG & 16) asm volatile("s_waitcnt lgkmcnt(0)");
         const unsigned long long q1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
+        if (XB && (XS & 16) && ks == 0 && !(DBG & 4)) { issue_dma(bn, lastc ? nxt : cur, schunk); __builtin_amdgcn_sched_barrier(0); }
         if (!(DBG & 1)) transform();
         __builtin_amdgcn_sched_barrier(0);
-        if (ks == 2 && !(DBG & 4) && !(DBG & 64)) {
+        if (!XB && ks == 2 && !(DBG & 4) && !(DBG & 64)) {
 #pragma unroll
           for (int it = 0; it < (SPLITSTG ? 3 : NLOAD); ++it) stage_store(it, bn, stg[it]);
+        }
+        // XS: the DMA pieces of the next chunk have landed once at most the 8 (4) weight reloads of k-step 2 are outstanding behind them
+        if (XB && ks == 3) {      // (every wave: one that issued no pieces has only those reloads outstanding and does not wait)
+          constexpr int NWL = (P27 ? 3 : 4) * (HALF ? 1 : 2) * NBQ;      // weight loads issued behind the pieces and not yet consumed
+          if constexpr (NWL == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else if constexpr (NWL == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          else if constexpr (NWL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else if constexpr (NWL == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         }
         if (SPLITSTG && ks == 3) {
 #pragma unroll
@@ -630,8 +728,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         // already waited for at the LDS writes of ks == 2, and __syncthreads()' vmcnt(0) drained the weight loads in flight (this and the
         // two epilogue barriers: 16.21 -> 16.05 ms per top-level launch; tuning variant 16384 = full barriers)
         if (ks == 3) { if (DBG & 16384) __syncthreads(); else lds_barrier(); }
-        if (!(DBG & 2)) raw_read(ks < 3 ? bo + (ks + 1) * 16 * CP : bn);     // raw inputs of the next k-step
+        if (!(DBG & 2)) {                                                    // raw inputs of the next k-step
+          if constexpr (XB) raw_read_x(ks < 3 ? bo + (ks + 1) * 64 : bn); else raw_read(ks < 3 ? bo + (ks + 1) * 16 * CPk : bn);
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if (XB && (XS & 20) == 4 && ks == 0 && !(DBG & 4)) { issue_dma(bn, lastc ? nxt : cur, schunk); __builtin_amdgcn_sched_barrier(0); }
         const unsigned long long q2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (DBG & 16) asm volatile("s_waitcnt vmcnt(4)");
         const unsigned long long q3 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
@@ -642,32 +743,34 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         constexpr bool ROWRELOAD = (DBG & 196608) != 196608;
         auto reload_row = [&](int nb, int q) {
           if ((DBG & 8) || (P27 && q == 2)) return;
-          const int k4 = chunk * 4 + ks + 1;
-          const int kl = k4 < nk4 ? k4 : 0;
+          const int k4 = chunk * 4 + ks + NBQ;
+          const int kl = k4 < nk4 ? k4 : k4 - nk4;      // wraps to the first k-step(s) of the next tile block
           const unsigned sb = wbase_b + static_cast<unsigned>(kl) * 8192u + nb * 4096u;
-          bq[nb][q] = buf_load16(wsrd, laneb + q * 1024u, sb);
+          bq[ks & (NBQ - 1)][nb][q] = buf_load16(wsrd, laneb + q * 1024u, sb);
         };
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
-            acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
+            acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[ks & (NBQ - 1)][0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
           if (ROWRELOAD && (i & 3) == 3) { __builtin_amdgcn_sched_barrier(0); reload_row(0, i >> 2); __builtin_amdgcn_sched_barrier(0); }
         }
         __builtin_amdgcn_sched_barrier(0);
+        static_assert(NBQ == 1 || ROWRELOAD, "two weight sets: row reload only");
         if (!(DBG & 8) && !ROWRELOAD) issue_b(0, chunk * 4 + ks + 1);       // weights of the next k-step, as each register block frees up
         __builtin_amdgcn_sched_barrier(0);
         if (!HALF) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
-              acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
+              acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[ks & (NBQ - 1)][1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
             if (ROWRELOAD && (i & 3) == 3) { __builtin_amdgcn_sched_barrier(0); reload_row(1, i >> 2); __builtin_amdgcn_sched_barrier(0); }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
         if (DBG & 32) __builtin_amdgcn_s_setprio(0);
         if (!HALF && !(DBG & 8) && !ROWRELOAD) issue_b(1, chunk * 4 + ks + 1);
-        if (ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
+        if (XB && !(XS & 20) && ks == 0 && !(DBG & 4)) issue_dma(bn, lastc ? nxt : cur, schunk);
+        if (!XB && ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
                                          // the first wait that covers them is the one for the NEXT weight batch (1.5 k-steps away)
 #pragma unroll
           for (int it = 0; it < (SPLITSTG ? 3 : NLOAD); ++it) stg[it] = (DBG & 384) == 128 ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
@@ -953,6 +1056,25 @@ __global__ __launch_bounds__(256) void lrelu_bits_bwd_pool_kernel(const float4* 
   gpool[i] = acc;
 }
 
+// NDHWC -> the x-blocked layout of the XS staging (see wino3d_kernel): G[b][z][y][xb][c][0..3] = x[b][z][y][4 xb - 1 + i][c], zero outside.
+// One thread = one 16-byte granule; the lanes of a wave are consecutive channels: four 256-byte reads, one 1 KiB write.
+__global__ __launch_bounds__(256) void to_xblk_kernel(const float* __restrict__ x, f32x4* __restrict__ g, int64_t ngran, int W, int Wb, int C) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= ngran) return;
+  const int c = static_cast<int>(i % C);
+  const int64_t r = i / C;
+  const int xb = static_cast<int>(r % Wb);
+  const int64_t row = r / Wb;
+  const float* src = x + (row * W) * C + c;
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int xs = 4 * xb - 1 + e;
+    v[e] = (xs >= 0 && xs < W) ? src[static_cast<int64_t>(xs) * C] : 0.f;
+  }
+  __builtin_nontemporal_store(v, g + i);
+}
+
 #ifdef DF_TUNING      // instrumented kernel variants + knobs of the tuning library only (include/deepfluids_hip_debug.h)
 int g_wino_dbg = 0;
 int g_wino_spx = 0;     // slices per XCD override
@@ -964,7 +1086,7 @@ constexpr int g_wino_spx = 0;
 extern "C" {
 
 #ifdef DF_TUNING
-void df_debug_set_wino(int v) { g_wino_dbg = v & 0xfffff; g_wino_spx = v >> 20; }
+void df_debug_set_wino(int v) { g_wino_dbg = v & 0x3fffff; g_wino_spx = v >> 22; }
 int df_debug_wino_prof(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_prof), z, sizeof(z)); }
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_prof), 32 * sizeof(unsigned long long));
@@ -972,6 +1094,57 @@ int df_debug_wino_prof(unsigned long long* out, int reset) {
 #endif
 
 #ifdef DF_TUNING
+static int64_t wino_grid(WinoArgs& a, int64_t ntb);
+// Round-4 probe: df_wino_conv_fwd (flags = DF_CONV_BIAS | DF_CONV_LRELU) with the input staged by LDS-DMA from an x-blocked copy `xg`
+// ([B, D, H, 2 ceil(W/8) + 1, Cin, 4] floats, written here by to_xblk_kernel unless variant & 256).  variant & 15 = XS of wino3d_kernel:
+// 1 all waves issue the DMA pieces behind k-step 0's MFMAs | 3 waves 4-7 only | 5 / 7 the same in front of the MFMAs;
+// variant & 16: DBG 4 (no staging at all, timing only).
+int64_t df_debug_wino_xblk_elems(int64_t B, int64_t D, int64_t H, int64_t W, int64_t C) { return B * D * H * (2 * ceil_div(W, 8) + 1) * C * 4; }
+int df_debug_wino_conv_fwd_xblk(const float* x, float* xg, const float* wp, const float* bias, float* y, int64_t B, int64_t D, int64_t H, int64_t W,
+                                int64_t Cin, int64_t Cout, float leak, int variant, df_stream_t stream) {
+  DF_REQUIRE(x && xg && wp && bias && y, DF_EINVAL, "df_debug_wino_conv_fwd_xblk: null pointer");
+  DF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE, "df_debug_wino_conv_fwd_xblk: shape");
+  WinoArgs a;
+  a.x = xg; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
+  a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y; a.y2 = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
+  a.B = (int)B; a.D = (int)D; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.nbz = (int)ceil_div(D, 4); a.nby = (int)ceil_div(H, 8); a.nbx = (int)ceil_div(W, 8);
+  a.Wb = 2 * a.nbx + 1;
+  DF_REQUIRE(D * H * a.Wb * 4 * Cin <= (1LL << 29), DF_ESHAPE, "df_debug_wino_conv_fwd_xblk: one batch volume of the copy must stay below 2 GiB");
+  const int64_t ntb = B * a.nbz * a.nby * a.nbx;
+  a.ncs = (int)(Cout / 32);
+  a.ntb = (int)ntb;
+  a.flags = DF_CONV_BIAS | DF_CONV_LRELU; a.leak = leak;
+  hipStream_t s = df::as_stream(stream);
+  if (!(variant & 256)) {
+    const int64_t ngran = B * D * H * a.Wb * Cin;
+    hipLaunchKernelGGL(to_xblk_kernel, dim3((unsigned)ceil_div(ngran, 256)), dim3(256), 0, s, x, reinterpret_cast<f32x4*>(xg), ngran, (int)W, a.Wb, (int)Cin);
+  }
+  const int64_t grid = wino_grid(a, ntb);
+  constexpr int F = DF_CONV_BIAS | DF_CONV_LRELU;
+  switch (variant & 127) {
+    case 1: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 1>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 3>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 5: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 5>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 7: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 7>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 9: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 9>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 11: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 11>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 13: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 13>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 15: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 15>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 17: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 17>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 25: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 25>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 27: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 27>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 32 + 1: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 33>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 32 + 9: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 41>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 32 + 11: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 43>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 32 + 13: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 45>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 32 + 17: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 49>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 32 + 31: hipLaunchKernelGGL((wino3d_kernel<4, F, 0, 0, 33>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 3 + 64: hipLaunchKernelGGL((wino3d_kernel<4, F, 0, 0, 3>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    default: return df::fail(DF_EINVAL, "df_debug_wino_conv_fwd_xblk: unknown variant");
+  }
+  return df::launched("df_debug_wino_conv_fwd_xblk");
+}
 // The "bf16x3 in the Winograd domain" experiment (wino3d_kernel PREC = 1), tuning library only: same arguments as df_wino_pack_weights /
 // df_wino_conv_fwd.  df_debug_set_wino: 0 production order | 32 xi_x-major MFMA order | diagnosis variants (results wrong by construction)
 // 1 no transform | 2 no LDS operand reads | 4 no staging | 8 no weight loads and sums | 16 staged chunk stored one k-step later |
@@ -987,7 +1160,6 @@ int df_debug_wino_pack_weights_bf16x3(const float* w, float* wp, int64_t cin, in
                      (int)cout, mode, total);
   return df::launched("df_debug_wino_pack_weights_bf16x3");
 }
-static int64_t wino_grid(WinoArgs& a, int64_t ntb);
 int df_debug_wino_conv_fwd_bf16x3(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src, float* y,
                                   int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak,
                                   df_stream_t stream) {
@@ -1133,6 +1305,9 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 384: hipLaunchKernelGGL((wino3d_kernel<384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // staging loads confined to a 1 MB window (L2-resident, L1 misses)
     case 100: hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // production kernel, compile-time flags (baseline of the experiments)
     case (17 << 11): hipLaunchKernelGGL((wino3d_kernel<(17 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 262144: hipLaunchKernelGGL((wino3d_kernel<262144, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 524288: hipLaunchKernelGGL((wino3d_kernel<524288, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case (262144 | 4): hipLaunchKernelGGL((wino3d_kernel<(262144 | 4), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
 #endif
     default: return df::fail(DF_EINVAL, "df_wino_conv_fwd: unknown debug variant");
   }

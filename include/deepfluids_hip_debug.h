@@ -40,6 +40,13 @@ int df_debug_wino_pack_weights_bf16x3(const float* w, float* wp, int64_t cin, in
 int df_debug_wino_conv_fwd_bf16x3(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src, float* y,
                                   int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, void* stream);
 
+/* Round-4 probe (DESIGN.md 4.1b "x-blocked staging"): df_wino_conv_fwd(BIAS | LRELU) with the input staged by LDS-DMA from an x-blocked copy
+ * `xg` of x (df_debug_wino_xblk_elems floats; written by the call unless variant & 256).  variant & 15: 1 all waves issue the DMA pieces
+ * behind k-step 0's MFMAs, 3 only waves 4-7 (one per SIMD), 5 / 7 the same in front of the MFMAs; 19: variant 3 without any staging (timing). */
+int64_t df_debug_wino_xblk_elems(int64_t B, int64_t D, int64_t H, int64_t W, int64_t C);
+int df_debug_wino_conv_fwd_xblk(const float* x, float* xg, const float* wp, const float* bias, float* y, int64_t B, int64_t D, int64_t H, int64_t W,
+                                int64_t Cin, int64_t Cout, float leak, int variant, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
