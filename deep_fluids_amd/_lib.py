@@ -130,8 +130,10 @@ def use_tuning_library():
 
 
 def lib():
-    global _lib
+    global _lib, LIB_PATH
     if _lib is None:
+        if os.environ.get("DF_HIP_LIBRARY"):          # sanitizer runs only (tools/run_asan.sh): another BUILD of the same library
+            LIB_PATH = os.environ["DF_HIP_LIBRARY"]
         if not os.path.exists(LIB_PATH):
             raise DeepFluidsHipError(
                 "libdeepfluids_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "

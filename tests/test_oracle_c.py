@@ -10,7 +10,7 @@ import pytest
 import df_oracle as orc
 from conftest import ROOT
 
-LIB = os.path.join(ROOT, "oracle", "libdf_oracle.so")
+LIB = os.environ.get("DF_ORACLE_LIBRARY") or os.path.join(ROOT, "oracle", "libdf_oracle.so")      # (tools/run_asan.sh: the ASAN build)
 I64 = ctypes.c_int64
 
 
