@@ -39,6 +39,12 @@ SIGNATURES = {
     "df_lrelu_bwd": (I32, [P, P, P, F32, I64, P]),
     "df_add": (I32, [P, P, P, I64, P]),
     "df_upsample2x_fwd": (I32, [P, P, I64, I64, I64, I64, I64, I32, P]),
+    "df_conv_general_out_dims": (I32, [I64, I64, I64, I32, I32, I32, P, P, P]),
+    "df_conv_general_fwd": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, I32, I32, F32, P]),
+    "df_conv_general_dgrad": (I32, [P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, I32, P]),
+    "df_conv_general_wgrad": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, I32, P]),
+    "df_resize_nn_fwd": (I32, [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P]),
+    "df_resize_nn_bwd": (I32, [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P]),
     "df_upsample2x_bwd": (I32, [P, P, I64, I64, I64, I64, I64, I32, P]),
     "df_lrelu_bwd_pool2x": (I32, [P, P, P, P, F32, I64, I64, I64, I64, I64, I32, P]),
     "df_linear_workspace_bytes": (I64, [I64, I64, I64]),

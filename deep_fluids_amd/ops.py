@@ -893,6 +893,83 @@ class _Upsample2x(torch.autograd.Function):
         return gx
 
 
+class _ConvGeneral(torch.autograd.Function):
+    """slim.conv2d / conv3d with ANY cubic kernel and stride, TF 'SAME' on any extents (ops.py:12-16: the wrappers' own defaults are
+    k=4, s=2) -- the general-shape vector-ALU kernels of conv_general.hip.  The call sites of the reference's trainers (k=3, s=1|2, even
+    extents) never come here: they run on the matrix-core kernels (_ConvSame3 / _ConvSame3S2)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, leak, k, s):
+        x = _prep(x, "x"); w = _prep(w, "weights"); b = _prep(b, "biases")
+        nd = x.dim() - 2
+        kz = k if nd == 3 else 1
+        cin, cout = int(w.shape[-2]), int(w.shape[-1])
+        if tuple(w.shape[:-2]) != (k,) * nd or x.shape[-1] != cin:
+            raise ValueError("conv: weights %s do not match input %s / k=%d" % (tuple(w.shape), tuple(x.shape), k))
+        B = int(x.shape[0])
+        D = int(x.shape[1]) if nd == 3 else 1
+        H, W = int(x.shape[-3]), int(x.shape[-2])
+        od = [-(-D // s) if nd == 3 else 1, -(-H // s), -(-W // s)]
+        y = torch.empty((B,) + tuple(od[3 - nd:]) + (cout,), dtype=torch.float32, device=x.device)
+        flags = DF_CONV_BIAS | (DF_CONV_LRELU if leak is not None else 0)
+        _count("conv", "general-valu k%d s%d" % (k, s), (B, D, H, W), cin, cout)
+        call("df_conv_general_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, D, H, W, cin, cout, kz, k, s, flags,
+             float(leak if leak is not None else 0.0), _stream())
+        if ACTIVATION_FETCH is not None and leak is not None:
+            ACTIVATION_FETCH.append(y)
+        ctx.save_for_backward(x, w, y if leak is not None else None)
+        ctx.leak = leak
+        ctx.geom = (B, D, H, W, cin, cout, kz, k, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        B, D, H, W, cin, cout, kz, k, s = ctx.geom
+        gy = _prep(gy, "grad")
+        if ctx.leak is not None:
+            dp = torch.empty_like(gy)
+            call("df_lrelu_bwd", _ptr(gy), _ptr(y), _ptr(dp), float(ctx.leak), gy.numel(), _stream())
+        else:
+            dp = gy
+        gw = torch.empty_like(w)
+        gb = torch.empty(cout, dtype=torch.float32, device=x.device)
+        call("df_conv_general_wgrad", _ptr(x), _ptr(dp), _ptr(gw), _ptr(gb), B, D, H, W, cin, cout, kz, k, s, _stream())
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            call("df_conv_general_dgrad", _ptr(dp), _ptr(w), _ptr(gx), B, D, H, W, cin, cout, kz, k, s, _stream())
+        return gx, gw, gb, None, None, None
+
+
+class _ResizeNN(torch.autograd.Function):
+    """tf.image.resize_nearest_neighbor(align_corners=False) to ANY size per spatial axis (ops.py:66-73): src = min(floor(dst in / out), in - 1)."""
+
+    @staticmethod
+    def forward(ctx, x, new_size):
+        x = _prep(x, "x")
+        is3d = x.dim() == 5
+        B, C = int(x.shape[0]), int(x.shape[-1])
+        D = int(x.shape[1]) if is3d else 1
+        H, W = int(x.shape[-3]), int(x.shape[-2])
+        ns = [int(v) for v in new_size]
+        if len(ns) != (3 if is3d else 2) or min(ns) <= 0:
+            raise ValueError("resize: new_size %r does not match a %d-D tensor" % (new_size, x.dim()))
+        Do, Ho, Wo = (ns[0], ns[1], ns[2]) if is3d else (1, ns[0], ns[1])
+        y = _empty(((B, Do, Ho, Wo, C) if is3d else (B, Ho, Wo, C)), x)
+        call("df_resize_nn_fwd", _ptr(x), _ptr(y), B, D, H, W, C, Do, Ho, Wo, _stream())
+        ctx.geom = (B, D, H, W, C, Do, Ho, Wo, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, D, H, W, C, Do, Ho, Wo, shp = ctx.geom
+        gy = _prep(gy, "grad")
+        gx = _empty(shp, gy)
+        call("df_resize_nn_bwd", _ptr(gy), _ptr(gx), B, D, H, W, C, Do, Ho, Wo, _stream())
+        return gx, None
+
+
 class _Curl2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, psi):
@@ -1198,17 +1275,23 @@ def _act_leak(act):
 
 
 def _conv(x, o_dim, nd, data_format, name, k, s, act):
-    if k != 3 or s not in (1, 2):
-        raise NotImplementedError("deep_fluids_amd convs implement the generator / encoder call sites: k=3, s=1|2 "
-                                  "(model.py:26,42,68,84,127-143,163-179); got k=%d s=%d" % (k, s))
+    k, s = int(k), int(s)
+    if not (1 <= k <= 7 and 1 <= s <= 4):
+        raise ValueError("conv: kernel size 1..7 and stride 1..4 (got k=%d s=%d)" % (k, s))
     if nd == 2 and data_format == "NCHW":
         x = nchw_to_nhwc(x)
     cin = int(x.shape[-1])
     lname = _layer_name(name, "Conv")
-    w = get_variable(lname + "/weights", (3,) * nd + (cin, int(o_dim)), "xavier", x.device)
+    w = get_variable(lname + "/weights", (k,) * nd + (cin, int(o_dim)), "xavier", x.device)
     b = get_variable(lname + "/biases", (int(o_dim),), "zeros", x.device)
     leak, post = _act_leak(act)
-    y = (_ConvSame3 if s == 1 else _ConvSame3S2).apply(x, w, b, leak)
+    # the reference's own call sites (k=3; s=1, or s=2 on even extents: model.py:26,42,68,84,127-143,163-179) run on the matrix cores;
+    # every other (k, s, extent) of the wrapper (its defaults are k=4, s=2, ops.py:12-16) on the general-shape kernels
+    fast = k == 3 and (s == 1 or (s == 2 and not any(int(d) % 2 for d in x.shape[1:-1])))
+    if fast:
+        y = (_ConvSame3 if s == 1 else _ConvSame3S2).apply(x, w, b, leak)
+    else:
+        y = _ConvGeneral.apply(x, w, b, leak, k, s)
     if post is not None:
         y = post(y)
     if nd == 2 and data_format == "NCHW":
@@ -1217,7 +1300,7 @@ def _conv(x, o_dim, nd, data_format, name, k, s, act):
 
 
 def conv2d(x, o_dim, data_format="NHWC", name=None, k=4, s=2, act=None):
-    """ops.py:12-13 (slim.conv2d, SAME).  Implemented for the generator's k=3, s=1 call sites."""
+    """ops.py:12-13 (slim.conv2d, SAME; the wrapper's defaults k=4, s=2 included)."""
     return _conv(x, o_dim, 2, data_format, name, k, s, act)
 
 
@@ -1238,12 +1321,14 @@ def linear(x, o_dim, name=None, act=None):
 
 
 def resize_nearest_neighbor(x, new_size, data_format="NHWC"):
-    """ops.py:66-73, restricted to the exact 2x the reference uses."""
+    """ops.py:66-73 (tf.image.resize_nearest_neighbor, align_corners=False): any target size; the exact 2x of the reference's call sites
+    takes the vectorised kernel."""
     if data_format == "NCHW":
         x = nchw_to_nhwc(x)
-    if tuple(new_size) != (2 * x.shape[1], 2 * x.shape[2]):
-        raise NotImplementedError("resize_nearest_neighbor: exact 2x only (got %s -> %s)" % (tuple(x.shape[1:3]), tuple(new_size)))
-    y = _Upsample2x.apply(x)
+    if tuple(int(v) for v in new_size) == (2 * x.shape[1], 2 * x.shape[2]) and x.shape[-1] % 4 == 0:
+        y = _Upsample2x.apply(x)
+    else:
+        y = _ResizeNN.apply(x, tuple(int(v) for v in new_size))
     return nhwc_to_nchw(y) if data_format == "NCHW" else y
 
 
@@ -1254,10 +1339,14 @@ def upscale(x, scale, data_format="NHWC"):
 
 
 def upscale3(x, scale):
-    """ops.py:79-91: two 2-D nearest resizes == one 3-D nearest 2x (src = dst >> 1)."""
-    if scale != 2:
-        raise NotImplementedError("upscale3: scale 2 only (model.py:78)")
-    return _Upsample2x.apply(x)
+    """ops.py:79-91: two 2-D nearest resizes == one 3-D nearest resize by `scale` (src = dst // scale); scale 2 (model.py:78) takes the
+    vectorised kernel."""
+    scale = int(scale)
+    if scale == 2 and x.shape[-1] % 4 == 0:
+        return _Upsample2x.apply(x)
+    if scale < 1:
+        raise ValueError("upscale3: scale must be a positive integer")
+    return _ResizeNN.apply(x, tuple(int(d) * scale for d in x.shape[1:4]))
 
 
 def jacobian(x, data_format="NHCW"):

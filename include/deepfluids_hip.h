@@ -137,6 +137,28 @@ int df_lrelu_bwd_pool2x(const float* gy, const float* y, float* gx, float* gpool
 int df_upsample2x_bwd(const float* gy, float* gx, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int is_3d,
                       df_stream_t stream);
 
+/* ---- wrapper generality (conv_general.hip): the shapes of the reference's call surface that its trainers never use ------------------
+ * ops.py:12-16 `conv2d / conv3d(x, o_dim, k=4, s=2, act)` = slim.conv2d / conv3d, padding 'SAME', ANY cubic kernel 1 <= k <= 7 and stride
+ * 1 <= s <= 4, any extents (odd ones included): out = ceil(n / s), pad_total = max((out - 1) s + k - n, 0), pad_before = pad_total / 2.
+ * 2-D: D = 1, kz = 1; 3-D: kz = k.  Weights in the TF layout [kz, k, k, Cin, Cout] (no packing).  Plain vector-ALU kernels, fixed summation
+ * order: correct on every shape, not fast -- k = 3, s in {1, 2} on even extents take the matrix-core kernels above. */
+int df_conv_general_out_dims(int64_t D, int64_t H, int64_t W, int kz, int k, int s, int64_t* Do, int64_t* Ho, int64_t* Wo);
+/* y [B,Do,Ho,Wo,Cout] = conv(x [B,D,H,W,Cin], w) (+ bias) (+ lrelu);  flags: DF_CONV_BIAS | DF_CONV_LRELU. */
+int df_conv_general_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin,
+                        int64_t Cout, int kz, int k, int s, int flags, float leak, df_stream_t stream);
+/* gx [B,D,H,W,Cin] from gy [B,Do,Ho,Wo,Cout] (B, D, H, W = the INPUT extents of the forward conv). */
+int df_conv_general_dgrad(const float* gy, const float* w, float* gx, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz,
+                          int k, int s, df_stream_t stream);
+/* gw [kz,k,k,Cin,Cout] and gb [Cout] (gb may be NULL). */
+int df_conv_general_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin,
+                          int64_t Cout, int kz, int k, int s, df_stream_t stream);
+/* ops.py:66-73 `resize_nearest_neighbor(x, new_size)` = tf.image.resize_nearest_neighbor, align_corners=False, ANY target size:
+ * y[.., o, ..] = x[.., min(floor(o * in / out), in - 1), ..] per spatial axis (D = Do = 1 for 2-D); bwd = its adjoint in gather form. */
+int df_resize_nn_fwd(const float* x, float* y, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int64_t Do, int64_t Ho, int64_t Wo,
+                     df_stream_t stream);
+int df_resize_nn_bwd(const float* gy, float* gx, int64_t B, int64_t D, int64_t H, int64_t W, int64_t C, int64_t Do, int64_t Ho, int64_t Wo,
+                     df_stream_t stream);
+
 /* linear ops.py:23-24 (slim.fully_connected): y[B,N] = x[B,K] . w[K,N] + bias[N]  (bias may be NULL). */
 int64_t df_linear_workspace_bytes(int64_t B, int64_t K, int64_t N); /* > 0 only for the large-K/small-N split-K path */
 int df_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t K, int64_t N,

@@ -271,6 +271,30 @@ def upscale_nn(x, scale=2):
     return x
 
 
+def resize_nn(x, new_size):
+    """tf.image.resize_nearest_neighbor(x, new_size), align_corners=False, per spatial axis (ops.py:66-73; TF 1.15 absent: restated from
+    its documented index rule src = min(floor(dst * in / out), in - 1))."""
+    x = np.asarray(x)
+    for a, out in enumerate(new_size):
+        n = x.shape[1 + a]
+        idx = np.minimum((np.arange(out, dtype=np.int64) * n) // out, n - 1)
+        x = np.take(x, idx, axis=1 + a)
+    return x
+
+
+def resize_nn_bwd(g, in_shape):
+    """Adjoint of :func:`resize_nn`: scatter-add of g onto the source cells."""
+    g = np.asarray(g)
+    for a in reversed(range(g.ndim - 2)):
+        n, out = in_shape[1 + a], g.shape[1 + a]
+        idx = np.minimum((np.arange(out, dtype=np.int64) * n) // out, n - 1)
+        shp = list(g.shape); shp[1 + a] = n
+        acc = np.zeros(shp, g.dtype)
+        np.add.at(acc, (slice(None),) * (1 + a) + (idx,), g)
+        g = acc
+    return g
+
+
 def upscale_nn_bwd(g, scale=2):
     g = np.asarray(g)
     nd = g.ndim - 2

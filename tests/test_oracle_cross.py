@@ -160,3 +160,48 @@ def test_ae_gradients_numpy_vs_torch_fp64(xshape, filters, use_curl):
     np.testing.assert_allclose(info["u"], it["u"].numpy(), atol=1e-12)
     for k in p:
         np.testing.assert_allclose(info["grads"][k], it["grads"][k].numpy(), atol=1e-11, err_msg=k)
+
+
+@pytest.mark.parametrize("shape,cin,cout,k,s", [((2, 16, 12), 3, 5, 4, 2), ((1, 9, 7, 5), 2, 3, 3, 2), ((1, 11, 13), 3, 4, 2, 3), ((1, 3, 4), 1, 2, 7, 4),
+                                                ((1, 6, 5, 7), 2, 2, 5, 1)])
+def test_general_kernel_and_stride_same_conv_numpy_vs_torch(shape, cin, cout, k, s):
+    """The wrappers' generality (ops.py:12-16: any k, any stride, 'SAME'; defaults k=4, s=2): the NumPy oracle's TF-'SAME' rule
+    (out = ceil(n/s), pad_before = pad_total // 2) against explicit F.pad + F.conv*(stride) and autograd."""
+    import torch.nn.functional as F
+    rng = np.random.RandomState(k * 10 + s)
+    nd = len(shape) - 1
+    x = rng.randn(*shape, cin); w = rng.randn(*((k,) * nd), cin, cout) / k ** nd; b = rng.randn(cout)
+    ref = orc.conv_same(x, w, b, stride=s)
+    pads = []
+    for a in reversed(range(nd)):                       # F.pad takes the LAST axis first
+        n = shape[1 + a]
+        o = -(-n // s); pt = max((o - 1) * s + k - n, 0)
+        pads += [pt // 2, pt - pt // 2]
+    xt = torch.tensor(x, requires_grad=True); wt = torch.tensor(w, requires_grad=True); bt = torch.tensor(b, requires_grad=True)
+    perm_in = (0, nd + 1) + tuple(range(1, nd + 1))
+    xp = F.pad(xt.permute(*perm_in), pads)
+    wk = wt.permute(nd + 1, nd, *range(nd))
+    y = (F.conv3d if nd == 3 else F.conv2d)(xp, wk, bt, stride=s).permute(0, *range(2, nd + 2), 1)
+    np.testing.assert_allclose(y.detach().numpy(), ref, atol=1e-12)
+    go = rng.randn(*ref.shape)
+    (y * torch.tensor(go)).sum().backward()
+    dx, dw, db = orc.conv_same_bwd(x, w, go, stride=s)
+    np.testing.assert_allclose(xt.grad.numpy(), dx, atol=1e-12)
+    np.testing.assert_allclose(wt.grad.numpy(), dw, atol=1e-11)
+    np.testing.assert_allclose(bt.grad.numpy(), db, atol=1e-11)
+
+
+@pytest.mark.parametrize("shape,new", [((2, 5, 7, 3), (11, 4)), ((1, 4, 4, 2), (12, 12)), ((1, 3, 4, 5, 2), (7, 4, 13))])
+def test_resize_nearest_numpy_vs_torch_legacy_nearest(shape, new):
+    """tf.image.resize_nearest_neighbor(align_corners=False) restated (src = floor(dst in / out)) against torch's legacy 'nearest'
+    interpolation, which uses the same index rule, and its autograd."""
+    import torch.nn.functional as F
+    rng = np.random.RandomState(3)
+    x = rng.randn(*shape)
+    nd = len(shape) - 2
+    xt = torch.tensor(x, requires_grad=True)
+    y = F.interpolate(xt.permute(0, nd + 1, *range(1, nd + 1)), size=new, mode="nearest").permute(0, *range(2, nd + 2), 1)
+    np.testing.assert_array_equal(y.detach().numpy(), orc.resize_nn(x, new))
+    go = rng.randn(*y.shape)
+    (y * torch.tensor(go)).sum().backward()
+    np.testing.assert_allclose(xt.grad.numpy(), orc.resize_nn_bwd(go, x.shape), atol=1e-12)
