@@ -279,7 +279,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   constexpr int XROWB = 51 * 16, XROWS = 60;        // XS: bytes per LDS row (3 pieces x 17 slots x 16 B), halo rows per chunk (6 planes x 10)
   constexpr int BUFk = XB ? XROWS * XROWB / 4 : CKW * CPk;
   constexpr int BUFF = BX ? BBUF / 4 : BUFk;      // floats per LDS buffer
-  __shared__ __attribute__((aligned(16))) float sIn[2 * BUFF];
+  // (experiment XS & 128: THREE staging buffers -- the pieces of chunk c + 2 are issued at the start of chunk c and waited for at the end of
+  //  chunk c + 1: ~7 k-steps of slack instead of 2-3)
+  constexpr bool TRI = (XS & 128) != 0;
+  constexpr int NSB = TRI ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) float sIn[NSB * BUFF];
   __shared__ float sBias[32];        // this worker's cout slice of the bias (the slice is fixed for the worker's whole life)
   // lrelu-mask operands of a tile block's outputs, fetched by LDS-DMA loads (no registers); PREC = 1: behind the epilogue's exchange area in
   // the idle input buffer (32 + 32 of its 75.5 KB)
@@ -410,7 +414,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(dsrd, (lds_ptr)(sInB + bufbytes + r * XROWB), 16, vo, soff, 0, 0);
     };
     if (lane < 51) {
-      if constexpr ((XS & 8) != 0) {      // unrolled: the compiler counts the pieces in its vmcnt waits (a rolled loop makes it assume none were issued)
+      if constexpr (TRI) {        // exactly 8 pieces per wave (the surplus one of waves 4-7 repeats row 59): the chunk-end wait counts on it
+        static_assert(!TRI || !XASYM, "three staging buffers: symmetric issue only");
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) { const int r0 = wave + 8 * j; one_row(r0 < XROWS ? r0 : XROWS - 1); }
+      } else if constexpr ((XS & 8) != 0) {      // unrolled: the compiler counts the pieces in its vmcnt waits (a rolled loop makes it assume none were issued)
         int w0 = XASYM ? wave - 4 : wave;
 #pragma unroll
         for (int j = 0; j < (XASYM ? 15 : 8); ++j) {
@@ -625,7 +633,8 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     stage_store_b(0, stz);
   } else if constexpr (XB) {
     issue_dma(0, cur, 0u);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (TRI) { issue_dma(BUFk * 4, cur, 256u); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     set_offs(cur);
     const __amdgpu_buffer_rsrc_t srd0 = make_srd(cur.xb, vol_bytes);
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       issue_bw(0, 0, 0);
       if (!half) issue_bw(1, 0, 0);
     } else {
-      if constexpr (XB) raw_read_x(pb * BUFk * 4); else raw_read(pb * BUFk * 4);
+      if constexpr (XB) raw_read_x(pb * BUFk * 4); else raw_read(pb * BUFk * 4);      // (TRI: pb = chunk counter mod 3)
       // [r3] the weights of k-step 0 are the same for every tile block of the worker and the last k-step of a block has already reloaded
       // them (issue_b / reload_row wrap around): they stay in their registers across the epilogue (16.13 -> 16.05 ms per top-level
       // launch; tuning variant 65536 = reloaded at every block start)
@@ -683,10 +692,16 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(msrd, (lds_ptr)(sM + (n2 * 8 + s) * kT + wave * 64), 4, mv, so_, 0, 0);
         }
     };
-    auto main_loop = [&](auto half_c) {
+    auto main_loop = [&](auto half_c, auto lw_c) {
     constexpr bool HALF = decltype(half_c)::value;      // this wave owns one 16-cout block only (acc[0], weights of block hnb)
+    // (experiment XS & 64, timing only: this copy of the loop -- taken by waves 4-7 -- reads its "weights" from LDS (whatever is there) instead of
+    //  global memory: the vmcnt queue of the waves that stage (4-7 with XS & 2) then holds the staging pieces only -- what a design in which
+    //  the weights arrive through an LDS ring would give them; the ring's own fill traffic is not modelled)
+    constexpr bool LW = decltype(lw_c)::value;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-      const int bo = ((chunk + pb) & 1) * BUFk * 4, bn = BUFk * 4 - bo;      // byte offsets of this / the other buffer
+      const int bo = TRI ? ((chunk + pb) % 3) * BUFk * 4 : ((chunk + pb) & 1) * BUFk * 4;      // byte offsets of this / the next chunk's buffer
+      const int bn = TRI ? ((chunk + 1 + pb) % 3) * BUFk * 4 : BUFk * 4 - bo;
+      const int bn2 = ((chunk + 2 + pb) % 3) * BUFk * 4;                                       // TRI: where the pieces of chunk + 2 go
       const bool lastc = chunk + 1 == nchunk;
       if constexpr (!XB) {
         if (lastc) set_offs(nxt);                    // the last chunk stages the next tile block's first chunk
@@ -700,7 +715,12 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         const unsigned long long q0 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (DBG & 16) asm volatile("s_waitcnt lgkmcnt(0)");
         const unsigned long long q1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
-        if (XB && (XS & 16) && ks == 0 && !(DBG & 4)) { issue_dma(bn, lastc ? nxt : cur, schunk); __builtin_amdgcn_sched_barrier(0); }
+        if (XB && TRI && ks == 0 && !(DBG & 4)) {
+          const int cc = chunk + 2;
+          issue_dma(bn2, cc < nchunk ? cur : nxt, static_cast<unsigned>(cc < nchunk ? cc : cc - nchunk) * 256u);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (XB && !TRI && (XS & 16) && ks == 0 && !(DBG & 4)) { issue_dma(bn, lastc ? nxt : cur, schunk); __builtin_amdgcn_sched_barrier(0); }
         if (!(DBG & 1)) transform();
         __builtin_amdgcn_sched_barrier(0);
         if (!XB && ks == 2 && !(DBG & 4) && !(DBG & 64)) {
@@ -709,8 +729,9 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         }
         // XS: the DMA pieces of the next chunk have landed once at most the 8 (4) weight reloads of k-step 2 are outstanding behind them
         if (XB && ks == 3) {      // (every wave: one that issued no pieces has only those reloads outstanding and does not wait)
-          constexpr int NWL = (P27 ? 3 : 4) * (HALF ? 1 : 2) * NBQ;      // weight loads issued behind the pieces and not yet consumed
-          if constexpr (NWL == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          constexpr int NWL = (LW ? 0 : (P27 ? 3 : 4) * (HALF ? 1 : 2) * NBQ) + (TRI ? 8 : 0);      // loads issued behind the pieces that must have landed
+          if constexpr (NWL == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if constexpr (NWL == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
           else if constexpr (NWL == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
           else if constexpr (NWL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
           else if constexpr (NWL == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -732,7 +753,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           if constexpr (XB) raw_read_x(ks < 3 ? bo + (ks + 1) * 64 : bn); else raw_read(ks < 3 ? bo + (ks + 1) * 16 * CPk : bn);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (XB && (XS & 20) == 4 && ks == 0 && !(DBG & 4)) { issue_dma(bn, lastc ? nxt : cur, schunk); __builtin_amdgcn_sched_barrier(0); }
+        if (XB && !TRI && (XS & 20) == 4 && ks == 0 && !(DBG & 4)) { issue_dma(bn, lastc ? nxt : cur, schunk); __builtin_amdgcn_sched_barrier(0); }
         const unsigned long long q2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (DBG & 16) asm volatile("s_waitcnt vmcnt(4)");
         const unsigned long long q3 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
@@ -746,7 +767,8 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           const int k4 = chunk * 4 + ks + NBQ;
           const int kl = k4 < nk4 ? k4 : k4 - nk4;      // wraps to the first k-step(s) of the next tile block
           const unsigned sb = wbase_b + static_cast<unsigned>(kl) * 8192u + nb * 4096u;
-          bq[ks & (NBQ - 1)][nb][q] = buf_load16(wsrd, laneb + q * 1024u, sb);
+          if constexpr (LW) bq[ks & (NBQ - 1)][nb][q] = *reinterpret_cast<const f32x4*>(sInB + bo + (nb * 4 + q) * 1024 + lane * 16);
+          else bq[ks & (NBQ - 1)][nb][q] = buf_load16(wsrd, laneb + q * 1024u, sb);
         };
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -769,7 +791,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         }
         if (DBG & 32) __builtin_amdgcn_s_setprio(0);
         if (!HALF && !(DBG & 8) && !ROWRELOAD) issue_b(1, chunk * 4 + ks + 1);
-        if (XB && !(XS & 20) && ks == 0 && !(DBG & 4)) issue_dma(bn, lastc ? nxt : cur, schunk);
+        if (XB && !TRI && !(XS & 20) && ks == 0 && !(DBG & 4)) issue_dma(bn, lastc ? nxt : cur, schunk);
         if (!XB && ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
                                          // the first wait that covers them is the one for the NEXT weight batch (1.5 k-steps away)
 #pragma unroll
@@ -864,7 +886,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     if constexpr (BX) {
       if (half) main_loop_b(std::true_type{}); else main_loop_b(std::false_type{});
     } else {
-      if (half) main_loop(std::true_type{}); else main_loop(std::false_type{});
+      if constexpr ((XS & 64) != 0) {
+        main_loop(std::false_type{}, std::true_type{});      // (every wave: a single copy of the loop -- two copies in one kernel spill 150-250 B)
+      } else {
+        if (half) main_loop(std::true_type{}, std::false_type{}); else main_loop(std::false_type{}, std::false_type{});
+      }
     }
 
     const unsigned long long tp2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
@@ -899,7 +925,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         if (DBG & 16384) __syncthreads(); else lds_barrier();
       }
     } else {
-      const int lb = ((nchunk - 1 + pb) & 1) * BUFF;
+      const int lb = TRI ? ((nchunk - 1 + pb) % 3) * BUFF : ((nchunk - 1 + pb) & 1) * BUFF;
       const float* const sM = BX ? sIn + lb + 8192 : sMs;
       f32x4* sO = reinterpret_cast<f32x4*>(sIn + lb);      // [xi_z][tz][e][lane] float4 = (oy0ox0, oy0ox1, oy1ox0, oy1ox1)
       // this wave combines accumulator element e = xi_z of its own z-row:  tile (ty = lane>>4, tx = e), cout = lane & 15
@@ -1006,7 +1032,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       g_wino_prof[0] += tp1 - tp0; g_wino_prof[1] += tp2 - tp1; g_wino_prof[2] += tp3 - tp2; g_wino_prof[3] += 1;
       for (int i = 0; i < 8; ++i) g_wino_prof[4 + i] += ph[i];
     }
-    pb = (pb + nchunk) & 1;
+    pb = TRI ? (pb + nchunk) % 3 : (pb + nchunk) & 1;
     cur = nxt;
   }
 }
@@ -1141,6 +1167,14 @@ int df_debug_wino_conv_fwd_xblk(const float* x, float* xg, const float* wp, cons
     case 32 + 17: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 49>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
     case 32 + 31: hipLaunchKernelGGL((wino3d_kernel<4, F, 0, 0, 33>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
     case 3 + 64: hipLaunchKernelGGL((wino3d_kernel<4, F, 0, 0, 3>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 98: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 128 + 64 + 1>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;                 // three buffers + LDS "weights"
+    case 102: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 128 + 1>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;                     // three buffers, global weights
+    case 64 + 32 + 1: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 64 + 1>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;            // all waves stage, LDS "weights"
+    case 64 + 32 + 17: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 64 + 17>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 64 + 32 + 4: hipLaunchKernelGGL((wino3d_kernel<4, F, 0, 0, 64 + 3>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;            // no staging, LDS "weights"
+    case 64 + 32 + 3: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 64 + 3>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;            // waves 4-7 stage (behind the MFMAs, rolled) and take LDS "weights"
+    case 64 + 32 + 19: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 64 + 19>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;          // ... pieces at the start of k-step 0
+    case 64 + 32 + 7: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 64 + 7>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;            // ... in front of the MFMAs
     default: return df::fail(DF_EINVAL, "df_debug_wino_conv_fwd_xblk: unknown variant");
   }
   return df::launched("df_debug_wino_conv_fwd_xblk");
