@@ -619,6 +619,10 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 
   f32x4 acc[2][16];
   const int nchunk = a.Cin / CKW;
+  // (experiments 1048576 / 2097152: the 5 staging loads of a thread are not issued as one burst behind k-step 0's MFMAs -- all 8 waves at the same
+  //  moment: 40 instructions of 16 lines each into the CU's vector-memory path -- but ONE per MFMA row, behind that row's weight reload, during
+  //  k-step 1 (stores just before the chunk barrier) / during k-step 0 (stores in k-step 2 as in production))
+  constexpr bool SPREAD1 = (DBG & 1048576) != 0, SPREAD0 = (DBG & 2097152) != 0, SPREAD = SPREAD1 || SPREAD0;
   constexpr bool SPLITSTG = (DBG & 196608) == 131072;      // (experiment 131072: staging in two batches -- 3 pieces loaded behind k-step 0 and
                                                             //  written in k-step 2, 2 pieces loaded behind k-step 1 and written in k-step 3)      // (experiment: static priority for the later-dispatched half)
 
@@ -723,7 +727,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         if (XB && !TRI && (XS & 16) && ks == 0 && !(DBG & 4)) { issue_dma(bn, lastc ? nxt : cur, schunk); __builtin_amdgcn_sched_barrier(0); }
         if (!(DBG & 1)) transform();
         __builtin_amdgcn_sched_barrier(0);
-        if (!XB && ks == 2 && !(DBG & 4) && !(DBG & 64)) {
+        if (!XB && ks == (SPREAD1 ? 3 : 2) && !(DBG & 4) && !(DBG & 64)) {
 #pragma unroll
           for (int it = 0; it < (SPLITSTG ? 3 : NLOAD); ++it) stage_store(it, bn, stg[it]);
         }
@@ -774,7 +778,12 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         for (int i = 0; i < 16; ++i) {
           if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
             acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[ks & (NBQ - 1)][0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
-          if (ROWRELOAD && (i & 3) == 3) { __builtin_amdgcn_sched_barrier(0); reload_row(0, i >> 2); __builtin_amdgcn_sched_barrier(0); }
+          if (ROWRELOAD && (i & 3) == 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            reload_row(0, i >> 2);
+            if (!XB && SPREAD && ks == (SPREAD1 ? 1 : 0) && !(DBG & 4)) stg[i >> 2] = stage_load(i >> 2, ssrd, schunk);      // pieces 0..3
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         static_assert(NBQ == 1 || ROWRELOAD, "two weight sets: row reload only");
@@ -785,14 +794,19 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           for (int i = 0; i < 16; ++i) {
             if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
               acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[ks & (NBQ - 1)][1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
-            if (ROWRELOAD && (i & 3) == 3) { __builtin_amdgcn_sched_barrier(0); reload_row(1, i >> 2); __builtin_amdgcn_sched_barrier(0); }
+            if (ROWRELOAD && (i & 3) == 3) {
+              __builtin_amdgcn_sched_barrier(0);
+              reload_row(1, i >> 2);
+              if (!XB && SPREAD && ks == (SPREAD1 ? 1 : 0) && !(DBG & 4) && (i >> 2) == 1) stg[4] = stage_load(4, ssrd, schunk);      // piece 4
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
         if (DBG & 32) __builtin_amdgcn_s_setprio(0);
         if (!HALF && !(DBG & 8) && !ROWRELOAD) issue_b(1, chunk * 4 + ks + 1);
         if (XB && !TRI && !(XS & 20) && ks == 0 && !(DBG & 4)) issue_dma(bn, lastc ? nxt : cur, schunk);
-        if (!XB && ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
+        if (!XB && !SPREAD && ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
                                          // the first wait that covers them is the one for the NEXT weight batch (1.5 k-steps away)
 #pragma unroll
           for (int it = 0; it < (SPLITSTG ? 3 : NLOAD); ++it) stg[it] = (DBG & 384) == 128 ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
@@ -1112,7 +1126,7 @@ constexpr int g_wino_spx = 0;
 extern "C" {
 
 #ifdef DF_TUNING
-void df_debug_set_wino(int v) { g_wino_dbg = v & 0x3fffff; g_wino_spx = v >> 22; }
+void df_debug_set_wino(int v) { g_wino_dbg = v & 0xffffff; g_wino_spx = v >> 24; }
 int df_debug_wino_prof(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_prof), z, sizeof(z)); }
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_prof), 32 * sizeof(unsigned long long));
@@ -1339,6 +1353,8 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 384: hipLaunchKernelGGL((wino3d_kernel<384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // staging loads confined to a 1 MB window (L2-resident, L1 misses)
     case 100: hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // production kernel, compile-time flags (baseline of the experiments)
     case (17 << 11): hipLaunchKernelGGL((wino3d_kernel<(17 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 1048576: hipLaunchKernelGGL((wino3d_kernel<1048576, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
+    case 2097152: hipLaunchKernelGGL((wino3d_kernel<2097152, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 262144: hipLaunchKernelGGL((wino3d_kernel<262144, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 524288: hipLaunchKernelGGL((wino3d_kernel<524288, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case (262144 | 4): hipLaunchKernelGGL((wino3d_kernel<(262144 | 4), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
