@@ -21,6 +21,18 @@
 //     a lane needs 8 coalesced 16-byte global loads per k-step (L2 / L1 hits: the two tz waves read the same words).
 //   * epilogue: inverse transform in y,x in registers, the four xi_z partial planes are combined through the idle LDS
 //     buffer, then bias / lrelu / residual / lrelu-mask as in conv.hip.  The dgrad is the same kernel on mode-1 weights.
+//
+// Compile-time switches of wino3d_kernel.  The release library instantiates DBG = 0, PREC = 0, XS = 0 only (FL = the epilogue, MODE = plain /
+// up-sampling-aware / pooled); everything else exists in the -DDF_TUNING library for tools/wino_diag.py, wino_probe.py, wino_xblk_probe.py:
+//   DBG bits (diagnosis: results wrong by construction unless noted)   1 no input transform | 2 no raw LDS reads | 4 no staging | 8 no weight loads |
+//     16 per-phase cycle counters (correct results) | 64 staging loads kept alive, no LDS writes | 128 staged zeros (LDS writes only) |
+//     256 staging loads read an always-cached address | 384 ... confined to a 1 MB L2-resident window | 512 no output stores |
+//     262144 / 524288 weight loads of the z-row-1 waves / of all waves through a zero-length descriptor |
+//     1048576 / 2097152 (correct results) staging loads one per MFMA row during k-step 1 / 0 instead of one burst
+//   XS bits (round-4 probe, correct results unless noted): 1 LDS-DMA staging from the x-blocked copy | 2 waves 4-7 issue | 4 in front of k-step 0's
+//     MFMAs | 8 unrolled issue | 16 at the start of k-step 0 | 32 two weight register sets | 64 "weights" from LDS (timing only) | 128 three buffers
+//   PREC 1: bf16x3 in the Winograd domain (round 3).   The switches of rounds 1-3 whose experiments were negative (cache policies, chunk-pair
+//   permutation, split staging, reload orders, full barriers, setprio) were removed in round 4; their numbers are in profiles/LAB_NOTES.md.
 #include <type_traits>
 #include "df_common.hpp"
 #include "conv_args.hpp"
@@ -43,7 +55,6 @@ constexpr int PY = 12, PZ = 144;          // LDS pitches (dwords) of a channel p
 constexpr int CP = 866;                   // dwords per channel plane (6*144 = 864, +2: staging writes spread over banks)
 constexpr int HY = 10, HX = 10, HV = 600; // halo block 6 x 10 x 10
 constexpr int NLOAD = 5;                  // ceil(600 * 4 float4 pieces / 512 threads)
-constexpr int BUF = CKW * CP;             // dwords per LDS buffer
 // internal epilogue flags (beyond the public DF_CONV_*), part of the compile-time FL of the specialised instantiations:
 //   kSignBits: also emit the sign pattern of the output, one byte per lane and cout block holding the signs of the lane's 8 outputs
 //              (what a later masked dgrad of the same geometry needs of it: 1/32 of the activation's bytes);
@@ -227,11 +238,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* p, unsign
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-// the same with a cache-policy operand (gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1)
-template <int AUX>
-__device__ __forceinline__ f32x4 buf_load16_aux(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
-}
 
 // Barrier that orders LDS traffic only.  __syncthreads() is a full fence: its s_waitcnt vmcnt(0) also waits for the acknowledgement of
 // every global STORE issued before it -- in the epilogue that exposed two HBM write round trips per tile block.
@@ -381,8 +387,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   };
   auto stage_load = [&](int it, __amdgpu_buffer_rsrc_t srd, unsigned chunkbytes) -> f32x4 {
     if ((DBG & 384) == 256) return buf_load16(wsrd_dbg, static_cast<unsigned>(lane) * 16u, 0u);      // always-cached address (latency experiment)
-    constexpr int SAUX = (DBG >> 11) & 31;      // (experiment: cache policy of the staging loads)
-    return buf_load16_aux<SAUX>(srd, so[it], chunkbytes);
+    return buf_load16(srd, so[it], chunkbytes);
   };
   char* sInB = reinterpret_cast<char*>(sIn);
   auto stage_store = [&](int it, int bufbytes, const f32x4& v) {
@@ -391,7 +396,6 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   };
 
   // ---- XS staging: DMA instruction = halo row r = hz * 10 + hy; lane = (piece g, slot c), 51 of 64 lanes active -------------------------
-  constexpr int NXM = XASYM ? 15 : 8;           // rows per issuing wave
   const bool xissuer = XB && (!XASYM || wave >= 4);
   const int xg = lane / 17, xc = lane - xg * 17;
   const unsigned xvoff = (lane < 51 && xc < 16) ? static_cast<unsigned>((xg * a.Cin + xc) * 16) : 0x80000000u;      // pad slot: zeros
@@ -555,13 +559,9 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   //  -- same instructions, no cache traffic: what the DUPLICATE weight stream of the two z-row waves costs the CU's vector-memory path)
   const __amdgpu_buffer_rsrc_t wsrd = make_srd(a.wp, ((DBG & 524288) || ((DBG & 262144) && th == 1)) ? 0u : static_cast<unsigned>(a.Cin) * a.Cout * 256u);
   const unsigned wbase_b = static_cast<unsigned>((cs * 4 + mz) * nk4) * 8192u + static_cast<unsigned>(hnb) * 4096u;
-  // (experiment, DBG & 1024) odd cout slices walk the 16-channel chunks pairwise swapped (1,0,3,2,...): the two slices that share an XCD
-  // then request the two 64-byte halves of each 128-byte line of the input at the same time
-  const int cperm = ((DBG & 1024) && ((a.Cin / CKW) & 1) == 0) ? (cs & 1) : 0;
   auto issue_b = [&](int nb, int k4) {
     const int kl = k4 < nk4 ? k4 : 0;        // wraps to the first k-step of the next tile block
-    const int k2 = (((kl >> 2) ^ cperm) << 2) | (kl & 3);
-    const unsigned sb = wbase_b + static_cast<unsigned>(k2) * 8192u + nb * 4096u;      // wave-uniform
+    const unsigned sb = wbase_b + static_cast<unsigned>(kl) * 8192u + nb * 4096u;      // wave-uniform
 #pragma unroll
     for (int q = 0; q < 4; ++q) bq[0][nb][q] = buf_load16(wsrd, laneb + q * 1024u, sb);
   };
@@ -623,8 +623,6 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   //  moment: 40 instructions of 16 lines each into the CU's vector-memory path -- but ONE per MFMA row, behind that row's weight reload, during
   //  k-step 1 (stores just before the chunk barrier) / during k-step 0 (stores in k-step 2 as in production))
   constexpr bool SPREAD1 = (DBG & 1048576) != 0, SPREAD0 = (DBG & 2097152) != 0, SPREAD = SPREAD1 || SPREAD0;
-  constexpr bool SPLITSTG = (DBG & 196608) == 131072;      // (experiment 131072: staging in two batches -- 3 pieces loaded behind k-step 0 and
-                                                            //  written in k-step 2, 2 pieces loaded behind k-step 1 and written in k-step 3)      // (experiment: static priority for the later-dispatched half)
 
   // ---- prologue: first block's chunk 0 -> buffer 0 ------------------------------------------------------------------------------
   BlockInfo cur = decode(seq(0));
@@ -644,7 +642,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const __amdgpu_buffer_rsrc_t srd0 = make_srd(cur.xb, vol_bytes);
     f32x4 stg[NLOAD];
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, srd0, static_cast<unsigned>(cperm) * (CKW * 4u));
+    for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, srd0, 0u);
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) stage_store(it, 0, stg[it]);
   }
@@ -668,7 +666,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       // [r3] the weights of k-step 0 are the same for every tile block of the worker and the last k-step of a block has already reloaded
       // them (issue_b / reload_row wrap around): they stay in their registers across the epilogue (16.13 -> 16.05 ms per top-level
       // launch; tuning variant 65536 = reloaded at every block start)
-      if (it == 0 || (DBG & 196608) == 65536) {
+      if (it == 0) {
         issue_b(0, 0);
         if (!half) issue_b(1, 0);
         if (NBQ == 2) { issue_b1(0); if (!half) issue_b1(1); }
@@ -711,7 +709,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         if (lastc) set_offs(nxt);                    // the last chunk stages the next tile block's first chunk
       }
       const __amdgpu_buffer_rsrc_t ssrd = make_srd(lastc ? nxt.xb : cur.xb, vol_bytes);
-      const unsigned schunk = XB ? static_cast<unsigned>(lastc ? 0 : chunk + 1) * 256u : static_cast<unsigned>((lastc ? 0 : chunk + 1) ^ cperm) * (CKW * 4u);
+      const unsigned schunk = XB ? static_cast<unsigned>(lastc ? 0 : chunk + 1) * 256u : static_cast<unsigned>(lastc ? 0 : chunk + 1) * (CKW * 4u);
       f32x4 stg[XB ? 1 : NLOAD];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -729,7 +727,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (!XB && ks == (SPREAD1 ? 3 : 2) && !(DBG & 4) && !(DBG & 64)) {
 #pragma unroll
-          for (int it = 0; it < (SPLITSTG ? 3 : NLOAD); ++it) stage_store(it, bn, stg[it]);
+          for (int it = 0; it < NLOAD; ++it) stage_store(it, bn, stg[it]);
         }
         // XS: the DMA pieces of the next chunk have landed once at most the 8 (4) weight reloads of k-step 2 are outstanding behind them
         if (XB && ks == 3) {      // (every wave: one that issued no pieces has only those reloads outstanding and does not wait)
@@ -741,18 +739,14 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           else if constexpr (NWL == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         }
-        if (SPLITSTG && ks == 3) {
-#pragma unroll
-          for (int it = 3; it < NLOAD; ++it) stage_store(it, bn, stg[it]);
-        }
         if (ks == 2 && (DBG & 64)) {       // keep the loads alive without the LDS writes
 #pragma unroll
           for (int it = 0; it < NLOAD; ++it) asm volatile("" :: "v"(stg[it]));
         }
         // next chunk staged by everyone; everyone is done reading the planes it overwrote.  [r3] An LDS-only barrier: the staged data was
         // already waited for at the LDS writes of ks == 2, and __syncthreads()' vmcnt(0) drained the weight loads in flight (this and the
-        // two epilogue barriers: 16.21 -> 16.05 ms per top-level launch; tuning variant 16384 = full barriers)
-        if (ks == 3) { if (DBG & 16384) __syncthreads(); else lds_barrier(); }
+        // two epilogue barriers: 16.21 -> 16.05 ms per top-level launch, round 3)
+        if (ks == 3) lds_barrier();
         if (!(DBG & 2)) {                                                    // raw inputs of the next k-step
           if constexpr (XB) raw_read_x(ks < 3 ? bo + (ks + 1) * 64 : bn); else raw_read(ks < 3 ? bo + (ks + 1) * 16 * CPk : bn);
         }
@@ -761,11 +755,9 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         const unsigned long long q2 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (DBG & 16) asm volatile("s_waitcnt vmcnt(4)");
         const unsigned long long q3 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
-        if (DBG & 32) __builtin_amdgcn_s_setprio(3);
         // [r3] a xi_y row's weight registers are reloaded right after its 4 MFMAs, not after the cout block's 16: every weight load is in
         // flight up to 12 MFMAs longer before the next k-step needs it (16.52 -> 16.27 ms per top-level launch; tuning variant 196608 = the
         // old order)
-        constexpr bool ROWRELOAD = (DBG & 196608) != 196608;
         auto reload_row = [&](int nb, int q) {
           if ((DBG & 8) || (P27 && q == 2)) return;
           const int k4 = chunk * 4 + ks + NBQ;
@@ -778,7 +770,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         for (int i = 0; i < 16; ++i) {
           if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
             acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[ks & (NBQ - 1)][0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
-          if (ROWRELOAD && (i & 3) == 3) {
+          if ((i & 3) == 3) {
             __builtin_amdgcn_sched_barrier(0);
             reload_row(0, i >> 2);
             if (!XB && SPREAD && ks == (SPREAD1 ? 1 : 0) && !(DBG & 4)) stg[i >> 2] = stage_load(i >> 2, ssrd, schunk);      // pieces 0..3
@@ -786,15 +778,13 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        static_assert(NBQ == 1 || ROWRELOAD, "two weight sets: row reload only");
-        if (!(DBG & 8) && !ROWRELOAD) issue_b(0, chunk * 4 + ks + 1);       // weights of the next k-step, as each register block frees up
         __builtin_amdgcn_sched_barrier(0);
         if (!HALF) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
               acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[ks & (NBQ - 1)][1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
-            if (ROWRELOAD && (i & 3) == 3) {
+            if ((i & 3) == 3) {
               __builtin_amdgcn_sched_barrier(0);
               reload_row(1, i >> 2);
               if (!XB && SPREAD && ks == (SPREAD1 ? 1 : 0) && !(DBG & 4) && (i >> 2) == 1) stg[4] = stage_load(4, ssrd, schunk);      // piece 4
@@ -803,17 +793,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (DBG & 32) __builtin_amdgcn_s_setprio(0);
-        if (!HALF && !(DBG & 8) && !ROWRELOAD) issue_b(1, chunk * 4 + ks + 1);
         if (XB && !TRI && !(XS & 20) && ks == 0 && !(DBG & 4)) issue_dma(bn, lastc ? nxt : cur, schunk);
         if (!XB && !SPREAD && ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
                                          // the first wait that covers them is the one for the NEXT weight batch (1.5 k-steps away)
 #pragma unroll
-          for (int it = 0; it < (SPLITSTG ? 3 : NLOAD); ++it) stg[it] = (DBG & 384) == 128 ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
-        }
-        if (SPLITSTG && ks == 1) {
-#pragma unroll
-          for (int it = 3; it < NLOAD; ++it) stg[it] = stage_load(it, ssrd, schunk);
+          for (int it = 0; it < NLOAD; ++it) stg[it] = (DBG & 384) == 128 ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (DBG & 16) {
@@ -932,11 +916,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         };
         if (!half) emit(acc[nb]);
         else if (nb == hnb) emit(acc[0]);
-        if (DBG & 16384) __syncthreads(); else lds_barrier();
+        lds_barrier();
         const float m0 = sP[((0 * 2 + th) * 4 + xz) * 64 + lane], m1 = sP[((1 * 2 + th) * 4 + xz) * 64 + lane];
         const float m3 = sP[((3 * 2 + th) * 4 + xz) * 64 + lane];
         if (inb) yo[nb * 16] = prev + (m0 + 2.f * m1 - m3);
-        if (DBG & 16384) __syncthreads(); else lds_barrier();
+        lds_barrier();
       }
     } else {
       const int lb = TRI ? ((nchunk - 1 + pb) % 3) * BUFF : ((nchunk - 1 + pb) & 1) * BUFF;
@@ -951,7 +935,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       constexpr bool SB = FL >= 0 && (FL & kSignBits) != 0, MB = FL >= 0 && (FL & kMaskBits) != 0, NOY = FL >= 0 && (FL & kNoPrimary) != 0;
       if (full && (eflags & DF_CONV_MASK) && !MB) mask_dma();
       // the fp32-mask DMA path counts on vmcnt(8) with nothing but its own loads outstanding: keep the draining barriers there
-      const bool full_bar = (DBG & 16384) != 0 || ((eflags & DF_CONV_MASK) && !MB);
+      const bool full_bar = (eflags & DF_CONV_MASK) && !MB;
       const int64_t wbase = (static_cast<int64_t>(cur.id) * a.ncs + cs) * kBitBytesPerBlock + wave * 128 + lane;
       float rres[2][8];
 #pragma unroll
@@ -1320,16 +1304,12 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 2: hipLaunchKernelGGL((wino3d_kernel<2, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 3: hipLaunchKernelGGL((wino3d_kernel<3, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 7: hipLaunchKernelGGL((wino3d_kernel<7, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 32: hipLaunchKernelGGL((wino3d_kernel<32, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 272: hipLaunchKernelGGL((wino3d_kernel<272, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 16:      // cycle profile (df_debug_wino_prof) of the SPECIALISED epilogues where they exist
       if (flags == (DF_CONV_BIAS | DF_CONV_LRELU)) hipLaunchKernelGGL((wino3d_kernel<16, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
       else if (flags == DF_CONV_MASK) hipLaunchKernelGGL((wino3d_kernel<16, DF_CONV_MASK>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
       else hipLaunchKernelGGL((wino3d_kernel<16, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
       break;
-    case 1024: hipLaunchKernelGGL((wino3d_kernel<1024, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case (1024 | (1 << 11)): hipLaunchKernelGGL((wino3d_kernel<(1024 | (1 << 11)), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 1536: hipLaunchKernelGGL((wino3d_kernel<1536, -1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     // diagnosis variants (results are wrong by construction, timing only): 4 no staging at all | 8 no weight loads | 64 staging loads
     // kept alive but not written to LDS | 128 staging loads replaced by zeros | 256 staging loads read an always-cached address
     case 4: hipLaunchKernelGGL((wino3d_kernel<4, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
@@ -1340,19 +1320,8 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 256: hipLaunchKernelGGL((wino3d_kernel<256, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 512: hipLaunchKernelGGL((wino3d_kernel<512, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 9: hipLaunchKernelGGL((wino3d_kernel<9, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    // cache policy of the staging loads: aux << 11  (sc0 | nt | sc0+nt | sc1 | sc1+nt | sc0+sc1)
-    case (1 << 11): hipLaunchKernelGGL((wino3d_kernel<(1 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case (2 << 11): hipLaunchKernelGGL((wino3d_kernel<(2 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case (3 << 11): hipLaunchKernelGGL((wino3d_kernel<(3 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case (16 << 11): hipLaunchKernelGGL((wino3d_kernel<(16 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case (18 << 11): hipLaunchKernelGGL((wino3d_kernel<(18 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 16384: hipLaunchKernelGGL((wino3d_kernel<16384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 65536: hipLaunchKernelGGL((wino3d_kernel<65536, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 131072: hipLaunchKernelGGL((wino3d_kernel<131072, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
-    case 196608: hipLaunchKernelGGL((wino3d_kernel<196608, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // weights reloaded per cout block (the order before round 3)
     case 384: hipLaunchKernelGGL((wino3d_kernel<384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // staging loads confined to a 1 MB window (L2-resident, L1 misses)
     case 100: hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // production kernel, compile-time flags (baseline of the experiments)
-    case (17 << 11): hipLaunchKernelGGL((wino3d_kernel<(17 << 11), DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 1048576: hipLaunchKernelGGL((wino3d_kernel<1048576, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 2097152: hipLaunchKernelGGL((wino3d_kernel<2097152, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 262144: hipLaunchKernelGGL((wino3d_kernel<262144, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;

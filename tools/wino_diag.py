@@ -15,12 +15,10 @@ from deep_fluids_amd._lib import call, query, lib  # noqa: E402
 from deep_fluids_amd.ops import _ptr, _stream  # noqa: E402
 from tools.gpu_probe import timeit  # noqa: E402
 
-NAMES = {1048576: "staging loads one per MFMA row during k-step 1, stores before the barrier", 2097152: "staging loads one per MFMA row during k-step 0", 262144: "weight loads of the z-row-1 waves through a zero-length descriptor (half the weight stream)", 524288: "every weight load through a zero-length descriptor", 262144 | 4: "half the weight stream, no staging", 100: "production kernel, compile-time flags", 131072: "staging in two batches (3 pieces behind k-step 0 / written in 2, 2 pieces behind k-step 1 / written in 3)", 0: "production kernel", 1: "no transform (VALU)", 2: "no raw LDS reads", 4: "no staging (loads + LDS writes)", 8: "no weight loads",
+NAMES = {1048576: "staging loads one per MFMA row during k-step 1, stores before the barrier", 2097152: "staging loads one per MFMA row during k-step 0", 262144: "weight loads of the z-row-1 waves through a zero-length descriptor (half the weight stream)", 524288: "every weight load through a zero-length descriptor", 262144 | 4: "half the weight stream, no staging", 100: "production kernel, compile-time flags", 0: "production kernel", 1: "no transform (VALU)", 2: "no raw LDS reads", 4: "no staging (loads + LDS writes)", 8: "no weight loads",
          12: "no staging, no weight loads", 9: "no transform, no weight loads", 64: "staging loads alive, no LDS writes", 128: "staging loads -> zeros (LDS writes kept)",
-         256: "staging loads read an always-cached address", 384: "staging loads confined to a 1 MB window (L2 hits, L1 misses)", 196608: "weights reloaded per cout block of 16 MFMAs (the order before round 3)", 512: "no output stores", 32: "setprio 3 around the MFMAs", 7: "MFMA only (no transform / raw reads / staging)",
-         16384: "chunk + epilogue barriers as full __syncthreads() (vmcnt(0): the order before round 3)", 1024: "odd slices walk chunk pairs swapped", 1024 | (1 << 11): "swapped chunk pairs + staging sc0",
-         1 << 11: "staging loads sc0", 2 << 11: "staging loads nt", 3 << 11: "staging loads sc0 nt", 16 << 11: "staging loads sc1",
-         18 << 11: "staging loads sc1 nt", 17 << 11: "staging loads sc0 sc1", 65536: "k-step 0 weights reloaded at every tile block start (the order before round 3)"}
+         256: "staging loads read an always-cached address", 384: "staging loads confined to a 1 MB window (L2 hits, L1 misses)", 512: "no output stores", 7: "MFMA only (no transform / raw reads / staging)",
+         }
 
 
 def main():
