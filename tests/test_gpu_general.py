@@ -94,3 +94,37 @@ def test_upscale_by_other_integer_factors():
     x3 = rng.uniform(-1, 1, (1, 2, 3, 4, 2)).astype(np.float32)
     np.testing.assert_array_equal(host(ops.upscale3(dev(x3), 3)), orc.upscale_nn(x3, 3))
     np.testing.assert_array_equal(host(ops.upscale3(dev(x3), 1)), x3)
+
+
+def test_random_shapes_property_sweep():
+    """A seeded random sweep over (dimension, extents, channels, kernel, stride): general conv forward / gradients and the stencils against the
+    oracle on shapes nobody hand-picked (40 cases, a few ms each)."""
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.ops import _ConvGeneral
+    rng = np.random.RandomState(2024)
+    for case in range(40):
+        nd = int(rng.randint(2, 4))
+        shape = (int(rng.randint(1, 3)),) + tuple(int(rng.randint(2, 10)) for _ in range(nd))
+        cin, cout = int(rng.randint(1, 7)), int(rng.randint(1, 7))
+        k, s = int(rng.randint(1, 6)), int(rng.randint(1, 4))
+        x = rng.uniform(-1, 1, shape + (cin,)).astype(np.float32)
+        w = (rng.uniform(-1, 1, (k,) * nd + (cin, cout)) / np.sqrt(cin * k ** nd)).astype(np.float32)
+        b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+        xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+        y = _ConvGeneral.apply(xt, wt, bt, None, k, s)
+        ref = orc.conv_same(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), stride=s)
+        go = rng.uniform(-1, 1, ref.shape).astype(np.float32)
+        (y * dev(go)).sum().backward()
+        dx, dw, db = orc.conv_same_bwd(x.astype(np.float64), w.astype(np.float64), go.astype(np.float64), stride=s)
+        tag = (case, shape, cin, cout, k, s)
+        assert rel_linf(host(y), ref) < TOL and rel_linf(host(xt.grad), dx) < TOL, tag
+        assert rel_linf(host(wt.grad), dw) < TOL and rel_linf(host(bt.grad), db) < TOL, tag
+        # stencils on the same random extents (>= 2 per axis): bit-exact
+        if nd == 3:
+            v = rng.uniform(-1, 1, shape + (3,)).astype(np.float32)
+            j, c = ops.jacobian3(dev(v))
+            oj, oc = orc.jacobian3(v)
+            np.testing.assert_array_equal(host(j), oj); np.testing.assert_array_equal(host(c), oc)
+        else:
+            p = rng.uniform(-1, 1, shape + (1,)).astype(np.float32)
+            np.testing.assert_array_equal(host(ops.curl(dev(p))), orc.curl(p))
