@@ -28,7 +28,8 @@
 //     16 per-phase cycle counters (correct results) | 64 staging loads kept alive, no LDS writes | 128 staged zeros (LDS writes only) |
 //     256 staging loads read an always-cached address | 384 ... confined to a 1 MB L2-resident window | 512 no output stores |
 //     262144 / 524288 weight loads of the z-row-1 waves / of all waves through a zero-length descriptor |
-//     1048576 / 2097152 (correct results) staging loads one per MFMA row during k-step 1 / 0 instead of one burst
+//     1048576 / 2097152 (correct results) staging loads one per MFMA row during k-step 1 / 0 instead of one burst |
+//     4194304 staging loads fully coalesced (1 KiB contiguous per wave instruction), still L1-missing
 //   XS bits (round-4 probe, correct results unless noted): 1 LDS-DMA staging from the x-blocked copy | 2 waves 4-7 issue | 4 in front of k-step 0's
 //     MFMAs | 8 unrolled issue | 16 at the start of k-step 0 | 32 two weight register sets | 64 "weights" from LDS (timing only) | 128 three buffers
 //   PREC 1: bf16x3 in the Winograd domain (round 3).   The switches of rounds 1-3 whose experiments were negative (cache policies, chunk-pair
@@ -387,6 +388,11 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   };
   auto stage_load = [&](int it, __amdgpu_buffer_rsrc_t srd, unsigned chunkbytes) -> f32x4 {
     if ((DBG & 384) == 256) return buf_load16(wsrd_dbg, static_cast<unsigned>(lane) * 16u, 0u);      // always-cached address (latency experiment)
+    if (DBG & 4194304) {      // (experiment, timing only: FULLY COALESCED staging loads -- lane i reads 16 B at base + 16 i, 1 KiB contiguous per wave
+                              //  instruction, 8 full lines -- that miss L1: the base walks the tensor with the real offsets' block / chunk part)
+      const unsigned basev = (so[it] == 0x80000000u ? 0u : so[it]) & 0x7FFFFC00u;
+      return buf_load16(srd, __builtin_amdgcn_readfirstlane(basev) + static_cast<unsigned>(lane) * 16u, chunkbytes & ~1023u);
+    }
     return buf_load16(srd, so[it], chunkbytes);
   };
   char* sInB = reinterpret_cast<char*>(sIn);
@@ -435,6 +441,20 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         for (int r = XASYM ? wave - 4 : wave; r < XROWS; r += XASYM ? 4 : 8) one_row(r);
       }
     }
+  };
+
+  // (experiment XS & 256, with three buffers: piece j of the wave is issued behind MFMA row j of k-step 0 instead of all 8 in one burst)
+  auto issue_piece = [&](int j, int bufbytes, const BlockInfo& bi, unsigned chunkbytes) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const __amdgpu_buffer_rsrc_t dsrd = make_srd(bi.xb, vol_bytes);
+    const int rowb = a.Wb * a.Cin * 16;
+    const int base = (((bi.z0 - 1) * a.H + (bi.y0 - 1)) * a.Wb + (bi.x0 >> 2)) * a.Cin * 16 + static_cast<int>(chunkbytes);
+    const int r0 = wave + 8 * j, r = r0 < XROWS ? r0 : XROWS - 1;
+    const int hz = r / 10, hy = r - hz * 10;
+    const bool ok = static_cast<unsigned>(bi.z0 - 1 + hz) < static_cast<unsigned>(a.D) && static_cast<unsigned>(bi.y0 - 1 + hy) < static_cast<unsigned>(a.H);
+    const unsigned soff = static_cast<unsigned>(base + (hz * a.H + hy) * rowb);
+    const unsigned vo = xvoff | (ok ? 0u : 0x80000000u);      // (lanes >= 51 carry the out-of-range bit in xvoff already ... but they must not WRITE: exec mask)
+    if (lane < 51) __builtin_amdgcn_raw_ptr_buffer_load_lds(dsrd, (lds_ptr)(sInB + bufbytes + r * XROWB), 16, vo, soff, 0, 0);
   };
 
   // ---- PREC = 1 staging plan: thread p < 400 owns the z-column (hy, hx, channel quad) of the halo block -------------------------
@@ -717,7 +737,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         const unsigned long long q0 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
         if (DBG & 16) asm volatile("s_waitcnt lgkmcnt(0)");
         const unsigned long long q1 = (DBG & 16) ? __builtin_readcyclecounter() : 0ull;
-        if (XB && TRI && ks == 0 && !(DBG & 4)) {
+        if (XB && TRI && !(XS & 256) && ks == 0 && !(DBG & 4)) {
           const int cc = chunk + 2;
           issue_dma(bn2, cc < nchunk ? cur : nxt, static_cast<unsigned>(cc < nchunk ? cc : cc - nchunk) * 256u);
           __builtin_amdgcn_sched_barrier(0);
@@ -773,6 +793,10 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           if ((i & 3) == 3) {
             __builtin_amdgcn_sched_barrier(0);
             reload_row(0, i >> 2);
+            if (XB && TRI && (XS & 256) && ks == 0 && !(DBG & 4)) {
+              const int cc = chunk + 2;
+              issue_piece(i >> 2, bn2, cc < nchunk ? cur : nxt, static_cast<unsigned>(cc < nchunk ? cc : cc - nchunk) * 256u);
+            }
             if (!XB && SPREAD && ks == (SPREAD1 ? 1 : 0) && !(DBG & 4)) stg[i >> 2] = stage_load(i >> 2, ssrd, schunk);      // pieces 0..3
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -787,6 +811,10 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
             if ((i & 3) == 3) {
               __builtin_amdgcn_sched_barrier(0);
               reload_row(1, i >> 2);
+              if (XB && TRI && (XS & 256) && ks == 0 && !(DBG & 4)) {
+                const int cc = chunk + 2;
+                issue_piece(4 + (i >> 2), bn2, cc < nchunk ? cur : nxt, static_cast<unsigned>(cc < nchunk ? cc : cc - nchunk) * 256u);
+              }
               if (!XB && SPREAD && ks == (SPREAD1 ? 1 : 0) && !(DBG & 4) && (i >> 2) == 1) stg[4] = stage_load(4, ssrd, schunk);      // piece 4
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -1110,7 +1138,7 @@ constexpr int g_wino_spx = 0;
 extern "C" {
 
 #ifdef DF_TUNING
-void df_debug_set_wino(int v) { g_wino_dbg = v & 0xffffff; g_wino_spx = v >> 24; }
+void df_debug_set_wino(int v) { g_wino_dbg = v & 0x3ffffff; g_wino_spx = v >> 26; }
 int df_debug_wino_prof(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_prof), z, sizeof(z)); }
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_prof), 32 * sizeof(unsigned long long));
@@ -1165,6 +1193,8 @@ int df_debug_wino_conv_fwd_xblk(const float* x, float* xg, const float* wp, cons
     case 32 + 17: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 49>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
     case 32 + 31: hipLaunchKernelGGL((wino3d_kernel<4, F, 0, 0, 33>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
     case 3 + 64: hipLaunchKernelGGL((wino3d_kernel<4, F, 0, 0, 3>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;
+    case 104: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 256 + 128 + 64 + 1>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;           // three buffers + LDS "weights", pieces spread over k-step 0
+    case 106: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 256 + 128 + 1>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;                // three buffers, global weights, pieces spread
     case 98: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 128 + 64 + 1>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;                 // three buffers + LDS "weights"
     case 102: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 128 + 1>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;                     // three buffers, global weights
     case 64 + 32 + 1: hipLaunchKernelGGL((wino3d_kernel<0, F, 0, 0, 64 + 1>), dim3((unsigned)grid), dim3(kT), 0, s, a); break;            // all waves stage, LDS "weights"
@@ -1322,6 +1352,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
     case 9: hipLaunchKernelGGL((wino3d_kernel<9, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 384: hipLaunchKernelGGL((wino3d_kernel<384, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // staging loads confined to a 1 MB window (L2-resident, L1 misses)
     case 100: hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;      // production kernel, compile-time flags (baseline of the experiments)
+    case 4194304: hipLaunchKernelGGL((wino3d_kernel<4194304, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 1048576: hipLaunchKernelGGL((wino3d_kernel<1048576, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 2097152: hipLaunchKernelGGL((wino3d_kernel<2097152, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;
     case 262144: hipLaunchKernelGGL((wino3d_kernel<262144, DF_CONV_BIAS | DF_CONV_LRELU>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); break;

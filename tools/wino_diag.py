@@ -15,7 +15,7 @@ from deep_fluids_amd._lib import call, query, lib  # noqa: E402
 from deep_fluids_amd.ops import _ptr, _stream  # noqa: E402
 from tools.gpu_probe import timeit  # noqa: E402
 
-NAMES = {1048576: "staging loads one per MFMA row during k-step 1, stores before the barrier", 2097152: "staging loads one per MFMA row during k-step 0", 262144: "weight loads of the z-row-1 waves through a zero-length descriptor (half the weight stream)", 524288: "every weight load through a zero-length descriptor", 262144 | 4: "half the weight stream, no staging", 100: "production kernel, compile-time flags", 0: "production kernel", 1: "no transform (VALU)", 2: "no raw LDS reads", 4: "no staging (loads + LDS writes)", 8: "no weight loads",
+NAMES = {4194304: "staging loads FULLY COALESCED (1 KiB contiguous per instruction, walking the tensor: L1 misses)", 1048576: "staging loads one per MFMA row during k-step 1, stores before the barrier", 2097152: "staging loads one per MFMA row during k-step 0", 262144: "weight loads of the z-row-1 waves through a zero-length descriptor (half the weight stream)", 524288: "every weight load through a zero-length descriptor", 262144 | 4: "half the weight stream, no staging", 100: "production kernel, compile-time flags", 0: "production kernel", 1: "no transform (VALU)", 2: "no raw LDS reads", 4: "no staging (loads + LDS writes)", 8: "no weight loads",
          12: "no staging, no weight loads", 9: "no transform, no weight loads", 64: "staging loads alive, no LDS writes", 128: "staging loads -> zeros (LDS writes kept)",
          256: "staging loads read an always-cached address", 384: "staging loads confined to a 1 MB window (L2 hits, L1 misses)", 512: "no output stores", 7: "MFMA only (no transform / raw reads / staging)",
          }
@@ -36,7 +36,7 @@ def main():
     base = None
     y0 = None
     for v in variants:
-        lib().df_debug_set_wino(ctypes.c_int((v << 2) | (int(os.environ.get("SPX", "0")) << 24)))
+        lib().df_debug_set_wino(ctypes.c_int((v << 2) | (int(os.environ.get("SPX", "0")) << 26)))
         f = lambda: call("df_wino_conv_fwd", _ptr(x), _ptr(ww), _ptr(bias), None, None, _ptr(y), B, D, H, W, C, C, 9, 0.2, s)
         t = timeit(f, 4, 2)
         base = base or t

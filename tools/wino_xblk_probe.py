@@ -17,7 +17,7 @@ from deep_fluids_amd.ops import _ptr, _stream  # noqa: E402
 from tools.gpu_probe import timeit  # noqa: E402
 
 I64, F32, P = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
-NAMES = {98: "THREE staging buffers (pieces 2 chunks ahead) + LDS weights (timing only)", 102: "THREE staging buffers, global weights", 97: "LDS weights (timing only) + all waves stage, behind", 113: "LDS weights + all waves stage, start of k-step 0", 99: "LDS weights + waves 4-7 stage, behind", 115: "LDS weights + waves 4-7 stage, start of k-step 0", 103: "LDS weights + waves 4-7 stage, in front", 100: "LDS weights, no staging at all", 33: "two weight sets + all waves, behind (rolled)", 41: "two weight sets + all waves, behind, unrolled", 43: "two weight sets + waves 4-7, behind, unrolled", 45: "two weight sets + all waves, in front, unrolled", 49: "two weight sets + all waves, start of k-step 0 (rolled)", 63: "two weight sets, no staging at all (timing only)", 67: "no staging at all, one weight set (timing only)", 17: "all waves, at the start of k-step 0 (rolled)", 25: "all waves, start of k-step 0, unrolled", 27: "waves 4-7, start of k-step 0, unrolled", 35: "waves 4-7 variant without any staging (timing only)", 1: "all waves issue, behind k-step 0's MFMAs (rolled)", 3: "waves 4-7 issue, behind the MFMAs (rolled)",
+NAMES = {104: "three buffers + LDS weights, pieces SPREAD one per MFMA row of k-step 0 (timing only)", 106: "three buffers, global weights, pieces spread one per MFMA row of k-step 0", 98: "THREE staging buffers (pieces 2 chunks ahead) + LDS weights (timing only)", 102: "THREE staging buffers, global weights", 97: "LDS weights (timing only) + all waves stage, behind", 113: "LDS weights + all waves stage, start of k-step 0", 99: "LDS weights + waves 4-7 stage, behind", 115: "LDS weights + waves 4-7 stage, start of k-step 0", 103: "LDS weights + waves 4-7 stage, in front", 100: "LDS weights, no staging at all", 33: "two weight sets + all waves, behind (rolled)", 41: "two weight sets + all waves, behind, unrolled", 43: "two weight sets + waves 4-7, behind, unrolled", 45: "two weight sets + all waves, in front, unrolled", 49: "two weight sets + all waves, start of k-step 0 (rolled)", 63: "two weight sets, no staging at all (timing only)", 67: "no staging at all, one weight set (timing only)", 17: "all waves, at the start of k-step 0 (rolled)", 25: "all waves, start of k-step 0, unrolled", 27: "waves 4-7, start of k-step 0, unrolled", 35: "waves 4-7 variant without any staging (timing only)", 1: "all waves issue, behind k-step 0's MFMAs (rolled)", 3: "waves 4-7 issue, behind the MFMAs (rolled)",
          5: "all waves, in front of the MFMAs (rolled)", 7: "waves 4-7, in front of the MFMAs (rolled)",
          9: "all waves, behind, unrolled", 11: "waves 4-7, behind, unrolled", 13: "all waves, in front, unrolled", 15: "waves 4-7, in front, unrolled",
          19: "waves 4-7 variant without any staging (timing only)"}
