@@ -168,6 +168,10 @@ class Trainer(object):
 
     def load(self, path):
         with np.load(path) as d:
+            missing = [k for slices, _, _, _ in self._ckpt_slabs() for k in slices if k not in d.files]
+            if missing:      # (tf.train.Saver.restore fails the same way on a graph / checkpoint mismatch)
+                raise ValueError("checkpoint %s does not hold this trainer's variables (e.g. %s): a different architecture / scope "
+                                 "name was trained in that model_dir" % (path, missing[0]))
             for slices, fp, fm, fv in self._ckpt_slabs():
                 for k, (o, n) in slices.items():
                     fp[o:o + n].copy_(torch.from_numpy(d[k].reshape(-1)))

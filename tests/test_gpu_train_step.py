@@ -270,6 +270,9 @@ def test_train_loop_scalars_nan_guard_and_test_sweep(tmp_path):
     assert os.path.exists(os.path.join(model_dir, "model.ckpt-5.npz"))
     with np.load(os.path.join(model_dir, "4_G.npz")) as d:
         assert d["G"].shape == (3, 4, 16, 8, 2) and d["z"].shape == (3, 4, 3)
+    # a trainer of another scope started on this model_dir must refuse the checkpoint it finds there, with a clear message
+    with pytest.raises(ValueError, match="does not hold this trainer's variables"):
+        Trainer(cfg, name="G9")
     # NaN guard: poison the parameters -> the next logged step must raise the reference's assertion
     cfg_nan = default_config(is_3d=False, res_x=8, res_y=16, filters=16, batch_size=4, num_samples=n, log_step=2, test_step=2)
     tr2 = Trainer(cfg_nan, name="G2")                   # (no model_dir in ITS config: a trainer auto-restores the model_dir it is given)
