@@ -309,6 +309,8 @@ class Trainer(object):
         rank0 = self.grad_sync is None or not self.grad_sync.enabled or self.grad_sync.rank == 0
         if model_dir and rank0:
             os.makedirs(model_dir, exist_ok=True)
+            with open(os.path.join(model_dir, "params.json"), "w") as fp:        # util.py:52-59 save_config
+                json.dump({k: v for k, v in sorted(vars(self.config).items())}, fp, indent=4, sort_keys=True, default=str)
         # test1: each parameter varied over [-1, 1] with the others at 0 (trainer.py:230-241)
         z_samples = []
         for i in range(self.c_num):

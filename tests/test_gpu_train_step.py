@@ -268,6 +268,7 @@ def test_train_loop_scalars_nan_guard_and_test_sweep(tmp_path):
     assert abs(lines[1]["misc/epoch"] - 2 * 4 / float(n)) < 1e-12
     assert abs(lines[0]["loss/g_loss"] - (lines[0]["loss/g_loss_l1"] + lines[0]["loss/g_loss_j_l1"])) < 1e-5
     assert os.path.exists(os.path.join(model_dir, "model.ckpt-5.npz"))
+    assert js.load(open(os.path.join(model_dir, "params.json")))["filters"] == 16                  # util.py:52-59
     with np.load(os.path.join(model_dir, "4_G.npz")) as d:
         assert d["G"].shape == (3, 4, 16, 8, 2) and d["z"].shape == (3, 4, 3)
     # a trainer of another scope started on this model_dir must refuse the checkpoint it finds there, with a clear message
