@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--init-timeout", type=float, default=120.0,
                     help="N > 1: seconds the rendezvous / the RCCL communicator creation + first all-reduce may take before the watchdog "
                          "prints a diagnostic JSON line (rccl_ranks 0) and exits non-zero")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N = 1: do not run the two rocprofv3 --pmc passes that measure `roofline.traffic` in this run (the committed offline table "
+                         "profiles/pmc_latest.json is used instead)")
     ap.add_argument("--no-other-leg", action="store_true", help="N > 1: skip the short leg in the other scaling mode")
     ap.add_argument("--other-steps", type=int, default=5)
     ap.add_argument("--sidecar", default=None, help="where the full record goes (default gpurun_out/bench_full_n<N>.json)")
@@ -275,7 +278,43 @@ def l1_vs_oracle(filters, precision="fp32", is_3d=True):
     return float(np.abs(u - ref).sum() / np.abs(ref).sum())
 
 
-def roofline_of(ks, prefix, pmc, with_traffic):
+def live_pmc(timeout_s=240.0):
+    """`roofline.traffic` measured IN THIS RUN on this box: two rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE: one counter
+    set per pass, no other trace domains -- MI355X_MICROARCH.md) over tools/pmc_target.py, the roofline kernels at the benchmark's shapes, as a
+    child process; summarised by tools/pmc_summary.py (FETCH_SIZE doubled per the guide's gfx950 correction).  Returns the `kernels` table or
+    None (rocprofv3 missing, a pass failed or timed out): the caller then falls back to the committed offline table and says so."""
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="dfpmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.time()
+    try:
+        dirs = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, c)
+            left = timeout_s - (time.time() - t0)
+            if left < 20:
+                return None
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "tools", "pmc_target.py")], cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=left)
+            if r.returncode != 0:
+                return None
+            dirs[c] = d
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_summary
+        tab = pmc_summary.summarize(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"])["kernels"]
+        return tab or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def roofline_of(ks, prefix, pmc, with_traffic, pmc_source=None):
     """Roofline object of the dominant instance (largest total time) of a kernel family.
     MFMA-bound families: `achieved` = multiply-add flops the kernel EXECUTES on the matrix pipe / time (<= peak); the
     convolution's algorithmic (direct-form) rate is reported beside it as `algorithmic_tflops` (it exceeds the peak when a Winograd
@@ -309,7 +348,7 @@ def roofline_of(ks, prefix, pmc, with_traffic):
     # on the same kernel at the default shape (B = 16, 64x96x64, F = 128)
     fam = prefix.split("<")[0]
     out["traffic"] = pmc.get(fam, {}).get("traffic_bytes") if with_traffic else None
-    out["traffic_source"] = "profiles/pmc_latest.json (offline rocprofv3 --pmc passes, not measured in this run)" if out["traffic"] else None
+    out["traffic_source"] = (pmc_source or "profiles/pmc_latest.json (offline rocprofv3 --pmc passes, not measured in this run)") if out["traffic"] else None
     return out
 
 
@@ -577,7 +616,7 @@ def run_leg(tr, sync, x, y, warmup, steps, world, dist, torch, timer=None):
 def compact(out):
     """The printed line: headline objects first, bulky diagnostics (per-kernel table, dispatch log, standalone stencil table, the
     extras' nested rooflines, long notes) only in the sidecar file."""
-    def slim(r, keep=("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_copy_rate", "traffic", "avg_launch_ms", "avg_launch_us",
+    def slim(r, keep=("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_copy_rate", "traffic", "traffic_source", "avg_launch_ms", "avg_launch_us",
                       "launches", "algorithmic_tflops", "algorithmic_speedup", "wgrad_form", "algorithmic_bytes_per_voxel")):
         return None if not isinstance(r, dict) else ({k: r[k] for k in keep if k in r} if "error" not in r else r)
     head = ["metric", "value", "unit", "per_gpu", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -694,11 +733,17 @@ def main():
     vox_per_step = global_batch * Z * Y * X
     value = vox_per_step * a.steps / elapsed
 
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
-    except (OSError, ValueError, KeyError):
-        pmc = {}
     default_shape = list(a.res) == [64, 96, 64] and per_gpu == 16 and a.filters == 128 and a.precision == "fp32"   # the PMC passes' shape
+    pmc, pmc_source = None, None
+    if world == 1 and default_shape and not a.no_live_pmc:
+        pmc = live_pmc()
+        if pmc:
+            pmc_source = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE passes over tools/pmc_target.py (2 x FETCH_SIZE + WRITE_SIZE)"
+    if not pmc:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
+        except (OSError, ValueError, KeyError):
+            pmc = {}
 
     out = {
         "metric": "velocity-field voxels/sec (3D %dx%dx%d train step), whole job; per-GPU in `per_gpu`" % (Z, Y, X),
@@ -724,9 +769,9 @@ def main():
         "allreduce": comm,           # per step: bytes, buckets, comm_span_ms, exposed_ms (after backward), hidden_ms (under backward)
         "other_scaling_leg": other,
         "loss": loss,
-        "roofline_wgrad": roofline_of(ks, "wgrad_kernel", pmc, default_shape),
-        "roofline_conv": roofline_of(ks, "conv_mfma_kernel", pmc, default_shape),
-        "roofline_wino": roofline_of(ks, "wino3d_kernel", pmc, default_shape),
+        "roofline_wgrad": roofline_of(ks, "wgrad_kernel", pmc, default_shape, pmc_source),
+        "roofline_conv": roofline_of(ks, "conv_mfma_kernel", pmc, default_shape, pmc_source),
+        "roofline_wino": roofline_of(ks, "wino3d_kernel", pmc, default_shape, pmc_source),
         "roofline_tail_fwd": roofline_of(ks, "velocity_loss3d_fwd_kernel", {}, False),
         "roofline_tail_bwd": roofline_of(ks, "velocity_loss3d_bwd_kernel", {}, False),
         "stencils_standalone": None,
@@ -746,7 +791,7 @@ def main():
             out["stencils_standalone"] = stencil_rooflines(per_gpu, Z, Y, X)
             out["roofline_stencil"] = dict(out["stencils_standalone"]["jacobian3d_fwd_kernel<j,c>"], kernel="jacobian3d_fwd_kernel<j,c>",
                                            traffic=pmc.get("jacobian3d_fwd_kernel", {}).get("traffic_bytes") if default_shape else None,
-                                           traffic_source="profiles/pmc_latest.json" if default_shape else None,
+                                           traffic_source=(pmc_source or "profiles/pmc_latest.json") if default_shape else None,
                                            note="standalone launches over rotating buffers (cold HBM); the train step itself runs the fused "
                                                 "tail (roofline_tail_fwd / _bwd)")
             copy_gbs = out["stencils_standalone"]["copy_rate"]["achieved"]

@@ -6,10 +6,10 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --sidecar $O/r04_bench_full_n1.json > $O/r04_bench_n1.json 2> $O/r04_bench_n1.err
-python $R/bench.py --batch 2 --steps 50 --warmup 10 --no-alt --no-cpu-baseline --sidecar $O/r04_bench_full_b2.json > $O/r04_bench_b2.json 2> /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b16 -- python $R/bench.py --steps 5 --warmup 2 --no-alt --no-cpu-baseline --sidecar /tmp/side_prof.json > $O/r04_bench_prof.json 2> /dev/null
+python $R/bench.py --batch 2 --steps 50 --warmup 10 --no-alt --no-cpu-baseline --no-live-pmc --sidecar $O/r04_bench_full_b2.json > $O/r04_bench_b2.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b16 -- python $R/bench.py --steps 5 --warmup 2 --no-alt --no-cpu-baseline --no-live-pmc --sidecar /tmp/side_prof.json > $O/r04_bench_prof.json 2> /dev/null
 python $R/tools/summarize_trace.py $(find $O/prof_b16 -name "*kernel_trace.csv" | head -1) > $O/r04_bench_kernel_by_grid.md; rm -rf $O/prof_b16
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b2 -- python $R/bench.py --batch 2 --steps 10 --warmup 3 --no-alt --no-cpu-baseline --sidecar /tmp/side_prof2.json > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b2 -- python $R/bench.py --batch 2 --steps 10 --warmup 3 --no-alt --no-cpu-baseline --no-live-pmc --sidecar /tmp/side_prof2.json > /dev/null 2>&1
 python $R/tools/summarize_trace.py $(find $O/prof_b2 -name "*kernel_trace.csv" | head -1) > $O/r04_bench_b2_kernel_by_grid.md; rm -rf $O/prof_b2
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_$C -- python $R/tools/pmc_target.py > $O/pmc_$C.log 2>&1
