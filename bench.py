@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the Deep Fluids velocity-field train step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--scaling weak|strong]
 
 N > 1: one rank per GPU over RCCL.  Either launch it under ``python -m torch.distributed.run --nproc-per-node N ...`` (the
 ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or run it as plain ``python bench.py --gpus N``:
@@ -13,6 +13,11 @@ fwd -> curl3 -> jacobian3 -> L1 + Jacobian-L1 -> backward -> (bucketed grad all-
 cosine LR.  Synthetic inputs resident in HBM, random-init (Xavier) weights.
   --scaling weak   (default) per-GPU batch 16, global batch 16 N;
   --scaling strong global batch 16 split N ways (16 -> 2 per GPU at N = 8).
+--config picks another BASELINE.json workload for the SAME contract line (default cfg3, the metric's own): cfg2 = 2-D 128x96 batch 64
+per GPU (Trainer, GeneratorBE), cfg4 = 3-D 112x160x112 batch 4 per GPU (32 / 8 GPUs), cfg5 = AE3 128^3 filters 64 batch 4 per GPU
+(AETrainer: encoder + decoder).  At N > 1 the cfg3 line additionally carries short cfg2 and cfg4 data-parallel legs (`extra_leg_cfg2`,
+`extra_leg_cfg4`; --no-extra-legs skips them) and every leg a `cross_rank` check: the reduced flat gradient is bit-identical on every
+rank and the mean of the shard losses equals ONE process's loss on the gathered global batch to 1e-6.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -32,15 +37,34 @@ PEAK_HBM_GBS = 8000.0
 EXEC_RATIO = {"wino3d_kernel": 8.0 / 27.0, "wino2d_kernel": 4.0 / 9.0, "conv_mfma_kernel": 1.0, "wgrad_kernel": None}
 
 
+# BASELINE.json `configs` as bench workloads (cfg2 = trainer.py:136-184 on GeneratorBE; cfg3 / cfg4 = trainer3.py:14-63 on
+# GeneratorBE3; cfg5 = build_model_ae, trainer3.py:240-309, on AE3).  `batch` = per-GPU batch of the weak leg = global batch of the strong leg.
+WORKLOADS = {
+    "cfg2": dict(kind="de", res=[128, 96], batch=64, filters=128, num_samples=21000, unit="pixels/s", model="GeneratorBE",
+                 name="cfg2: 2D smoke_pos_size {grid} (Y,X)", step="fwd+curl+jacobian+L1 losses+bwd+Adam"),
+    "cfg3": dict(kind="de", res=[64, 96, 64], batch=16, filters=128, num_samples=6600, unit="voxels/s", model="GeneratorBE3",
+                 name="cfg3: 3D smoke3 {grid} (Z,Y,X)", step="fwd+curl3+jacobian3+L1 losses+bwd+Adam"),
+    "cfg4": dict(kind="de", res=[112, 160, 112], batch=4, filters=128, num_samples=20000, unit="voxels/s", model="GeneratorBE3",
+                 name="cfg4: 3D smoke3 {grid} (Z,Y,X) (BASELINE: global batch 32 = 4 per GPU x 8)", step="fwd+curl3+jacobian3+L1 losses+bwd+Adam"),
+    "cfg5": dict(kind="ae", res=[128, 128, 128], batch=4, filters=64, num_samples=5000, unit="voxels/s", model="AE3 (EncoderBE3 + GeneratorBE3) z_num=16",
+                 name="cfg5: 3D autoencoder liquid3 {grid}", step="encoder+decoder fwd+curl3+jacobian3+L1 losses+latent loss+bwd+Adam"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=16, help="weak: per-GPU batch; strong: GLOBAL batch (split over the GPUs)")
+    ap.add_argument("--config", default="cfg3", choices=sorted(WORKLOADS),
+                    help="BASELINE.json workload (default cfg3 = the metric's own; cfg2 2-D 128x96 B=64/GPU, cfg4 112x160x112 B=4/GPU, cfg5 AE3 128^3 F=64 B=4/GPU)")
+    ap.add_argument("--batch", type=int, default=None, help="weak: per-GPU batch; strong: GLOBAL batch (split over the GPUs); default: the workload's (cfg3: 16)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--res", type=int, nargs=3, default=[64, 96, 64], metavar=("Z", "Y", "X"))
-    ap.add_argument("--filters", type=int, default=128)
+    ap.add_argument("--res", type=int, nargs="+", default=None, metavar="N", help="grid (Z Y X | Y X); default: the workload's (cfg3: 64 96 64)")
+    ap.add_argument("--filters", type=int, default=None)
+    ap.add_argument("--no-extra-legs", action="store_true", help="N > 1, --config cfg3: skip the short cfg2 and cfg4 data-parallel legs appended to the line")
+    ap.add_argument("--extra-leg-steps", type=int, default=5)
+    ap.add_argument("--no-cross-rank-check", action="store_true", help="N > 1: skip the gradient-checksum / global-batch-loss check of each leg")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="conv arithmetic: fp32 = exact fp32 MFMA (the BASELINE cfg3 dtype, default); bf16x3 = opt-in split-bf16 "
                          "MFMA mode (16-bit operand significands, fp32 accumulate)")
@@ -57,7 +81,14 @@ def parse():
     ap.add_argument("--other-steps", type=int, default=5)
     ap.add_argument("--sidecar", default=None, help="where the full record goes (default gpurun_out/bench_full_n<N>.json)")
     ap.add_argument("--full-line", action="store_true", help="print the full record instead of the compact line")
-    return ap.parse_args()
+    a = ap.parse_args()
+    wl = WORKLOADS[a.config]
+    a.batch = wl["batch"] if a.batch is None else a.batch
+    a.res = list(wl["res"]) if a.res is None else list(a.res)
+    a.filters = wl["filters"] if a.filters is None else a.filters
+    if len(a.res) != len(wl["res"]):
+        ap.error("--config %s takes a %d-D grid" % (a.config, len(wl["res"])))
+    return a
 
 
 def self_launch(a):
@@ -274,6 +305,35 @@ def l1_vs_oracle(filters, precision="fp32", is_3d=True):
         u = tr.generate(torch.from_numpy(y).cuda()).cpu().numpy().astype(np.float64)
     psi = orc.generator_fwd(y.astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()}, oshape, filters)
     ref = orc.curl3(psi) if is_3d else orc.curl(psi)
+    ops.reset_variables()
+    return float(np.abs(u - ref).sum() / np.abs(ref).sum())
+
+
+def l1_vs_oracle_ae(filters, z_num=16, spatial=(16, 16, 16)):
+    """cfg5's parity figure: relative L1 of the auto-encoder's reconstructed velocity field (AE3 forward + curl3) vs the fp64 oracle on
+    identical inputs / weights at a reduced grid."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import df_oracle as orc
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import AETrainer, default_config
+    ops.reset_variables()
+    rng = np.random.RandomState(123)
+    xshape = list(spatial) + [3]
+    p = orc.ae_init(rng, xshape, filters, z_num)
+    x, _ = orc.synthetic_batch(rng, 1, spatial)
+    cfg = default_config(is_3d=True, res_x=spatial[2], res_y=spatial[1], res_z=spatial[0], filters=filters, batch_size=1, num_samples=100,
+                         z_num=z_num, p_num=2)
+    tr = AETrainer(cfg)
+    tr.load_variables(p)
+    y = torch.zeros((1, 2, 3), device="cuda")
+    with torch.no_grad():
+        u = tr.build_model(torch.from_numpy(x).cuda(), y).G_.cpu().numpy().astype(np.float64)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    z = orc.encoder_fwd(x.astype(np.float64), p64, filters, z_num, "AE/enc", 3, 0)
+    psi = orc.generator_fwd(z, p64, xshape, filters, "AE/dec", 4, 0)
+    ref = orc.curl3(psi)
     ops.reset_variables()
     return float(np.abs(u - ref).sum() / np.abs(ref).sum())
 
@@ -628,8 +688,18 @@ def compact(out):
     line["cpu_baseline"] = None if not isinstance(cb, dict) else {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "ms_per_step", "cpu", "error") if k in cb}
     line["l1_vs_ref"] = out.get("l1_vs_ref")
     line["l1_vs_ref_fullsize"] = out.get("l1_vs_ref_fullsize")
-    for k in ("step_ms", "value_median", "rccl_ranks", "counted_ranks", "dist_backend", "distinct_devices", "allreduce", "other_scaling_leg", "loss"):
+    for k in ("step_ms", "value_median", "rccl_ranks", "counted_ranks", "dist_backend", "distinct_devices", "allreduce", "other_scaling_leg",
+              "cross_rank", "loss"):
         line[k] = out.get(k)
+    for k in ("extra_leg_cfg2", "extra_leg_cfg4"):          # N > 1: the 2-D workload and cfg4's grid as data-parallel legs of the same job
+        e = out.get(k)
+        if isinstance(e, dict) and "error" not in e:
+            e = {q: e[q] for q in ("config", "grid", "scaling", "global_batch", "batch_per_gpu", "steps", "ms_per_step", "value", "unit", "allreduce",
+                                   "loss", "other_scaling_leg", "cross_rank") if q in e}
+            if isinstance(e.get("cross_rank"), dict):
+                e["cross_rank"] = {q: e["cross_rank"][q] for q in ("ok", "grad_identical_on_all_ranks", "loss_rel_diff") if q in e["cross_rank"]}
+        if e is not None:
+            line[k] = e
     for k in ("alt_bf16x3_mode", "extra_2d_128x96", "extra_cfg4_slice", "extra_ae_cfg5"):
         e = out.get(k)
         if isinstance(e, dict) and "error" not in e:
@@ -645,6 +715,118 @@ def compact(out):
     return line
 
 
+def workload_job(name, res, filters, per_gpu, global_batch, world, rank, profile=True):
+    """Trainer + resident inputs of one BASELINE workload on this rank: same seed on every rank -> identical initial variables
+    (enable_data_parallel additionally broadcasts rank 0's state); inputs from RandomState(123 + rank).  Returns (trainer, GradSync | None,
+    make(batch) -> (x, y))."""
+    import numpy as np
+    import torch
+    from deep_fluids_amd import ops
+    from deep_fluids_amd.trainer import Trainer, AETrainer, default_config
+    wl = WORKLOADS[name]
+    is_3d = len(res) == 3
+    kw = dict(is_3d=is_3d, res_x=res[-1], res_y=res[-2], res_z=res[0] if is_3d else 1, filters=filters, batch_size=global_batch,
+              num_samples=wl["num_samples"], random_seed=123)
+    ops.reset_variables()
+    if wl["kind"] == "ae":
+        tr = AETrainer(default_config(z_num=16, p_num=2, **kw))
+    else:
+        tr = Trainer(default_config(**kw))
+    sync = tr.enable_data_parallel(profile=profile) if world > 1 else None
+
+    def make(batch):
+        x, y = make_inputs(batch, res, 123 + rank, ops)
+        if wl["kind"] == "ae":      # supervised latent part: y[:, :, -1] (trainer3.py:268); [B, dof = 2, frames]
+            y = torch.from_numpy(np.random.RandomState(1000 + rank).uniform(-1, 1, (batch, 2, 10)).astype(np.float32)).cuda()
+        return x, y
+    return tr, sync, make
+
+
+def cross_rank_check(tr, x, y, world, rank, dist, torch, max_samples=2):
+    """One extra, untimed forward + backward + exchange (no optimizer step) on <= `max_samples` samples per rank:
+    (1) the reduced flat gradient must be BIT-identical on every rank after GradSync.finish() (exact integer checksum of its bit
+        pattern + float64 sum, MIN == MAX over the ranks);
+    (2) the mean of the ranks' shard losses must equal the loss ONE process computes on the gathered global batch (rank 0, forward only,
+        same parameters) to 1e-6 relative -- reduce_mean over the global batch == mean of equal-sized shard means."""
+    from deep_fluids_amd.dist import all_equal_across_ranks
+    n = min(int(x.shape[0]), max_samples)
+    xs, ys = x[:n].contiguous(), y[:n].contiguous()
+    m, gscale = tr.forward_backward(xs, ys)
+    g = tr.flat_g
+    bits = int(g.view(torch.int32).to(torch.int64).sum().item())
+    gsum = float(g.double().sum().item())
+    same = all_equal_across_ranks([float(bits & 0xFFFFFFFF), float((bits >> 32) & 0xFFFFFFFF), gsum])
+    host = dist.get_backend() == "gloo"
+    lt = m.g_loss.detach().double().reshape(1)
+    lt = lt.cpu() if host else lt
+    dist.all_reduce(lt)
+    shard_mean = float(lt.item()) / world
+
+    def gather(t):
+        src = t.cpu() if host else t
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src)
+        return torch.cat(parts, 0).to(t.device)
+    xg, yg = gather(xs), gather(ys)
+    out = None
+    if rank == 0:
+        with torch.no_grad():
+            mg = tr.build_model(xg, yg)
+        glob = float(mg.g_loss.detach().double().item())
+        rel = abs(shard_mean - glob) / max(abs(glob), 1e-30)
+        out = {"grad_identical_on_all_ranks": bool(same), "grad_sum": gsum, "grad_scale": gscale, "samples_per_rank": n,
+               "loss_shard_mean": shard_mean, "loss_global_batch_one_process": glob, "loss_rel_diff": rel, "tolerance": 1e-6,
+               "ok": bool(same and rel <= 1e-6)}
+        del mg
+    del m, xg, yg
+    return out
+
+
+def dp_leg(name, a, world, rank, dist, torch, steps, warmup, scaling="weak", res=None, batch=None, filters=None, timer=None, other=True):
+    """One data-parallel leg of workload `name`: warm-up + `steps` timed steps (barrier + device sync on both sides, MAX over ranks),
+    all-reduce timing, optionally the short leg in the other scaling mode, and the cross-rank check.  Returns (record, state) where
+    state = (trainer, x, y, last graph, per-step HIP-event times) for the caller's own diagnostics."""
+    wl = WORKLOADS[name]
+    res = list(res or wl["res"]); batch = batch or wl["batch"]; filters = filters or wl["filters"]
+    if scaling == "strong":
+        if batch % world:
+            raise SystemExit("--scaling strong: the global batch %d is not divisible by %d GPUs" % (batch, world))
+        per_gpu, global_batch = batch // world, batch
+    else:
+        per_gpu, global_batch = batch, batch * world
+    tr, sync, make = workload_job(name, res, filters, per_gpu, global_batch, world, rank)
+    x, y = make(batch if world > 1 else per_gpu)          # N > 1: enough samples for either leg
+    xm, ym = x[:per_gpu].contiguous(), y[:per_gpu].contiguous()
+    units = 1
+    for r in res:
+        units *= r
+    for _ in range(min(warmup, 1)):
+        tr.train_step(xm, ym)
+    torch.cuda.synchronize()
+    elapsed, step_ms, last, comm = run_leg(tr, sync, xm, ym, max(warmup - 1, 0), steps, world, dist, torch, timer)
+    loss = float(last.g_loss.detach())
+    assert loss == loss, "Model diverged with loss = NaN"        # trainer.py:275
+    rec = {"config": name, "workload": "%s fp32, %s filters=%d num_conv=4, per-GPU batch %d, full train step (%s)" % (
+               wl["name"].format(grid="x".join(str(r) for r in res)), wl["model"], filters, per_gpu, wl["step"]),
+           "grid": res, "scaling": scaling, "global_batch": global_batch, "batch_per_gpu": per_gpu, "params": tr.n_params, "steps": steps,
+           "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "value": global_batch * units * steps / elapsed, "unit": wl["unit"],
+           "units_per_step": global_batch * units, "allreduce": comm, "loss": loss, "other_scaling_leg": None, "cross_rank": None}
+    if world > 1 and other:
+        o_mode = "strong" if scaling == "weak" else "weak"
+        o_per = (batch // world) if o_mode == "strong" else batch
+        if o_per >= 1 and (o_mode == "weak" or batch % world == 0):
+            xo, yo = x[:o_per].contiguous(), y[:o_per].contiguous()
+            o_el, o_ms, o_last, o_comm = run_leg(tr, sync, xo, yo, 2, a.other_steps, world, dist, torch)
+            o_glob = o_per * world
+            rec["other_scaling_leg"] = {"scaling": o_mode, "global_batch": o_glob, "batch_per_gpu": o_per, "steps": a.other_steps, "warmup": 2,
+                                        "ms_per_step": o_el / a.other_steps * 1e3, "value": o_glob * units * a.other_steps / o_el,
+                                        "unit": wl["unit"], "allreduce": o_comm, "loss": float(o_last.g_loss.detach())}
+            del o_last, xo, yo
+    if world > 1 and not a.no_cross_rank_check:
+        rec["cross_rank"] = cross_rank_check(tr, xm, ym, world, rank, dist, torch)
+    return rec, (tr, xm, ym, last, step_ms, elapsed)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -654,7 +836,6 @@ def main():
     import torch.distributed as dist
     from deep_fluids_amd import _lib, ops
     from deep_fluids_amd.dist import init_from_env, verify_world
-    from deep_fluids_amd.trainer import Trainer, default_config
 
     env_rank, env_world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     dog = Watchdog(env_rank, env_world) if env_world > 1 else None
@@ -672,68 +853,67 @@ def main():
     if dog:
         dog.disarm()
 
-    if a.scaling == "strong":
-        if a.batch % world:
-            raise SystemExit("--scaling strong: the global batch %d is not divisible by %d GPUs" % (a.batch, world))
-        per_gpu, global_batch = a.batch // world, a.batch
-    else:
-        per_gpu, global_batch = a.batch, a.batch * world
-
-    Z, Y, X = a.res
+    wl = WORKLOADS[a.config]
+    is_3d = len(a.res) == 3
     with ops.options(conv_precision=a.precision):
-        rel_l1 = l1_vs_oracle(a.filters, a.precision) if rank == 0 else None
-        cfg = default_config(is_3d=True, res_x=X, res_y=Y, res_z=Z, filters=a.filters, batch_size=global_batch,
-                             num_samples=6600, random_seed=123)     # smoke3_obs_buo: 11*4*150 samples
-        tr = Trainer(cfg)                                           # same seed on every rank -> identical init
-        sync = tr.enable_data_parallel(profile=True) if world > 1 else None
-        x, y = make_inputs(a.batch if world > 1 else per_gpu, a.res, 123 + rank, ops)     # N > 1: enough samples for either leg
-        xm, ym = x[:per_gpu].contiguous(), y[:per_gpu].contiguous()
-
+        rel_l1 = None
+        if rank == 0:
+            rel_l1 = l1_vs_oracle_ae(a.filters) if wl["kind"] == "ae" else l1_vs_oracle(a.filters, a.precision, is_3d=is_3d)
         if dog:
-            dog.arm("warm-up steps (first gradient all-reduces)", a.init_timeout + 60.0 * a.warmup)
-        for _ in range(min(a.warmup, 1)):
-            tr.train_step(xm, ym)
-        torch.cuda.synchronize()
+            dog.arm("first leg (first gradient all-reduces)", a.init_timeout + 60.0 * (a.warmup + a.steps))
+        timer = _lib.KernelTimer(select_kernel)
+        rec, (tr, xm, ym, last, step_ms, elapsed) = dp_leg(a.config, a, world, rank, dist, torch, a.steps, a.warmup, a.scaling, a.res, a.batch,
+                                                           a.filters, timer, other=not a.no_other_leg)
         if dog:
             dog.disarm()
-        timer = _lib.KernelTimer(select_kernel)
-        elapsed, step_ms, last, comm = run_leg(tr, sync, xm, ym, max(a.warmup - 1, 0), a.steps, world, dist, torch, timer)
+        per_gpu, global_batch = rec["batch_per_gpu"], rec["global_batch"]
         ks = timer.summary()
         pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * (len(step_ms) - 1) + 0.5))]
         step_stats = {"median_ms": pct(0.5), "p10_ms": pct(0.1), "p90_ms": pct(0.9), "min_ms": step_ms[0], "max_ms": step_ms[-1],
                       "source": "HIP events on the launch stream, one per step"}
-        loss = float(last.g_loss.detach())
-        assert loss == loss, "Model diverged with loss = NaN"        # trainer.py:275
-
-        # N > 1: the OTHER scaling mode as a short second leg of the same job, so that one driver invocation yields both curves
-        other = None
-        if world > 1 and not a.no_other_leg:
-            o_mode = "strong" if a.scaling == "weak" else "weak"
-            o_per = (a.batch // world) if o_mode == "strong" else a.batch
-            if o_per >= 1 and (o_mode == "weak" or a.batch % world == 0):
-                xo, yo = x[:o_per].contiguous(), y[:o_per].contiguous()
-                o_el, o_ms, o_last, o_comm = run_leg(tr, sync, xo, yo, 2, a.other_steps, world, dist, torch)
-                o_glob = o_per * world
-                other = {"scaling": o_mode, "global_batch": o_glob, "batch_per_gpu": o_per, "steps": a.other_steps, "warmup": 2,
-                         "ms_per_step": o_el / a.other_steps * 1e3, "value": o_glob * Z * Y * X * a.other_steps / o_el, "unit": "voxels/s",
-                         "allreduce": o_comm, "loss": float(o_last.g_loss.detach())}
-                del o_last, xo, yo
+        loss, comm, other = rec["loss"], rec["allreduce"], rec["other_scaling_leg"]
 
         # which algorithm every conv / weight-gradient call of a step takes (one extra, untimed step)
         dispatch = {}
         with ops.options(dispatch_counts=dispatch):
             tr.train_step(xm, ym)
         torch.cuda.synchronize()
+        n_params = tr.n_params
+
+        # N > 1, the metric's own config: short data-parallel legs of the 2-D workload and of cfg4's grid in the SAME job, so that one
+        # driver invocation per N yields the 2-D and the 3-D numbers north_star asks for
+        extra_legs = {}
+        if world > 1 and a.config == "cfg3" and not a.no_extra_legs and a.precision == "fp32":
+            del tr, last, xm, ym
+            torch.cuda.empty_cache()
+            for name in ("cfg2", "cfg4"):
+                if dog:
+                    dog.arm("extra leg %s" % name, a.init_timeout + 120.0 * a.extra_leg_steps)
+                try:
+                    r, st = dp_leg(name, a, world, rank, dist, torch, a.extra_leg_steps, 2, "weak", other=not a.no_other_leg)
+                    del st
+                    extra_legs["extra_leg_" + name] = r
+                except Exception as e:      # every rank takes the same path (shape / memory errors are deterministic); never the metric line
+                    extra_legs["extra_leg_" + name] = {"error": repr(e)[:300]}
+                if dog:
+                    dog.disarm()
+                ops.reset_variables()
+                torch.cuda.empty_cache()
+            tr = last = xm = ym = None
 
     if rank != 0:
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
-    vox_per_step = global_batch * Z * Y * X
+    units = 1
+    for r in a.res:
+        units *= r
+    vox_per_step = global_batch * units
     value = vox_per_step * a.steps / elapsed
+    grid_s = "x".join(str(r) for r in a.res)
 
-    default_shape = list(a.res) == [64, 96, 64] and per_gpu == 16 and a.filters == 128 and a.precision == "fp32"   # the PMC passes' shape
+    default_shape = a.config == "cfg3" and list(a.res) == [64, 96, 64] and per_gpu == 16 and a.filters == 128 and a.precision == "fp32"   # the PMC passes' shape
     pmc, pmc_source = None, None
     if world == 1 and default_shape and not a.no_live_pmc:
         pmc = live_pmc()
@@ -745,22 +925,23 @@ def main():
         except (OSError, ValueError, KeyError):
             pmc = {}
 
+    what = "pixels" if not is_3d else "voxels"
     out = {
-        "metric": "velocity-field voxels/sec (3D %dx%dx%d train step), whole job; per-GPU in `per_gpu`" % (Z, Y, X),
-        "value": value, "unit": "voxels/s", "per_gpu": value / world,
+        "metric": "velocity-field %s/sec (%s %s train step), whole job; per-GPU in `per_gpu`" % (what, "3D" if is_3d else "2D", grid_s),
+        "value": value, "unit": wl["unit"], "per_gpu": value / world,
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
         "dtype": "f32" if a.precision == "fp32" else "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": "cfg3: 3D smoke3 %dx%dx%d (Z,Y,X) fp32, GeneratorBE3 filters=%d num_conv=4, per-GPU batch %d, full train "
-                               "step (fwd+curl3+jacobian3+L1 losses+bwd+Adam)" % (Z, Y, X, a.filters, per_gpu),
-                   "global_batch": global_batch, "batch_per_gpu": per_gpu, "grid": [Z, Y, X], "params": tr.n_params,
+        "config": {"workload": rec["workload"],
+                   "global_batch": global_batch, "batch_per_gpu": per_gpu, "grid": list(a.res), "params": n_params,
                    "parallelism": "dp%d" % world},
         "roofline": None,            # filled below: the kernel family with the largest share of the step
         "roofline_stencil": None,    # the standalone jacobian3 kernel (the >= 70 % target); the step itself runs the fused tail
         "cpu_baseline": None,
         "l1_vs_ref": {"value": rel_l1, "tolerance": 1e-4,
-                      "case": "relative L1 of the velocity field vs the fp64 oracle, grid 16x24x16, filters %d" % a.filters},
+                      "case": ("relative L1 of the auto-encoder's reconstructed velocity field vs the fp64 oracle, grid 16x16x16, filters %d" % a.filters) if wl["kind"] == "ae"
+                              else "relative L1 of the velocity field vs the fp64 oracle, grid %s, filters %d" % ("16x24x16" if is_3d else "32x24", a.filters)},
         "l1_vs_ref_fullsize": None,
         "step_ms": step_stats,
         "value_median": vox_per_step / (step_stats["median_ms"] * 1e-3) if world == 1 else None,
@@ -768,27 +949,29 @@ def main():
         "counted_ranks": wv["ranks"], "dist_backend": wv["backend"], "devices": wv["devices"], "distinct_devices": wv["distinct_devices"],
         "allreduce": comm,           # per step: bytes, buckets, comm_span_ms, exposed_ms (after backward), hidden_ms (under backward)
         "other_scaling_leg": other,
+        "cross_rank": rec["cross_rank"],
         "loss": loss,
         "roofline_wgrad": roofline_of(ks, "wgrad_kernel", pmc, default_shape, pmc_source),
         "roofline_conv": roofline_of(ks, "conv_mfma_kernel", pmc, default_shape, pmc_source),
-        "roofline_wino": roofline_of(ks, "wino3d_kernel", pmc, default_shape, pmc_source),
+        "roofline_wino": roofline_of(ks, "wino3d_kernel" if is_3d else "wino2d_kernel", pmc, default_shape, pmc_source),
         "roofline_tail_fwd": roofline_of(ks, "velocity_loss3d_fwd_kernel", {}, False),
         "roofline_tail_bwd": roofline_of(ks, "velocity_loss3d_bwd_kernel", {}, False),
         "stencils_standalone": None,
         "dispatch": dispatch,
         "kernels": {k: {"launches": v["launches"], "ms_total": v["seconds"] * 1e3} for k, v in sorted(ks.items())},
     }
+    out.update(extra_legs)
     fam = {}
     for k, v in ks.items():
         fam[k.split(" ")[0]] = fam.get(k.split(" ")[0], 0.0) + v["seconds"]
     dom = max((f for f in fam if not (f.startswith("jacobian") or f.startswith("velocity_loss"))), key=lambda f: fam[f], default=None)
     out["roofline"] = {"wgrad_kernel": out["roofline_wgrad"], "conv_mfma_kernel": out["roofline_conv"],
-                       "wino3d_kernel": out["roofline_wino"]}.get(dom)
+                       "wino3d_kernel": out["roofline_wino"], "wino2d_kernel": out["roofline_wino"]}.get(dom)
     for key in ("alt_bf16x3_mode", "extra_2d_128x96", "extra_cfg4_slice", "extra_ae_cfg5"):
         out[key] = None
-    if world == 1:
+    if world == 1 and is_3d:
         try:
-            out["stencils_standalone"] = stencil_rooflines(per_gpu, Z, Y, X)
+            out["stencils_standalone"] = stencil_rooflines(per_gpu, *a.res)
             out["roofline_stencil"] = dict(out["stencils_standalone"]["jacobian3d_fwd_kernel<j,c>"], kernel="jacobian3d_fwd_kernel<j,c>",
                                            traffic=pmc.get("jacobian3d_fwd_kernel", {}).get("traffic_bytes") if default_shape else None,
                                            traffic_source=(pmc_source or "profiles/pmc_latest.json") if default_shape else None,
@@ -801,19 +984,24 @@ def main():
                     out[k]["avg_launch_us"] = out[k]["avg_launch_ms"] * 1e3
         except Exception as e:
             out["stencils_standalone"] = {"error": repr(e)[:300]}
-    if world == 1 and not a.no_alt and a.precision == "fp32":
+    elif world == 1:
+        out["roofline_stencil"] = roofline_of(ks, "jacobian2d_fwd_kernel", {}, False)
+    if world == 1 and not a.no_alt and a.precision == "fp32" and a.config == "cfg3":
+        from deep_fluids_amd.trainer import default_config
+        cfg = default_config(is_3d=True, res_x=a.res[2], res_y=a.res[1], res_z=a.res[0], filters=a.filters, batch_size=global_batch,
+                             num_samples=wl["num_samples"], random_seed=123)
         del tr, last
         extras(out, a, cfg, xm, ym, vox_per_step, pmc)
     try:
-        if world == 1 and not a.no_cpu_baseline:
-            par = {} if (a.precision == "fp32" and len(a.res) == 3) else None
+        if world == 1 and not a.no_cpu_baseline and wl["kind"] == "de":
+            par = {} if (a.precision == "fp32" and is_3d) else None
             out["cpu_baseline"] = cpu_baseline(a.res, a.filters, a.cpu_seconds, par)
             out["l1_vs_ref_fullsize"] = par
     except Exception as e:      # an extra must never take the metric line down with it
         out["cpu_baseline"] = {"error": repr(e)[:300]}
     # the full record goes to a sidecar file, the printed line stays short (headline objects first)
     try:
-        side = a.sidecar or os.path.join(ROOT, "gpurun_out", "bench_full_n%d.json" % world)
+        side = a.sidecar or os.path.join(ROOT, "gpurun_out", "bench_full_n%d%s.json" % (world, "" if a.config == "cfg3" else "_" + a.config))
         os.makedirs(os.path.dirname(side), exist_ok=True)
         out["sidecar"] = os.path.relpath(side, ROOT)
         with open(side, "w") as f:

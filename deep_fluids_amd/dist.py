@@ -208,6 +208,49 @@ class GradSync(object):
         return out
 
 
+def broadcast_(t, src=0, group=None):
+    """In-place broadcast of a tensor from rank ``src``; device tensors over gloo (the single-GPU sharing configuration) are staged
+    through host memory.  No-op without an initialised process group."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def broadcast_trainer_state(slabs, scalars, src=0, group=None):
+    """Make every rank start from rank ``src``'s training state: ``slabs`` = flat device tensors (parameters, Adam slots) broadcast in
+    place; ``scalars`` = list of Python numbers (global step, learning rate, Adam step counts) returned as rank ``src`` holds them.
+    Only rank 0 writes checkpoints (Trainer.train), so after a restore-on-start on a node without a shared file system -- or whenever
+    one rank does not see the file -- the ranks would otherwise train divergent replicas with different loop lengths."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return list(scalars)
+    for t in slabs:
+        broadcast_(t, src, group)
+    h = torch.tensor([float(v) for v in scalars], dtype=torch.float64)
+    dev = slabs[0].device if (slabs and slabs[0].is_cuda and dist.get_backend(group) != "gloo") else torch.device("cpu")
+    h = h.to(dev)
+    dist.broadcast(h, src=src, group=group)
+    return h.cpu().tolist()
+
+
+def all_equal_across_ranks(value, group=None):
+    """True iff the float64 scalar / small vector ``value`` is bit-identical on every rank (MIN == MAX over the group)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return True
+    v = torch.as_tensor(value, dtype=torch.float64).reshape(-1).clone()
+    on_dev = torch.cuda.is_available() and dist.get_backend(group) != "gloo"
+    lo = v.cuda() if on_dev else v.cpu()
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool((lo == hi).all().item())
+
+
 def shard_batch(global_batch, rank, world):
     """rank r of N takes samples [r*B/N, (r+1)*B/N); B must divide evenly."""
     if global_batch % world != 0:

@@ -27,7 +27,7 @@ from . import ops
 from .ops import curl, curl3, jacobian, jacobian3, l1_mean, mse_mean, get_conv_shape, _ptr, _stream, call
 from .model import GeneratorBE, GeneratorBE3, AE, AE3, DiscriminatorPatch, DiscriminatorPatch3
 from .ops import concat, kl_bernoulli
-from .dist import GradSync
+from .dist import GradSync, broadcast_trainer_state
 
 
 def default_config(**over):
@@ -168,10 +168,20 @@ class Trainer(object):
 
     def load(self, path):
         with np.load(path) as d:
-            missing = [k for slices, _, _, _ in self._ckpt_slabs() for k in slices if k not in d.files]
+            # everything is checked BEFORE the first copy: a mismatching checkpoint must not leave the slabs half overwritten
+            need = [k + sfx for slices, _, _, _ in self._ckpt_slabs() for k in slices for sfx in ("", "/Adam", "/Adam_1")]
+            need += ["step", "g_lr", "beta_power_t"] + list(self._ckpt_extra())
+            missing = [k for k in need if k not in d.files]
             if missing:      # (tf.train.Saver.restore fails the same way on a graph / checkpoint mismatch)
                 raise ValueError("checkpoint %s does not hold this trainer's variables (e.g. %s): a different architecture / scope "
                                  "name was trained in that model_dir" % (path, missing[0]))
+            for slices, _, _, _ in self._ckpt_slabs():
+                for k, (o, n) in slices.items():
+                    for sfx in ("", "/Adam", "/Adam_1"):
+                        if int(d[k + sfx].size) != n:
+                            raise ValueError("checkpoint %s: variable %s has %d elements (shape %s), this trainer's has %d (shape %s): "
+                                             "different filters / resolution / architecture" % (
+                                                 path, k + sfx, d[k + sfx].size, tuple(d[k + sfx].shape), n, tuple(ops._VARS[k].shape)))
             for slices, fp, fm, fv in self._ckpt_slabs():
                 for k, (o, n) in slices.items():
                     fp[o:o + n].copy_(torch.from_numpy(d[k].reshape(-1)))
@@ -180,11 +190,14 @@ class Trainer(object):
             self.step = int(d["step"]); self.g_lr = float(d["g_lr"]); self._adam_t = int(d["beta_power_t"])
             self._ckpt_load_extra(d)
 
+    def effective_model_dir(self):
+        """util.py:37-38: ``--load_path`` IS the model directory when given (restore from it AND keep writing into it)."""
+        return getattr(self.config, "load_path", "") or getattr(self.config, "model_dir", None)
+
     def _auto_restore(self):
         """``sv.prepare_or_wait_for_session`` (trainer.py:107-123): a trainer started on a ``model_dir`` (= ``--load_path`` when given,
         util.py:37-38) that already holds checkpoints continues from the latest one -- variables, Adam slots, global step, g_lr."""
-        d = getattr(self.config, "load_path", "") or getattr(self.config, "model_dir", None)
-        self.restored_from = latest_checkpoint(d)
+        self.restored_from = latest_checkpoint(self.effective_model_dir())
         if self.restored_from is not None:
             self.load(self.restored_from)
             print("[*] restored %s (step %d)" % (self.restored_from, self.step))
@@ -202,7 +215,21 @@ class Trainer(object):
             n = sum(self.var_slices[k][1] for k in ks)
             buckets.append((off, n, [ops._VARS[k] for k in ks]))
         self.grad_sync = GradSync(self.flat_g, buckets, group, profile=profile, force=force)
+        self.sync_state_from_rank0(group)
         return self.grad_sync
+
+    def _state_scalars(self):
+        return [self.step, self.g_lr, self._adam_t]
+
+    def _set_state_scalars(self, v):
+        self.step, self.g_lr, self._adam_t = int(round(v[0])), float(v[1]), int(round(v[2]))
+
+    def sync_state_from_rank0(self, group=None):
+        """Every rank continues from RANK 0's state (parameters, Adam slots, global step, g_lr, Adam step counts): only rank 0 writes
+        checkpoints, so a restore-on-start that one rank could not see (no shared file system) must not leave replicas that differ --
+        their ``range(step, max_step)`` loops would have different lengths and the gradient exchange would hang."""
+        slabs = [t for _, fp, fm, fv in self._ckpt_slabs() for t in (fp, fm, fv)]
+        self._set_state_scalars(broadcast_trainer_state(slabs, self._state_scalars(), 0, group))
 
     # ---- graph (trainer.py:136-172 / trainer3.py:14-51) -------------------------------------------------
     def build_model(self, x, y):
@@ -246,13 +273,19 @@ class Trainer(object):
         return out
 
     # ---- one `sess.run(g_optim)` + `sess.run(g_lr_update)` (trainer.py:269, 284-288) -------------------------
-    def train_step(self, x, y):
+    def forward_backward(self, x, y):
+        """Forward + backward + (data parallel) the bucketed gradient exchange, WITHOUT the optimizer step: afterwards ``flat_g`` holds the
+        gradient summed over the ranks; returns (graph, the scale 1/world the optimizer folds in)."""
         self.flat_g.zero_()
         if self.grad_sync is not None:
             self.grad_sync.begin_step()
         m = self.build_model(x, y)
         m.g_loss.backward()
         gscale = self.grad_sync.finish() if self.grad_sync is not None else 1.0
+        return m, gscale
+
+    def train_step(self, x, y):
+        m, gscale = self.forward_backward(x, y)
         self._apply_adam(gscale)
         self._advance_lr()
         return m
@@ -302,7 +335,7 @@ class Trainer(object):
         (trainer.py:271-276); every ``test_step`` steps the fixed parameter sweeps are generated (trainer.py:230-241, 281-282;
         stored as ``<model_dir>/<step>_G.npz`` instead of PNG sheets); the last checkpoint is written at the end
         (trainer.py:290-292).  Only rank 0 of a data-parallel job writes files.  Returns the logged records."""
-        model_dir = model_dir or self.config.model_dir
+        model_dir = model_dir or self.effective_model_dir()
         log_step = log_step or self.config.log_step
         test_step = test_step or self.config.test_step
         max_step = self.max_step if max_step is None else max_step
@@ -356,7 +389,7 @@ class Trainer(object):
         sweep the last one (the frame number) over its ``y_num[2]`` values in [-1, 1], run the inference graph in batches of
         ``test_batch_size``, de-normalise with the dataset's velocity range (``batch_manager.denorm``) and dump frame i to
         ``<model_dir>/<p1>_<p2>/<i>.npz`` under key ``x`` (np.savez_compressed) -- the files the reference's visualisation scripts read."""
-        model_dir = model_dir or self.config.model_dir
+        model_dir = model_dir or self.effective_model_dir()
         test_b_num = test_b_num or self.config.test_batch_size
         y1, y2, y3 = (int(v) for v in batch_manager.y_num[:3])
         if y3 % test_b_num != 0:                                     # trainer.py:324 asserts; the default 100 rarely divides test data
@@ -503,6 +536,13 @@ class GANTrainer(Trainer):
 
     def _ckpt_load_extra(self, d):
         self._adam_t_d = int(d["beta_power_t_d"])
+
+    def _state_scalars(self):
+        return super(GANTrainer, self)._state_scalars() + [self._adam_t_d]
+
+    def _set_state_scalars(self, v):
+        super(GANTrainer, self)._set_state_scalars(v)
+        self._adam_t_d = int(round(v[3]))
 
     def enable_data_parallel(self, group=None, profile=False, force=False):
         """Two gradient slabs -> two bucketed exchanges: G's per generator block (as in ``Trainer``), D's as one bucket."""

@@ -106,3 +106,47 @@ def test_watchdog_prints_a_diagnostic_line_and_exits_nonzero(tmp_path):
     code2 = code.replace("time.sleep(30)", "d.disarm(); time.sleep(1.5); print('alive')")
     r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=60)
     assert r2.returncode == 0 and r2.stdout.strip().endswith("alive")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("config,res,batch,filters,kind,unit", [("cfg2", [128, 96], 64, 128, "de", "pixels/s"), ("cfg3", [64, 96, 64], 16, 128, "de", "voxels/s"),
+                                                                ("cfg4", [112, 160, 112], 4, 128, "de", "voxels/s"), ("cfg5", [128, 128, 128], 4, 64, "ae", "voxels/s")])
+def test_config_switch_resolves_the_baseline_workloads(monkeypatch, config, res, batch, filters, kind, unit):
+    """--config {cfg2,cfg3,cfg4,cfg5}: BASELINE.json's grids / per-GPU batches / widths; explicit --res / --batch / --filters still win;
+    the N > 1 command line carries the switch through the self-launch."""
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", config])
+    a = b.parse()
+    assert (a.config, a.res, a.batch, a.filters) == (config, res, batch, filters)
+    wl = b.WORKLOADS[config]
+    assert wl["kind"] == kind and wl["unit"] == unit and config in wl["name"].format(grid="x")
+    small = ["16", "24"] if len(res) == 2 else ["16", "24", "16"]
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", config, "--gpus", "8", "--res"] + small + ["--batch", "2", "--filters", "32"])
+    a = b.parse()
+    assert (a.res, a.batch, a.filters) == ([int(v) for v in small], 2, 32)
+    seen = {}
+    monkeypatch.setattr(b.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd) or 0)
+    assert b.self_launch(a) == 0
+    assert seen["cmd"][seen["cmd"].index("--config") + 1] == config
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", config, "--res", "8"] + (["8", "8", "8"] if len(res) == 3 else []))
+    with pytest.raises(SystemExit):       # a grid of the wrong dimensionality for the workload
+        b.parse()
+
+
+def test_compact_line_carries_extra_legs_and_cross_rank():
+    b = _bench()
+    leg = {"config": "cfg2", "grid": [128, 96], "scaling": "weak", "global_batch": 128, "batch_per_gpu": 64, "steps": 5, "ms_per_step": 21.0,
+           "value": 7.4e7, "unit": "pixels/s", "allreduce": {"comm_span_ms": 1.0, "exposed_ms": 0.1, "hidden_ms": 0.9}, "loss": 0.5,
+           "other_scaling_leg": None, "workload": "w" * 300,
+           "cross_rank": {"ok": True, "grad_identical_on_all_ranks": True, "loss_rel_diff": 2e-8, "grad_sum": 1.0, "loss_shard_mean": 0.5}}
+    out = {"metric": "m", "value": 1.0, "unit": "voxels/s", "per_gpu": 1.0, "n_gpus": 2, "steps": 2, "warmup": 1, "ms_per_step": 198.0,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "cfg3"},
+           "cross_rank": leg["cross_rank"], "extra_leg_cfg2": leg, "extra_leg_cfg4": {"error": "boom"}}
+    line = b.compact(out)
+    assert line["cross_rank"]["ok"] is True
+    assert line["extra_leg_cfg2"]["cross_rank"] == {"ok": True, "grad_identical_on_all_ranks": True, "loss_rel_diff": 2e-8}
+    assert "workload" not in line["extra_leg_cfg2"] and line["extra_leg_cfg2"]["allreduce"]["hidden_ms"] == 0.9
+    assert line["extra_leg_cfg4"] == {"error": "boom"}
+    json.dumps(line)

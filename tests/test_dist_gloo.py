@@ -172,3 +172,35 @@ def test_check_world_refuses_rccl_on_shared_devices():
     with pytest.raises(RuntimeError, match="returned 1"):
         check_world("nccl", 2, 1, ["a", "b"])
     assert verify_world() == {"ranks": 1, "backend": None, "devices": [verify_world()["devices"][0]], "distinct_devices": 1}
+
+
+def _state_worker(rank, world, port, out):
+    from deep_fluids_amd.dist import broadcast_trainer_state, all_equal_across_ranks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank 0 "restored a checkpoint" (step 7, decayed lr, trained slabs); the other ranks did not see the file: fresh init, step 0
+    g = torch.Generator().manual_seed(100 + rank)
+    slabs = [torch.randn(37, generator=g) for _ in range(3)]
+    scalars = [7, 3.25e-5, 7] if rank == 0 else [0, 1e-4, 0]
+    before = all_equal_across_ranks([float(s.double().sum()) for s in slabs])
+    got = broadcast_trainer_state(slabs, scalars)
+    after = all_equal_across_ranks([float(s.double().sum()) for s in slabs] + got)
+    out[rank] = ([s.clone().numpy() for s in slabs], got, before, after)
+    dist.destroy_process_group()
+
+
+def test_state_broadcast_makes_every_rank_continue_from_rank0():
+    """restore-on-start is per rank but only rank 0 writes checkpoints; enable_data_parallel() broadcasts rank 0's
+    parameters / Adam slots / step / g_lr / Adam step count so that no rank trains a divergent replica or runs a different loop length."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_state_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(100)
+    ref = [torch.randn(37, generator=g).numpy() for _ in range(3)]
+    for r in range(world):
+        slabs, got, before, after = out[r]
+        for a, b in zip(slabs, ref):
+            np.testing.assert_array_equal(a, b)
+        assert got == [7.0, 3.25e-5, 7.0]
+        assert before is False and after is True
