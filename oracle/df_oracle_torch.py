@@ -44,12 +44,15 @@ def jacobian3(x):
 
 
 def conv_same(x, w, b):
-    """channels-last x [B,*S,Cin], TF weights [*k,Cin,Cout]; k=3, stride 1."""
+    """channels-last x [B,*S,Cin], TF weights [*k,Cin,Cout]; odd cubic k (3 on the trainers' path; conv_k / last_k = 1, 5 are accepted
+    by the generator surface, model.py:5-6), stride 1, TF 'SAME' = symmetric pad k // 2."""
     nd = x.dim() - 2
+    pad = int(w.shape[0]) // 2
+    assert int(w.shape[0]) % 2 == 1
     if nd == 3:
-        y = F.conv3d(x.permute(0, 4, 1, 2, 3), w.permute(4, 3, 0, 1, 2).contiguous(), b, padding=1)
+        y = F.conv3d(x.permute(0, 4, 1, 2, 3), w.permute(4, 3, 0, 1, 2).contiguous(), b, padding=pad)
         return y.permute(0, 2, 3, 4, 1)
-    y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1).contiguous(), b, padding=1)
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1).contiguous(), b, padding=pad)
     return y.permute(0, 2, 3, 1)
 
 

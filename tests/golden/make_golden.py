@@ -275,6 +275,37 @@ def capture_generators(model):
     print("generators.npz: %d arrays; layer_plans.json: %s" % (len(res), sorted(plans)))
 
 
+def capture_generator_args(model):
+    """Non-default generator arguments the surface accepts (model.py:5-6,48-49; config.py:20,22 expose --repeat / --num_conv): num_conv,
+    repeat, conv_k, last_k.  Separate files (generators_args.npz, layer_plans_args.json) so that the round-1 fixtures stay byte-identical."""
+    cases = {
+        # tag: (fn, c_num, output_shape, filters, batch, kwargs)
+        "g3_nc2_rep3": ("GeneratorBE3", 3, [8, 16, 8, 3], 8, 2, dict(num_conv=2, repeat=3)),
+        "g2_nc5_lastk1": ("GeneratorBE", 3, [16, 8, 1], 8, 2, dict(num_conv=5, last_k=1)),
+        "g3_nc3_convk5": ("GeneratorBE3", 2, [8, 8, 8, 3], 4, 1, dict(num_conv=3, conv_k=5)),
+        "g2_convk5_lastk1_rep2": ("GeneratorBE", 3, [16, 8, 2], 8, 2, dict(conv_k=5, last_k=1, repeat=2)),
+    }
+    res, plans = {}, {}
+    for tag, (fn, c_num, oshape, filters, batch, kw) in cases.items():
+        rng = np.random.RandomState(321)
+        WEIGHTS.clear(); del PLAN[:]
+        WEIGHTS.update(orc.generator_init(rng, c_num, oshape, filters, **kw))
+        for k in list(WEIGHTS):
+            if k.endswith("biases"):
+                WEIGHTS[k] = rng.uniform(-0.1, 0.1, size=WEIGHTS[k].shape).astype(np.float32)
+        z = rng.uniform(-1, 1, size=(batch, c_num)).astype(np.float32)
+        out, var_names = getattr(model, fn)(_t(z), filters, oshape, **kw)
+        res[tag + "_z"] = z; res[tag + "_out"] = np.asarray(out)
+        for k, v in WEIGHTS.items():
+            res[tag + "|" + k] = v
+        plans[tag] = {"fn": fn, "c_num": c_num, "output_shape": oshape, "filters": filters, "kwargs": kw,
+                      "layers": list(PLAN), "variables": list(var_names)}
+    np.savez_compressed(os.path.join(HERE, "generators_args.npz"), **res)
+    with open(os.path.join(HERE, "layer_plans_args.json"), "w") as f:
+        json.dump(plans, f, indent=1, sort_keys=True)
+    print("generators_args.npz: %d arrays; layer_plans_args.json: %s" % (len(res), sorted(plans)))
+
+
 def main():
     install_stub()
     sys.path.insert(0, REF)
@@ -282,6 +313,7 @@ def main():
     import model    # the reference's own module
     capture_stencils(ops)
     capture_generators(model)
+    capture_generator_args(model)
 
 
 if __name__ == "__main__":

@@ -43,7 +43,7 @@ def _worst(errs, n=4):
     return sorted(rel.items(), key=lambda kv: -kv[1])[:n]
 
 
-def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteered=False):
+def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteered=False, use_curl=True):
     """One default-dispatch train step (or, backward=False, the inference graph) on the GPU and on the PyTorch-CPU oracle.
 
     3-D, backward: the step is run TWICE on the same weights -- once with ``ops.ACTIVATION_FETCH`` (the fp32 activations are fetched
@@ -58,14 +58,14 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteere
     ops.reset_variables()
     is_3d = len(spatial) == 3
     rng = np.random.RandomState(seed)
-    oshape = list(spatial) + [3 if is_3d else 1]
+    oshape = list(spatial) + ([3 if is_3d else 1] if use_curl else [3 if is_3d else 2])      # trainer.py:48-55
     p = orc.generator_init(rng, 3, oshape, filters)
     for k in p:
         if k.endswith("biases"):
             p[k] = rng.uniform(-0.05, 0.05, p[k].shape).astype(np.float32)
     x, y = orc.synthetic_batch(rng, batch, spatial)
     cfg = default_config(is_3d=is_3d, res_x=spatial[-1], res_y=spatial[-2], res_z=spatial[0] if is_3d else 1, filters=filters,
-                         batch_size=batch, num_samples=1000)
+                         batch_size=batch, num_samples=1000, use_curl=use_curl)
     tr = Trainer(cfg)
     tr.load_variables(p)
     torch.set_num_threads(max(1, min(len(__import__("os").sched_getaffinity(0)), 64)))
@@ -75,7 +75,7 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteere
         u = host(tr.generate(dev(y)))
         with torch.no_grad():
             psi = ort.generator_fwd(torch.from_numpy(y), pt, oshape, filters)
-            ref = (ort.jacobian3(psi)[1] if is_3d else ort.curl(psi)).numpy()
+            ref = ((ort.jacobian3(psi)[1] if is_3d else ort.curl(psi)) if use_curl else psi).numpy()
         out["velocity_rel_l1"] = rel_l1(u, ref)
         ops.reset_variables()
         return out
@@ -110,7 +110,7 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteere
     zt, xt = torch.from_numpy(y), torch.from_numpy(x)
     if unsteered:
         own = {}
-        raw = ort.train_step(zt, xt, pt, None, oshape, filters, is_3d, own_masks=own, update=False)
+        raw = ort.train_step(zt, xt, pt, None, oshape, filters, is_3d, own_masks=own, update=False, use_curl=use_curl)
         e0 = _grad_errs(gr, raw["grads"])
         out["unsteered_grad_rel_linf"] = _worst(e0)[0][1]
         nel = sum(int(v.numel()) for v in own.values())
@@ -123,7 +123,7 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteere
                   "x".join(map(str, spatial)), filters, batch, out["unsteered_grad_rel_linf"], out["lrelu_sign_disagree_frac"], nel,
                   out["l1_sign_disagree_frac"]))
         del raw, own, uo, su
-    info = ort.train_step(zt, xt, pt, ort.new_opt(pt), oshape, filters, is_3d, masks=masks, sign_u=torch.from_numpy(u))
+    info = ort.train_step(zt, xt, pt, ort.new_opt(pt), oshape, filters, is_3d, masks=masks, sign_u=torch.from_numpy(u), use_curl=use_curl)
     out["velocity_rel_l1"] = rel_l1(u, info["u"].numpy())
     out["loss_rel"] = abs(loss - info["loss"]) / abs(info["loss"])
     errs = _grad_errs(gr, info["grads"])
@@ -131,8 +131,10 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteere
     out["grad_rel_linf"] = out["grad_worst"][0][1]
     out["last_bias_abs"] = errs["__last_bias_abs"]
     out["n_layers_fetched"] = len(masks)
-    print("step vs torch oracle %s F=%d B=%d: velocity rel-L1 %.2e  loss rel %.1e  worst gradients %s  |last-bias grad|/gmax %.1e" % (
-        "x".join(map(str, spatial)), filters, batch, out["velocity_rel_l1"], out["loss_rel"], out["grad_worst"], out["last_bias_abs"]))
+    out["unsteered"] = unsteered
+    print("step vs torch oracle %s F=%d B=%d%s: velocity rel-L1 %.2e  loss rel %.1e  worst gradients %s  |last-bias grad|/gmax %.1e" % (
+        "x".join(map(str, spatial)), filters, batch, "" if use_curl else " use_curl=False", out["velocity_rel_l1"], out["loss_rel"],
+        out["grad_worst"], out["last_bias_abs"]))
     ops.reset_variables()
     return out
 
@@ -606,26 +608,24 @@ def test_cfg5_ae3_train_step_w128_rows_vs_fp64_oracle():
     _ae_step_case(True, (16, 32, 128), 64, False, steer=True, grad_tol=2e-4)
 
 
-def test_cfg5_ae3_full_train_step_vs_torch_oracle():
-    """BASELINE cfg5's OWN shape -- AE3 (F = 64, z_num = 16) at 128^3, one sample -- as a full train step (build_model_ae,
-    trainer3.py:240-279): velocity, code, loss terms and every gradient (stride-2 native weight gradients at Wo = 64 ... 8, the
-    320 -> 320 layer, the 196,608 -> 16 FC, 64 -> 64 Winograd forms at W = 128) against the PyTorch-CPU oracle's autograd, steered
-    on the GPU's linear pieces and -- bounded -- on the oracle's own.  Falls back to 64^3 (printed) when the host has < 100 GB free."""
+def _ae_step_vs_torch_oracle(spatial, filters, z_num, seed, p_num=2):
+    """One AETrainer step (build_model_ae, trainer3.py:240-279 / trainer.py:357-423), batch 1, on the GPU and through the PyTorch-CPU
+    oracle's autograd on the same weights: velocity, code, loss terms, every gradient -- steered on the GPU's linear pieces and, bounded,
+    on the oracle's own."""
     from deep_fluids_amd import ops
     from deep_fluids_amd.trainer import AETrainer, default_config
     ops.reset_variables()
-    free_gb = _host_mem_available_gb()
-    R = 128 if free_gb >= 100.0 else 64
-    filters, z_num, p_num = 64, 16, 2
-    rng = np.random.RandomState(41)
-    xshape = [R, R, R, 3]
+    is_3d = len(spatial) == 3
+    rng = np.random.RandomState(seed)
+    xshape = list(spatial) + [3 if is_3d else 2]
     p = orc.ae_init(rng, xshape, filters, z_num)
     for k in p:
         if k.endswith("biases"):
             p[k] = rng.uniform(-0.05, 0.05, p[k].shape).astype(np.float32)
-    x, _ = orc.synthetic_batch(rng, 1, (R, R, R))
+    x, _ = orc.synthetic_batch(rng, 1, tuple(spatial))
     y = rng.uniform(-1, 1, (1, p_num, 5)).astype(np.float32)
-    cfg = default_config(is_3d=True, res_x=R, res_y=R, res_z=R, filters=filters, batch_size=1, num_samples=1000, z_num=z_num, p_num=p_num)
+    cfg = default_config(is_3d=is_3d, res_x=spatial[-1], res_y=spatial[-2], res_z=spatial[0] if is_3d else 1, filters=filters, batch_size=1,
+                         num_samples=1000, z_num=z_num, p_num=p_num)
     tr = AETrainer(cfg)
     assert sorted(tr.var_names) == sorted(p)
     tr.load_variables(p)
@@ -645,7 +645,7 @@ def test_cfg5_ae3_full_train_step_vs_torch_oracle():
     torch.set_num_threads(max(1, min(len(__import__("os").sched_getaffinity(0)), 64)))
     pt = ort.to_torch(p)
     xt, yl = torch.from_numpy(x), torch.from_numpy(y[:, :, -1].copy())
-    info = ort.ae_grads(xt, yl, pt, filters, z_num, p_num, True, enc_masks=enc_masks, dec_masks=dec_masks, sign_u=torch.from_numpy(u))
+    info = ort.ae_grads(xt, yl, pt, filters, z_num, p_num, is_3d, enc_masks=enc_masks, dec_masks=dec_masks, sign_u=torch.from_numpy(u))
 
     def errs_of(ref):
         ref = {k: v.numpy().astype(np.float64) for k, v in ref.items()}
@@ -655,15 +655,29 @@ def test_cfg5_ae3_full_train_step_vs_torch_oracle():
     worst = errs_of(info["grads"])
     ev, ez = rel_l1(u, info["u"].numpy()), rel_linf(zc, info["z"].numpy())
     own_e, own_d = {}, {}
-    raw = ort.ae_grads(xt, yl, pt, filters, z_num, p_num, True, own_enc=own_e, own_dec=own_d)
+    raw = ort.ae_grads(xt, yl, pt, filters, z_num, p_num, is_3d, own_enc=own_e, own_dec=own_d)
     worst_raw = errs_of(raw["grads"])
     nel = sum(int(v.numel()) for v in list(own_e.values()) + list(own_d.values()))
     dis = (sum(int((own_e[k] != enc_masks[k]).sum()) for k in own_e) + sum(int((own_d[k] != dec_masks[k]).sum()) for k in own_d)) / float(nel)
-    print("AE3 %d^3 F=64 B=1 train step vs torch oracle (host MemAvailable %.0f GB): velocity rel-L1 %.2e, z rel-Linf %.2e, loss rel %.1e, "
+    print("AE %s F=%d B=1 train step vs torch oracle: velocity rel-L1 %.2e, z rel-Linf %.2e, loss rel %.1e, "
           "worst gradients steered %s / un-steered %s, lrelu sign decisions that differ %.2e of %d" % (
-              R, free_gb, ev, ez, abs(loss - info["loss"]) / abs(info["loss"]), worst, worst_raw[:2], dis, nel))
-    assert ev <= 1e-4 and ez < 1e-4
-    assert abs(loss - info["loss"]) < 1e-5 * abs(info["loss"]) and abs(loss_p - info["loss_p"]) < 1e-4 * abs(info["loss_p"]) + 1e-8
-    assert worst[0][1] < 2e-4, worst
-    assert worst_raw[0][1] < 5e-2 and dis < 1e-3, (worst_raw, dis)
+              "x".join(map(str, spatial)), filters, ev, ez, abs(loss - info["loss"]) / abs(info["loss"]), worst, worst_raw[:2], dis, nel))
     ops.reset_variables()
+    return {"velocity_rel_l1": ev, "z_rel_linf": ez, "loss_rel": abs(loss - info["loss"]) / abs(info["loss"]),
+            "loss_p_ok": abs(loss_p - info["loss_p"]) < 1e-4 * abs(info["loss_p"]) + 1e-8, "grad_worst": worst,
+            "unsteered_grad_worst": worst_raw, "lrelu_sign_disagree_frac": dis}
+
+
+def test_cfg5_ae3_full_train_step_vs_torch_oracle():
+    """BASELINE cfg5's OWN shape -- AE3 (F = 64, z_num = 16) at 128^3, one sample -- as a full train step (build_model_ae,
+    trainer3.py:240-279): velocity, code, loss terms and every gradient (stride-2 native weight gradients at Wo = 64 ... 8, the
+    320 -> 320 layer, the 196,608 -> 16 FC, 64 -> 64 Winograd forms at W = 128) against the PyTorch-CPU oracle's autograd, steered
+    on the GPU's linear pieces and -- bounded -- on the oracle's own.  Falls back to 64^3 (printed) when the host has < 100 GB free."""
+    free_gb = _host_mem_available_gb()
+    R = 128 if free_gb >= 100.0 else 64
+    print("cfg5 AE3 full train step at %d^3 (host MemAvailable %.0f GB)" % (R, free_gb))
+    r = _ae_step_vs_torch_oracle((R, R, R), 64, 16, seed=41)
+    assert r["velocity_rel_l1"] <= 1e-4 and r["z_rel_linf"] < 1e-4, r
+    assert r["loss_rel"] < 1e-5 and r["loss_p_ok"], r
+    assert r["grad_worst"][0][1] < 2e-4, r
+    assert r["unsteered_grad_worst"][0][1] < 5e-2 and r["lrelu_sign_disagree_frac"] < 1e-3, r

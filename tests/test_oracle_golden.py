@@ -98,6 +98,28 @@ def test_generator_graph_structure(golden_generators, tag):
     assert [l["name"] for l in pl["layers"]] == ["G/0_fc"] + ["G/%d_conv" % i for i in range(1, nl)]
 
 
+@pytest.mark.parametrize("tag", ["g3_nc2_rep3", "g2_nc5_lastk1", "g3_nc3_convk5", "g2_convk5_lastk1_rep2"])
+def test_generator_nondefault_arguments_graph_structure(tag):
+    """num_conv / repeat / conv_k / last_k away from their defaults (model.py:5-6,48-49; --repeat / --num_conv are reference flags,
+    config.py:20,22): the restated generator == the reference's model.py executed with the same keyword arguments, bit for bit."""
+    g = dict(np.load(os.path.join(GOLDEN, "generators_args.npz")))
+    pl = json.load(open(os.path.join(GOLDEN, "layer_plans_args.json")))[tag]
+    kw = pl["kwargs"]
+    p = {k.split("|", 1)[1]: v for k, v in g.items() if k.startswith(tag + "|")}
+    out = orc.generator_fwd(g[tag + "_z"], p, pl["output_shape"], pl["filters"], num_conv=kw.get("num_conv", 4), repeat=kw.get("repeat", 0))
+    np.testing.assert_array_equal(out, g[tag + "_out"])
+    assert sorted(p) == pl["variables"]
+    rep, x0, nl = orc.generator_plan(pl["output_shape"], pl["filters"], kw.get("num_conv", 4), kw.get("repeat", 0))
+    assert nl == len(pl["layers"]) == 2 + rep * kw.get("num_conv", 4)
+    if "repeat" in kw:
+        assert rep == kw["repeat"]
+    ks = [l["k"] for l in pl["layers"][1:]]
+    assert ks[:-1] == [kw.get("conv_k", 3)] * (nl - 2) and ks[-1] == kw.get("last_k", 3)
+    # the same initialiser reproduces the variable shapes the reference's layers asserted on
+    q = orc.generator_init(np.random.RandomState(0), pl["c_num"], pl["output_shape"], pl["filters"], **kw)
+    assert {k: v.shape for k, v in q.items()} == {k: v.shape for k, v in p.items()}
+
+
 def test_parameter_counts_at_baseline_shapes():
     plans = json.load(open(os.path.join(GOLDEN, "layer_plans.json")))
     assert plans["cfg2_2d_128x96"]["n_params"] == 2977409
