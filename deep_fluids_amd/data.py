@@ -194,3 +194,34 @@ def write_synthetic_dataset(root, spatial, num_p=(3, 2), num_frames=4, seed=0, a
     with open(os.path.join(root, "v_range.txt"), "w") as f:
         f.write("%.3f\n%.3f\n" % (-vmax, vmax))
     return num_p[0] * num_p[1] * num_frames
+
+
+def write_synthetic_ae_dataset(root, spatial, num_scenes=2, num_frames=4, seed=0):
+    """A tiny dataset in the on-disk format of the reference's moving-source scenes (scene/smoke3_mov.py:18-38,176-182,286-326 --
+    what ``--arch=ae`` trains on, run.bat:56,73): ``v/<scene>_<frame>.npz`` with x = velocity [(Z,)Y,X,2|3] and y = source positions
+    [dof, frames]; ``n.npz`` with the noise tracks ``nx`` (and ``nz`` in 3-D) [scenes, frames]; ``args.txt``; ``v_range.txt``."""
+    rng = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "v"), exist_ok=True)
+    is_3d = len(spatial) == 3
+    dof = 2 if is_3d else 1
+    lines = ["num_param: 2", "path_format: %d_%d.npz", "p0: scenes", "p1: frames", "min_scenes: 0", "max_scenes: %d" % (num_scenes - 1),
+             "num_scenes: %d" % num_scenes, "min_frames: 0", "max_frames: %d" % (num_frames - 1), "num_frames: %d" % num_frames,
+             "num_simulations: %d" % (num_scenes * num_frames), "num_dof: %d" % dof]
+    with open(os.path.join(root, "args.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    nx = rng.uniform(-1, 1, (num_scenes, num_frames)).astype(np.float32)
+    nz = rng.uniform(-1, 1, (num_scenes, num_frames)).astype(np.float32)
+    vmax = 0.0
+    for i in range(num_scenes):
+        for t in range(num_frames):
+            x = rng.uniform(-2, 2, size=list(spatial) + [3 if is_3d else 2]).astype(np.float32)
+            vmax = max(vmax, float(np.abs(x).max()))
+            y = np.stack([nx[i], nz[i]])[:dof].astype(np.float32)           # [dof, frames]; the trainer reads y[:, :, -1]
+            np.savez_compressed(os.path.join(root, "v", "%d_%d.npz" % (i, t)), x=x, y=y)
+    if is_3d:
+        np.savez_compressed(os.path.join(root, "n.npz"), nx=nx, nz=nz)
+    else:
+        np.savez_compressed(os.path.join(root, "n.npz"), nx=nx)
+    with open(os.path.join(root, "v_range.txt"), "w") as f:
+        f.write("%.3f\n%.3f\n" % (-vmax, vmax))
+    return num_scenes * num_frames

@@ -37,7 +37,7 @@ def default_config(**over):
              optimizer="adam", beta1=0.5, beta2=0.999, lr_update="decay", lr_update_step=120000,
              start_step=0, random_seed=123, num_samples=21000, c_num=3, use_curl3_alias=True,
              z_num=16, use_sparse=False, sparsity=0.01, w4=1.0, w5=1.0, p_num=2, x_channels=None, w3=0.005,
-             log_step=500, test_step=1000, test_batch_size=100, model_dir=None, load_path="", save_sec=3600,   # config.py:62-68
+             log_step=500, test_step=1000, test_batch_size=100, model_dir=None, load_path="", code_path="", save_sec=3600,   # config.py:62-68
              fused_tail=True)
     c.update(over)
     return SimpleNamespace(**c)
@@ -480,6 +480,82 @@ class AETrainer(Trainer):
             loss = loss + loss_kl * self.w5
         return SimpleNamespace(s=out, G_=x_, x_=x_, z=z, G_jaco_=x_jaco_, G_vort_=x_vort_, x_jaco=x_jaco,
                                g_loss_l1=loss_l1, g_loss_j_l1=loss_j_l1, loss_p=loss_p, loss_kl=loss_kl, g_loss=loss, loss=loss)
+
+
+    # ---- `test_ae` (trainer.py:475-583, trainer3.py:311-367; `--arch=ae --is_train=False`) ------------------------------------
+    def encode(self, x):
+        """The code ``z`` of the inference graph (``build_test_model_ae``, trainer.py:464-473 / trainer3.py:311-320)."""
+        ae = AE3 if self.is_3d else AE
+        with torch.no_grad():
+            _, z, _ = ae(x, self.filters, self.z_num, name=self.name, num_conv=self.num_conv, repeat=self.repeat,
+                         use_sparse=self.use_sparse, reuse=True)
+        return z
+
+    def decode(self, z):
+        """``sess.run(self.x_, {self.z: z})`` (trainer.py:541-542): feeding the code tensor bypasses the encoder AND the sigmoid of
+        ``use_sparse``; the decoder 'dec' (+ curl when ``use_curl``) turns the fed code into the velocity field."""
+        gen = GeneratorBE3 if self.is_3d else GeneratorBE
+        with torch.no_grad():
+            out, _ = gen(z, self.filters, self._x_shape(), name=self.name + "/dec", num_conv=self.num_conv, repeat=self.repeat, reuse=True)
+            if self.config.use_curl:
+                out = curl3(out) if self.is_3d else curl(out)
+        return out
+
+    def test_(self, batch_manager, model_dir=None, code_path=None, test_b_num=None):
+        return self.test_ae(batch_manager, model_dir, code_path, test_b_num)
+
+    def test_ae(self, batch_manager, model_dir=None, code_path=None, test_b_num=None):
+        """``Trainer.test_ae``.  Without ``code_path`` (trainer.py:478-523): encode the whole dataset in file order
+        (``batch_manager.batch_``) and write ``<model_dir>/code<z_num>.npz`` -- ``x`` = codes of frames 0..F-2 of every scene, ``y`` =
+        codes of frames 1..F-1, ``p`` = per-frame source-position increments from ``<data root>/n.npz`` (nx [, nz]), ``s`` scenes,
+        ``f`` frames: the training set of the latent-space integrator.  With ``code_path`` (trainer.py:524-571): read
+        ``<code_path>/code_out.npz`` (``z_out``, ``z_gt`` [scenes, frames, z_num]), decode both in batches of ``test_batch_size``,
+        de-normalise and write ``<model_dir>/v<scene>.npz`` with ``v`` / ``v_gt`` (the arrays the reference builds and whose save it
+        leaves commented out, trainer.py:569-571; its PNG sheets are visualisation, out of scope).  Returns the written path(s)."""
+        model_dir = model_dir or self.effective_model_dir()
+        test_b_num = test_b_num or self.config.test_batch_size
+        code_path = code_path if code_path is not None else getattr(self.config, "code_path", "")
+        os.makedirs(model_dir, exist_ok=True)
+        if not code_path:
+            with np.load(os.path.join(batch_manager.root, "n.npz")) as data:
+                nx = data["nx"]
+                nz = data["nz"] if self.is_3d else None
+            num_sims, num_frames = nx.shape[0], nx.shape[1]
+            dx_list = (nx[:, 1:] - nx[:, :-1]).reshape([-1, 1])
+            if self.is_3d:
+                dz_list = (nz[:, 1:] - nz[:, :-1]).reshape([-1, 1])
+                p_list = np.concatenate((dx_list, dz_list), axis=-1)
+            else:
+                p_list = dx_list
+            c_list = []
+            for x, _ in batch_manager.batch_(test_b_num):
+                c_list.append(self.encode(torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(self.device)).cpu().numpy())
+            c_list = np.concatenate(c_list)
+            x_list, y_list = [], []
+            for i in range(num_sims):
+                s1, s2 = i * num_frames, (i + 1) * num_frames
+                x_list.append(c_list[s1:s2 - 1, :])
+                y_list.append(c_list[s1 + 1:s2, :])
+            x_list, y_list = np.concatenate(x_list), np.concatenate(y_list)
+            out = os.path.join(model_dir, "code%d.npz" % self.z_num)
+            np.savez_compressed(out, x=x_list, y=y_list, p=p_list, s=num_sims, f=num_frames)
+            return out
+        with np.load(os.path.join(code_path, "code_out.npz")) as data:
+            z_, z_gt_ = data["z_out"], data["z_gt"]
+        num_sims, num_frames = z_.shape[0], z_[0].shape[0]
+        num_iters = int(num_frames / test_b_num)
+        paths = []
+        for s in range(num_sims):
+            v, v_gt = [], []
+            for i in range(num_iters):
+                for src, dst in ((z_[s], v), (z_gt_[s], v_gt)):
+                    zz = torch.from_numpy(np.ascontiguousarray(src[i * test_b_num:(i + 1) * test_b_num, :], np.float32)).to(self.device)
+                    vv, _ = batch_manager.denorm(self.decode(zz).cpu().numpy())
+                    dst.append(vv)
+            out = os.path.join(model_dir, "v%d.npz" % s)
+            np.savez_compressed(out, v=np.concatenate(v, axis=0), v_gt=np.concatenate(v_gt, axis=0))
+            paths.append(out)
+        return paths
 
 
 class _Slab(object):

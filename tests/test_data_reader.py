@@ -1,4 +1,5 @@
 """CPU: the dataset reader (deep_fluids_amd/data.py) on a tiny dataset written in the reference's on-disk format."""
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -38,3 +39,24 @@ def test_batch_manager_ae_layout(tmp_path):
     x, y = bm.batch()
     bm.stop_thread()
     assert tuple(x.shape) == (2, 4, 6, 4, 3) and tuple(y.shape) == (2, 2, 3) and bm.dof == 2
+
+
+def test_synthetic_ae_dataset_has_the_moving_source_layout(tmp_path):
+    """scene/smoke3_mov.py:18-38,286-326: v/<scene>_<frame>.npz (x, y [dof, frames]), n.npz (nx, nz [scenes, frames]), args.txt with
+    p0 = scenes, p1 = frames; BatchManager(arch='ae') sorts by (scene, frame) and batch_ walks that order."""
+    from deep_fluids_amd.data import write_synthetic_ae_dataset
+    root = str(tmp_path / "d")
+    n = write_synthetic_ae_dataset(root, (4, 6, 4), num_scenes=3, num_frames=4, seed=1)
+    assert n == 12
+    cfg = SimpleNamespace(random_seed=1, data_path=root, is_3d=True, arch="ae", data_type="velocity", batch_size=2,
+                          res_x=4, res_y=6, res_z=4, num_worker=1)
+    bm = BatchManager(cfg, device=None)
+    assert [os.path.basename(q) for q in bm.paths[:5]] == ["0_0.npz", "0_1.npz", "0_2.npz", "0_3.npz", "1_0.npz"]
+    assert bm.label_dim == [2, 4] and bm.c_num == 2 and bm.y_num == [3, 4]
+    nn = np.load(os.path.join(root, "n.npz"))
+    assert nn["nx"].shape == (3, 4) and nn["nz"].shape == (3, 4)
+    got = list(bm.batch_(4))
+    assert len(got) == 3 and got[0][0].shape == (4, 4, 6, 4, 3) and np.abs(got[0][0]).max() <= 1.0
+    root2 = str(tmp_path / "d2")
+    write_synthetic_ae_dataset(root2, (6, 4), num_scenes=2, num_frames=3)
+    assert "nz" not in np.load(os.path.join(root2, "n.npz")).files

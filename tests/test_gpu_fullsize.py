@@ -25,7 +25,7 @@ def _rel_max(a, b):
     return ((a - b).abs().max() / b.abs().max()).item()
 
 
-def _grad_errs(gpu_grads, ref_grads):
+def _grad_errs(gpu_grads, ref_grads, last_bias_is_roundoff=True):
     """Per-variable L-inf error relative to that variable's gradient scale, floored at 1e-3 of the global scale.  The LAST conv's
     bias gradient is mathematically zero (curl annihilates constants): in any finite precision it is the roundoff of a
     sign-cancelling sum over all voxels, so two correct implementations share no digits of it -- it is checked separately to be
@@ -33,7 +33,8 @@ def _grad_errs(gpu_grads, ref_grads):
     ref = {k: np.asarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v, np.float64) for k, v in ref_grads.items()}
     gmax = max(np.abs(v).max() for v in ref.values())
     last_bias = sorted((k for k in ref if k.endswith("biases")), key=lambda k: int(k.split("/")[1].split("_")[0]))[-1]
-    errs = {k: float(np.abs(gpu_grads[k] - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-3 * gmax)) for k in gpu_grads if k != last_bias}
+    errs = {k: float(np.abs(gpu_grads[k] - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-3 * gmax)) for k in gpu_grads
+            if not (last_bias_is_roundoff and k == last_bias)}         # use_curl=False: the last bias gradient is an ordinary gradient
     errs["__last_bias_abs"] = float(np.abs(gpu_grads[last_bias]).max() / gmax)
     return errs
 
@@ -111,7 +112,7 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteere
     if unsteered:
         own = {}
         raw = ort.train_step(zt, xt, pt, None, oshape, filters, is_3d, own_masks=own, update=False, use_curl=use_curl)
-        e0 = _grad_errs(gr, raw["grads"])
+        e0 = _grad_errs(gr, raw["grads"], use_curl)
         out["unsteered_grad_rel_linf"] = _worst(e0)[0][1]
         nel = sum(int(v.numel()) for v in own.values())
         out["lrelu_sign_disagree_frac"] = sum(int((own[k] != masks[k]).sum()) for k in own) / float(nel)
@@ -126,7 +127,7 @@ def _step_vs_torch_oracle(spatial, filters, batch, seed, backward=True, unsteere
     info = ort.train_step(zt, xt, pt, ort.new_opt(pt), oshape, filters, is_3d, masks=masks, sign_u=torch.from_numpy(u), use_curl=use_curl)
     out["velocity_rel_l1"] = rel_l1(u, info["u"].numpy())
     out["loss_rel"] = abs(loss - info["loss"]) / abs(info["loss"])
-    errs = _grad_errs(gr, info["grads"])
+    errs = _grad_errs(gr, info["grads"], use_curl)
     out["grad_worst"] = _worst(errs)
     out["grad_rel_linf"] = out["grad_worst"][0][1]
     out["last_bias_abs"] = errs["__last_bias_abs"]

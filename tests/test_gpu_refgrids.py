@@ -35,21 +35,22 @@ def test_runbat_smoke3_vel_buo_32x64x112_train_step():
     assert r["n_layers_fetched"] == 16, r
     _assert_production_dispatch_identical(r, 3)
     assert r["velocity_rel_l1"] <= 1e-4 and r["loss_rel"] < 1e-5, r
-    assert r["grad_rel_linf"] < 2e-4, r
-    assert r["unsteered_grad_rel_linf"] < 5e-2 and r["lrelu_sign_disagree_frac"] < 1e-3 and r["l1_sign_disagree_frac"] < 1e-3, r
+    assert r["grad_rel_linf"] < 3e-5, r                                # measured 9.4e-6
+    # un-steered: measured 6.1e-3 (x3); sign decisions that differ: 2.2e-7 of 2.7e8 lrelu's, 0 of the |.| terms
+    assert r["unsteered_grad_rel_linf"] < 2e-2 and r["lrelu_sign_disagree_frac"] < 1e-5 and r["l1_sign_disagree_frac"] < 1e-5, r
     assert r["last_bias_abs"] < 1e-3, r
 
 
-@pytest.mark.parametrize("spatial,seed", [((48, 72, 96), 52), ((96, 48, 96), 53)])
-def test_runbat_liquid3_without_curl_train_step(spatial, seed):
+@pytest.mark.parametrize("spatial,seed,unsteered_bound", [((48, 72, 96), 52, 4e-3), ((96, 48, 96), 53, 2e-3)])
+def test_runbat_liquid3_without_curl_train_step(spatial, seed, unsteered_bound):
     """run.bat:42 (liquid3_vis 96x72x48: x0 = 6x9x12, an ODD coarse extent through the Winograd tiles and the 27-point up-sampling
     forms) and run.bat:37 (liquid3_d_r 96x48x96): --use_curl=False, the generator emits the 3-channel velocity itself."""
     r = _step_vs_torch_oracle(spatial, 128, 1, seed=seed, unsteered=True, use_curl=False)
     assert r["n_layers_fetched"] == 16, r
     _assert_production_dispatch_identical(r, 3)
     assert r["velocity_rel_l1"] <= 1e-4 and r["loss_rel"] < 1e-5, r
-    assert r["grad_rel_linf"] < 2e-4, r
-    assert r["unsteered_grad_rel_linf"] < 5e-2 and r["lrelu_sign_disagree_frac"] < 1e-3, r
+    assert r["grad_rel_linf"] < 5e-5, r                                # measured 1.6e-5 / 1.5e-5 (last conv's bias included: no curl)
+    assert r["unsteered_grad_rel_linf"] < unsteered_bound and r["lrelu_sign_disagree_frac"] < 1e-5, r      # measured 1.2e-3 / 6.5e-4 (x3)
 
 
 def test_runbat_liquid_pos_size_2d_64x128_without_curl_train_step():
@@ -57,19 +58,19 @@ def test_runbat_liquid_pos_size_2d_64x128_without_curl_train_step():
     r = _step_vs_torch_oracle((64, 128), 128, 2, seed=54, unsteered=True, use_curl=False)
     assert r["n_layers_fetched"] == 20, r
     assert r["velocity_rel_l1"] <= 1e-4 and r["loss_rel"] < 1e-5, r
-    assert r["grad_rel_linf"] < 2e-4, r
-    assert r["unsteered_grad_rel_linf"] < 5e-2 and r["lrelu_sign_disagree_frac"] < 1e-3, r
+    assert r["grad_rel_linf"] < 1e-5, r                                # measured 1.8e-6
+    assert r["unsteered_grad_rel_linf"] < 2e-3 and r["lrelu_sign_disagree_frac"] < 1e-5, r      # measured 1.7e-5 (one flip away from ~1e-3)
 
 
-@pytest.mark.parametrize("spatial,seed", [((48, 72, 48), 55), ((128, 96), 56)])
-def test_runbat_smoke_mov_autoencoder_train_step(spatial, seed):
+@pytest.mark.parametrize("spatial,seed,unsteered_bound", [((48, 72, 48), 55, 1.5e-2), ((128, 96), 56, 5e-2)])
+def test_runbat_smoke_mov_autoencoder_train_step(spatial, seed, unsteered_bound):
     """run.bat:73 (AE3 48x72x48, --filter=64 --z_num=16, batch 4 -> 1 here) and run.bat:56 (2-D AE 128x96): build_model_ae
     (trainer3.py:240-279 / trainer.py:357-423) as a full train step vs the PyTorch-CPU oracle's autograd."""
     r = _ae_step_vs_torch_oracle(spatial, 64, 16, seed)
     assert r["velocity_rel_l1"] <= 1e-4 and r["z_rel_linf"] < 1e-4, r
     assert r["loss_rel"] < 1e-5 and r["loss_p_ok"], r
-    assert r["grad_worst"][0][1] < 2e-4, r
-    assert r["unsteered_grad_worst"][0][1] < 5e-2 and r["lrelu_sign_disagree_frac"] < 1e-3, r
+    assert r["grad_worst"][0][1] < 3e-5, r                             # measured 7.5e-6 / 8.1e-6
+    assert r["unsteered_grad_worst"][0][1] < unsteered_bound and r["lrelu_sign_disagree_frac"] < 1e-5, r     # measured 4.3e-3 / 1.9e-2 (x3)
 
 
 # ---------------------------------------------------------------- (b) non-default generator arguments
@@ -145,11 +146,16 @@ def test_trainer_step_with_nondefault_num_conv_and_repeat_vs_fp64_oracle(is_3d, 
     tr = Trainer(cfg)
     assert sorted(tr.var_names) == sorted(p)
     tr.load_variables(p)
-    m = tr.train_step(dev(x), dev(y))
+    # gradients are compared on the linear pieces the GPU is on (lrelu slopes from its fetched activations, |.| signs from its velocity):
+    # un-steered, one pre-activation within rounding of zero moves single gradients by 1-2e-2 here (measured), see test_gpu_fullsize.py
+    with ops.options(activation_fetch=[]):
+        m = tr.train_step(dev(x), dev(y))
+        masks = {i + 1: host(t) > 0 for i, t in enumerate(ops.ACTIVATION_FETCH)}
+    assert len(masks) == len(p) // 2 - 2
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     opt = {"m": {k: np.zeros_like(v) for k, v in p64.items()}, "v": {k: np.zeros_like(v) for k, v in p64.items()}, "t": 0, "lr": cfg.lr_max}
     _, _, info = orc.train_step(y.astype(np.float64), x.astype(np.float64), p64, opt, oshape, filters, is_3d, num_conv=kw.get("num_conv", 4),
-                                repeat=kw.get("repeat", 0))
+                                repeat=kw.get("repeat", 0), masks=masks, sign_u=host(m.G_))
     assert rel_l1(host(m.G_), info["u"]) <= 1e-4
     assert abs(float(m.g_loss.detach()) - info["loss"]) < 1e-5 * abs(info["loss"])
     gr = tr.grads_numpy()
@@ -157,7 +163,8 @@ def test_trainer_step_with_nondefault_num_conv_and_repeat_vs_fp64_oracle(is_3d, 
     last_bias = sorted((k for k in gr if k.endswith("biases")), key=lambda k: int(k.split("/")[1].split("_")[0]))[-1]
     worst = sorted(((float(np.abs(gr[k] - info["grads"][k]).max() / max(np.abs(info["grads"][k]).max(), 1e-3 * gmax)), k) for k in gr if k != last_bias),
                    reverse=True)[:3]
-    assert worst[0][0] < 1e-3, worst
+    print("trainer step %s %s F=%d: worst gradients (steered) %s" % (kw, spatial, filters, worst))
+    assert worst[0][0] < 2e-4, worst
     if tr.grad_sync is None:      # bucket ids follow num_conv: fc | one bucket per block | last conv
         ids = sorted({tr._bucket_id(k) for k in tr.var_names})
         assert ids == list(range(len(ids)))
