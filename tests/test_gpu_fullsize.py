@@ -153,15 +153,15 @@ def test_cfg3_default_dispatch_train_step_vs_torch_oracle_b2():
     r = _step_vs_torch_oracle((64, 96, 64), 128, 2, seed=11, unsteered=True)
     assert r["n_layers_fetched"] == 16, r
     _assert_production_dispatch_identical(r, 3)
-    assert r["lrelu_sign_disagree_frac"] < 1e-3 and r["l1_sign_disagree_frac"] < 1e-3, r      # measured: see the printed line
+    assert r["lrelu_sign_disagree_frac"] < 1e-5 and r["l1_sign_disagree_frac"] < 1e-5, r      # measured 3.2e-7 of 4.6e8 / 0 (round 5)
     assert r["velocity_rel_l1"] <= 1e-4, r           # north-star tolerance (measured ~2e-6: fp32 vs fp32)
     assert r["loss_rel"] < 1e-5, r
-    assert r["grad_rel_linf"] < 2e-4, r              # measured 1.4e-5 (on the GPU's linear piece; 2-4e-3 with the oracle's own signs)
+    assert r["grad_rel_linf"] < 5e-5, r              # measured 1.3e-5 (on the GPU's linear piece); bound = measured x 3, round 5
     # and WITHOUT steering (the oracle on its own linear pieces): a handful of pre-activations within rounding error of zero moves the
     # cancelling gradient sums by 1.6e-2 (measured, round 3); a kernel that flipped even 1e-4 of the masks consistently in forward and
     # backward would pass the steered check above and fail this bound (and the sign-disagreement bound) by an order of magnitude
-    assert r["unsteered_grad_rel_linf"] < 5e-2, r
-    assert r["last_bias_abs"] < 1e-3, r
+    assert r["unsteered_grad_rel_linf"] < 5e-2, r    # measured 1.61e-2 (x 3); the run.bat grids have their own, tighter bounds (test_gpu_refgrids.py)
+    assert r["last_bias_abs"] < 1e-5, r              # measured 8e-7
 
 
 def _host_mem_available_gb():
@@ -194,7 +194,7 @@ def test_cfg4_full_grid_train_step_vs_torch_oracle():
     assert r["n_layers_fetched"] == 20, r
     _assert_production_dispatch_identical(r, 4)
     assert r["loss_rel"] < 1e-5, r
-    assert r["grad_rel_linf"] < 2e-4, r          # measured 2.5e-5
+    assert r["grad_rel_linf"] < 1e-4, r          # measured 2.7e-5
     assert r["last_bias_abs"] < 1e-3, r
 
 
@@ -543,8 +543,8 @@ def test_cfg2_train_step_128x96_vs_torch_oracle_and_batch64_identity():
     assert r["n_layers_fetched"] == 20, r
     assert r["velocity_rel_l1"] <= 1e-4, r
     assert r["loss_rel"] < 1e-5, r
-    assert r["grad_rel_linf"] < 2e-4, r
-    assert r["unsteered_grad_rel_linf"] < 5e-2 and r["lrelu_sign_disagree_frac"] < 1e-3, r      # see the cfg3 test
+    assert r["grad_rel_linf"] < 3e-5, r                                                        # measured 7.1e-6
+    assert r["unsteered_grad_rel_linf"] < 5e-2 and r["lrelu_sign_disagree_frac"] < 1e-5, r      # measured 1.8e-2 / 2.4e-7 (see the cfg3 test)
     assert r["last_bias_abs"] < 1e-3, r
     from deep_fluids_amd import ops
     from deep_fluids_amd.trainer import Trainer, default_config
@@ -606,7 +606,7 @@ def test_cfg5_ae3_train_step_w128_rows_vs_fp64_oracle():
     """cfg5's row length at a reduced grid: AE3 F = 64 on 16x32x128 (5 levels down to 1x2x8; W = 128 | 64 | 32 | 16 | 8 row variants
     of every conv / weight-gradient kernel, stride-2 adjoints), full train step at batch 2 against the fp64 NumPy oracle."""
     from test_gpu_ae import _ae_step_case
-    _ae_step_case(True, (16, 32, 128), 64, False, steer=True, grad_tol=2e-4)
+    _ae_step_case(True, (16, 32, 128), 64, False, steer=True, grad_tol=6e-5)      # measured 1.8e-5
 
 
 def _ae_step_vs_torch_oracle(spatial, filters, z_num, seed, p_num=2):
@@ -680,5 +680,5 @@ def test_cfg5_ae3_full_train_step_vs_torch_oracle():
     r = _ae_step_vs_torch_oracle((R, R, R), 64, 16, seed=41)
     assert r["velocity_rel_l1"] <= 1e-4 and r["z_rel_linf"] < 1e-4, r
     assert r["loss_rel"] < 1e-5 and r["loss_p_ok"], r
-    assert r["grad_worst"][0][1] < 2e-4, r
-    assert r["unsteered_grad_worst"][0][1] < 5e-2 and r["lrelu_sign_disagree_frac"] < 1e-3, r
+    assert r["grad_worst"][0][1] < 7e-5, r                                                              # measured 2.2e-5
+    assert r["unsteered_grad_worst"][0][1] < 1.2e-2 and r["lrelu_sign_disagree_frac"] < 1e-5, r          # measured 3.7e-3 / 2.5e-7 (x 3)
