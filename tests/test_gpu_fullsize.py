@@ -680,5 +680,6 @@ def test_cfg5_ae3_full_train_step_vs_torch_oracle():
     r = _ae_step_vs_torch_oracle((R, R, R), 64, 16, seed=41)
     assert r["velocity_rel_l1"] <= 1e-4 and r["z_rel_linf"] < 1e-4, r
     assert r["loss_rel"] < 1e-5 and r["loss_p_ok"], r
-    assert r["grad_worst"][0][1] < 7e-5, r                                                              # measured 2.2e-5
-    assert r["unsteered_grad_worst"][0][1] < 1.2e-2 and r["lrelu_sign_disagree_frac"] < 1e-5, r          # measured 3.7e-3 / 2.5e-7 (x 3)
+    tight = R == 128      # bounds = measured x 3 at cfg5's own grid (round 5); the 64^3 fallback keeps the generic ones
+    assert r["grad_worst"][0][1] < (7e-5 if tight else 2e-4), r                                         # measured 2.2e-5
+    assert r["unsteered_grad_worst"][0][1] < (1.2e-2 if tight else 5e-2) and r["lrelu_sign_disagree_frac"] < (1e-5 if tight else 1e-3), r   # 3.7e-3 / 2.5e-7
