@@ -595,7 +595,44 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
                 "note": "BASELINE cfg5's shape (AE3 encoder + decoder train step, 128^3, F = 64), fp32; parity at this shape: "
                         "tests/test_gpu_fullsize.py::test_cfg5_*"}
 
+    def ref_grids():
+        """The reference's OWN documented workloads (run.bat) at their native grids and batch sizes: ms/step of the full train step
+        (parity at these grids: tests/test_gpu_refgrids.py)."""
+        import numpy as np
+        cases = [  # key, run.bat line, (Z,)Y,X, batch, filters, use_curl, kind
+            ("smoke3_vel_buo_32x64x112", 21, [32, 64, 112], 4, 128, True, "de"),
+            ("smoke3_obs_buo_64x96x64", 27, [64, 96, 64], 3, 128, True, "de"),
+            ("liquid3_d_r_96x48x96", 37, [96, 48, 96], 3, 128, False, "de"),
+            ("liquid3_vis_48x72x96", 42, [48, 72, 96], 3, 128, False, "de"),
+            ("liquid_pos_size_2d_64x128", 32, [64, 128], 8, 128, False, "de"),
+            ("smoke_pos_size_2d_128x96", 13, [128, 96], 8, 128, True, "de"),
+            ("ae_smoke_mov_2d_128x96", 56, [128, 96], 8, 64, True, "ae"),
+            ("ae3_smoke3_mov_48x72x48", 73, [48, 72, 48], 4, 64, True, "ae"),
+        ]
+        res = {}
+        for key, line, grid, B, F, use_curl, kind in cases:
+            ops.reset_variables()
+            is3 = len(grid) == 3
+            kw = dict(is_3d=is3, res_x=grid[-1], res_y=grid[-2], res_z=grid[0] if is3 else 1, filters=F, batch_size=B, num_samples=6000,
+                      use_curl=use_curl)
+            xr, yr = make_inputs(B, grid, 3, ops)
+            if kind == "ae":
+                tr = AETrainer(default_config(z_num=16, p_num=2 if is3 else 1, **kw))
+                yr = torch.from_numpy(np.random.RandomState(4).uniform(-1, 1, (B, 2 if is3 else 1, 10)).astype(np.float32)).cuda()
+            else:
+                tr = Trainer(default_config(**kw))
+            el, m = timed_steps(tr, xr, yr, 2, 5)
+            n = B
+            for g in grid:
+                n *= g
+            res[key] = {"run_bat_line": line, "grid": grid, "batch": B, "filters": F, "use_curl": use_curl, "arch": kind, "ms_per_step": el * 1e3,
+                        "value": n / el, "unit": "voxels/s" if is3 else "pixels/s", "params": tr.n_params}
+            del tr, m, xr, yr
+            torch.cuda.empty_cache()
+        return res
+
     guarded("alt_bf16x3_mode", alt_bf16x3)
+    guarded("extra_ref_grids", ref_grids)
     guarded("extra_2d_128x96", two_d)
     guarded("extra_cfg4_slice", cfg4_slice)
     guarded("extra_ae_cfg5", ae_cfg5)
@@ -711,6 +748,9 @@ def compact(out):
                     c[q + "_frac"] = e[q].get("frac")
             e = c
         line[k] = e
+    rg = out.get("extra_ref_grids")      # the reference's own run.bat workloads: ms/step only
+    if isinstance(rg, dict):
+        line["extra_ref_grids_ms"] = rg if "error" in rg else {k: round(v["ms_per_step"], 2) for k, v in rg.items()}
     line["sidecar"] = out.get("sidecar")
     return line
 
@@ -967,7 +1007,7 @@ def main():
     dom = max((f for f in fam if not (f.startswith("jacobian") or f.startswith("velocity_loss"))), key=lambda f: fam[f], default=None)
     out["roofline"] = {"wgrad_kernel": out["roofline_wgrad"], "conv_mfma_kernel": out["roofline_conv"],
                        "wino3d_kernel": out["roofline_wino"], "wino2d_kernel": out["roofline_wino"]}.get(dom)
-    for key in ("alt_bf16x3_mode", "extra_2d_128x96", "extra_cfg4_slice", "extra_ae_cfg5"):
+    for key in ("alt_bf16x3_mode", "extra_ref_grids", "extra_2d_128x96", "extra_cfg4_slice", "extra_ae_cfg5"):
         out[key] = None
     if world == 1 and is_3d:
         try:
