@@ -463,17 +463,30 @@ def stencil_rooflines(B, Z, Y, X):
     for name, (bpv, fn) in cases.items():
         for _ in range(3):
             fn(nxt())
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        # ONE figure per kernel (round 5): the average DURATION of a launch, each launch bracketed by its own pair of HIP events on the launch
+        # stream -- what rocprofv3's kernel trace reports (profiles/r0*_bench_kernel_by_grid.md) and what `achieved` is defined on.  The
+        # back-to-back rate of 20 launches between ONE event pair is kept beside it (`back_to_back_us`): consecutive launches overlap their
+        # ramp-down / ramp-up, which made rounds 2-4 print a figure 4-6 % above the per-kernel duration.
         n = 20
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in evs:
+            i = nxt()
+            a.record()
+            fn(i)
+            b.record()
+        torch.cuda.synchronize()
+        t = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / n
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):
             fn(nxt())
         e1.record()
         torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) * 1e-3 / n
+        tb = e0.elapsed_time(e1) * 1e-3 / n
         ach = bpv * nv / t / 1e9
         out[name] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                     "frac_of_copy_rate": ach / copy_gbs, "avg_launch_us": t * 1e6, "algorithmic_bytes_per_voxel": bpv, "traffic": None}
+                     "frac_of_copy_rate": ach / copy_gbs, "avg_launch_us": t * 1e6, "back_to_back_us": tb * 1e6,
+                     "algorithmic_bytes_per_voxel": bpv, "traffic": None}
     return out
 
 

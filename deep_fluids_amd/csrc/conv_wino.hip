@@ -1385,6 +1385,14 @@ int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, floa
   a.ntb = (int)ntb;
   a.flags = flags; a.leak = leak;
   const int64_t grid = wino_grid(a, ntb);
+#ifdef DF_TUNING      // round-5 breakdown of the 27-point form (tools/r05_breakdown_probe.py; results wrong by construction, timing only)
+#define DF_WU(V) case V: hipLaunchKernelGGL((wino3d_kernel<V, DF_CONV_BIAS | DF_CONV_LRELU, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); return df::launched("df_wino_upconv_fwd")
+  switch (g_wino_dbg >> 2) {
+    DF_WU(1); DF_WU(2); DF_WU(3); DF_WU(4); DF_WU(7); DF_WU(8); DF_WU(64); DF_WU(128); DF_WU(512);
+    default: break;
+  }
+#undef DF_WU
+#endif
   hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
   return df::launched("df_wino_upconv_fwd");
 }
@@ -1468,6 +1476,14 @@ int df_wino_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B,
   a.ntb = (int)ntb;
   a.flags = 0; a.leak = 0.f;
   const int64_t grid = wino_grid(a, ntb);
+#ifdef DF_TUNING
+#define DF_WP(V) case V: hipLaunchKernelGGL((wino3d_kernel<V, 0, 2>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); return df::launched("df_wino_upconv_dgrad")
+  switch (g_wino_dbg >> 2) {
+    DF_WP(1); DF_WP(2); DF_WP(3); DF_WP(4); DF_WP(7); DF_WP(8); DF_WP(64); DF_WP(128);
+    default: break;
+  }
+#undef DF_WP
+#endif
   hipLaunchKernelGGL((wino3d_kernel<0, 0, 2>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
   return df::launched("df_wino_upconv_dgrad");
 }
