@@ -56,6 +56,14 @@ constexpr int PY = 12, PZ = 144;          // LDS pitches (dwords) of a channel p
 constexpr int CP = 866;                   // dwords per channel plane (6*144 = 864, +2: staging writes spread over banks)
 constexpr int HY = 10, HX = 10, HV = 600; // halo block 6 x 10 x 10
 constexpr int NLOAD = 5;                  // ceil(600 * 4 float4 pieces / 512 threads)
+// MODE 3 (round 5): the up-sampling-aware forward stages the COARSE halo block itself -- 4 x 6 x 6 coarse voxels instead of the 6 x 10 x 10
+// fine positions that repeat them (4.2x fewer staging loads) -- and builds the 27 live transform points from the 3 x 3 coarse patch per
+// plane a tile sees.  A coarse row (pz, py) of a channel is stored as FOUR 16-byte windows, window t = (c[t], c[t+1], c[t+2], -) = the three
+// columns tile column tx = t needs, so a lane fetches a patch row with ONE aligned ds_read_b128 (the 16 (ty, tx) lanes of a channel read 64
+// consecutive dwords: conflict-free); every staged value is written to the (up to three) windows that contain it.
+constexpr int UPY = 16, UPZ = 6 * UPY, UCP = 4 * UPZ + 4;
+constexpr int UHV = 144;                  // coarse halo block 4 x 6 x 6
+constexpr int NLU = 2;                    // ceil(144 * 4 pieces / 512 threads): every thread one piece, wave 0 a second one
 // internal epilogue flags (beyond the public DF_CONV_*), part of the compile-time FL of the specialised instantiations:
 //   kSignBits: also emit the sign pattern of the output, one byte per lane and cout block holding the signs of the lane's 8 outputs
 //              (what a later masked dgrad of the same geometry needs of it: 1/32 of the activation's bytes);
@@ -223,6 +231,20 @@ __device__ __forceinline__ f32x2 pk_bt23(f32x2 p, f32x2 q) {
   return d;
 }
 
+// MODE 3 x stage on a coarse row (c0, c1 | c2, -):  P = (c0, c1) -> (c0 - c1, c1 + c1);  P, Q = (c2, -) -> (-, c1 - c2).  Packed results on
+// purpose: a single-register temporary gets allocated into the never-read xi_x = 2 word of a weight quad whose load is still in flight
+// (27-point modes), and its write then waits on vmcnt.
+__device__ __forceinline__ f32x2 pk_x01(f32x2 p) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(p));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_x3(f32x2 p, f32x2 q) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(d) : "v"(p), "v"(q));
+  return d;
+}
+
 __device__ unsigned long long g_wino_prof[32];
 
 struct BlockInfo {
@@ -278,13 +300,21 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // keeps the matrix pipe busy while its partner waits for HBM.  XS & 4: issued in front of k-step 0's MFMAs instead of behind them.
 template <int DBG, int FL = -1, int MODE = 0, int PREC = 0, int XS = 0>
 __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
-  constexpr bool UP = MODE == 1, POOL = MODE == 2, P27 = MODE != 0;
+  constexpr bool UPC = MODE == 3;                    // UP with the coarse halo block staged as such (see UPY / UCP above)
+  constexpr bool UP = MODE == 1 || UPC, POOL = MODE == 2, P27 = MODE != 0;
   constexpr bool BX = PREC == 1;
   constexpr bool XB = XS != 0, XASYM = (XS & 2) != 0;
   static_assert(!XB || (!UP && !BX), "x-blocked staging: plain / pooled fp32 modes only");
-  constexpr int PZk = PZ, CPk = CP;
+  static_assert(!UPC || !BX, "coarse staging: fp32 mode only");
+  constexpr int PZk = UPC ? UPZ : PZ, CPk = UPC ? UCP : CP;      // pitches INSIDE a buffer; the buffer stride below keeps the plain size (the
+                                                                // epilogue's 32 KB exchange area lives in the idle buffer)
+  constexpr int NL = UPC ? NLU : NLOAD;              // staging pieces per thread and chunk
+#ifndef DF_KEEPQ
+#define DF_KEEPQ 0
+#endif
+  constexpr bool KEEPQ = DF_KEEPQ != 0;
   constexpr int XROWB = 51 * 16, XROWS = 60;        // XS: bytes per LDS row (3 pieces x 17 slots x 16 B), halo rows per chunk (6 planes x 10)
-  constexpr int BUFk = XB ? XROWS * XROWB / 4 : CKW * CPk;
+  constexpr int BUFk = XB ? XROWS * XROWB / 4 : CKW * CP;
   constexpr int BUFF = BX ? BBUF / 4 : BUFk;      // floats per LDS buffer
   // (experiment XS & 128: THREE staging buffers -- the pieces of chunk c + 2 are issued at the start of chunk c and waited for at the end of
   //  chunk c + 1: ~7 k-steps of slack instead of 2-3)
@@ -357,18 +387,39 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   int ldst[NLOAD];
   unsigned so[NLOAD];
 #pragma unroll
-  for (int it = 0; it < NLOAD; ++it) {
+  for (int it = 0; it < NL; ++it) {
     int p = it * kT + tid;
+    if (UPC) {
+      if (p > UHV * 4 - 1) p = UHV * 4 - 1;   // (pieces 576.. do not exist: the second pass is taken by wave 0 only, see stage_pass)
+      const int hv = p >> 2, q4 = p & 3;
+      const int px = hv % 6, py = (hv / 6) % 6, pz = hv / 36;
+      ldst[it] = ((q4 * 4) * UCP + pz * UPZ + py * UPY) * 4 + px * 16;      // window px, element 0 (may lie beyond the row: see stage_store)
+      continue;
+    }
     if (p > HV * 4 - 1) p = HV * 4 - 1;     // the tail threads of the last pass duplicate the last piece (same data, same slot)
     const int hv = p >> 2, q4 = p & 3;
     const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
     ldst[it] = ((q4 * 4) * CPk + hz * PZk + hy * PY + hx) * 4;        // bytes, buffer 0
   }
+  // pass `it` of the staging is taken by every wave, except the coarse block's second pass (64 pieces: wave 0) -- wave-uniform
+  auto stage_pass = [&](int it) -> bool { return !UPC || it == 0 || wave == 0; };
   const unsigned vol_bytes = static_cast<unsigned>(XB ? a.D * a.H * a.Wb * 4 : UP ? (a.D >> 1) * (a.H >> 1) * (a.W >> 1) : a.D * a.H * a.W) * a.Cin * 4u;
   auto set_offs = [&](const BlockInfo& bi) {
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
+    for (int it = 0; it < NL; ++it) {
       int p = it * kT + tid;
+      if (UPC) {      // coarse voxel (pz, py, px) of the 4 x 6 x 6 block whose origin is the coarse voxel under fine (z0 - 1, y0 - 1, x0 - 1)
+        if (p > UHV * 4 - 1) p = UHV * 4 - 1;
+        const int hv = p >> 2, q4 = p & 3;
+        const int px = hv % 6, py = (hv / 6) % 6, pz = hv / 36;
+        const int Dc = a.D >> 1, Hc = a.H >> 1, Wc = a.W >> 1;
+        const int cz = (bi.z0 >> 1) - 1 + pz, cy = (bi.y0 >> 1) - 1 + py, cx = (bi.x0 >> 1) - 1 + px;
+        bool ok = static_cast<unsigned>(cz) < static_cast<unsigned>(Dc) && static_cast<unsigned>(cy) < static_cast<unsigned>(Hc) &&
+                  static_cast<unsigned>(cx) < static_cast<unsigned>(Wc);      // fine g in range <=> coarse g >> 1 in range (even extents)
+        if (DBG & 4) ok = false;
+        so[it] = ok ? static_cast<unsigned>(((cz * Hc + cy) * Wc + cx) * a.Cin + q4 * 4) * 4u : 0x80000000u;
+        continue;
+      }
       if (p > HV * 4 - 1) p = HV * 4 - 1;
       const int hv = p >> 2, q4 = p & 3;
       const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
@@ -397,6 +448,20 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   };
   char* sInB = reinterpret_cast<char*>(sIn);
   auto stage_store = [&](int it, int bufbytes, const f32x4& v) {
+    if constexpr (UPC) {      // coarse column px lives in window px - k at element k, k = 0..2, for windows 0..3
+      int p = it * kT + tid;
+      if (p > UHV * 4 - 1) p = UHV * 4 - 1;
+      const int px = (p >> 2) % 6;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int t = px - k;
+        if (t >= 0 && t <= 3) {
+          float* d = reinterpret_cast<float*>(sInB + (ldst[it] + bufbytes - k * 12));
+          d[0] = v[0]; d[UCP] = v[1]; d[2 * UCP] = v[2]; d[3 * UCP] = v[3];
+        }
+      }
+      return;
+    }
     float* d = reinterpret_cast<float*>(sInB + (ldst[it] + bufbytes));
     d[0] = v[0]; d[CPk] = v[1]; d[2 * CPk] = v[2]; d[3 * CPk] = v[3];
   };
@@ -518,6 +583,13 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   const int abase = kq * CPk + (2 * mth) * PZk + (2 * ty) * PY + 2 * tx;
   const int offA = abase + za * PZk, offB = abase + zb * PZk;
 
+  // MODE 3: the tile's fine planes 2 mth + {0..3} repeat the coarse planes mth + {0, 1, 1, 2} (fine halo index h <-> coarse (h + 1) >> 1), its
+  // fine rows / columns the coarse rows ty + {0, 1, 1, 2} / columns tx + {0, 1, 1, 2}: the lane reads the 3 x 3 patch of the two coarse planes
+  // its xi_z combines and applies the SAME operations to the same values as the fine-grid transform (bit-identical operands):
+  //   per axis  (d0 - d2, d1 + d2, -, d1 - d3)  with  d = (c0, c1, c1, c2)   ->   (c0 - c1, c1 + c1, -, c1 - c2)
+  const int uoffA = (kq * UCP + (mth + ((za + 1) >> 1)) * UPZ + ty * UPY + tx * 4) * 4;      // bytes: window tx of coarse row ty
+  const int uoffB = (kq * UCP + (mth + ((zb + 1) >> 1)) * UPZ + ty * UPY + tx * 4) * 4;
+  f32x4 ua[3], ub[3];      // [coarse row]: (c0, c1, c2, -)
   f32x2 ra[8], rb[8];      // raw inputs [y][x pair] of planes za / zb
   f32x2 T[8], U[8];        // after the z / y transform
   f32x2 A2[8];             // A operands of a k-step: A2[xi_y*2 + h] = (xi_x = 2h, 2h+1)
@@ -525,6 +597,17 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   // XS: x pair h of this lane's tile = floats 2 tx + 2 h, + 1 of the row = piece (tx + h) >> 1, element 2 ((tx + h) & 1)
   const int xrowA = ((2 * mth + za) * 10 + 2 * ty) * XROWB + kq * 16, xrowB = ((2 * mth + zb) * 10 + 2 * ty) * XROWB + kq * 16;
   const int xp0 = (tx >> 1) * (17 * 16) + (tx & 1) * 8, xp1 = ((tx + 1) >> 1) * (17 * 16) + ((tx + 1) & 1) * 8;
+  auto raw_read_up = [&](int idxbytes) {      // idxbytes: LDS byte offset of channel plane 4 ks (+ buffer)
+    int ia = idxbytes + uoffA, ib = idxbytes + uoffB;
+    asm volatile("" : "+v"(ia), "+v"(ib));
+    __builtin_assume((ia & 15) == 0);
+    __builtin_assume((ib & 15) == 0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      ua[r] = *reinterpret_cast<const f32x4*>(sInB + ia + r * UPY * 4);
+      ub[r] = *reinterpret_cast<const f32x4*>(sInB + ib + r * UPY * 4);
+    }
+  };
   auto raw_read_x = [&](int idxbytes) {   // idxbytes: buffer + 64 ks (the k-step's 4 channels are slots 4 ks .. 4 ks + 3)
     int ia0 = idxbytes + xrowA + xp0, ia1 = idxbytes + xrowA + xp1, ib0 = idxbytes + xrowB + xp0, ib1 = idxbytes + xrowB + xp1;
     asm volatile("" : "+v"(ia0), "+v"(ia1), "+v"(ib0), "+v"(ib1));
@@ -538,6 +621,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     }
   };
   auto raw_read = [&](int idxbytes) {   // idxbytes: LDS byte offset of plane 4 ks (+ buffer), without this lane's offset
+    if constexpr (UPC) { raw_read_up(idxbytes); return; }
     int ia = idxbytes + offAb, ib = idxbytes + offBb;
     asm volatile("" : "+v"(ia), "+v"(ib));     // opaque: the 16 row reads become 8 ds_read2_b64 with small immediate offsets
     __builtin_assume((ia & 7) == 0);
@@ -550,7 +634,24 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       rb[y * 2 + 1] = *reinterpret_cast<const f32x2*>(sInB + ib + (y * PY + 2) * 4);
     }
   };
+  auto transform_up = [&]() {
+    f32x2 tl2[3], th2[3];      // z: rows as (c0, c1) and (c2, -)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      tl2[r] = pk_fma(f32x2{ub[r][0], ub[r][1]}, qs2, f32x2{ua[r][0], ua[r][1]});
+      th2[r] = pk_fma(f32x2{ub[r][2], ub[r][3]}, qs2, f32x2{ua[r][2], ua[r][3]});
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k == 2) { A2[4] = f32x2{0.f, 0.f}; A2[5] = f32x2{0.f, 0.f}; continue; }      // xi_y = 2 is never multiplied
+      const f32x2 ul = k == 0 ? pk_sub(tl2[0], tl2[1]) : k == 1 ? pk_add(tl2[1], tl2[1]) : pk_sub(tl2[1], tl2[2]);      // y
+      const f32x2 uh = k == 0 ? pk_sub(th2[0], th2[1]) : k == 1 ? pk_add(th2[1], th2[1]) : pk_sub(th2[1], th2[2]);
+      A2[k * 2 + 0] = pk_x01(ul);                                                       // x: xi_x = 0, 1: (c0 - c1, c1 + c1)
+      A2[k * 2 + 1] = pk_x3(ul, uh);                                                    // xi_x = (2), 3: (-, c1 - c2)
+    }
+  };
   auto transform = [&]() {
+    if constexpr (UPC) { transform_up(); return; }
 #pragma unroll
     for (int j = 0; j < 8; ++j) T[j] = pk_fma(rb[j], qs2, ra[j]);          // z
 #pragma unroll
@@ -662,9 +763,9 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     const __amdgpu_buffer_rsrc_t srd0 = make_srd(cur.xb, vol_bytes);
     f32x4 stg[NLOAD];
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) stg[it] = stage_load(it, srd0, 0u);
+    for (int it = 0; it < NL; ++it) if (stage_pass(it)) stg[it] = stage_load(it, srd0, 0u);
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) stage_store(it, 0, stg[it]);
+    for (int it = 0; it < NL; ++it) if (stage_pass(it)) stage_store(it, 0, stg[it]);
   }
   __syncthreads();
 
@@ -747,7 +848,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (!XB && ks == (SPREAD1 ? 3 : 2) && !(DBG & 4) && !(DBG & 64)) {
 #pragma unroll
-          for (int it = 0; it < NLOAD; ++it) stage_store(it, bn, stg[it]);
+          for (int it = 0; it < NL; ++it) if (stage_pass(it)) stage_store(it, bn, stg[it]);
         }
         // XS: the DMA pieces of the next chunk have landed once at most the 8 (4) weight reloads of k-step 2 are outstanding behind them
         if (XB && ks == 3) {      // (every wave: one that issued no pieces has only those reloads outstanding and does not wait)
@@ -761,7 +862,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         }
         if (ks == 2 && (DBG & 64)) {       // keep the loads alive without the LDS writes
 #pragma unroll
-          for (int it = 0; it < NLOAD; ++it) asm volatile("" :: "v"(stg[it]));
+          for (int it = 0; it < NL; ++it) if (stage_pass(it)) asm volatile("" :: "v"(stg[it]));
         }
         // next chunk staged by everyone; everyone is done reading the planes it overwrote.  [r3] An LDS-only barrier: the staged data was
         // already waited for at the LDS writes of ks == 2, and __syncthreads()' vmcnt(0) drained the weight loads in flight (this and the
@@ -791,6 +892,9 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
           if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
             acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[ks & (NBQ - 1)][0][i >> 2][i & 3], acc[0][i], 0, 0, 0);
           if ((i & 3) == 3) {
+            // 27-point modes never read the xi_x = 2 word of a weight quad: without this use of the WHOLE quad the register allocator hands that
+            // dead register to an A operand, whose write then has to wait (s_waitcnt vmcnt) for the quad's load issued a moment ago
+            if (P27 && KEEPQ) asm volatile("" :: "v"(bq[ks & (NBQ - 1)][0][i >> 2]));
             __builtin_amdgcn_sched_barrier(0);
             reload_row(0, i >> 2);
             if (XB && TRI && (XS & 256) && ks == 0 && !(DBG & 4)) {
@@ -809,6 +913,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
             if (!P27 || ((i >> 2) != 2 && (i & 3) != 2))
               acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i >> 1][i & 1], bq[ks & (NBQ - 1)][1][i >> 2][i & 3], acc[1][i], 0, 0, 0);
             if ((i & 3) == 3) {
+              if (P27 && KEEPQ) asm volatile("" :: "v"(bq[ks & (NBQ - 1)][1][i >> 2]));
               __builtin_amdgcn_sched_barrier(0);
               reload_row(1, i >> 2);
               if (XB && TRI && (XS & 256) && ks == 0 && !(DBG & 4)) {
@@ -825,7 +930,8 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         if (!XB && !SPREAD && ks == 0 && !(DBG & 4)) {     // staging loads of the next chunk, right behind a weight batch: vmcnt retires in order, so
                                          // the first wait that covers them is the one for the NEXT weight batch (1.5 k-steps away)
 #pragma unroll
-          for (int it = 0; it < NLOAD; ++it) stg[it] = (DBG & 384) == 128 ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
+          for (int it = 0; it < NL; ++it)
+            if (stage_pass(it)) stg[it] = (DBG & 384) == 128 ? f32x4{0.f, 0.f, 0.f, 0.f} : stage_load(it, ssrd, schunk);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (DBG & 16) {
@@ -1386,14 +1492,17 @@ int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, floa
   a.flags = flags; a.leak = leak;
   const int64_t grid = wino_grid(a, ntb);
 #ifdef DF_TUNING      // round-5 breakdown of the 27-point form (tools/r05_breakdown_probe.py; results wrong by construction, timing only)
-#define DF_WU(V) case V: hipLaunchKernelGGL((wino3d_kernel<V, DF_CONV_BIAS | DF_CONV_LRELU, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); return df::launched("df_wino_upconv_fwd")
-  switch (g_wino_dbg >> 2) {
+#define DF_WU(V) case V: hipLaunchKernelGGL((wino3d_kernel<V, DF_CONV_BIAS | DF_CONV_LRELU, 3>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); return df::launched("df_wino_upconv_fwd")
+#define DF_WU1(V) case 1000 + V: hipLaunchKernelGGL((wino3d_kernel<V, DF_CONV_BIAS | DF_CONV_LRELU, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a); return df::launched("df_wino_upconv_fwd")
+  switch (g_wino_dbg >> 2) {      // V: coarse-block staging (MODE 3, production); 1000 + V: the fine-grid staging of rounds 2-4 (MODE 1)
     DF_WU(1); DF_WU(2); DF_WU(3); DF_WU(4); DF_WU(7); DF_WU(8); DF_WU(64); DF_WU(128); DF_WU(512);
+    DF_WU1(0); DF_WU1(1); DF_WU1(2); DF_WU1(3); DF_WU1(4); DF_WU1(7); DF_WU1(8); DF_WU1(64); DF_WU1(128); DF_WU1(512);
     default: break;
   }
 #undef DF_WU
+#undef DF_WU1
 #endif
-  hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+  hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU, 3>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
   return df::launched("df_wino_upconv_fwd");
 }
 
@@ -1452,7 +1561,7 @@ int df_wino_upconv_fwd_bits(const float* xc, const float* wp, const float* bias,
   a.ntb = (int)ntb;
   a.flags = DF_CONV_BIAS | DF_CONV_LRELU; a.leak = leak;
   const int64_t grid = wino_grid(a, ntb);
-  hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU | kSignBits, 1>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
+  hipLaunchKernelGGL((wino3d_kernel<0, DF_CONV_BIAS | DF_CONV_LRELU | kSignBits, 3>), dim3((unsigned)grid), dim3(kT), 0, df::as_stream(stream), a);
   return df::launched("df_wino_upconv_fwd_bits");
 }
 

@@ -343,6 +343,22 @@ def test_wino_upconv_fwd_vs_oracle(ops, cshape, cin, cout):
     call("df_wino_upconv_fwd", _ptr(xt), _ptr(wp), _ptr(bt), _ptr(y), B, D, H, W, cin, cout, 9, 0.2, s)
     ref = orc.lrelu(orc.conv_same(orc.upscale_nn(xc.astype(np.float64)), w.astype(np.float64), b.astype(np.float64)))
     assert rel_linf(host(y), ref) < TOL
+    # [r5] the coarse-block staging (wino3d_kernel MODE 3) feeds the matrix cores the SAME operand values in the same order as the plain
+    # Winograd kernel sees on the materialised up-sampling (the skipped xi = 2 products are exact zeros): bit-identical outputs, also the
+    # sign words of the _bits variant
+    xf = xt.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3).contiguous()
+    yp = torch.full_like(y, float("nan"))
+    call("df_wino_conv_fwd", _ptr(xf), _ptr(wp), _ptr(bt), None, None, _ptr(yp), B, 2 * D, 2 * H, 2 * W, cin, cout, 9, 0.2, s)
+    assert torch.equal(y, yp)
+    nb = query("df_wino_signbits_bytes", B, 2 * D, 2 * H, 2 * W, cout)
+    b1 = torch.zeros(nb, dtype=torch.uint8, device="cuda"); b2 = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    y1 = torch.full_like(y, float("nan")); y2 = torch.full_like(y, float("nan"))
+    call("df_wino_upconv_fwd_bits", _ptr(xt), _ptr(wp), _ptr(bt), _ptr(y1), _ptr(b1), B, D, H, W, cin, cout, 0.2, s)
+    call("df_wino_conv_fwd_bits", _ptr(xf), _ptr(wp), _ptr(bt), None, _ptr(y2), _ptr(b2), B, 2 * D, 2 * H, 2 * W, cin, cout, 9, 0.2, s)
+    assert torch.equal(y1, y) and torch.equal(y2, y)
+    full = (2 * D) % 4 == 0 and (2 * H) % 8 == 0 and (2 * W) % 8 == 0      # (sign bits of outputs outside the tensor are don't-care)
+    if full:
+        assert torch.equal(b1, b2)
 
 
 @pytest.mark.parametrize("cshape,cin,cout", [((1, 2, 4, 16), 32, 32), ((2, 4, 6, 8), 32, 64), ((1, 3, 5, 7), 128, 128),
