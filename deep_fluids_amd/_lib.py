@@ -68,6 +68,7 @@ SIGNATURES = {
     "df_conv_s2_fwd": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),
     "df_conv_s2_wgrad_workspace_bytes": (I64, [I64, I64, I64, I64, I64, I64, I32]),
     "df_conv_s2_wgrad": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
+    "df_conv_s2_dgrad": (I32, [P, P, P, I64, I64, I64, I64, I64, I64, I32, P]),
     "df_upconv_packed_elems": (I64, [I64, I64, I32, I32]),
     "df_upconv_pack_weights": (I32, [P, P, I64, I64, I32, I32, P]),
     "df_upconv_fwd": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),

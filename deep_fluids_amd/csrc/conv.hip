@@ -119,16 +119,19 @@ inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 // out[o] = sum_k in[2o + k] w[k]; the LDS tile is the (2T+1)-wide input footprint of the output tile.
 // KT = taps per in-plane axis (3; 2 for the parity-class convs of an up-sampled input), KZ = taps along z.
 // CKT = input channels per LDS chunk (16; 32 for the 8-tap parity-class convs, whose 16-channel chunks are only 16 steps long)
-template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, bool VEC, int S, int KT, int CKT = CK>
+// KTX = taps along x when it differs from KT (= taps along y); P8: the packed weights of a class are laid out for 2x2(x2) taps
+// (tap id dz*4 + dy*2 + dx) although this instantiation walks only the KZ x KT x KTX taps that are not identically zero -- the
+// parity classes of the STRIDE-2 dgrad (pack mode 2), whose odd-parity axes have ONE tap: 27 live taps of the 64 stored.
+template <int KZ, int TZ, int TY, int TX, int WM, int WN, int MB, int NB, bool VEC, int S, int KT, int CKT = CK, int KTX = KT, bool P8 = false>
 __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in) {
   static_assert(TZ * TY * TX == 128 && WM * MB * 32 == 128 && WM * WN == 4, "tile shape");
-  constexpr int HZ = (TZ - 1) * S + KZ, HY = (TY - 1) * S + KT, HX = (TX - 1) * S + KT, HV = HZ * HY * HX;
+  constexpr int HZ = (TZ - 1) * S + KZ, HY = (TY - 1) * S + KT, HX = (TX - 1) * S + KTX, HV = HZ * HY * HX;
   constexpr int LSTR = CKT + 4;             // LDS row stride (floats): (CKT+4)/4 odd -> conflict-free ds_read_b128
   constexpr int QPV = CKT / 4;              // float4 pieces per staged voxel
   constexpr int NPIECE = HV * QPV;
   constexpr int NLOAD = (NPIECE + kThreads - 1) / kThreads;
   constexpr int LBATCH = NLOAD < 8 ? NLOAD : 8;        // staging loads in flight per thread (bounds the registers)
-  constexpr int NTAP = KZ * KT * KT;
+  constexpr int NTAP = KZ * KT * KTX;
   constexpr int NTILE = WN * NB * 32;
   __shared__ __attribute__((aligned(16))) float sA[HV * LSTR];
 
@@ -248,15 +251,16 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a_in
     f32x4 af[2][MB], bf[3][NB];
     auto lds_a = [&](int step, f32x4 (&dst)[MB]) {
       const int tap = step / C8, c8 = step % C8;
-      const int dz = tap / (KT * KT), dy = (tap / KT) % KT, dx = tap % KT;
+      const int dz = tap / (KT * KTX), dy = (tap / KTX) % KT, dx = tap % KTX;
       const int toff = ((dz * HY + dy) * HX + dx) * S4 + c8 * 2;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) dst[mb] = sA4[aidx[mb] + toff];
     };
     auto glb_b = [&](int step, f32x4 (&dst)[NB]) {
       const int tap = step / C8, c8 = step % C8;
+      const int wtap = P8 ? (tap / (KT * KTX)) * 4 + ((tap / KTX) % KT) * 2 + tap % KTX : tap;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) dst[nb] = (bchunk + (tap * tapstride + c8 * bstep))[boff[nb]];
+      for (int nb = 0; nb < NB; ++nb) dst[nb] = (bchunk + (wtap * tapstride + c8 * bstep))[boff[nb]];
     };
     glb_b(0, bf[0]);
     glb_b(1, bf[1]);
@@ -327,6 +331,42 @@ int launch_n(const ConvArgs& a, hipStream_t s) {
   if (nt == 128) return launch<KZ, TZ, TY, TX, 2, 2, 2, 2, S, KT>(a, s);
   if (nt == 64) return launch<KZ, TZ, TY, TX, 2, 2, 2, 1, S, KT>(a, s);
   return launch<KZ, TZ, TY, TX, 4, 1, 1, 1, S, KT>(a, s);
+}
+
+// One parity class of the stride-2 dgrad with its LIVE taps only (nz x ny x nx in {1, 2}^3; 128-wide N tile, 64 | 32-channel chunks).
+template <int KZ, int KTY, int KTX, int TZ, int TY, int TX>
+int launch_s2d_class(const ConvArgs& a_in, hipStream_t s) {
+  ConvArgs a = a_in;
+  a.nz = (int)ceil_div(a.D, TZ); a.ny = (int)ceil_div(a.H, TY); a.nx = (int)ceil_div(a.W, TX);
+  const int64_t nt = static_cast<int64_t>(a.B) * a.nz * a.ny * a.nx;
+  DF_REQUIRE(nt < (1LL << 31), DF_ESHAPE, "df_conv_s2_dgrad: too many tiles");
+  a.ntiles = (int)nt;
+  dim3 grid((unsigned)nt, (unsigned)(a.Npad / 128), 1u);
+  constexpr int CKT = KZ * KTY * KTX >= 4 ? 32 : 64;      // few taps: longer chunks (a chunk is taps x CKT / 8 MFMA steps between two barriers)
+  hipLaunchKernelGGL((conv_mfma_kernel<KZ, TZ, TY, TX, 2, 2, 2, 2, true, 1, KTY, CKT, KTX, true>), grid, dim3(kThreads), 0, s, a);
+  return df::launched("df_conv_s2_dgrad");
+}
+template <int TZ, int TY, int TX>
+int launch_s2d_3d(const ConvArgs& a, int nz, int ny, int nx, hipStream_t s) {
+  switch (nz * 4 + ny * 2 + nx) {      // taps per axis in {1, 2}
+    case 7: return launch_s2d_class<1, 1, 1, TZ, TY, TX>(a, s);
+    case 8: return launch_s2d_class<1, 1, 2, TZ, TY, TX>(a, s);
+    case 9: return launch_s2d_class<1, 2, 1, TZ, TY, TX>(a, s);
+    case 10: return launch_s2d_class<1, 2, 2, TZ, TY, TX>(a, s);
+    case 11: return launch_s2d_class<2, 1, 1, TZ, TY, TX>(a, s);
+    case 12: return launch_s2d_class<2, 1, 2, TZ, TY, TX>(a, s);
+    case 13: return launch_s2d_class<2, 2, 1, TZ, TY, TX>(a, s);
+    default: return launch_s2d_class<2, 2, 2, TZ, TY, TX>(a, s);
+  }
+}
+template <int TY, int TX>
+int launch_s2d_2d(const ConvArgs& a, int ny, int nx, hipStream_t s) {
+  switch (ny * 2 + nx) {
+    case 3: return launch_s2d_class<1, 1, 1, 1, TY, TX>(a, s);
+    case 4: return launch_s2d_class<1, 1, 2, 1, TY, TX>(a, s);
+    case 5: return launch_s2d_class<1, 2, 1, 1, TY, TX>(a, s);
+    default: return launch_s2d_class<1, 2, 2, 1, TY, TX>(a, s);
+  }
 }
 
 }  // namespace
@@ -488,6 +528,47 @@ static int upconv_fwd_impl(const float* xc, const float* wp, const float* bias, 
 int df_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
                   int64_t Wc, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream) {
   return upconv_fwd_impl(xc, wp, bias, y, B, Dc, Hc, Wc, Cin, Cout, kz, flags, leak, stream, 0);
+}
+
+// Input gradient of the stride-2 conv (df_conv_s2_fwd; reference: the encoder's / discriminator's down-sampling layers, model.py:141-143,
+// 177-179, 94-99): gx[B, 2Do, 2Ho, 2Wo, Cin] from gy[B, Do, Ho, Wo, Cout] and the mode-2 packed weights of df_upconv_pack_weights.
+// Per axis dx[2m] = g[m-1] w[2] + g[m] w[0] (two taps), dx[2m+1] = g[m] w[1] (ONE tap): the 8 (4) parity classes have 8, 4, 4, 2, 4, 2, 2, 1
+// live taps -- 27 of the 64 the generic parity-class kernel (df_upconv_fwd on the same operand, the fallback below) multiplies.
+int df_conv_s2_dgrad(const float* gy, const float* wp, float* gx, int64_t B, int64_t Do, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout,
+                     int kz, df_stream_t stream) {
+  DF_REQUIRE(gy && wp && gx, DF_EINVAL, "df_conv_s2_dgrad: null pointer");
+  DF_REQUIRE(B > 0 && Do > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0, DF_EINVAL, "df_conv_s2_dgrad: non-positive extent");
+  DF_REQUIRE(kz == 1 || kz == 3, DF_ESHAPE, "df_conv_s2_dgrad: kz must be 1 (2-D) or 3 (3-D)");
+  DF_REQUIRE(kz == 3 || Do == 1, DF_ESHAPE, "df_conv_s2_dgrad: Do must be 1 when kz == 1");
+  DF_REQUIRE(Cin > 4 && Cout > 4, DF_ESHAPE, "df_conv_s2_dgrad: MFMA path only (channels > 4)");
+  DF_REQUIRE(df::aligned16(wp), DF_EALIGN, "df_conv_s2_dgrad: packed weights must be 16-byte aligned");
+  const int64_t Kpad = round_up(Cout, CK), Npad = round_up(Cin, ntile_for(Cin));      // K = the forward conv's Cout, N = its Cin
+  const bool special = ntile_for(Cin) == 128 && Kpad % 64 == 0 && Cout % 4 == 0 && df::aligned16(gy);
+  if (!special)      // other channel counts: the generic 2x2(x2)-tap parity-class kernel on the zero-padded taps
+    return upconv_fwd_impl(gy, wp, nullptr, gx, B, Do, Ho, Wo, Cout, Cin, kz, 0, 0.f, stream, 0);
+  hipStream_t s = df::as_stream(stream);
+  const int ncls = kz == 3 ? 8 : 4;
+  for (int c = 0; c < ncls; ++c) {
+    const int bz = kz == 3 ? (c >> 2) & 1 : 0, by = (c >> 1) & 1, bx = c & 1;      // output parity per axis: 0 -> two taps, 1 -> one
+    ConvArgs a;
+    a.x = gy; a.bias = nullptr; a.residual = nullptr; a.mask_src = nullptr; a.y = gx;
+    a.B = (int)B; a.D = (int)Do; a.H = (int)Ho; a.W = (int)Wo; a.Cin = (int)Cout; a.Cout = (int)Cin;
+    a.Di = a.D; a.Hi = a.H; a.Wi = a.W;
+    a.Kpad = (int)Kpad; a.Npad = (int)Npad;
+    a.wp = reinterpret_cast<const f32x4*>(wp) + static_cast<int64_t>(c) * (kz == 3 ? 8 : 4) * Kpad * Npad / 4;
+    a.flags = 0; a.leak = 0.f;
+    a.nz = a.ny = a.nx = a.ntiles = 0;
+    a.pz = kz == 3 ? 1 - bz : 0; a.py = 1 - by; a.px = 1 - bx;      // as conv_mfma_kernel sets them per class of a one-launch parity conv
+    a.is = 1; a.iz = a.iy = a.ix = 0; a.xD = a.D; a.xH = a.H; a.xW = a.W;
+    a.os = 2; a.oz = bz; a.oy = by; a.ox = bx;
+    a.yD = kz == 3 ? 2 * a.D : 1; a.yH = 2 * a.H; a.yW = 2 * a.W;
+    a.nclass = 1; a.wclass = 0;
+    int e;
+    if (kz == 3) e = a.W >= 12 ? launch_s2d_3d<2, 4, 16>(a, 2 - bz, 2 - by, 2 - bx, s) : launch_s2d_3d<4, 4, 8>(a, 2 - bz, 2 - by, 2 - bx, s);
+    else e = a.W >= 12 ? launch_s2d_2d<8, 16>(a, 2 - by, 2 - bx, s) : launch_s2d_2d<16, 8>(a, 2 - by, 2 - bx, s);
+    if (e) return e;
+  }
+  return DF_OK;
 }
 int df_upconv_fwd_bf16x3(const float* xc, const float* wp, const float* bias, float* y, int64_t B, int64_t Dc, int64_t Hc,
                          int64_t Wc, int64_t Cin, int64_t Cout, int kz, int flags, float leak, df_stream_t stream) {

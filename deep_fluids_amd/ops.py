@@ -740,8 +740,10 @@ class _ConvSame3S2(torch.autograd.Function):
                 wpd = torch.empty(query("df_upconv_packed_elems", cin, cout, kz, 2), dtype=torch.float32, device=x.device)
                 call("df_upconv_pack_weights", _ptr(w), _ptr(wpd), cin, cout, kz, 2, _stream())
                 gx = torch.empty((B, D, H, W, cin), dtype=torch.float32, device=x.device)
-                call("df_upconv_fwd", _ptr(dp), _ptr(wpd), None, _ptr(gx), odims[0], odims[1], odims[2], odims[3], cout, cin, kz, 0, 0.0,
-                     _stream())
+                # [r5] df_conv_s2_dgrad: the same parity classes, each on a kernel specialised on its LIVE taps (27 of the 64 the generic
+                # 2x2x2-tap parity-class kernel df_upconv_fwd multiplies -- half of the mode-2 operand is structural zeros)
+                _count("dgrad-s2", "parity-class-live-taps", odims, cin, cout)
+                call("df_conv_s2_dgrad", _ptr(dp), _ptr(wpd), _ptr(gx), odims[0], odims[1], odims[2], odims[3], cin, cout, kz, _stream())
                 gx = gx.view(x.shape)
             else:
                 if up is None:

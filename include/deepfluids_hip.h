@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DF_VERSION 203 /* 0.2.3: + df_conv_s2_wgrad; 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
+#define DF_VERSION 204 /* 0.2.4: + df_conv_s2_dgrad; 0.2.3: + df_conv_s2_wgrad; 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
 
 enum {
   DF_OK = 0,
@@ -229,6 +229,14 @@ int df_conv_s2_fwd(const float* x, const float* wp, const float* bias, float* y,
 int64_t df_conv_s2_wgrad_workspace_bytes(int64_t B, int64_t Do, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout, int kz);
 int df_conv_s2_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t Do, int64_t Ho, int64_t Wo, int64_t Cin,
                      int64_t Cout, int kz, void* workspace, int64_t workspace_bytes, df_stream_t stream);
+/* Input gradient of that stride-2 conv (TF autodiff of slim.conv2d/conv3d(stride=2): model.py:141-143, 177-179; the discriminator's
+ * model.py:94-99): gx [B,2Do|1,2Ho,2Wo,Cin] from gy [B,Do,Ho,Wo,Cout].  `wp` = df_upconv_pack_weights(w, Cin, Cout, kz, mode 2).  Per axis
+ * dx[2m] = g[m-1] w[2] + g[m] w[0], dx[2m+1] = g[m] w[1]: 8 (4) parity classes with 8,4,4,2,4,2,2,1 (4,2,2,1) LIVE taps; each class runs a
+ * kernel specialised on its tap counts (27 tap-products per coarse voxel and channel pair; the generic 2x2x2-tap parity-class kernel --
+ * df_upconv_fwd on the same operand, used here for channel counts without a specialisation -- multiplies 64, a stride-1 dgrad on the
+ * zero-inserted gradient 216).  Every output voxel is written exactly once (no accumulation). */
+int df_conv_s2_dgrad(const float* gy, const float* wp, float* gx, int64_t B, int64_t Do, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout,
+                     int kz, df_stream_t stream);
 /* ---- up-sampling-aware first conv of a generator block --------------------------------------------------------------
  * model.py:36-37 / 78-79 feed `upscale(x, 2)` into the next block's first conv.  conv(nearest_up2x(xc), w) is computed
  * WITHOUT materialising the up-sampled tensor as 8 (3-D) / 4 (2-D) parity-class convs with 2x2x2 / 2x2 pre-summed taps

@@ -21,7 +21,9 @@ TOL = 2e-5
     # output rows of 8 | 16 | 32 | 64 voxels, even channels >= 32: the NATIVE stride-2 weight gradient (df_conv_s2_wgrad), incl. channel
     # counts that are not multiples of the 128-wide workgroup tile (192 = 128 + 64) and a single-plane output (Do = 1)
     ((1, 4, 4, 16), 32, 64, 0.2), ((2, 4, 8, 32), 64, 32, 0.2), ((1, 2, 4, 64), 32, 32, None), ((1, 2, 2, 128), 32, 64, 0.2),
-    ((1, 4, 4, 16), 192, 192, 0.2), ((2, 8, 64), 64, 64, 0.2), ((1, 6, 4, 32), 128, 128, 0.2)])
+    ((1, 4, 4, 16), 192, 192, 0.2), ((2, 8, 64), 64, 64, 0.2), ((1, 6, 4, 32), 128, 128, 0.2),
+    # [r5] df_conv_s2_dgrad's live-tap specialisations (Cin > 64, Cout % 64 == 0; both tile shapes, 3-D and 2-D, ragged tiles, the AE's widths)
+    ((1, 6, 10, 28), 128, 128, 0.2), ((2, 12, 32), 192, 128, None), ((1, 4, 4, 8), 320, 320, 0.2), ((1, 2, 6, 40), 256, 64, 0.2)])
 def test_conv_stride2_fwd_bwd(shape, cin, cout, leak):
     from deep_fluids_amd import ops
     from deep_fluids_amd.ops import _ConvSame3S2
@@ -47,6 +49,35 @@ def test_conv_stride2_fwd_bwd(shape, cin, cout, leak):
     assert max(errs.values()) < TOL, errs
     native = shape[-1] // 2 in (8, 16, 32, 64) and cin >= 32 and cout >= 32
     assert any(k.startswith("wgrad-s2 native") for k in counts) == native, counts
+    assert any(k.startswith("dgrad-s2 parity-class-live-taps") for k in counts), counts
+
+
+@pytest.mark.parametrize("oshape,cin,cout", [((2, 8, 12, 16), 128, 128), ((1, 5, 7, 9), 192, 192), ((2, 12, 20), 128, 64), ((1, 3, 5, 6), 96, 48)])
+def test_conv_s2_dgrad_live_taps_vs_generic_parity_class_kernel(oshape, cin, cout):
+    """df_conv_s2_dgrad (kernels specialised on the 8,4,4,2,4,2,2,1 live taps of the stride-2 adjoint's parity classes) == df_upconv_fwd on the
+    same mode-2 operand (the generic 2x2x2-tap kernel multiplying the structural zeros too) up to fp32 summation order; channel counts
+    without a specialisation (96 -> 48) take that generic kernel inside df_conv_s2_dgrad: bit-identical there."""
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream
+    nd = len(oshape) - 1
+    kz = 3 if nd == 3 else 1
+    rng = np.random.RandomState(cin + cout + sum(oshape))
+    w = dev((rng.uniform(-1, 1, (3,) * nd + (cin, cout)) / np.sqrt(cout * 3 ** nd)).astype(np.float32))
+    g = dev(rng.uniform(-1, 1, oshape + (cout,)).astype(np.float32))
+    s = _stream()
+    B = oshape[0]
+    Do, Ho, Wo = (oshape[1], oshape[2], oshape[3]) if nd == 3 else (1, oshape[1], oshape[2])
+    wp = torch.empty(query("df_upconv_packed_elems", cin, cout, kz, 2), device="cuda")
+    call("df_upconv_pack_weights", _ptr(w), _ptr(wp), cin, cout, kz, 2, s)
+    fine = (B,) + tuple(2 * d for d in oshape[1:]) + (cin,)
+    a = torch.full(fine, float("nan"), device="cuda"); b = torch.full(fine, float("nan"), device="cuda")
+    call("df_conv_s2_dgrad", _ptr(g), _ptr(wp), _ptr(a), B, Do, Ho, Wo, cin, cout, kz, s)
+    call("df_upconv_fwd", _ptr(g), _ptr(wp), None, _ptr(b), B, Do, Ho, Wo, cout, cin, kz, 0, 0.0, s)
+    assert not torch.isnan(a).any()
+    if cin <= 64 or cout % 64:
+        assert torch.equal(a, b)
+    else:
+        assert ((a - b).abs().max() / b.abs().max()).item() < 5e-6
 
 
 @pytest.mark.parametrize("shape,cin,cout", [((1, 4, 8, 32), 16, 128), ((2, 16, 32), 32, 64), ((1, 4, 4, 16), 16, 20)])
