@@ -20,6 +20,8 @@ FAMILIES = [  # (key, regex on the kernel name, algorithmic read bytes, algorith
     ("velocity_du3d (tail backward, before the curl3 adjoint)", r"velocity_du3d_vec_kernel", 150994944, 75497472),
     ("wino3d_kernel", r"wino3d_kernel<0, 9, 0[,>]", 3221225472, 3221225472),
     ("wino3d_kernel_dgrad_mask", r"wino3d_kernel<0, 4, 0[,>]", 6442450944, 3221225472),
+    ("wino3d_kernel_up27 (MODE 3: coarse input 32x48x32, coarse-block staging)", r"wino3d_kernel<0, 9, 3[,>]", 402653184, 3221225472),
+    ("wino3d_kernel_pool27 (MODE 2: pooled adjoint, accumulates into the coarse tensor)", r"wino3d_kernel<0, 0, 2[,>]", 3221225472 + 402653184, 402653184),
     ("wgrad_kernel", r"wgrad_wxyz_(fused_)?kernel<8, 128", 6442450944, 1769472),
     ("wgrad_wxyz_reduce_kernel", r"wgrad_wxyz_reduce_kernel", 0, 1769472),
 ]

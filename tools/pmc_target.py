@@ -31,6 +31,15 @@ for _ in range(2):
     call("df_wino_conv_fwd", _ptr(xin), _ptr(ww), _ptr(bias), None, None, _ptr(y), B, Z, Y, X, F, F, 9, 0.2, s)
 for _ in range(2):
     call("df_wino_conv_fwd", _ptr(xin), _ptr(ww), None, None, _ptr(xin), _ptr(y), B, Z, Y, X, F, F, 4, 0.2, s)
+# [r5] the 27-point forms at the same level: up-sampling-aware forward (coarse 32x48x32 -> 64x96x64, wino3d_kernel MODE 3) and its pooled adjoint (MODE 2)
+xc = torch.rand((B, Z // 2, Y // 2, X // 2, F), device="cuda") - 0.5
+wwd = torch.empty(query("df_wino_packed_elems", F, F, 1), device="cuda")
+call("df_wino_pack_weights", _ptr(wt), _ptr(wwd), F, F, 1, s)
+acc = torch.zeros_like(xc)
+for _ in range(2):
+    call("df_wino_upconv_fwd", _ptr(xc), _ptr(ww), _ptr(bias), _ptr(y), B, Z // 2, Y // 2, X // 2, F, F, 9, 0.2, s)
+for _ in range(2):
+    call("df_wino_upconv_dgrad", _ptr(xin), _ptr(wwd), _ptr(acc), B, Z // 2, Y // 2, X // 2, F, F, s)
 gw = torch.empty_like(wt); gb = torch.empty(F, device="cuda")
 nb = query("df_conv_wgrad_workspace_bytes", B, Z, Y, X, F, F, 3)
 ws = torch.empty(nb // 4 + 1, device="cuda")
