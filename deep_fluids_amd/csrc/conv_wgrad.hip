@@ -1074,8 +1074,13 @@ __device__ __forceinline__ void wgrad_wxyz_body(const WxyzArgs& aa, int range, i
   if (ci0 >= a.Cin || co0 >= a.Cout) return;
 
   const int ppe = (a.pairs_per_range + a.nsub - 1) / a.nsub;
-  const int p0 = range * a.pairs_per_range + sub * ppe;
-  int p1 = p0 + ppe;
+  // [r5] 64 -> 64 layers: the nsub = 4 waves that split a range take INTERLEAVED tile-row pairs (pair = first + sub + nsub i), not contiguous
+  // sub-ranges: at any time they stream neighbouring rows and share the y-halo rows of x through the L1 -- 5.84 -> 5.68 ms at 128^3 x 4
+  // (tools/r05_wgrad64_probe.py; tuning variant 16 = the contiguous split of rounds 3-4).  Same partial slots, fixed summation order.
+  constexpr bool IL = (CS == 64) != ((DBG & 16) != 0);
+  const int pstep = IL ? a.nsub : 1;
+  const int p0 = range * a.pairs_per_range + (IL ? sub : sub * ppe);
+  int p1 = IL ? (range + 1) * a.pairs_per_range : p0 + ppe;
   if (p1 > (range + 1) * a.pairs_per_range) p1 = (range + 1) * a.pairs_per_range;
   if (p1 > a.npairs) p1 = a.npairs;
   const int erange = range * a.nsub + sub;
@@ -1215,8 +1220,8 @@ __device__ __forceinline__ void wgrad_wxyz_body(const WxyzArgs& aa, int range, i
       }
   };
 
-  for (int pair = p0; pair < p1; ++pair) {
-    const Row nxt = row_setup(pair + 1);
+  for (int pair = p0; pair < p1; pair += pstep) {
+    const Row nxt = row_setup(pair + pstep);
 #pragma unroll
     for (int x0 = 0; x0 < Wc - 8; x0 += 8) {
 #pragma unroll
@@ -2374,6 +2379,11 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
 #undef DF_WXYZ_DBG
 #endif
 #define DF_WXYZ64(WP) hipLaunchKernelGGL((wgrad_wxyz_fused_kernel<WP, 64>), gridf, dim3(kThreads), 0, s, aa)
+#ifdef DF_TUNING
+    if (Cin == 64 && W == 128 && g_wgrad_dbg == 16) hipLaunchKernelGGL((wgrad_wxyz_fused_kernel<16, 64, 16>), gridf, dim3(kThreads), 0, s, aa);
+    else if (Cin == 64 && W == 64 && g_wgrad_dbg == 16) hipLaunchKernelGGL((wgrad_wxyz_fused_kernel<8, 64, 16>), gridf, dim3(kThreads), 0, s, aa);
+    else
+#endif
     if (Cin == 64) { if (W == 128) DF_WXYZ64(16); else if (W == 64) DF_WXYZ64(8); else if (W == 32) DF_WXYZ64(4); else DF_WXYZ64(2); }
     else
     if (W == 64) DF_WXYZ(8); else if (W == 32) DF_WXYZ(4); else if (W == 16) DF_WXYZ(2); else if (W == 112) DF_WXYZ(14); else if (W == 128) DF_WXYZ(16); else DF_WXYZ(7);
