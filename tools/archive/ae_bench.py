@@ -7,7 +7,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from deep_fluids_amd import ops  # noqa: E402
 from deep_fluids_amd.trainer import AETrainer, default_config  # noqa: E402

@@ -2,7 +2,7 @@
 """Diagnostic: per-shape time of the conv entry points in one AE3 (cfg5 shape) train step."""
 import collections, os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from deep_fluids_amd import ops, _lib
 from deep_fluids_amd.trainer import AETrainer, default_config

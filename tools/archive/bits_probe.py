@@ -2,7 +2,7 @@
 """Masked dgrad at cfg3: mask from the fp32 activation (DF_CONV_MASK + mask_src) vs from sign-bit words; forward with / without bit output."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from deep_fluids_amd._lib import call, query  # noqa: E402
 from deep_fluids_amd.ops import _ptr, _stream  # noqa: E402

@@ -2,7 +2,7 @@
 """GB/s of the element-wise kernels at the cfg3 top-level size (GPU box)."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from deep_fluids_amd._lib import call  # noqa: E402
 from deep_fluids_amd.ops import _ptr, _stream  # noqa: E402

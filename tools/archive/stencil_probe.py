@@ -2,7 +2,7 @@
 """Tuning probe for the 3-D stencil kernels (GPU box): variants x cold/warm input."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from deep_fluids_amd import _lib as _libmod  # noqa: E402
 _libmod.use_tuning_library()      # needs `make -C deep_fluids_amd/csrc tuning`

@@ -2,7 +2,7 @@
 """Timing of the thin last-layer kernels at cfg3 (gpurun tuning aid)."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from deep_fluids_amd._lib import call, query  # noqa: E402
 from deep_fluids_amd.ops import _ptr, _stream, _pack  # noqa: E402
