@@ -128,13 +128,25 @@ __global__ __launch_bounds__(kT) void conv_gen_wgrad_kernel(const float* __restr
   }
 }
 
-// gb[co] = sum over all (b, o) of gy, in order (one thread per channel)
-__global__ __launch_bounds__(64) void conv_gen_bgrad_kernel(const float* __restrict__ gy, float* __restrict__ gb, int64_t nvox, int Cout) {
-  const int co = blockIdx.x * 64 + threadIdx.x;
-  if (co >= Cout) return;
+// gb[co] = sum over all (b, o) of gy: 64 channels x 16 voxel sub-ranges per workgroup, each sub-range summed in order, the 16 partial sums
+// combined in a fixed order (deterministic).  [r5] was one thread per channel over ALL voxels; like conv_gen_wgrad_kernel this stays a
+// correctness path (a few thousand threads in flight) for call sites the reference never uses -- seconds per call on 10^7-voxel grids.
+__global__ __launch_bounds__(1024) void conv_gen_bgrad_kernel(const float* __restrict__ gy, float* __restrict__ gb, int64_t nvox, int Cout) {
+  __shared__ float sB[16][64];
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int co = blockIdx.x * 64 + lane;
+  const int64_t per = (nvox + 15) / 16, v0 = sub * per, v1 = v0 + per < nvox ? v0 + per : nvox;
   float acc = 0.f;
-  for (int64_t v = 0; v < nvox; ++v) acc += gy[v * Cout + co];
-  gb[co] = acc;
+  if (co < Cout)
+    for (int64_t v = v0; v < v1; ++v) acc += gy[v * Cout + co];
+  sB[sub][lane] = acc;
+  __syncthreads();
+  if (sub == 0 && co < Cout) {
+    float t = sB[0][lane];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) t += sB[i][lane];
+    gb[co] = t;
+  }
 }
 
 struct RsGeo {
@@ -232,7 +244,7 @@ int df_conv_general_wgrad(const float* x, const float* gy, float* gw, float* gb,
   DF_REQUIRE(nblk < (1LL << 31), DF_ESHAPE, "df_conv_general_wgrad: too many (tap, cin) pairs");
   hipLaunchKernelGGL(conv_gen_wgrad_kernel, dim3((unsigned)nblk), dim3(kT), 0, df::as_stream(stream), x, gy, gw, g);
   if (gb)
-    hipLaunchKernelGGL(conv_gen_bgrad_kernel, dim3((unsigned)ceil_div(Cout, 64)), dim3(64), 0, df::as_stream(stream), gy,
+    hipLaunchKernelGGL(conv_gen_bgrad_kernel, dim3((unsigned)ceil_div(Cout, 64)), dim3(1024), 0, df::as_stream(stream), gy,
                        gb, B * g.Do * g.Ho * g.Wo, (int)Cout);
   return df::launched("df_conv_general_wgrad");
 }
