@@ -596,9 +596,19 @@ int launch_thin_n_mfma(const ConvArgs& a, hipStream_t s) {
   t.B = a.B; t.D = a.D; t.H = a.H; t.W = a.W;
   t.K8 = a.Kpad >> 3; t.Npad = a.Npad;
   const int64_t planes = static_cast<int64_t>(a.B) * a.D;
-  int nsplit = (int)ceil_div(4 * df::kCUs, planes);      // y ranges per plane: fill the chip when there are few planes
-  if (nsplit > a.H / 4) nsplit = a.H / 4;               // (each range re-reads two halo rows)
-  if (nsplit < 1) nsplit = 1;
+  // y ranges per plane: one workgroup (4 waves = 4 ranges) per CU and round, so the launch takes rounds x (rows of a range + its two halo rows);
+  // [r5] pick the split that minimises that product instead of the smallest one that fills the chip (cfg4, 448 planes: 3 ranges per plane were
+  // 336 workgroups = two rounds of 54-row ranges; 2 ranges are one round of 80-row ranges)
+  int nsplit = 1;
+  {
+    int64_t best = -1;
+    const int smax = a.H / 4 > 1 ? a.H / 4 : 1;
+    for (int sp = 1; sp <= smax && sp <= 64; ++sp) {
+      const int64_t rows = ceil_div(a.H, sp);
+      const int64_t cost = ceil_div(ceil_div(planes * ceil_div(a.H, rows), 4), df::kCUs) * (rows + 2);
+      if (best < 0 || cost < best) { best = cost; nsplit = sp; }
+    }
+  }
   t.rows_per = (int)ceil_div(a.H, nsplit);
   t.nsplit = (int)ceil_div(a.H, t.rows_per);
   t.flags = a.flags; t.leak = a.leak;

@@ -60,10 +60,14 @@ constexpr int NLOAD = 5;                  // ceil(600 * 4 float4 pieces / 512 th
 // fine positions that repeat them (4.2x fewer staging loads) -- and builds the 27 live transform points from the 3 x 3 coarse patch per
 // plane a tile sees.  A coarse row (pz, py) of a channel is stored as FOUR 16-byte windows, window t = (c[t], c[t+1], c[t+2], -) = the three
 // columns tile column tx = t needs, so a lane fetches a patch row with ONE aligned ds_read_b128 (the 16 (ty, tx) lanes of a channel read 64
-// consecutive dwords: conflict-free); every staged value is written to the (up to three) windows that contain it.
+// consecutive dwords: conflict-free).  Staging is by WINDOW: thread = (window t of row (pz, py), channel quad) loads the three coarse voxels
+// px = t, t+1, t+2 (16 bytes = its 4 channels each; neighbours' loads hit the same lines) and writes its four channels' windows with four
+// ds_write_b128 (16 lanes = 4 quads x 4 windows cover 64 banks: conflict-free): 4 x 6 x 4 windows x 4 quads = 384 threads (waves 0-5).
+// (First version: every thread staged one voxel and scattered it to its <= 3 windows with 12 ds_write_b32 -- all lanes of an instruction on
+//  banks = k (mod 4), >= 4-way conflicts, 10 % of the kernel; profiles/r05_probes.md.)
 constexpr int UPY = 16, UPZ = 6 * UPY, UCP = 4 * UPZ + 4;
-constexpr int UHV = 144;                  // coarse halo block 4 x 6 x 6
-constexpr int NLU = 2;                    // ceil(144 * 4 pieces / 512 threads): every thread one piece, wave 0 a second one
+constexpr int UWIN = 4 * 6 * 4;           // windows of the coarse halo block: 4 planes x 6 rows x 4 windows
+constexpr int NLU = 3;                    // loads per staging thread: the window's three voxels
 // internal epilogue flags (beyond the public DF_CONV_*), part of the compile-time FL of the specialised instantiations:
 //   kSignBits: also emit the sign pattern of the output, one byte per lane and cout block holding the signs of the lane's 8 outputs
 //              (what a later masked dgrad of the same geometry needs of it: 1/32 of the activation's bytes);
@@ -389,11 +393,10 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
 #pragma unroll
   for (int it = 0; it < NL; ++it) {
     int p = it * kT + tid;
-    if (UPC) {
-      if (p > UHV * 4 - 1) p = UHV * 4 - 1;   // (pieces 576.. do not exist: the second pass is taken by wave 0 only, see stage_pass)
-      const int hv = p >> 2, q4 = p & 3;
-      const int px = hv % 6, py = (hv / 6) % 6, pz = hv / 36;
-      ldst[it] = ((q4 * 4) * UCP + pz * UPZ + py * UPY) * 4 + px * 16;      // window px, element 0 (may lie beyond the row: see stage_store)
+    if (UPC) {      // thread tid < 384 = (window w = tid >> 2, channel quad tid & 3); the three loads share one LDS destination (its window)
+      const int wq = tid < UWIN * 4 ? tid : UWIN * 4 - 1, q4 = wq & 3, w = wq >> 2;
+      const int t = w & 3, py = (w >> 2) % 6, pz = w / 24;
+      ldst[it] = ((q4 * 4) * UCP + pz * UPZ + py * UPY + t * 4) * 4;
       continue;
     }
     if (p > HV * 4 - 1) p = HV * 4 - 1;     // the tail threads of the last pass duplicate the last piece (same data, same slot)
@@ -402,16 +405,15 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     ldst[it] = ((q4 * 4) * CPk + hz * PZk + hy * PY + hx) * 4;        // bytes, buffer 0
   }
   // pass `it` of the staging is taken by every wave, except the coarse block's second pass (64 pieces: wave 0) -- wave-uniform
-  auto stage_pass = [&](int it) -> bool { return !UPC || it == 0 || wave == 0; };
+  auto stage_pass = [&](int) -> bool { return !UPC || wave < UWIN * 4 / 64; };      // MODE 3: waves 0-5 stage (wave-uniform)
   const unsigned vol_bytes = static_cast<unsigned>(XB ? a.D * a.H * a.Wb * 4 : UP ? (a.D >> 1) * (a.H >> 1) * (a.W >> 1) : a.D * a.H * a.W) * a.Cin * 4u;
   auto set_offs = [&](const BlockInfo& bi) {
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
       int p = it * kT + tid;
-      if (UPC) {      // coarse voxel (pz, py, px) of the 4 x 6 x 6 block whose origin is the coarse voxel under fine (z0 - 1, y0 - 1, x0 - 1)
-        if (p > UHV * 4 - 1) p = UHV * 4 - 1;
-        const int hv = p >> 2, q4 = p & 3;
-        const int px = hv % 6, py = (hv / 6) % 6, pz = hv / 36;
+      if (UPC) {      // coarse voxel (pz, py, px = t + it) of the 4 x 6 x 6 block whose origin is the coarse voxel under fine (z0 - 1, y0 - 1, x0 - 1)
+        const int wq = tid < UWIN * 4 ? tid : UWIN * 4 - 1, q4 = wq & 3, w = wq >> 2;
+        const int px = (w & 3) + it, py = (w >> 2) % 6, pz = w / 24;
         const int Dc = a.D >> 1, Hc = a.H >> 1, Wc = a.W >> 1;
         const int cz = (bi.z0 >> 1) - 1 + pz, cy = (bi.y0 >> 1) - 1 + py, cx = (bi.x0 >> 1) - 1 + px;
         bool ok = static_cast<unsigned>(cz) < static_cast<unsigned>(Dc) && static_cast<unsigned>(cy) < static_cast<unsigned>(Hc) &&
@@ -448,22 +450,21 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   };
   char* sInB = reinterpret_cast<char*>(sIn);
   auto stage_store = [&](int it, int bufbytes, const f32x4& v) {
-    if constexpr (UPC) {      // coarse column px lives in window px - k at element k, k = 0..2, for windows 0..3
-      int p = it * kT + tid;
-      if (p > UHV * 4 - 1) p = UHV * 4 - 1;
-      const int px = (p >> 2) % 6;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int t = px - k;
-        if (t >= 0 && t <= 3) {
-          float* d = reinterpret_cast<float*>(sInB + (ldst[it] + bufbytes - k * 12));
-          d[0] = v[0]; d[UCP] = v[1]; d[2 * UCP] = v[2]; d[3 * UCP] = v[3];
-        }
-      }
-      return;
-    }
     float* d = reinterpret_cast<float*>(sInB + (ldst[it] + bufbytes));
     d[0] = v[0]; d[CPk] = v[1]; d[2 * CPk] = v[2]; d[3 * CPk] = v[3];
+  };
+  // all pieces of a thread; MODE 3: the three loaded voxels (c0, c1, c2) x 4 channels -> the window (c0, c1, c2, -) of each channel
+  auto stage_store_all = [&](int bufbytes, const auto& v) {
+    if constexpr (XB) {      // (x-blocked LDS-DMA staging: nothing passes through registers)
+    } else if constexpr (UPC) {
+      if (!stage_pass(0)) return;
+      char* d = sInB + (ldst[0] + bufbytes);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(d + e * UCP * 4) = f32x4{v[0][e], v[1][e], v[2][e], 0.f};
+    } else {
+#pragma unroll
+      for (int it = 0; it < NLOAD; ++it) stage_store(it, bufbytes, v[it]);
+    }
   };
 
   // ---- XS staging: DMA instruction = halo row r = hz * 10 + hy; lane = (piece g, slot c), 51 of 64 lanes active -------------------------
@@ -764,8 +765,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
     f32x4 stg[NLOAD];
 #pragma unroll
     for (int it = 0; it < NL; ++it) if (stage_pass(it)) stg[it] = stage_load(it, srd0, 0u);
-#pragma unroll
-    for (int it = 0; it < NL; ++it) if (stage_pass(it)) stage_store(it, 0, stg[it]);
+    stage_store_all(0, stg);
   }
   __syncthreads();
 
@@ -847,8 +847,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         if (!(DBG & 1)) transform();
         __builtin_amdgcn_sched_barrier(0);
         if (!XB && ks == (SPREAD1 ? 3 : 2) && !(DBG & 4) && !(DBG & 64)) {
-#pragma unroll
-          for (int it = 0; it < NL; ++it) if (stage_pass(it)) stage_store(it, bn, stg[it]);
+          stage_store_all(bn, stg);
         }
         // XS: the DMA pieces of the next chunk have landed once at most the 8 (4) weight reloads of k-step 2 are outstanding behind them
         if (XB && ks == 3) {      // (every wave: one that issued no pieces has only those reloads outstanding and does not wait)
