@@ -67,7 +67,8 @@ constexpr int NLOAD = 5;                  // ceil(600 * 4 float4 pieces / 512 th
 //  banks = k (mod 4), >= 4-way conflicts, 10 % of the kernel; profiles/r05_probes.md.)
 constexpr int UPY = 16, UPZ = 6 * UPY, UCP = 4 * UPZ + 4;
 constexpr int UWIN = 4 * 6 * 4;           // windows of the coarse halo block: 4 planes x 6 rows x 4 windows
-constexpr int NLU = 3;                    // loads per staging thread: the window's three voxels
+constexpr int NLU = 2;                    // loads per staging thread: the window's outer voxels t and t + 2; the middle one comes from the
+                                          // neighbouring window's thread by DPP (the 16 lanes of a DPP row = 4 quads x the 4 windows of a row)
 // internal epilogue flags (beyond the public DF_CONV_*), part of the compile-time FL of the specialised instantiations:
 //   kSignBits: also emit the sign pattern of the output, one byte per lane and cout block holding the signs of the lane's 8 outputs
 //              (what a later masked dgrad of the same geometry needs of it: 1/32 of the activation's bytes);
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       int p = it * kT + tid;
       if (UPC) {      // coarse voxel (pz, py, px = t + it) of the 4 x 6 x 6 block whose origin is the coarse voxel under fine (z0 - 1, y0 - 1, x0 - 1)
         const int wq = tid < UWIN * 4 ? tid : UWIN * 4 - 1, q4 = wq & 3, w = wq >> 2;
-        const int px = (w & 3) + it, py = (w >> 2) % 6, pz = w / 24;
+        const int px = (w & 3) + 2 * it, py = (w >> 2) % 6, pz = w / 24;
         const int Dc = a.D >> 1, Hc = a.H >> 1, Wc = a.W >> 1;
         const int cz = (bi.z0 >> 1) - 1 + pz, cy = (bi.y0 >> 1) - 1 + py, cx = (bi.x0 >> 1) - 1 + px;
         bool ok = static_cast<unsigned>(cz) < static_cast<unsigned>(Dc) && static_cast<unsigned>(cy) < static_cast<unsigned>(Hc) &&
@@ -460,7 +461,15 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
       if (!stage_pass(0)) return;
       char* d = sInB + (ldst[0] + bufbytes);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(d + e * UCP * 4) = f32x4{v[0][e], v[1][e], v[2][e], 0.f};
+      for (int e = 0; e < 4; ++e) {
+        // lane = quad + 4 t inside a 16-lane DPP row: voxel t + 1 = first voxel of lane + 4 (row_shl:4); lanes 12-15 (t = 3) have no lane + 4 and
+        // keep `old` = the second voxel (t + 2 = 4) of lane - 4 (row_shr:4)
+        const float f0 = v[0][e], f2 = v[1][e];      // (bit_cast of a vector-ELEMENT lvalue reads element 0: copy to scalars first)
+        const int c0 = __builtin_bit_cast(int, f0), c2 = __builtin_bit_cast(int, f2);
+        const int fromlo = __builtin_amdgcn_update_dpp(0, c2, 0x114, 0xF, 0xF, false);            // row_shr:4
+        const int c1 = __builtin_amdgcn_update_dpp(fromlo, c0, 0x104, 0xF, 0xF, false);           // row_shl:4, out-of-row lanes keep fromlo
+        *reinterpret_cast<f32x4*>(d + e * UCP * 4) = f32x4{v[0][e], __builtin_bit_cast(float, c1), v[1][e], 0.f};
+      }
     } else {
 #pragma unroll
       for (int it = 0; it < NLOAD; ++it) stage_store(it, bufbytes, v[it]);
