@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 peak
 PEAK_HBM_GBS = 8000.0
 # fraction of the convolution's algorithmic (direct-form) multiply-adds the Winograd kernels execute on the matrix pipe
-EXEC_RATIO = {"wino3d_kernel": 8.0 / 27.0, "wino2d_kernel": 4.0 / 9.0, "conv_mfma_kernel": 1.0, "wgrad_kernel": None}
+EXEC_RATIO = {"wino3d_kernel": 8.0 / 27.0, "wino2d_kernel": 4.0 / 9.0, "conv_mfma_kernel": 1.0, "wgrad_kernel": None,
+              "wino3d_27pt_kernel up": 1.0 / 8.0, "wino3d_27pt_kernel pooled": 1.0 / 8.0}      # 27 of the 64 points: 27/8 MACs per output voxel and channel pair
 
 
 # BASELINE.json `configs` as bench workloads (cfg2 = trainer.py:136-184 on GeneratorBE; cfg3 / cfg4 = trainer3.py:14-63 on
@@ -126,6 +127,11 @@ def select_kernel(name, args):
     if name in ("df_wino_conv_fwd", "df_wino_conv_fwd_addup", "df_wino_conv_fwd_addup_bits", "df_wino_conv_fwd_bits"):
         B, D, H, W, cin, cout = args[6:12]
         return ("wino3d_kernel fwd/dgrad %dx%dx%d C%d->%d" % (D, H, W, cin, cout), 2.0 * 27 * cin * cout * B * D * H * W)
+    if name in ("df_wino_upconv_fwd", "df_wino_upconv_fwd_bits", "df_wino_upconv_dgrad"):      # the 27-point forms (fine grid = 2 x coarse)
+        o = {"df_wino_upconv_fwd": 4, "df_wino_upconv_fwd_bits": 5, "df_wino_upconv_dgrad": 3}[name]
+        B, Dc, Hc, Wc, cin, cout = args[o:o + 6]
+        kind = "pooled adjoint" if name.endswith("dgrad") else "up-sampling-aware forward"
+        return ("wino3d_27pt_kernel %s -> %dx%dx%d C%d->%d" % (kind, 2 * Dc, 2 * Hc, 2 * Wc, cin, cout), 2.0 * 27 * cin * cout * B * 8 * Dc * Hc * Wc)
     if name == "df_wino2d_conv_fwd":
         B, H, W, cin, cout = args[6:11]
         return ("wino2d_kernel fwd/dgrad %dx%d C%d->%d" % (H, W, cin, cout), 2.0 * 9 * cin * cout * B * H * W)
@@ -734,6 +740,9 @@ def compact(out):
     line = {k: out[k] for k in head}
     for k in ("roofline", "roofline_stencil", "roofline_wgrad", "roofline_tail_fwd", "roofline_tail_bwd"):
         line[k] = slim(out.get(k))
+    for k in ("roofline_up27", "roofline_pool27"):          # fraction + launch time only
+        if isinstance(out.get(k), dict):
+            line[k] = {q: out[k][q] for q in ("frac", "avg_launch_ms") if q in out[k]}
     cb = out.get("cpu_baseline")
     line["cpu_baseline"] = None if not isinstance(cb, dict) else {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "ms_per_step", "cpu", "error") if k in cb}
     line["l1_vs_ref"] = out.get("l1_vs_ref")
@@ -1007,6 +1016,8 @@ def main():
         "roofline_wgrad": roofline_of(ks, "wgrad_kernel", pmc, default_shape, pmc_source),
         "roofline_conv": roofline_of(ks, "conv_mfma_kernel", pmc, default_shape, pmc_source),
         "roofline_wino": roofline_of(ks, "wino3d_kernel" if is_3d else "wino2d_kernel", pmc, default_shape, pmc_source),
+        "roofline_up27": roofline_of(ks, "wino3d_27pt_kernel up", {}, False),          # the 27-point forms (verdict r4 item 3a)
+        "roofline_pool27": roofline_of(ks, "wino3d_27pt_kernel pooled", {}, False),
         "roofline_tail_fwd": roofline_of(ks, "velocity_loss3d_fwd_kernel", {}, False),
         "roofline_tail_bwd": roofline_of(ks, "velocity_loss3d_bwd_kernel", {}, False),
         "stencils_standalone": None,
