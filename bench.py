@@ -627,6 +627,7 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
             ("smoke_pos_size_2d_128x96", 13, [128, 96], 8, 128, True, "de"),
             ("ae_smoke_mov_2d_128x96", 56, [128, 96], 8, 64, True, "ae"),
             ("ae3_smoke3_mov_48x72x48", 73, [48, 72, 48], 4, 64, True, "ae"),
+            ("dg_smoke_pos_size_2d_128x96", 13, [128, 96], 8, 128, True, "dg"),      # the README's 2-D training command: --arch=dg (generator + PatchGAN)
         ]
         res = {}
         for key, line, grid, B, F, use_curl, kind in cases:
@@ -638,6 +639,9 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
             if kind == "ae":
                 tr = AETrainer(default_config(z_num=16, p_num=2 if is3 else 1, **kw))
                 yr = torch.from_numpy(np.random.RandomState(4).uniform(-1, 1, (B, 2 if is3 else 1, 10)).astype(np.float32)).cuda()
+            elif kind == "dg":
+                from deep_fluids_amd.trainer import GANTrainer
+                tr = GANTrainer(default_config(arch="dg", **kw))
             else:
                 tr = Trainer(default_config(**kw))
             el, m = timed_steps(tr, xr, yr, 2, 5)
