@@ -149,7 +149,9 @@ int df_conv_general_fwd(const float* x, const float* w, const float* bias, float
 /* gx [B,D,H,W,Cin] from gy [B,Do,Ho,Wo,Cout] (B, D, H, W = the INPUT extents of the forward conv). */
 int df_conv_general_dgrad(const float* gy, const float* w, float* gx, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kz,
                           int k, int s, df_stream_t stream);
-/* gw [kz,k,k,Cin,Cout] and gb [Cout] (gb may be NULL). */
+/* gw [kz,k,k,Cin,Cout] and gb [Cout] (gb may be NULL).  Expected cost: one workgroup per (tap, input channel) walks ALL output voxels in four
+ * sub-ranges (gb: 16 sub-ranges per 64 channels) -- a correctness path, SECONDS per call on 10^7-voxel grids; training at such sizes with a
+ * kernel / stride the matrix-core kernels do not take needs a dedicated kernel first. */
 int df_conv_general_wgrad(const float* x, const float* gy, float* gw, float* gb, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin,
                           int64_t Cout, int kz, int k, int s, df_stream_t stream);
 /* ops.py:66-73 `resize_nearest_neighbor(x, new_size)` = tf.image.resize_nearest_neighbor, align_corners=False, ANY target size:
