@@ -669,23 +669,30 @@ class Watchdog(object):
         import threading
         self.rank, self.world = rank, world
         self._lock = threading.Lock()
-        self._deadline, self._stage = None, None
+        self._deadline, self._stage, self._soft, self._fallback = None, None, False, None
         t = threading.Thread(target=self._run, daemon=True)
         t.start()
 
-    def arm(self, stage, seconds):
+    def arm(self, stage, seconds, soft=False, fallback=None):
+        """``soft`` (the optional extra legs that follow the metric's own leg): on expiry rank 0 prints ``fallback`` -- the contract line of the
+        leg that DID complete, with the stage that hung under `extra_legs_error` -- and every rank exits 0: a hang in an appended leg must not
+        cost the job its headline number."""
         with self._lock:
-            self._stage, self._deadline = stage, time.time() + seconds
+            self._stage, self._deadline, self._soft, self._fallback = stage, time.time() + seconds, soft, fallback
 
     def disarm(self):
         with self._lock:
-            self._stage, self._deadline = None, None
+            self._stage, self._deadline, self._soft, self._fallback = None, None, False, None
 
     def _run(self):
         while True:
             time.sleep(0.5)
             with self._lock:
-                stage, dl = self._stage, self._deadline
+                stage, dl, soft, fallback = self._stage, self._deadline, self._soft, self._fallback
+            if dl is not None and time.time() > dl and soft:
+                if self.rank == 0 and fallback is not None:
+                    print(json.dumps(dict(fallback, extra_legs_error="watchdog: stage %r did not complete in time" % stage)), flush=True)
+                os._exit(0)
             if dl is not None and time.time() > dl:
                 msg = {"metric": "velocity-field voxels/sec (3D train step), whole job", "value": None, "unit": "voxels/s",
                        "n_gpus": self.world, "rccl_ranks": 0, "error": "watchdog: stage %r did not complete in time" % stage,
@@ -952,9 +959,21 @@ def main():
         if world > 1 and a.config == "cfg3" and not a.no_extra_legs and a.precision == "fp32":
             del tr, last, xm, ym
             torch.cuda.empty_cache()
+            units0 = 1
+            for r in a.res:
+                units0 *= r
+            fallback = {"metric": "velocity-field voxels/sec (3D %s train step), whole job; per-GPU in `per_gpu`" % "x".join(str(r) for r in a.res),
+                        "value": global_batch * units0 * a.steps / elapsed, "unit": wl["unit"], "per_gpu": global_batch * units0 * a.steps / elapsed / world,
+                        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+                        "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                        "config": {"workload": rec["workload"], "global_batch": global_batch, "batch_per_gpu": per_gpu, "grid": list(a.res),
+                                   "params": n_params, "parallelism": "dp%d" % world},
+                        "rccl_ranks": wv["ranks"] if wv["backend"] == "nccl" else 0, "counted_ranks": wv["ranks"], "dist_backend": wv["backend"],
+                        "distinct_devices": wv["distinct_devices"], "allreduce": comm, "other_scaling_leg": other, "cross_rank": rec["cross_rank"],
+                        "loss": loss, "l1_vs_ref": {"value": rel_l1, "tolerance": 1e-4}} if rank == 0 else None
             for name in ("cfg2", "cfg4"):
                 if dog:
-                    dog.arm("extra leg %s" % name, a.init_timeout + 120.0 * a.extra_leg_steps)
+                    dog.arm("extra leg %s" % name, a.init_timeout + 120.0 * a.extra_leg_steps, soft=True, fallback=fallback)
                 try:
                     r, st = dp_leg(name, a, world, rank, dist, torch, a.extra_leg_steps, 2, "weak", other=not a.no_other_leg)
                     del st
