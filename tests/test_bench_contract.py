@@ -150,3 +150,20 @@ def test_compact_line_carries_extra_legs_and_cross_rank():
     assert "workload" not in line["extra_leg_cfg2"] and line["extra_leg_cfg2"]["allreduce"]["hidden_ms"] == 0.9
     assert line["extra_leg_cfg4"] == {"error": "boom"}
     json.dumps(line)
+
+
+def test_watchdog_soft_stage_prints_the_fallback_line_and_exits_zero():
+    """A hang in one of the OPTIONAL extra legs (cfg2 / cfg4 appended to the cfg3 line at N > 1) must not cost the job its headline number:
+    rank 0 prints the already-measured contract line with `extra_legs_error`, every rank exits 0."""
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r); import importlib.util as u; s = u.spec_from_file_location('b', %r); "
+            "m = u.module_from_spec(s); s.loader.exec_module(m); d = m.Watchdog(0, 8); "
+            "d.arm('extra leg cfg4', 0.6, soft=True, fallback={'metric': 'm', 'value': 1.5e8, 'n_gpus': 8}); time.sleep(30)"
+            % (ROOT, os.path.join(ROOT, "bench.py")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0
+    msg = json.loads(r.stdout.strip().splitlines()[-1])
+    assert msg["value"] == 1.5e8 and msg["n_gpus"] == 8 and "extra leg cfg4" in msg["extra_legs_error"]
+    code1 = code.replace("d = m.Watchdog(0, 8)", "d = m.Watchdog(3, 8)").replace(", fallback={'metric': 'm', 'value': 1.5e8, 'n_gpus': 8}", "")
+    r1 = subprocess.run([sys.executable, "-c", code1], capture_output=True, text=True, timeout=60)
+    assert r1.returncode == 0 and r1.stdout.strip() == ""
