@@ -1047,6 +1047,7 @@ struct WxyzArgs {
 // UP: x is the COARSE tensor of an up-sampling-aware conv (fine position p reads xc[p >> 1] on every axis; a.D/H/W are the fine extents):
 // the transform points with index 2 vanish for the duplicated input, so only xi_z, xi_y in {0, 1, 3} workgroup types exist and the
 // xi_x = 2 products are skipped -- 27 of the 64 products (wgrad_up2_kernel's parity-class form needs 48 per coarse voxel).
+constexpr int kWxyzLds = 4 * 64 * 64 + 4 * 64;      // floats: the 64 -> 64 kernels' in-workgroup sum of the four waves' partials (one xi_x slot at a time)
 // XCD-aware bijective block remap shared by the kernels below: workgroup b runs on XCD b % 8; every XCD gets a contiguous run
 __device__ __forceinline__ int wxyz_wg(int nwg) {
   const int bid = blockIdx.x, q = nwg >> 3, rem = nwg & 7;
@@ -1056,7 +1057,7 @@ __device__ __forceinline__ int wxyz_wg(int nwg) {
 
 // the work of ONE workgroup: voxel range `range`, transform point (xi_z, xi_y) number `sel` of the (GZ, GY) class
 template <int WP8, int CS, bool GZ, bool GY, bool UP, int DBG>
-__device__ __forceinline__ void wgrad_wxyz_body(const WxyzArgs& aa, int range, int sel) {
+__device__ __forceinline__ void wgrad_wxyz_body(const WxyzArgs& aa, int range, int sel, float* lds) {      // lds: kWxyzLds floats when CS == 64
   const WgradArgs& a = aa.w;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1237,6 +1238,44 @@ __device__ __forceinline__ void wgrad_wxyz_body(const WxyzArgs& aa, int range, i
   }
 
   // ---- partial: slot = (xi_z, xi_y) * 4 + xi_x -----------------------------------------------------------------------------------
+  if constexpr (CS == 64) {
+    // [r5] 64 -> 64: the four waves of the workgroup hold four partial sums of the SAME 64 x 64 tile (they split the range).  They are added
+    // here, in wave order, through LDS -- one partial per range instead of four: a quarter of the partial writes and of the fixed-order
+    // reduce's reads (cfg5: 25 reduce launches of 146 us per step).  One xi_x slot (4 x 16 KB) at a time.
+    float (*sR)[64 * 64] = reinterpret_cast<float (*)[64 * 64]>(lds);
+    float (*sBs)[64] = reinterpret_cast<float (*)[64]>(lds + 4 * 64 * 64);
+    float* P1 = a.partial + static_cast<int64_t>(range) * 64 * a.Cinp * a.Coutp;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (UP && d == 2) continue;
+      const int slot = zy * 4 + d;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+            sR[sub][(2 * i + s) * 64 + 2 * r + t] = acc[d][s][t][e];
+          }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = q * kThreads + tid;
+        const float v = ((sR[0][j] + sR[1][j]) + sR[2][j]) + sR[3][j];
+        P1[(static_cast<int64_t>(slot) * a.Cinp + ci0 + (j >> 6)) * a.Coutp + co0 + (j & 63)] = v;
+      }
+      __syncthreads();
+    }
+    if (a.want_bias && GZ && GY && sel == 0 && blockIdx.y == 0) {      // (workgroup-uniform: all four waves sit on quadrant (0, 0))
+      bsum[0] += __shfl_xor(bsum[0], 32, 64);
+      bsum[1] += __shfl_xor(bsum[1], 32, 64);
+      if (half == 0) { sBs[sub][2 * r] = bsum[0]; sBs[sub][2 * r + 1] = bsum[1]; }
+      __syncthreads();
+      if (tid < 64) a.bpartial[static_cast<int64_t>(range) * a.Coutp + co0 + tid] = ((sBs[0][tid] + sBs[1][tid]) + sBs[2][tid]) + sBs[3][tid];
+    }
+    return;
+  }
   float* P = a.partial + static_cast<int64_t>(erange) * 64 * a.Cinp * a.Coutp;
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
@@ -1266,8 +1305,9 @@ __device__ __forceinline__ void wgrad_wxyz_body(const WxyzArgs& aa, int range, i
 template <int WP8, int CS, bool GZ, bool GY, bool UP = false, int DBG = 0>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_kernel(const WxyzArgs aa) {
   constexpr int NT = ((UP && GZ) ? 1 : 2) * ((UP && GY) ? 1 : 2);      // workgroup types of this launch
+  __shared__ float sLds[CS == 64 ? kWxyzLds : 1];
   const int wg = wxyz_wg(aa.w.nranges * NT);
-  wgrad_wxyz_body<WP8, CS, GZ, GY, UP, DBG>(aa, wg / NT, wg % NT);
+  wgrad_wxyz_body<WP8, CS, GZ, GY, UP, DBG>(aa, wg / NT, wg % NT, sLds);
 }
 
 // All 16 (xi_z, xi_y) types of a voxel range in ONE launch, adjacent in the grid: they run at the same time on the same XCD, so the
@@ -1280,10 +1320,11 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_fused_kernel(const Wxy
   const int xiz = type >> 2, xiy = type & 3;
   const bool gz = xiz == 1 || xiz == 2, gy = xiy == 1 || xiy == 2;
   const int sel = (gz ? xiz - 1 : xiz / 3) * 2 + (gy ? xiy - 1 : xiy / 3);
-  if (gz && gy) wgrad_wxyz_body<WP8, CS, true, true, false, DBG>(aa, range, sel);
-  else if (gz) wgrad_wxyz_body<WP8, CS, true, false, false, DBG>(aa, range, sel);
-  else if (gy) wgrad_wxyz_body<WP8, CS, false, true, false, DBG>(aa, range, sel);
-  else wgrad_wxyz_body<WP8, CS, false, false, false, DBG>(aa, range, sel);
+  __shared__ float sLds[CS == 64 ? kWxyzLds : 1];
+  if (gz && gy) wgrad_wxyz_body<WP8, CS, true, true, false, DBG>(aa, range, sel, sLds);
+  else if (gz) wgrad_wxyz_body<WP8, CS, true, false, false, DBG>(aa, range, sel, sLds);
+  else if (gy) wgrad_wxyz_body<WP8, CS, false, true, false, DBG>(aa, range, sel, sLds);
+  else wgrad_wxyz_body<WP8, CS, false, false, false, DBG>(aa, range, sel, sLds);
 }
 
 // The up-sampling-aware form has 9 live (xi_z, xi_y) types (xi in {0, 1, 3} per axis): one launch as well (four launches by class
@@ -1295,10 +1336,11 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wxyz_up_fused_kernel(const 
   const int zi = t9 / 3, yi = t9 % 3;                      // 0 -> xi = 0, 1 -> xi = 1, 2 -> xi = 3
   const bool gz = zi == 1, gy = yi == 1;
   const int selz = zi == 2 ? 1 : 0, sely = yi == 2 ? 1 : 0;
-  if (gz && gy) wgrad_wxyz_body<WP8, CS, true, true, true, 0>(aa, range, 0);
-  else if (gz) wgrad_wxyz_body<WP8, CS, true, false, true, 0>(aa, range, sely);
-  else if (gy) wgrad_wxyz_body<WP8, CS, false, true, true, 0>(aa, range, selz);
-  else wgrad_wxyz_body<WP8, CS, false, false, true, 0>(aa, range, selz * 2 + sely);
+  __shared__ float sLds[CS == 64 ? kWxyzLds : 1];
+  if (gz && gy) wgrad_wxyz_body<WP8, CS, true, true, true, 0>(aa, range, 0, sLds);
+  else if (gz) wgrad_wxyz_body<WP8, CS, true, false, true, 0>(aa, range, sely, sLds);
+  else if (gy) wgrad_wxyz_body<WP8, CS, false, true, true, 0>(aa, range, selz, sLds);
+  else wgrad_wxyz_body<WP8, CS, false, false, true, 0>(aa, range, selz * 2 + sely, sLds);
 }
 
 // gw[dz][dy][dx][ci][co] = G^T_z G^T_y G^T_x of the summed (fixed order) partials U[xi_z][xi_y][xi_x]; index 3 of every axis carries a
@@ -2391,7 +2433,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
 #undef DF_WXYZ64
     const int64_t rgx = ceil_div(Cin * Cout, 32);
     hipLaunchKernelGGL(wgrad_wxyz_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
-                       p.nranges * p.nsub, (int)Cin, (int)Cout, p.Cinp, p.Coutp, 0);
+                       Cin == 64 ? p.nranges : p.nranges * p.nsub, (int)Cin, (int)Cout, p.Cinp, p.Coutp, 0);      // (64 -> 64: summed in the workgroup)
     return df::launched("df_conv_wgrad(winograd-xyz)");
   } else if (algo == 2) {
     WxyArgs aa;
@@ -2639,7 +2681,7 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
 #undef DF_UWXYZ64
     const int64_t rgx = ceil_div(Cin * Cout, 32);
     hipLaunchKernelGGL(wgrad_wxyz_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
-                       p.nranges * p.nsub, (int)Cin, (int)Cout, p.Cinp, p.Coutp, 1);
+                       Cin == 64 ? p.nranges : p.nranges * p.nsub, (int)Cin, (int)Cout, p.Cinp, p.Coutp, 1);
     return df::launched("df_upconv_wgrad(winograd-xyz, 27-point)");
   }
   const Plan p = make_up_plan(B, Dc, Hc, Wc, Cin, Cout, kz);

@@ -21,10 +21,11 @@ def run(B, D, H, W, C):
     s = _stream()
     x = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
     g = torch.rand((B, D, H, W, C), device="cuda") * 2 - 1
-    nb = query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, C, 3)
+    nb = max(query("df_conv_wgrad_workspace_bytes", B, D, H, W, C, C, 3), 64 * 4 * 64 * 64 * 64 * 4 + (1 << 22))
     ws = torch.empty((nb + 3) // 4, device="cuda")
     res = {}
-    for tag, algo, dbg in (("direct", 1, 0), ("xyz interleaved (production)", 4, 0), ("xyz contiguous (rounds 3-4)", 4, 16)):
+    for tag, algo, dbg in (("direct", 1, 0), ("xyz interleaved (production)", 4, 0), ("xyz contiguous (rounds 3-4)", 4, 16),
+                           ("xyz interleaved, 64 ranges", 4 | (64 << 3), 0), ("xyz interleaved, 16 ranges", 4 | (16 << 3), 0)):
         lib().df_debug_set_wgrad(ctypes.c_int(dbg))
         gw = torch.empty((27, C, C), device="cuda"); gb = torch.empty(C, device="cuda")
         f = lambda: call("df_conv_wgrad_algo", _ptr(x), _ptr(g), _ptr(gw), _ptr(gb), B, D, H, W, C, C, 3, _ptr(ws), nb, algo, s)
