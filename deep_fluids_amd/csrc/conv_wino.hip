@@ -22,8 +22,10 @@
 //   * epilogue: inverse transform in y,x in registers, the four xi_z partial planes are combined through the idle LDS
 //     buffer, then bias / lrelu / residual / lrelu-mask as in conv.hip.  The dgrad is the same kernel on mode-1 weights.
 //
-// Compile-time switches of wino3d_kernel.  The release library instantiates DBG = 0, PREC = 0, XS = 0 only (FL = the epilogue, MODE = plain /
-// up-sampling-aware / pooled); everything else exists in the -DDF_TUNING library for tools/wino_diag.py, wino_probe.py, wino_xblk_probe.py:
+// Compile-time switches of wino3d_kernel.  The release library instantiates DBG = 0, PREC = 0, XS = 0 only (FL = the epilogue, MODE = 0 plain |
+// 3 up-sampling-aware forward with the coarse halo block staged (round 5; MODE 1 = its round-2 form staging the fine positions, tuning library
+// only) | 2 pooled adjoint); everything else exists in the -DDF_TUNING library for tools/r05_breakdown_probe.py, r05_upc_check.py and
+// tools/archive/wino_diag.py, wino_probe.py, wino_xblk_probe.py:
 //   DBG bits (diagnosis: results wrong by construction unless noted)   1 no input transform | 2 no raw LDS reads | 4 no staging | 8 no weight loads |
 //     16 per-phase cycle counters (correct results) | 64 staging loads kept alive, no LDS writes | 128 staged zeros (LDS writes only) |
 //     256 staging loads read an always-cached address | 384 ... confined to a 1 MB L2-resident window | 512 no output stores |
@@ -314,8 +316,8 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   constexpr int PZk = UPC ? UPZ : PZ, CPk = UPC ? UCP : CP;      // pitches INSIDE a buffer; the buffer stride below keeps the plain size (the
                                                                 // epilogue's 32 KB exchange area lives in the idle buffer)
   constexpr int NL = UPC ? NLU : NLOAD;              // staging pieces per thread and chunk
-#ifndef DF_KEEPQ
-#define DF_KEEPQ 0
+#ifndef DF_KEEPQ      // (-DDF_KEEPQ=1: keep the whole weight quad of a 27-point row live up to its reload -- the cure of the "dead xi_x = 2 word" hazard
+#define DF_KEEPQ 0    //  that round 5 used before all transform temporaries were register PAIRS; costs 8 VGPRs, not needed any more)
 #endif
   constexpr bool KEEPQ = DF_KEEPQ != 0;
   constexpr int XROWB = 51 * 16, XROWS = 60;        // XS: bytes per LDS row (3 pieces x 17 slots x 16 B), halo rows per chunk (6 planes x 10)
