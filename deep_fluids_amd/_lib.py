@@ -101,6 +101,10 @@ SIGNATURES = {
     "df_upconv_dgrad_bf16x3": (I32, [P, P, P, I64, I64, I64, I64, I64, I64, I32, P]),
     "df_conv_wgrad_bf16x3": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
     "df_upconv_wgrad_bf16x3": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
+    "df_adam_tf1_step_dev": (I32, [P, P, P, P, I64, P, F32, F32, F32, P]),
+    "df_gd_step": (I32, [P, P, I64, F32, F32, P]),
+    "df_gd_step_dev": (I32, [P, P, I64, P, P]),
+    "df_store_scalars": (I32, [P, I64, F32, F32, F32, F32, P]),
     "df_conv_wgrad_workspace_bytes": (I64, [I64, I64, I64, I64, I64, I64, I32]),
     "df_conv_wgrad": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
     "df_conv_wgrad_algo": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, I32, P]),

@@ -2338,7 +2338,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     sa.Wp = (int)(ceil_div(W + 1, 8) * 8);
     sa.nrows = sp.nrows; sa.nstreams = sp.nstreams; sa.rows_per = sp.rows_per; sa.ncib = sp.ncib;
     hipStream_t s = df::as_stream(stream);
-    if (hipError_t e = hipMemsetAsync(zeros, 0, kZeroBytes, s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
+    if (hipError_t e = df::zero_async(zeros, kZeroBytes, s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
     dim3 grid((unsigned)(sp.nstreams * sp.ncib / 4));
 #define DF_WS(KZ, CO) hipLaunchKernelGGL((wgrad_small_n_kernel<KZ, CO>), grid, dim3(kThreads), 0, s, sa)
     if (kz == 3) { if (Cout == 1) DF_WS(3, 1); else if (Cout == 2) DF_WS(3, 2); else if (Cout == 3) DF_WS(3, 3); else DF_WS(3, 4); }
@@ -2391,7 +2391,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   a.nqi = p.nqi; a.nqj = p.nqj; a.nsub = p.nsub;
   a.up = 0; a.gD = a.D; a.gH = a.H; a.gW = a.W;
   hipStream_t s = df::as_stream(stream);
-  if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(W, Cin, Cout), s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
+  if (hipError_t e = df::zero_async(zeros, zero_row_bytes(W, Cin, Cout), s)) return df::fail((int)e, "df_conv_wgrad: memset: %s", hipGetErrorString(e));
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)ceil_div(Cin, 128), (unsigned)ceil_div(Cout, 128));
   if (use_bf16x3) {
     launch_wgrad_bf16x3(W, grid, s, a);
@@ -2559,7 +2559,7 @@ int df_conv_s2_wgrad(const float* x, const float* gy, float* gw, float* gb, int6
   a.nqi = p.nqi; a.nqj = p.nqj; a.nsub = p.nsub;
   a.up = 0; a.gD = a.D; a.gH = a.H; a.gW = a.W;
   hipStream_t s = df::as_stream(stream);
-  if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(2 * Wo, Cin, Cout), s)) return df::fail((int)e, "df_conv_s2_wgrad: memset: %s", hipGetErrorString(e));
+  if (hipError_t e = df::zero_async(zeros, zero_row_bytes(2 * Wo, Cin, Cout), s)) return df::fail((int)e, "df_conv_s2_wgrad: memset: %s", hipGetErrorString(e));
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)ceil_div(Cin, 128), (unsigned)ceil_div(Cout, 128));
   if (Wo == 64) hipLaunchKernelGGL((wgrad_s2_kernel<8>), grid, dim3(kThreads), 0, s, a);
   else if (Wo == 32) hipLaunchKernelGGL((wgrad_s2_kernel<4>), grid, dim3(kThreads), 0, s, a);
@@ -2669,7 +2669,7 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
     a.up = 0; a.gD = a.D; a.gH = a.H; a.gW = a.W;
     aa.Ht = (int)Hc; aa.Dt = (int)Dc; aa.ntrows = p.nrows;
     hipStream_t s = df::as_stream(stream);
-    if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(W, Cin, Cout), s)) return df::fail((int)e, "df_upconv_wgrad: memset: %s", hipGetErrorString(e));
+    if (hipError_t e = df::zero_async(zeros, zero_row_bytes(W, Cin, Cout), s)) return df::fail((int)e, "df_upconv_wgrad: memset: %s", hipGetErrorString(e));
     const unsigned gy_ = (unsigned)ceil_div(Cin, 128), gz_ = (unsigned)ceil_div(Cout, 128);
     const dim3 gridu((unsigned)(p.nranges * 9), gy_, gz_);          // all 9 live (xi_z, xi_y) types of a range, adjacent
 #define DF_UWXYZ(WP) hipLaunchKernelGGL((wgrad_wxyz_up_fused_kernel<WP, 128>), gridu, dim3(kThreads), 0, s, aa)
@@ -2699,7 +2699,7 @@ static int upconv_wgrad_impl(const float* xc, const float* gy, float* gw, float*
   a.nqi = p.nqi; a.nqj = p.nqj; a.nsub = p.nsub;
   a.up = 1; a.gD = kz == 3 ? 2 * a.D : 1; a.gH = 2 * a.H; a.gW = 2 * a.W;
   hipStream_t s = df::as_stream(stream);
-  if (hipError_t e = hipMemsetAsync(zeros, 0, zero_row_bytes(Wc, Cin, Cout), s)) return df::fail((int)e, "df_upconv_wgrad: memset: %s", hipGetErrorString(e));
+  if (hipError_t e = df::zero_async(zeros, zero_row_bytes(Wc, Cin, Cout), s)) return df::fail((int)e, "df_upconv_wgrad: memset: %s", hipGetErrorString(e));
   dim3 grid((unsigned)(p.nranges * p.ndzdy), (unsigned)ceil_div(Cin, 128), (unsigned)ceil_div(Cout, 128));
   const int wp8 = a.Wp / 8;
   const bool exact = (Wc % 8) == 0;

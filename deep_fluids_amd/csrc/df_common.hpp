@@ -28,6 +28,21 @@ inline int launched(const char* what) {
 // MI355X), queried once per process.  Kernels that size themselves for it fall back to their smaller-footprint path when it is less.
 int64_t lds_optin_bytes();
 
+// Clear of a small workspace region as a KERNEL node.  Not hipMemsetAsync: inside a captured hipGraph (Trainer(graph=True)) ROCm 7.2 runs
+// memset nodes outside the order the capture recorded -- a replay that starts on an idle device executed them late, over memory the
+// graph's pool had meanwhile handed to another tensor (profiles/r06_probes.md, section 1).  `bytes` must be a multiple of 4.
+static __global__ void zero_words_kernel(uint32_t* __restrict__ p, int64_t n) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    p[i] = 0u;
+}
+inline hipError_t zero_async(void* p, int64_t bytes, hipStream_t s) {
+  const int64_t n = bytes / 4;
+  if (n <= 0) return hipSuccess;
+  const unsigned blocks = static_cast<unsigned>((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, s, static_cast<uint32_t*>(p), n);
+  return hipGetLastError();
+}
+
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kCUs = 256;          // MI355X
 

@@ -528,6 +528,42 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, c
   }
 }
 
+// The same update with lr_t / grad_scale read from device memory (scal[0], scal[1]): a captured hipGraph of the train step replays with
+// new values without touching the kernel node's arguments.  Identical arithmetic to adam_kernel (bitwise-equal parameters).
+__global__ __launch_bounds__(kThreads) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                            const float* __restrict__ scal, float b1, float b2, float eps) {
+  const float lr_t = scal[0], gscale = scal[1];
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// tf.train.GradientDescentOptimizer (trainer.py:163-165): p -= (lr * grad_scale) * g; DEV: the two scalars come from device memory.
+template <bool DEV>
+__global__ __launch_bounds__(kThreads) void gd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n, float lr,
+                                                      float gscale, const float* __restrict__ scal) {
+  if (DEV) { lr = scal[0]; gscale = scal[1]; }
+  const float a = lr * gscale;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kThreads)
+    p[i] = p[i] - a * g[i];
+}
+
+__global__ void store_scalars_kernel(float* __restrict__ dst, float v0, float v1, float v2, float v3, int n) {
+  if (threadIdx.x == 0) {
+    if (n > 0) dst[0] = v0;
+    if (n > 1) dst[1] = v1;
+    if (n > 2) dst[2] = v2;
+    if (n > 3) dst[3] = v3;
+  }
+}
+
 int check_n(const void* a, int64_t n, const char* fn) {
   DF_REQUIRE(a != nullptr, DF_EINVAL, "%s: null pointer", fn);
   DF_REQUIRE(n > 0, DF_EINVAL, "%s: n must be positive", fn);
@@ -730,6 +766,37 @@ int df_adam_tf1_step(float* p, const float* g, float* m, float* v, int64_t n, fl
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(kThreads), 0, df::as_stream(stream), p, g, m, v, n, lr_t, beta1,
                      beta2, eps, grad_scale);
   return df::launched("df_adam_tf1_step");
+}
+
+int df_adam_tf1_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* scalars, float beta1, float beta2,
+                         float eps, df_stream_t stream) {
+  if (int e = check_n(p, n, "df_adam_tf1_step_dev")) return e;
+  DF_REQUIRE(g && m && v && scalars, DF_EINVAL, "df_adam_tf1_step_dev: null pointer");
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n)), dim3(kThreads), 0, df::as_stream(stream), p, g, m, v, n, scalars, beta1,
+                     beta2, eps);
+  return df::launched("df_adam_tf1_step_dev");
+}
+
+int df_gd_step(float* p, const float* g, int64_t n, float lr, float grad_scale, df_stream_t stream) {
+  if (int e = check_n(p, n, "df_gd_step")) return e;
+  DF_REQUIRE(g, DF_EINVAL, "df_gd_step: null pointer");
+  hipLaunchKernelGGL((gd_kernel<false>), dim3(grid_for(n)), dim3(kThreads), 0, df::as_stream(stream), p, g, n, lr, grad_scale,
+                     (const float*)nullptr);
+  return df::launched("df_gd_step");
+}
+
+int df_gd_step_dev(float* p, const float* g, int64_t n, const float* scalars, df_stream_t stream) {
+  if (int e = check_n(p, n, "df_gd_step_dev")) return e;
+  DF_REQUIRE(g && scalars, DF_EINVAL, "df_gd_step_dev: null pointer");
+  hipLaunchKernelGGL((gd_kernel<true>), dim3(grid_for(n)), dim3(kThreads), 0, df::as_stream(stream), p, g, n, 0.f, 0.f, scalars);
+  return df::launched("df_gd_step_dev");
+}
+
+int df_store_scalars(float* dst, int64_t n, float v0, float v1, float v2, float v3, df_stream_t stream) {
+  DF_REQUIRE(dst, DF_EINVAL, "df_store_scalars: null pointer");
+  DF_REQUIRE(n >= 1 && n <= 4, DF_EINVAL, "df_store_scalars: n must be 1..4");
+  hipLaunchKernelGGL(store_scalars_kernel, dim3(1), dim3(64), 0, df::as_stream(stream), dst, v0, v1, v2, v3, (int)n);
+  return df::launched("df_store_scalars");
 }
 
 int df_concat2_fwd(const float* a, const float* b, float* y, int64_t rows, int64_t Ca, int64_t Cb, df_stream_t stream) {

@@ -116,6 +116,8 @@ class GradSync(object):
         self._ev = []                  # per step: (first-launch start, [bucket end events], backward-done, finish-done)
         self._cur = None
         self.launch_order = []         # bucket indices in the order their all-reduces were issued during the last step
+        self.suspended = False         # True: the hooks do nothing (a hipGraph capture of forward + backward is in progress; the
+        #                                exchange then is reduce_all() after the replay, Trainer._graph_step)
         if self.enabled:
             for bi, (_, _, params) in enumerate(buckets):
                 for p in params:
@@ -130,6 +132,8 @@ class GradSync(object):
 
     def _make_hook(self, bi):
         def hook(_p):
+            if self.suspended:
+                return
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self._launch(bi)
@@ -185,6 +189,20 @@ class GradSync(object):
             self._cur["done"].record()
             self._ev.append(self._cur)
             self._cur = None
+        return 1.0 / self.world
+
+    def reduce_all(self):
+        """The whole flat slab in ONE all-reduce on the current stream (no overlap with backward: the graph-replay schedule, where the
+        backward pass is a single graph launch that hooks cannot interleave with); returns the 1/world scale like finish()."""
+        if not self.enabled:
+            return 1.0
+        self.launch_order = ["all"]
+        if self._host_staged:
+            host = self.flat_grad.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat_grad.copy_(host)
+        else:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         return 1.0 / self.world
 
     def timing(self, reset=True):

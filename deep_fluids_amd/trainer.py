@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from . import ops
+from . import _lib as _lib_mod
 from .ops import curl, curl3, jacobian, jacobian3, l1_mean, mse_mean, get_conv_shape, _ptr, _stream, call
 from .model import GeneratorBE, GeneratorBE3, AE, AE3, DiscriminatorPatch, DiscriminatorPatch3
 from .ops import concat, kl_bernoulli
@@ -38,7 +39,7 @@ def default_config(**over):
              start_step=0, random_seed=123, num_samples=21000, c_num=3, use_curl3_alias=True,
              z_num=16, use_sparse=False, sparsity=0.01, w4=1.0, w5=1.0, p_num=2, x_channels=None, w3=0.005,
              log_step=500, test_step=1000, test_batch_size=100, model_dir=None, load_path="", code_path="", save_sec=3600,   # config.py:62-68
-             fused_tail=True)
+             fused_tail=True, graph=False)
     c.update(over)
     return SimpleNamespace(**c)
 
@@ -55,6 +56,13 @@ def latest_checkpoint(model_dir):
             if m and (best is None or int(m.group(1)) > best[0]):
                 best = (int(m.group(1)), os.path.join(model_dir, f))
     return None if best is None else best[1]
+
+
+def _detached(m):
+    """The step's outputs without their autograd graph.  A graph-mode trainer never hands out tensors that keep the graph alive: the
+    variables' AccumulateGrad nodes live as long as any graph that reaches them, remember the stream they were created on, and a later
+    capture on another stream would have to synchronise with that stream -- which a stream capture cannot (hipStreamEndCapture dies)."""
+    return SimpleNamespace(**{k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in vars(m).items()})
 
 
 class Trainer(object):
@@ -85,6 +93,10 @@ class Trainer(object):
         ops.set_random_seed(config.random_seed)
         self._build_variables()
         self.grad_sync = None
+        # graph=True: the whole step -- forward, backward, optimizer -- is captured ONCE per input shape into a hipGraph and replayed (the
+        # counterpart of `sess.run(g_optim)` executing a pre-built TF graph, trainer.py:265-269: no per-op host cost); see _graph_step
+        self.use_graph = bool(getattr(config, "graph", False))
+        self._graphs, self._graph_warm = {}, set()
         self.save_sec = getattr(config, "save_sec", 3600)      # config.py:68 -> Supervisor(save_model_secs=...), trainer.py:110-117
         if self._restore_in_base:
             self._auto_restore()
@@ -284,10 +296,97 @@ class Trainer(object):
         gscale = self.grad_sync.finish() if self.grad_sync is not None else 1.0
         return m, gscale
 
-    def train_step(self, x, y):
+    def _step_body(self, x, y, dev=None):
+        """Everything of one step that runs on the device.  ``dev`` = None: the optimizer's per-step scalars travel by value (eager);
+        a device float[4]: the optimizer kernels read them from there (the body is being captured / replayed)."""
         m, gscale = self.forward_backward(x, y)
-        self._apply_adam(gscale)
+        self._apply_optimizer(None if dev is not None else self._optimizer_scalars(gscale), dev)
+        return m
+
+    def train_step(self, x, y):
+        if self.use_graph:
+            return self._graph_step(x, y)
+        m = self._step_body(x, y)
         self._advance_lr()
+        return m
+
+    # ---- the step as a replayed hipGraph ------------------------------------------------------------------------------------------
+    def _dp_active(self):
+        return self.grad_sync is not None and self.grad_sync.enabled
+
+    def _graph_step(self, x, y):
+        """``train_step`` with the device work of the step replayed from a hipGraph captured on the second call with these input shapes
+        (the first call runs eagerly: one-time initialisations -- kernel attributes, code-object loading -- must not be recorded).
+
+        Captured: gradient-slab clear, generator / auto-encoder forward, loss tail, the whole autograd backward, the optimizer launch --
+        every C-ABI call of the eager step, on the capture stream, with outputs and workspaces from the graph's private pool (so
+        every pointer a kernel node holds stays valid).  What changes from step to step lives in device memory the graph reads: the
+        inputs (static buffers, refreshed by a device copy) and the optimizer's scalars lr_t / grad_scale (``df_store_scalars`` before
+        the launch; kernel arguments by value, so nothing the host may overwrite early).  The returned graph ``m`` is the SAME object
+        every step: its tensors are overwritten by the next replay.  Bitwise equal to the eager step (tests/test_gpu_graph.py).
+
+        Data parallel (world > 1): the capture holds forward + backward only, the exchange is ONE eager all-reduce of the flat slab
+        after the replay, then the optimizer launch -- no overlap with backward, which is the right trade where a graph matters
+        (small steps: the launch overhead saved exceeds the 0.1-0.3 ms exchange)."""
+        key = (tuple(x.shape), tuple(y.shape), self._dp_active())
+        st = self._graphs.get(key)
+        if st is None and key not in self._graph_warm:
+            self._graph_warm.add(key)
+            m = _detached(self._step_body(x, y))
+            self._advance_lr()
+            return m
+        if st is None:
+            st = self._graphs[key] = self._capture(x, y, key[2])
+        if x.data_ptr() != st.x.data_ptr():
+            st.x.copy_(x)
+        if y.data_ptr() != st.y.data_ptr():
+            st.y.copy_(y)
+        if st.dp:
+            st.graph.replay()
+            scal = self._optimizer_scalars(self._reduce_all())
+            self._apply_optimizer(scal, None)
+        else:
+            scal = self._optimizer_scalars(1.0)
+            call("df_store_scalars", _ptr(st.dev), len(scal), *(list(scal) + [0.0] * (4 - len(scal))), _stream())
+            st.graph.replay()
+        self._advance_lr()
+        return st.m
+
+    def _reduce_all(self):
+        return self.grad_sync.reduce_all()
+
+    def _capture(self, x, y, dp):
+        st = SimpleNamespace(dp=dp)
+        st.x, st.y = x.clone(), y.clone()
+        st.dev = torch.zeros(4, dtype=torch.float32, device=self.device)
+        st.graph = torch.cuda.CUDAGraph()
+        if _lib_mod.TIMER is not None:
+            raise RuntimeError("graph capture with a KernelTimer installed: event pairs cannot be recorded into a hipGraph")
+        # host-side bookkeeping (dispatch counters, fetch lists) would only see the capture pass, not the replays: off
+        with ops.options(dispatch_counts=None, activation_fetch=None, sign_bits_fetch=None):
+            if dp:
+                self.grad_sync.suspended = True
+                sync_d = getattr(self, "grad_sync_d", None)
+                if sync_d is not None:
+                    sync_d.suspended = True
+            try:
+                with torch.cuda.graph(st.graph):
+                    m = self._capture_body(st.x, st.y, st.dev, dp)
+                st.m = _detached(m)
+                del m
+            finally:
+                if dp:
+                    self.grad_sync.suspended = False
+                    if sync_d is not None:
+                        sync_d.suspended = False
+        return st
+
+    def _capture_body(self, x, y, dev, dp):
+        if not dp:
+            return self._step_body(x, y, dev)
+        self.flat_g.zero_()
+        m = self.build_model(x, y)
+        m.g_loss.backward()
         return m
 
     def _advance_lr(self):
@@ -414,16 +513,36 @@ class Trainer(object):
             np.savez_compressed(os.path.join(out_dir, "%d.npz" % i), x=G_)
         return out_dir
 
-    def _apply_adam(self, grad_scale):
+    def _optimizer_scalars(self, grad_scale):
+        """The optimizer's per-step host scalars ``[lr_t | lr, grad_scale]``; advances Adam's step count (beta powers)."""
         if self.config.optimizer == "gd":                       # trainer.py:163-165
-            self.flat_p.add_(self.flat_g, alpha=-self.g_lr * grad_scale)
-            return
+            return [float(self.g_lr), float(grad_scale)]
         self._adam_t += 1
         t = self._adam_t
-        lr_t = self.g_lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
-        call("df_adam_tf1_step", _ptr(self.flat_p), _ptr(self.flat_g), _ptr(self.flat_m), _ptr(self.flat_v),
-             self.n_params, float(lr_t), float(self.beta1), float(self.beta2), float(self.eps), float(grad_scale),
-             _stream())
+        return [float(self.g_lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)), float(grad_scale)]
+
+    def _apply_slab(self, p, g, m, v, n, lr, gscale, dev, dev_off=0):
+        """One optimizer launch over a flat slab; scalars by value (``dev`` None) or the pair ``dev[dev_off], dev[dev_off + 1]``."""
+        sp = None if dev is None else dev.data_ptr() + 4 * dev_off
+        if self.config.optimizer == "gd":
+            if dev is None:
+                call("df_gd_step", _ptr(p), _ptr(g), n, lr, gscale, _stream())
+            else:
+                call("df_gd_step_dev", _ptr(p), _ptr(g), n, sp, _stream())
+        elif dev is None:
+            call("df_adam_tf1_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, float(self.beta1), float(self.beta2), float(self.eps),
+                 gscale, _stream())
+        else:
+            call("df_adam_tf1_step_dev", _ptr(p), _ptr(g), _ptr(m), _ptr(v), n, sp, float(self.beta1), float(self.beta2),
+                 float(self.eps), _stream())
+
+    def _apply_optimizer(self, scal, dev):
+        lr, gscale = scal if scal is not None else (None, None)
+        self._apply_slab(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.n_params, lr, gscale, dev)
+
+    def _apply_adam(self, grad_scale):
+        """(kept for callers of the pre-graph API) one eager optimizer step with the gradients scaled by ``grad_scale``."""
+        self._apply_optimizer(self._optimizer_scalars(grad_scale), None)
 
 
 class Trainer3(Trainer):
@@ -626,10 +745,23 @@ class GANTrainer(Trainer):
         self.grad_sync_d = GradSync(self.D.g, [(0, self.D.n, list(self.D.vars))], group, profile=profile, force=force)
         return gs
 
-    def train_step(self, x, y):
+    def _optimizer_scalars(self, grad_scale):
+        """[G's lr_t | lr, grad_scale, D's lr_t | lr, grad_scale]: two optimizers with their own beta powers (trainer.py:160-165,183-184)."""
+        out = super(GANTrainer, self)._optimizer_scalars(grad_scale)
+        if self.config.optimizer == "gd":
+            return out + [float(self.g_lr), float(grad_scale)]
+        self._adam_t_d += 1
+        t = self._adam_t_d
+        return out + [float(self.g_lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)), float(grad_scale)]
+
+    def _apply_optimizer(self, scal, dev):
+        lg, sg, ld, sd = scal if scal is not None else (None,) * 4
+        self._apply_slab(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.n_params, lg, sg, dev, 0)
+        self._apply_slab(self.D.p, self.D.g, self.D.m, self.D.v, self.D.n, ld, sd, dev, 2)
+
+    def _forward_backward_gan(self, x, y, dp):
         disc = DiscriminatorPatch3 if self.is_3d else DiscriminatorPatch
         self.flat_g.zero_(); self.D.g.zero_()
-        dp = self.grad_sync is not None
         if dp:
             self.grad_sync.begin_step(); self.grad_sync_d.begin_step()
         m = self.build_model(x, y)
@@ -647,18 +779,24 @@ class GANTrainer(Trainer):
         # the post-accumulate hooks of a slab fire during exactly one of the two passes and its buckets are reduced once
         m.g_loss.backward(inputs=self.G_var, retain_graph=True)
         m.d_loss.backward(inputs=self.D.vars)
+        return m
+
+    def _step_body(self, x, y, dev=None):
+        dp = self.grad_sync is not None
+        m = self._forward_backward_gan(x, y, dp)
         gscale = 1.0
         if dp:
             gscale = self.grad_sync.finish()
             self.grad_sync_d.finish()
-        self._apply_adam(gscale)
-        if self.config.optimizer == "gd":                                              # trainer.py:163-165 (both optimizers)
-            self.D.p.add_(self.D.g, alpha=-self.g_lr * gscale)
-        else:
-            self._adam_t_d += 1
-            t = self._adam_t_d
-            lr_t = self.g_lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
-            call("df_adam_tf1_step", _ptr(self.D.p), _ptr(self.D.g), _ptr(self.D.m), _ptr(self.D.v), self.D.n, float(lr_t),
-                 float(self.beta1), float(self.beta2), float(self.eps), float(gscale), _stream())
-        self._advance_lr()
+        self._apply_optimizer(None if dev is not None else self._optimizer_scalars(gscale), dev)   # trainer.py:163-165 (both optimizers)
         return m
+
+    def _capture_body(self, x, y, dev, dp):
+        if not dp:
+            return self._step_body(x, y, dev)
+        return self._forward_backward_gan(x, y, False)
+
+    def _reduce_all(self):
+        s = self.grad_sync.reduce_all()
+        self.grad_sync_d.reduce_all()
+        return s

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DF_VERSION 204 /* 0.2.4: + df_conv_s2_dgrad; 0.2.3: + df_conv_s2_wgrad; 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
+#define DF_VERSION 205 /* 0.2.5: + df_adam_tf1_step_dev, df_gd_step(_dev), df_store_scalars (hipGraph replay of the train step); 0.2.4: + df_conv_s2_dgrad; 0.2.3: + df_conv_s2_wgrad; 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
 
 enum {
   DF_OK = 0,
@@ -203,6 +203,21 @@ int df_colsum(const float* g, float* gb, int64_t rows, int64_t C, void* workspac
  * with lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the caller on the host. */
 int df_adam_tf1_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
                      float eps, float grad_scale, df_stream_t stream);
+
+/* The same update with the two per-step scalars read from DEVICE memory -- scalars[0] = lr_t, scalars[1] = grad_scale -- so that a
+ * captured hipGraph of the whole train step (one `sess.run(g_optim)`, trainer.py:265-269) replays with the values the host stored
+ * before the launch; arithmetic identical to df_adam_tf1_step (bitwise-equal parameters). */
+int df_adam_tf1_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* scalars, float beta1, float beta2,
+                         float eps, df_stream_t stream);
+
+/* tf.train.GradientDescentOptimizer (the `gd` option, trainer.py:163-165):  p -= (lr * grad_scale) * g  over one flat slab;
+ * _dev: scalars[0] = lr, scalars[1] = grad_scale from device memory (graph replay, as above). */
+int df_gd_step(float* p, const float* g, int64_t n, float lr, float grad_scale, df_stream_t stream);
+int df_gd_step_dev(float* p, const float* g, int64_t n, const float* scalars, df_stream_t stream);
+
+/* dst[0..n-1] = v0..v(n-1), n <= 4, by a one-thread kernel whose arguments travel by value: the host-side update of the device
+ * scalars above, ordered on `stream` before the graph launch, with no host buffer that a later step could overwrite early. */
+int df_store_scalars(float* dst, int64_t n, float v0, float v1, float v2, float v3, df_stream_t stream);
 
 /* ---- convolutions on MFMA (exact fp32: v_mfma_f32_32x32x2_f32) ----------------------------- */
 

@@ -41,7 +41,10 @@ def run(case, world, rank, force_sync=False):
     from deep_fluids_amd.dist import shard_batch
     name, kw, gb, steps = make_case(case)
     lo, n = shard_batch(gb, rank, world)
-    cfg = T.default_config(batch_size=gb, **kw)            # max_step (the cosine period) follows the GLOBAL batch
+    graph = os.environ.get("DF_TEST_GRAPH") == "1"          # tests/test_gpu_graph.py: Trainer(graph=True) under data parallelism
+    if graph:
+        steps = 4                                           # eager warm-up, capture + replay, two more replays
+    cfg = T.default_config(batch_size=gb, graph=graph, **kw)            # max_step (the cosine period) follows the GLOBAL batch
     ops.reset_variables()
     tr = getattr(T, name)(cfg)                              # same seed on every rank -> identical initial variables
     if world > 1:
@@ -62,6 +65,7 @@ def run(case, world, rank, force_sync=False):
                 out["launch_order"] = np.asarray(tr.grad_sync.launch_order)
                 out["n_buckets"] = np.int64(len(tr.grad_sync.buckets))
     out["p"] = tr.flat_p.cpu().numpy()
+    out["n_graphs"] = np.int64(len(tr._graphs))
     if name == "GANTrainer":
         out["pd"] = tr.D.p.cpu().numpy()
     out["loss"] = np.float64(float(m.g_loss.detach()))

@@ -25,7 +25,7 @@ def test_library_present_and_exports_every_declared_symbol():
 
 def test_version_and_error_convention():
     h = _lib.lib()
-    assert h.df_version() == 204
+    assert h.df_version() == 205
     # null pointers / bad extents are argument errors (< 0) caught on the host, with a message
     assert h.df_jacobian3d_fwd(None, None, None, 1, 4, 4, 4, None) == -1
     assert b"null input" in h.df_last_error()

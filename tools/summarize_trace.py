@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 kernel trace per (kernel, grid size): the stats CSV merges all resolution levels of one kernel
 template; the judge-facing roofline needs the top-resolution launches on their own.
-usage: summarize_trace.py <prefix>_kernel_trace.csv > table.md
+usage: summarize_trace.py <prefix>_kernel_trace.csv [--steps N] > table.md
+``--steps N``: the trace holds N identical steps -> a header line with launches per step and the kernel-time sum per step.
 A second table lists, per kernel, only the launches within 2x of its longest one: the top-resolution launches of the persistent kernels
 (whose grid size is the same at every level)."""
 import collections
@@ -13,6 +14,10 @@ for r in csv.DictReader(open(sys.argv[1])):
     key = (r["Kernel_Name"], r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
     rows[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tot = sum(sum(v) for v in rows.values())
+if "--steps" in sys.argv:
+    n = int(sys.argv[sys.argv.index("--steps") + 1])
+    nl = sum(len(v) for v in rows.values())
+    print("**%d steps traced: %.1f kernel launches per step, kernel-time sum %.3f ms per step**\n" % (n, nl / float(n), tot / 1e6 / n))
 print("| kernel | grid (threads) | calls | total ms | avg us | % |\n|---|---|---|---|---|---|")
 for key, v in sorted(rows.items(), key=lambda kv: -sum(kv[1]))[:40]:
     print("| `%s` | %sx%sx%s | %d | %.2f | %.1f | %.2f |" % (key[0][:96], key[1], key[2], key[3], len(v), sum(v) / 1e6,
