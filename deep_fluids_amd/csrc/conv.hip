@@ -327,7 +327,13 @@ int launch(const ConvArgs& a_in, hipStream_t s) {
 
 template <int KZ, int TZ, int TY, int TX, int S, int KT = 3>
 int launch_n(const ConvArgs& a, hipStream_t s) {
-  const int nt = ntile_for(a.Cout);
+  int nt = ntile_for(a.Cout);
+  // Small launches (the low-resolution levels at the reference's default batch sizes, config.py:40): a workgroup's four waves run
+  // 2 x 2 blocks of 32 x 32 over the whole K = taps x Cin serially -- 61 us of MFMA issue at K = 1152 whatever the grid -- so with fewer
+  // workgroups than CUs the N tile is narrowed (same packed operand: Npad is a multiple of every N tile; same summation order per
+  // output, bitwise equal) until the grid fills the chip or the tile is 32 wide: 4x the workgroups, a quarter of the chain each.
+  const int64_t tiles = static_cast<int64_t>(a.B) * ceil_div(a.D, TZ) * ceil_div(a.H, TY) * ceil_div(a.W, TX) * (a.nclass > 1 ? a.nclass : 1);
+  while (nt > 32 && tiles * (a.Npad / nt) * 2 <= df::kCUs) nt >>= 1;
   if (nt == 128) return launch<KZ, TZ, TY, TX, 2, 2, 2, 2, S, KT>(a, s);
   if (nt == 64) return launch<KZ, TZ, TY, TX, 2, 2, 2, 1, S, KT>(a, s);
   return launch<KZ, TZ, TY, TX, 4, 1, 1, 1, S, KT>(a, s);

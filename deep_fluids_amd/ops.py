@@ -247,6 +247,54 @@ def _wgrad(x, dp, gw, gb, B, D, H, W, cin, cout, kz, sfx=""):
              int(WGRAD_ALGO), _stream())
 
 
+# Levels whose kernels cannot fill the chip (B x voxels x taps <= this) run the weight gradient of a layer on a SECOND stream, concurrently
+# with the same layer's dgrad: both only read the incoming gradient and each launches few workgroups with a long serial chain (the
+# low-resolution levels, and every level of the 2-D net at the reference's default batch 8).  Same kernels, same arguments: results are
+# bitwise those of the serial order.  0 = always serial.  Measured (profiles/r06_probes.md section 1): 2-D 128x96 B = 8 4.95 -> 4.46 ms;
+# above ~1M the two kernels each fill the chip and only contend (cfg3's 16x24x16 level at B = 16: +1.7 % on the step).
+CONCURRENT_WGRAD_WORK = int(_os.environ.get("DF_CONCURRENT_WGRAD_WORK", str(1 << 20)))
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return s
+
+
+class _WgradLane(object):
+    """The second stream of one backward node: ``run(fn, *tensors)`` launches ``fn`` there after everything issued so far on the
+    node's own stream; ``tensors`` (what fn reads or writes) stay referenced until ``join()`` makes the node's stream wait for the
+    lane -- the caching allocator would otherwise hand a freed block to the next allocation while the lane still uses it."""
+
+    def __init__(self, dims, like, taps):
+        n = int(taps)
+        for d in dims:
+            n *= int(d)
+        # (not while a hipGraph is being captured: ROCm 7.2 replays a forked graph no faster than the serial one, and its launch
+        #  costs the host 0.5-6 ms instead of 0.1 -- profiles/r06_probes.md, section 1)
+        self.on = 0 < n <= CONCURRENT_WGRAD_WORK and not torch.cuda.is_current_stream_capturing()
+        self.keep = []
+        if self.on:
+            self.main = torch.cuda.current_stream()
+            self.side = _side_stream(like.device)
+
+    def run(self, fn, *tensors):
+        if not self.on:
+            return fn()
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            fn()
+        self.keep.extend(tensors)
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+            self.keep = []
+
+
 def _use_wino(cin, cout, dims, kz):
     """0: direct kernel; 3: 3-D Winograd F(2x2x2,3x3x3) (conv_wino.hip); 2: 2-D Winograd F(2x2,3x3) (conv_wino2d.hip)."""
     if CONV_ALGO == "direct" or CONV_PRECISION != "fp32" or cin % 32 or cout % 32:
@@ -433,12 +481,13 @@ class _GenBlock(torch.autograd.Function):
         call("df_lrelu_bwd", _ptr(dy), _ptr(xs[n]), _ptr(dp), leak, dy.numel(), _stream())
         grads = [None] * (2 * n)
         dx0 = None
+        lane = _WgradLane(dims, dy, taps)
         for i in range(n, 0, -1):
             w = ws[i - 1]
             cin, cout = w.shape[-2], w.shape[-1]
             gw = torch.empty_like(w)
             gb = torch.empty(cout, dtype=torch.float32, device=dy.device)
-            _wgrad(xs[i - 1], dp, gw, gb, B, D, H, W, cin, cout, kz, _sfx(cin, cout))
+            lane.run(lambda: _wgrad(xs[i - 1], dp, gw, gb, B, D, H, W, cin, cout, kz, _sfx(cin, cout)), dp, gw, gb)
             grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
             wpd = _pack(w, taps, cin, cout, 1, dims)
             if i > 1:      # dgrad, times the lrelu slope of the layer below: directly the next dp
@@ -447,6 +496,7 @@ class _GenBlock(torch.autograd.Function):
                                mask_bits=mb).view(xs[i - 1].shape)
             elif ctx.needs_input_grad[0]:   # dgrad of the first layer + the skip gradient
                 dx0 = _conv_raw(dp, wpd, None, dy, None, dims, cout, cin, kz, DF_CONV_RESIDUAL, 0.0).view(xs[0].shape)
+        lane.join()
         return (dx0, None) + tuple(grads)
 
 
@@ -496,12 +546,13 @@ class _ConvChain(torch.autograd.Function):
         call("df_lrelu_bwd", _ptr(dy), _ptr(xs[n]), _ptr(dp), leak, dy.numel(), _stream())
         grads = [None] * (2 * n)
         dx0 = None
+        lane = _WgradLane(dims, dy, taps)
         for i in range(n, 0, -1):
             w = ws[i - 1]
             cin, cout = w.shape[-2], w.shape[-1]
             gw = torch.empty_like(w)
             gb = torch.empty(cout, dtype=torch.float32, device=dy.device)
-            _wgrad(xs[i - 1], dp, gw, gb, B, D, H, W, cin, cout, kz, _sfx(cin, cout))
+            lane.run(lambda: _wgrad(xs[i - 1], dp, gw, gb, B, D, H, W, cin, cout, kz, _sfx(cin, cout)), dp, gw, gb)
             grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
             if i > 1 or ctx.needs_input_grad[0]:
                 wpd = _pack(w, taps, cin, cout, 1, dims)
@@ -511,6 +562,7 @@ class _ConvChain(torch.autograd.Function):
                                    mask_bits=mb).view(xs[i - 1].shape)
                 else:
                     dx0 = _conv_raw(dp, wpd, None, None, None, dims, cout, cin, kz, 0, 0.0).view(xs[0].shape)
+        lane.join()
         return (dx0, None) + tuple(grads)
 
 
@@ -627,12 +679,13 @@ class _UpGenBlock(torch.autograd.Function):
         else:
             call("df_lrelu_bwd", _ptr(dy), _ptr(xs[n - 1]), _ptr(dp), leak, dy.numel(), _stream())
         grads = [None] * (2 * n)
+        lane = _WgradLane(fdims, dy, taps)
         for i in range(n, 0, -1):
             w = ws[i - 1]
             gw = torch.empty_like(w)
             gb = torch.empty(C, dtype=torch.float32, device=dy.device)
             if i > 1:
-                _wgrad(xs[i - 2], dp, gw, gb, B, D, H, W, C, C, kz, _sfx(C, C))
+                lane.run(lambda: _wgrad(xs[i - 2], dp, gw, gb, B, D, H, W, C, C, kz, _sfx(C, C)), dp, gw, gb)
                 wpd = _pack(w, taps, C, C, 1, fdims)
                 mb = ctx.bits[i - 2]      # sign bits of conv i-1's output (xs[i-2]), if its forward emitted them
                 dp = _conv_raw(dp, wpd, None, None, None if mb is not None else xs[i - 2], fdims, C, C, kz, DF_CONV_MASK, leak,
@@ -640,15 +693,18 @@ class _UpGenBlock(torch.autograd.Function):
             else:
                 nbytes = query("df_upconv_wgrad_workspace_bytes", cdims[0], cdims[1], cdims[2], cdims[3], C, C, kz)
                 wsb = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
-                if _sfx(C, C):
-                    call("df_upconv_wgrad" + _sfx(C, C), _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
-                         cdims[3], C, C, kz, _ptr(wsb), nbytes, _stream())
-                else:
-                    if DISPATCH_COUNTS is not None:
-                        f = query("df_upconv_wgrad_form", cdims[0], cdims[1], cdims[2], cdims[3], C, C, kz, int(WGRAD_ALGO))
-                        _count("upconv-wgrad", "winograd-xyz-27pt" if f == 3 else "parity-class", fdims, C, C)
-                    call("df_upconv_wgrad_algo", _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
-                         cdims[3], C, C, kz, _ptr(wsb), nbytes, int(WGRAD_ALGO), _stream())
+
+                def up_wgrad():
+                    if _sfx(C, C):
+                        call("df_upconv_wgrad" + _sfx(C, C), _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
+                             cdims[3], C, C, kz, _ptr(wsb), nbytes, _stream())
+                    else:
+                        if DISPATCH_COUNTS is not None:
+                            f = query("df_upconv_wgrad_form", cdims[0], cdims[1], cdims[2], cdims[3], C, C, kz, int(WGRAD_ALGO))
+                            _count("upconv-wgrad", "winograd-xyz-27pt" if f == 3 else "parity-class", fdims, C, C)
+                        call("df_upconv_wgrad_algo", _ptr(xc), _ptr(dp), _ptr(gw), _ptr(gb), cdims[0], cdims[1], cdims[2],
+                             cdims[3], C, C, kz, _ptr(wsb), nbytes, int(WGRAD_ALGO), _stream())
+                lane.run(up_wgrad, dp, gw, gb, wsb)
                 if ctx.needs_input_grad[0]:
                     if DISPATCH_COUNTS is not None:
                         _count("upconv-dgrad", "winograd-27pt-pooled" if (is3d and _use_wino(C, C, fdims, kz) == 3) else
@@ -670,6 +726,7 @@ class _UpGenBlock(torch.autograd.Function):
                         call("df_upconv_dgrad" + sfx, _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, C,
                              kz, _stream())
             grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
+        lane.join()
         return (dxc if ctx.needs_input_grad[0] else None, None) + tuple(grads)
 
 
@@ -1178,7 +1235,7 @@ ACTIVATION_FETCH = None
 # different option sets (a second thread entering `options` waits until the first leaves).
 _OPTION_ATTRS = {"conv_precision": "CONV_PRECISION", "conv_algo": "CONV_ALGO", "wgrad_algo": "WGRAD_ALGO",
                  "thin_valu_only": "THIN_VALU_ONLY", "sign_bit_masks": "SIGN_BIT_MASKS", "fused_blocks": "FUSED_BLOCKS",
-                 "dispatch_counts": "DISPATCH_COUNTS", "activation_fetch": "ACTIVATION_FETCH", "sign_bits_fetch": "SIGN_BITS_FETCH"}
+                 "dispatch_counts": "DISPATCH_COUNTS", "concurrent_wgrad_work": "CONCURRENT_WGRAD_WORK", "activation_fetch": "ACTIVATION_FETCH", "sign_bits_fetch": "SIGN_BITS_FETCH"}
 _OPTION_CHOICES = {"conv_precision": ("fp32", "bf16x3"), "conv_algo": ("auto", "direct", "winograd"), "wgrad_algo": (0, 1, 2, 3, 4)}
 _OPTION_LOCK = _threading.RLock()
 
@@ -1187,6 +1244,7 @@ _OPTION_LOCK = _threading.RLock()
 def options(**kw):
     """``with ops.options(conv_precision="bf16x3", conv_algo="direct", wgrad_algo=1, activation_fetch=[]): ...``
     Keys: conv_precision, conv_algo, wgrad_algo, thin_valu_only, sign_bit_masks, fused_blocks, dispatch_counts (a dict to count into),
+    concurrent_wgrad_work (weight gradients of levels up to that many B x voxels x taps run on a second stream; 0 = serial),
     activation_fetch / sign_bits_fetch (a list to append to).  Unknown keys and out-of-range values raise before anything changes."""
     for k, v in kw.items():
         if k not in _OPTION_ATTRS:

@@ -163,3 +163,17 @@ def test_graph_two_rank_data_parallel(tmp_path):
     assert np.abs(d_dp - d_ref).sum() / np.abs(d_ref).sum() < 2e-2
     assert abs(dp["loss"] - ref["loss"]) < 1e-4 * abs(ref["loss"])
     assert abs(dp["g_lr"] - ref["g_lr"]) < 1e-15
+
+
+@pytest.mark.parametrize("name", ["de2", "de3_f128", "ae2", "dg2"])
+def test_concurrent_weight_gradient_lane_is_bitwise_the_serial_order(name):
+    """ops.CONCURRENT_WGRAD_WORK: the weight gradients of the small levels run on a second stream next to the dgrad of the same
+    layer (fork after the incoming gradient, join at the end of the backward node).  Same kernels and arguments: bitwise equal."""
+    from deep_fluids_amd import ops
+    with ops.options(concurrent_wgrad_work=0):
+        a = _run(name, False, 3)
+    with ops.options(concurrent_wgrad_work=1 << 40):
+        b = _run(name, False, 3)
+    np.testing.assert_array_equal(a["loss"], b["loss"])
+    for k in ("p", "m", "v", "g"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
