@@ -71,7 +71,7 @@ def parse():
                          "MFMA mode (16-bit operand significands, fp32 accumulate)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra measurements appended at N=1 (bf16x3 mode, 2-D, cfg4, AE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the CPU-baseline sample (one warm-up + >= 5 timed full-grid steps at ~2.9 s each on the bench box)")
     ap.add_argument("--init-timeout", type=float, default=120.0,
                     help="N > 1: seconds the rendezvous / the RCCL communicator creation + first all-reduce may take before the watchdog "
                          "prints a diagnostic JSON line (rccl_ranks 0) and exits non-zero")
@@ -406,7 +406,26 @@ def roofline_of(ks, prefix, pmc, with_traffic, pmc_source=None):
             ratio, form = wgrad_exec_ratio(int(f[3][1:]), dims[0], dims[1], dims[2], cc[0], cc[1])
             out["wgrad_form"] = {3: "winograd-xyz", 2: "winograd-xy", 1: "winograd-x", 0: "direct"}.get(form, str(form))
         ach = alg * ratio
+        # algorithmic HBM bytes of one launch: every input and output element once (weights: < 0.1 %)
+        abytes = None
+        try:
+            f = k.split(" ")
+            cc = [int(t) for t in f[-2 if f[-1].startswith("B") else -1][1:].replace("->", "x").split("x")]
+            dims = [int(t) for t in [q for q in f if "x" in q and q[0].isdigit()][-1].split("x")]
+            taps = 27 if len(dims) == 3 and dims[0] > 1 else 9
+            vox = out["work_per_launch"] / (2.0 * taps * cc[0] * cc[1])
+            abytes = vox * (cc[0] + cc[1]) * 4.0
+            if "up-sampling-aware forward" in k:      # reads the COARSE tensor (1/8 of the voxels), writes the fine one
+                abytes = vox * (cc[0] / 8.0 + cc[1]) * 4.0
+            elif "pooled adjoint" in k:               # reads the fine gradient, accumulates into the coarse tensor (read + write)
+                abytes = vox * (cc[0] + 2.0 * cc[1] / 8.0) * 4.0
+        except Exception:
+            pass
         out.update(achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS,
+                   frac_definition="EXECUTED multiply-add flops on the fp32 matrix pipe / time / peak (this kernel executes %.3f of the "
+                                   "direct-form flops the roofline numerator of SURVEY 8(d) counts: %s)" % (
+                                       ratio, "Winograd F(2,3) per axis" if ratio < 1 else "direct form"),
+                   executed_over_algorithmic=ratio, algorithmic_bytes=abytes,
                    algorithmic_tflops=alg, algorithmic_speedup=1.0 / ratio,
                    note="achieved = multiply-add flops EXECUTED on the fp32 matrix pipe / time; algorithmic_tflops = direct-convolution "
                         "flops / time (the Winograd forms execute 1/algorithmic_speedup of them)")
@@ -414,6 +433,8 @@ def roofline_of(ks, prefix, pmc, with_traffic, pmc_source=None):
     # on the same kernel at the default shape (B = 16, 64x96x64, F = 128)
     fam = prefix.split("<")[0]
     out["traffic"] = pmc.get(fam, {}).get("traffic_bytes") if with_traffic else None
+    if out["traffic"] and out.get("algorithmic_bytes"):
+        out["traffic_over_algorithmic"] = out["traffic"] / out["algorithmic_bytes"]
     out["traffic_source"] = (pmc_source or "profiles/pmc_latest.json (offline rocprofv3 --pmc passes, not measured in this run)") if out["traffic"] else None
     return out
 
@@ -690,9 +711,14 @@ class Watchdog(object):
             with self._lock:
                 stage, dl, soft, fallback = self._stage, self._deadline, self._soft, self._fallback
             if dl is not None and time.time() > dl and soft:
+                err = "watchdog: stage %r did not complete in time" % stage
                 if self.rank == 0 and fallback is not None:
-                    print(json.dumps(dict(fallback, extra_legs_error="watchdog: stage %r did not complete in time" % stage)), flush=True)
-                os._exit(0)
+                    print(json.dumps(dict(fallback, extra_legs_error=err, truncated=True)), flush=True)
+                    os._exit(0)
+                # no completed leg to fall back on (rank 0), or a peer of the hung leg: say so; only rank 0 WITHOUT a line to print fails the
+                # job (exit 4 = soft expiry with nothing measured) -- a peer exiting non-zero would void rank 0's valid headline line
+                print(json.dumps({"error": err, "rank": self.rank, "soft": True}), file=sys.stdout if self.rank == 0 else sys.stderr, flush=True)
+                os._exit(4 if self.rank == 0 else 0)
             if dl is not None and time.time() > dl:
                 msg = {"metric": "velocity-field voxels/sec (3D train step), whole job", "value": None, "unit": "voxels/s",
                        "n_gpus": self.world, "rccl_ranks": 0, "error": "watchdog: stage %r did not complete in time" % stage,
@@ -744,7 +770,8 @@ def compact(out):
     """The printed line: headline objects first, bulky diagnostics (per-kernel table, dispatch log, standalone stencil table, the
     extras' nested rooflines, long notes) only in the sidecar file."""
     def slim(r, keep=("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_copy_rate", "traffic", "traffic_source", "avg_launch_ms", "avg_launch_us",
-                      "launches", "algorithmic_tflops", "algorithmic_speedup", "wgrad_form", "algorithmic_bytes_per_voxel")):
+                      "launches", "algorithmic_tflops", "algorithmic_speedup", "wgrad_form", "algorithmic_bytes_per_voxel", "frac_definition",
+                      "executed_over_algorithmic", "algorithmic_bytes", "traffic_over_algorithmic")):
         return None if not isinstance(r, dict) else ({k: r[k] for k in keep if k in r} if "error" not in r else r)
     head = ["metric", "value", "unit", "per_gpu", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config"]

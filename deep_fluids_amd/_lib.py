@@ -69,6 +69,7 @@ SIGNATURES = {
     "df_conv_s2_wgrad_workspace_bytes": (I64, [I64, I64, I64, I64, I64, I64, I32]),
     "df_conv_s2_wgrad": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P]),
     "df_conv_s2_dgrad": (I32, [P, P, P, I64, I64, I64, I64, I64, I64, I32, P]),
+    "df_conv_s2_dgrad_form": (I32, [P, I64, I64]),
     "df_upconv_packed_elems": (I64, [I64, I64, I32, I32]),
     "df_upconv_pack_weights": (I32, [P, P, I64, I64, I32, I32, P]),
     "df_upconv_fwd": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),
@@ -87,6 +88,9 @@ SIGNATURES = {
     "df_wino_signbits_bytes": (I64, [I64, I64, I64, I64, I64]),
     "df_wino_conv_fwd_bits": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, F32, P]),
     "df_wino_upconv_fwd_bits": (I32, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, F32, P]),
+    "df_wino43_packed_elems": (I64, [I64, I64, I32]),
+    "df_wino43_pack_weights": (I32, [P, P, I64, I64, I32, P]),
+    "df_wino43_conv": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, F32, P]),
     "df_wino2d_packed_elems": (I64, [I64, I64, I32]),
     "df_wino2d_pack_weights": (I32, [P, P, I64, I64, I32, P]),
     "df_wino2d_conv_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, F32, P]),

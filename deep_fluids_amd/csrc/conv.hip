@@ -540,6 +540,13 @@ int df_upconv_fwd(const float* xc, const float* wp, const float* bias, float* y,
 // 177-179, 94-99): gx[B, 2Do, 2Ho, 2Wo, Cin] from gy[B, Do, Ho, Wo, Cout] and the mode-2 packed weights of df_upconv_pack_weights.
 // Per axis dx[2m] = g[m-1] w[2] + g[m] w[0] (two taps), dx[2m+1] = g[m] w[1] (ONE tap): the 8 (4) parity classes have 8, 4, 4, 2, 4, 2, 2, 1
 // live taps -- 27 of the 64 the generic parity-class kernel (df_upconv_fwd on the same operand, the fallback below) multiplies.
+// 1: the live-tap parity-class kernels (27 | 9 tap-products); 0: the generic 2x2(x2)-tap parity-class kernel on the zero-padded taps
+static bool s2_dgrad_special(const float* gy, int64_t Cin, int64_t Cout) {
+  return ntile_for(Cin) == 128 && round_up(Cout, CK) % 64 == 0 && Cout % 4 == 0 && df::aligned16(gy);
+}
+
+int df_conv_s2_dgrad_form(const float* gy, int64_t Cin, int64_t Cout) { return s2_dgrad_special(gy, Cin, Cout) ? 1 : 0; }
+
 int df_conv_s2_dgrad(const float* gy, const float* wp, float* gx, int64_t B, int64_t Do, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout,
                      int kz, df_stream_t stream) {
   DF_REQUIRE(gy && wp && gx, DF_EINVAL, "df_conv_s2_dgrad: null pointer");
@@ -549,7 +556,7 @@ int df_conv_s2_dgrad(const float* gy, const float* wp, float* gx, int64_t B, int
   DF_REQUIRE(Cin > 4 && Cout > 4, DF_ESHAPE, "df_conv_s2_dgrad: MFMA path only (channels > 4)");
   DF_REQUIRE(df::aligned16(wp), DF_EALIGN, "df_conv_s2_dgrad: packed weights must be 16-byte aligned");
   const int64_t Kpad = round_up(Cout, CK), Npad = round_up(Cin, ntile_for(Cin));      // K = the forward conv's Cout, N = its Cin
-  const bool special = ntile_for(Cin) == 128 && Kpad % 64 == 0 && Cout % 4 == 0 && df::aligned16(gy);
+  const bool special = s2_dgrad_special(gy, Cin, Cout);
   if (!special)      // other channel counts: the generic 2x2(x2)-tap parity-class kernel on the zero-padded taps
     return upconv_fwd_impl(gy, wp, nullptr, gx, B, Do, Ho, Wo, Cout, Cin, kz, 0, 0.f, stream, 0);
   hipStream_t s = df::as_stream(stream);

@@ -1047,6 +1047,10 @@ struct WxyzArgs {
 // UP: x is the COARSE tensor of an up-sampling-aware conv (fine position p reads xc[p >> 1] on every axis; a.D/H/W are the fine extents):
 // the transform points with index 2 vanish for the duplicated input, so only xi_z, xi_y in {0, 1, 3} workgroup types exist and the
 // xi_x = 2 products are skipped -- 27 of the 64 products (wgrad_up2_kernel's parity-class form needs 48 per coarse voxel).
+// (66,560 B of static LDS: above the 64 KiB every CDNA part before gfx950 gives a workgroup -- this library is gfx950-only, Makefile ARCH)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "conv_wgrad.hip: the 64-channel (x,y,z) weight-gradient kernels need gfx950's 160 KB LDS (build with --offload-arch=gfx950)"
+#endif
 constexpr int kWxyzLds = 4 * 64 * 64 + 4 * 64;      // floats: the 64 -> 64 kernels' in-workgroup sum of the four waves' partials (one xi_x slot at a time)
 // XCD-aware bijective block remap shared by the kernels below: workgroup b runs on XCD b % 8; every XCD gets a contiguous run
 __device__ __forceinline__ int wxyz_wg(int nwg) {

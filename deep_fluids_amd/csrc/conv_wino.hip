@@ -307,6 +307,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // keeps the matrix pipe busy while its partner waits for HBM.  XS & 4: issued in front of k-step 0's MFMAs instead of behind them.
 template <int DBG, int FL = -1, int MODE = 0, int PREC = 0, int XS = 0>
 __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
+#ifndef DF_TUNING
+  // The release translation unit can only instantiate the production combination: every DBG / XS / PREC experiment path below is dead code
+  // there BY CONSTRUCTION (tests/test_cabi.py lists the instantiations the shipped library holds; DESIGN.md section 4 names them).
+  static_assert(DBG == 0 && PREC == 0 && XS == 0 && MODE != 1, "wino3d_kernel: experiment variants exist in the -DDF_TUNING library only");
+#endif
   constexpr bool UPC = MODE == 3;                    // UP with the coarse halo block staged as such (see UPY / UCP above)
   constexpr bool UP = MODE == 1 || UPC, POOL = MODE == 2, P27 = MODE != 0;
   constexpr bool BX = PREC == 1;

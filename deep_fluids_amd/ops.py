@@ -295,6 +295,14 @@ class _WgradLane(object):
             self.keep = []
 
 
+# Which 3-D Winograd family the plain stride-1 convs (forward and dgrad) take where `_use_wino` says 3:
+#   "f224"  F(2,3) x F(2,3) x F(4,3) (conv_wino43.hip, round 6): 6 matrix multiply-adds per output voxel and channel pair -- the default;
+#   "f222"  F(2,3)^3 (conv_wino.hip): 8 of them, about one bit more accurate.
+# The 27-point forms of an up-sampling block's first conv (forward / pooled adjoint) exist in the F(2,3)^3 family only; both families write /
+# read the same sign-word layout, so they mix freely inside a block.
+WINO3D_FAMILY = _os.environ.get("DF_WINO3D_FAMILY", "f224")
+
+
 def _use_wino(cin, cout, dims, kz):
     """0: direct kernel; 3: 3-D Winograd F(2x2x2,3x3x3) (conv_wino.hip); 2: 2-D Winograd F(2x2,3x3) (conv_wino2d.hip)."""
     if CONV_ALGO == "direct" or CONV_PRECISION != "fp32" or cin % 32 or cout % 32:
@@ -306,12 +314,13 @@ def _use_wino(cin, cout, dims, kz):
     return 2 if (CONV_ALGO == "winograd" or (dims[2] >= 16 and dims[3] >= 24)) else 0
 
 
-def _pack(w, taps, cin, cout, mode, dims=None, fp32=False):
+def _pack(w, taps, cin, cout, mode, dims=None, fp32=False, family=None):
     """Packed MFMA operand of w for the stride-1 conv on `dims` (mode 0: forward, mode 1: dgrad).  ``fp32=True`` forces the exact-fp32
-    operand format whatever CONV_PRECISION says (kernels that have no bf16x3 variant: the stride-2 forward)."""
+    operand format whatever CONV_PRECISION says (kernels that have no bf16x3 variant: the stride-2 forward).  ``family="f222"``: the
+    F(2,3)^3 operand whatever WINO3D_FAMILY says (the 27-point forms)."""
     algo = _use_wino(cin, cout, dims, 3 if taps == 27 else 1) if dims is not None else 0
     if algo:
-        fn = "df_wino" if algo == 3 else "df_wino2d"
+        fn = ("df_wino43" if (family or WINO3D_FAMILY) == "f224" else "df_wino") if algo == 3 else "df_wino2d"
         wp = torch.empty(query(fn + "_packed_elems", cin, cout, mode), dtype=torch.float32, device=w.device)
         call(fn + "_pack_weights", _ptr(w), _ptr(wp), cin, cout, mode, _stream())
         return wp
@@ -361,8 +370,12 @@ def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak,
     algo = _use_wino(cin, cout, dims, kz)
     if DISPATCH_COUNTS is not None:
         thin = min(cin, cout) <= 4
-        _count("conv", "winograd-f2x2x2" if algo == 3 else "winograd-f2x2" if algo == 2 else
+        _count("conv", ("winograd-f2x2x4" if WINO3D_FAMILY == "f224" else "winograd-f2x2x2") if algo == 3 else "winograd-f2x2" if algo == 2 else
                ("thin" + ("-valu-forced" if THIN_VALU_ONLY else "")) if thin else ("direct-mfma" + _sfx(cin, cout)), dims, cin, cout)
+    if algo == 3 and WINO3D_FAMILY == "f224":
+        call("df_wino43_conv", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(mask_bits), _ptr(y), None, _ptr(sign_bits),
+             B, D, H, W, cin, cout, flags, float(leak), _stream())
+        return y
     if algo == 3:
         if sign_bits is not None or mask_bits is not None:
             call("df_wino_conv_fwd_bits", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_bits), _ptr(y), _ptr(sign_bits), B, D, H, W, cin, cout,
@@ -599,8 +612,8 @@ class _UpGenBlock(torch.autograd.Function):
                 _count("upconv", "winograd-27pt" if (is3d and _use_wino(cin, cout, fdims, kz) == 3) else
                        "winograd2d-9pt" if (not is3d and _use_wino(cin, cout, fdims, kz) == 2) else "parity-class" + _sfx(cin, cout), fdims, cin, cout)
             if i == 0 and is3d and _use_wino(cin, cout, fdims, kz) == 3:
-                # 27-point up-sampling-aware Winograd form (conv_wino.hip, UP variant): same packed operand as a plain conv
-                wp = _pack(w, taps, cin, cout, 0, fdims)
+                # 27-point up-sampling-aware Winograd form (conv_wino.hip, UP variant): the F(2,3)^3 operand of a plain conv
+                wp = _pack(w, taps, cin, cout, 0, fdims, family="f222")
                 x = torch.empty(fshape, dtype=torch.float32, device=xc.device)
                 if sb is not None:
                     call("df_wino_upconv_fwd_bits", _ptr(xc), _ptr(wp), _ptr(b), _ptr(x), _ptr(sb), cdims[0], cdims[1], cdims[2], cdims[3],
@@ -627,21 +640,31 @@ class _UpGenBlock(torch.autograd.Function):
                 if i == n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3 and SIGN_BIT_MASKS and ACTIVATION_FETCH is None:
                     # block-end skip add fused into the last conv's epilogue, and of the conv's own activation only the sign bits are
                     # kept (all the backward tail needs of it): y = lrelu(conv(x)) + upscale(xc), tail_bits = (lrelu(conv(x)) > 0)
-                    _count("conv", "winograd-f2x2x2+addup+signwords", fdims, cin, cout)
+                    f224 = WINO3D_FAMILY == "f224"
+                    _count("conv", "winograd-%s+addup+signwords" % ("f2x2x4" if f224 else "f2x2x2"), fdims, cin, cout)
                     tail_bits = _new_bits(fdims, cout, xc)
                     y = torch.empty(fshape, dtype=torch.float32, device=xc.device)
-                    call("df_wino_conv_fwd_addup_bits", _ptr(x), _ptr(wp), _ptr(b), _ptr(xc), _ptr(y), _ptr(tail_bits), fdims[0], fdims[1],
-                         fdims[2], fdims[3], cin, cout, float(leak), _stream())
+                    if f224:
+                        call("df_wino43_conv", _ptr(x), _ptr(wp), _ptr(b), _ptr(xc), None, None, None, _ptr(y), _ptr(tail_bits), fdims[0], fdims[1],
+                             fdims[2], fdims[3], cin, cout, DF_CONV_BIAS | DF_CONV_LRELU | _lib.DF_CONV_ADDUP, float(leak), _stream())
+                    else:
+                        call("df_wino_conv_fwd_addup_bits", _ptr(x), _ptr(wp), _ptr(b), _ptr(xc), _ptr(y), _ptr(tail_bits), fdims[0], fdims[1],
+                             fdims[2], fdims[3], cin, cout, float(leak), _stream())
                     if SIGN_BITS_FETCH is not None:
                         SIGN_BITS_FETCH.append((tail_bits, fdims, cout))
                     x = None
                 elif i == n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3:
                     # (fp32 masks: the activation is a second output)
-                    _count("conv", "winograd-f2x2x2+addup", fdims, cin, cout)
+                    f224 = WINO3D_FAMILY == "f224"
+                    _count("conv", "winograd-%s+addup" % ("f2x2x4" if f224 else "f2x2x2"), fdims, cin, cout)
                     x_in, x = x, torch.empty(fshape, dtype=torch.float32, device=xc.device)
                     y = torch.empty(fshape, dtype=torch.float32, device=xc.device)
-                    call("df_wino_conv_fwd_addup", _ptr(x_in), _ptr(wp), _ptr(b), _ptr(xc), _ptr(x), _ptr(y), fdims[0], fdims[1],
-                         fdims[2], fdims[3], cin, cout, float(leak), _stream())
+                    if f224:
+                        call("df_wino43_conv", _ptr(x_in), _ptr(wp), _ptr(b), _ptr(xc), None, None, _ptr(x), _ptr(y), None, fdims[0], fdims[1],
+                             fdims[2], fdims[3], cin, cout, DF_CONV_BIAS | DF_CONV_LRELU | _lib.DF_CONV_ADDUP, float(leak), _stream())
+                    else:
+                        call("df_wino_conv_fwd_addup", _ptr(x_in), _ptr(wp), _ptr(b), _ptr(xc), _ptr(x), _ptr(y), fdims[0], fdims[1],
+                             fdims[2], fdims[3], cin, cout, float(leak), _stream())
                 else:
                     x = _conv_raw(x, wp, b, None, None, fdims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak, sign_bits=sb).view(fshape)
             xs.append(x)
@@ -712,7 +735,7 @@ class _UpGenBlock(torch.autograd.Function):
                     # dxc holds the skip path's sum-pool of dy (df_lrelu_bwd_pool2x above); += the conv path per parity class
                     if is3d and _use_wino(C, C, fdims, kz) == 3:
                         # pooled-output Winograd form (conv_wino.hip, POOL variant): 27 of the 64 products, coarse stores
-                        wpd = _pack(w, taps, C, C, 1, fdims)
+                        wpd = _pack(w, taps, C, C, 1, fdims, family="f222")
                         call("df_wino_upconv_dgrad", _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, C,
                              _stream())
                     elif not is3d and _use_wino(C, C, fdims, kz) == 2:
@@ -799,7 +822,9 @@ class _ConvSame3S2(torch.autograd.Function):
                 gx = torch.empty((B, D, H, W, cin), dtype=torch.float32, device=x.device)
                 # [r5] df_conv_s2_dgrad: the same parity classes, each on a kernel specialised on its LIVE taps (27 of the 64 the generic
                 # 2x2x2-tap parity-class kernel df_upconv_fwd multiplies -- half of the mode-2 operand is structural zeros)
-                _count("dgrad-s2", "parity-class-live-taps", odims, cin, cout)
+                if DISPATCH_COUNTS is not None:      # (the library falls back to the generic class kernel on other channel counts / an unaligned gradient)
+                    _count("dgrad-s2", "parity-class-live-taps" if query("df_conv_s2_dgrad_form", _ptr(dp), cin, cout) == 1 else
+                           "parity-class-generic", odims, cin, cout)
                 call("df_conv_s2_dgrad", _ptr(dp), _ptr(wpd), _ptr(gx), odims[0], odims[1], odims[2], odims[3], cin, cout, kz, _stream())
                 gx = gx.view(x.shape)
             else:
@@ -1233,17 +1258,17 @@ ACTIVATION_FETCH = None
 # to change them temporarily: it sets them, restores the previous values on exit -- also when the body raises, so a failing test cannot
 # leak its mode into the next one -- and holds a re-entrant lock for the duration of the block, so two threads cannot interleave
 # different option sets (a second thread entering `options` waits until the first leaves).
-_OPTION_ATTRS = {"conv_precision": "CONV_PRECISION", "conv_algo": "CONV_ALGO", "wgrad_algo": "WGRAD_ALGO",
+_OPTION_ATTRS = {"conv_precision": "CONV_PRECISION", "conv_algo": "CONV_ALGO", "wino3d_family": "WINO3D_FAMILY", "wgrad_algo": "WGRAD_ALGO",
                  "thin_valu_only": "THIN_VALU_ONLY", "sign_bit_masks": "SIGN_BIT_MASKS", "fused_blocks": "FUSED_BLOCKS",
                  "dispatch_counts": "DISPATCH_COUNTS", "concurrent_wgrad_work": "CONCURRENT_WGRAD_WORK", "activation_fetch": "ACTIVATION_FETCH", "sign_bits_fetch": "SIGN_BITS_FETCH"}
-_OPTION_CHOICES = {"conv_precision": ("fp32", "bf16x3"), "conv_algo": ("auto", "direct", "winograd"), "wgrad_algo": (0, 1, 2, 3, 4)}
+_OPTION_CHOICES = {"conv_precision": ("fp32", "bf16x3"), "conv_algo": ("auto", "direct", "winograd"), "wino3d_family": ("f224", "f222"), "wgrad_algo": (0, 1, 2, 3, 4)}
 _OPTION_LOCK = _threading.RLock()
 
 
 @_contextlib.contextmanager
 def options(**kw):
     """``with ops.options(conv_precision="bf16x3", conv_algo="direct", wgrad_algo=1, activation_fetch=[]): ...``
-    Keys: conv_precision, conv_algo, wgrad_algo, thin_valu_only, sign_bit_masks, fused_blocks, dispatch_counts (a dict to count into),
+    Keys: conv_precision, conv_algo, wino3d_family ("f224" | "f222"), wgrad_algo, thin_valu_only, sign_bit_masks, fused_blocks, dispatch_counts (a dict to count into),
     concurrent_wgrad_work (weight gradients of levels up to that many B x voxels x taps run on a second stream; 0 = serial),
     activation_fetch / sign_bits_fetch (a list to append to).  Unknown keys and out-of-range values raise before anything changes."""
     for k, v in kw.items():

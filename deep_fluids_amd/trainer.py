@@ -187,18 +187,20 @@ class Trainer(object):
             if missing:      # (tf.train.Saver.restore fails the same way on a graph / checkpoint mismatch)
                 raise ValueError("checkpoint %s does not hold this trainer's variables (e.g. %s): a different architecture / scope "
                                  "name was trained in that model_dir" % (path, missing[0]))
+            arrs = {}      # every array is read (and decompressed) ONCE: NpzFile is lazy, d[k] loads it each time
             for slices, _, _, _ in self._ckpt_slabs():
                 for k, (o, n) in slices.items():
                     for sfx in ("", "/Adam", "/Adam_1"):
-                        if int(d[k + sfx].size) != n:
+                        a = arrs[k + sfx] = d[k + sfx]
+                        if int(a.size) != n:
                             raise ValueError("checkpoint %s: variable %s has %d elements (shape %s), this trainer's has %d (shape %s): "
                                              "different filters / resolution / architecture" % (
-                                                 path, k + sfx, d[k + sfx].size, tuple(d[k + sfx].shape), n, tuple(ops._VARS[k].shape)))
+                                                 path, k + sfx, a.size, tuple(a.shape), n, tuple(ops._VARS[k].shape)))
             for slices, fp, fm, fv in self._ckpt_slabs():
                 for k, (o, n) in slices.items():
-                    fp[o:o + n].copy_(torch.from_numpy(d[k].reshape(-1)))
-                    fm[o:o + n].copy_(torch.from_numpy(d[k + "/Adam"].reshape(-1)))
-                    fv[o:o + n].copy_(torch.from_numpy(d[k + "/Adam_1"].reshape(-1)))
+                    fp[o:o + n].copy_(torch.from_numpy(np.ascontiguousarray(arrs.pop(k), np.float32).reshape(-1)))
+                    fm[o:o + n].copy_(torch.from_numpy(np.ascontiguousarray(arrs.pop(k + "/Adam"), np.float32).reshape(-1)))
+                    fv[o:o + n].copy_(torch.from_numpy(np.ascontiguousarray(arrs.pop(k + "/Adam_1"), np.float32).reshape(-1)))
             self.step = int(d["step"]); self.g_lr = float(d["g_lr"]); self._adam_t = int(d["beta_power_t"])
             self._ckpt_load_extra(d)
 
@@ -620,10 +622,12 @@ class AETrainer(Trainer):
                 out = curl3(out) if self.is_3d else curl(out)
         return out
 
-    def test_(self, batch_manager, model_dir=None, code_path=None, test_b_num=None):
-        return self.test_ae(batch_manager, model_dir, code_path, test_b_num)
+    def test_(self, batch_manager, model_dir=None, test_b_num=None, code_path=None):
+        """Positional arguments as ``Trainer.test_`` up to ``model_dir``; the batch size and ``code_path`` by keyword (the base class has
+        ``p1, p2`` in between, so a positional batch size could not mean the same thing on both)."""
+        return self.test_ae(batch_manager, model_dir, code_path=code_path, test_b_num=test_b_num)
 
-    def test_ae(self, batch_manager, model_dir=None, code_path=None, test_b_num=None):
+    def test_ae(self, batch_manager, model_dir=None, *, code_path=None, test_b_num=None):
         """``Trainer.test_ae``.  Without ``code_path`` (trainer.py:478-523): encode the whole dataset in file order
         (``batch_manager.batch_``) and write ``<model_dir>/code<z_num>.npz`` -- ``x`` = codes of frames 0..F-2 of every scene, ``y`` =
         codes of frames 1..F-1, ``p`` = per-frame source-position increments from ``<data root>/n.npz`` (nx [, nz]), ``s`` scenes,
@@ -662,13 +666,18 @@ class AETrainer(Trainer):
         with np.load(os.path.join(code_path, "code_out.npz")) as data:
             z_, z_gt_ = data["z_out"], data["z_gt"]
         num_sims, num_frames = z_.shape[0], z_[0].shape[0]
-        num_iters = int(num_frames / test_b_num)
+        # (the reference runs int(num_frames / test_b_num) full batches and silently drops the rest, trainer.py:531-533 -- with fewer frames
+        #  than test_batch_size it decodes nothing; here every frame is decoded: the last batch is the remainder)
+        if num_frames <= 0:
+            raise ValueError("test_ae: %s holds no frames" % os.path.join(code_path, "code_out.npz"))
+        test_b_num = max(1, min(int(test_b_num), num_frames))
+        num_iters = -(-num_frames // test_b_num)
         paths = []
         for s in range(num_sims):
             v, v_gt = [], []
             for i in range(num_iters):
                 for src, dst in ((z_[s], v), (z_gt_[s], v_gt)):
-                    zz = torch.from_numpy(np.ascontiguousarray(src[i * test_b_num:(i + 1) * test_b_num, :], np.float32)).to(self.device)
+                    zz = torch.from_numpy(np.ascontiguousarray(src[i * test_b_num:min((i + 1) * test_b_num, num_frames), :], np.float32)).to(self.device)
                     vv, _ = batch_manager.denorm(self.decode(zz).cpu().numpy())
                     dst.append(vv)
             out = os.path.join(model_dir, "v%d.npz" % s)

@@ -254,6 +254,9 @@ int df_conv_s2_wgrad(const float* x, const float* gy, float* gw, float* gb, int6
  * zero-inserted gradient 216).  Every output voxel is written exactly once (no accumulation). */
 int df_conv_s2_dgrad(const float* gy, const float* wp, float* gx, int64_t B, int64_t Do, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout,
                      int kz, df_stream_t stream);
+/* Which kernel df_conv_s2_dgrad takes for this gradient pointer (alignment) and channel counts (Cin / Cout of the FORWARD conv):
+ * 1 = each parity class on its live taps only, 0 = the generic 2x2(x2)-tap parity-class kernel (zero-padded taps).  Host-only. */
+int df_conv_s2_dgrad_form(const float* gy, int64_t Cin, int64_t Cout);
 /* ---- up-sampling-aware first conv of a generator block --------------------------------------------------------------
  * model.py:36-37 / 78-79 feed `upscale(x, 2)` into the next block's first conv.  conv(nearest_up2x(xc), w) is computed
  * WITHOUT materialising the up-sampled tensor as 8 (3-D) / 4 (2-D) parity-class convs with 2x2x2 / 2x2 pre-summed taps
@@ -311,6 +314,21 @@ int df_wino_upconv_dgrad(const float* g, const float* wp, float* acc, int64_t B,
  * Same packed weights and shape limits as df_wino_conv_fwd; D, H, W even. */
 int df_wino_conv_fwd_addup(const float* x, const float* wp, const float* bias, const float* xc, float* y, float* y2, int64_t B,
                            int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, float leak, df_stream_t stream);
+
+/* ---- round 6: F(2,3) x F(2,3) x F(4,3) Winograd family (conv_wino43.hip) -------------------------------------------------------------
+ * The same convolution as df_wino_conv_fwd* (slim.conv3d k=3 s=1 SAME, model.py:66-70; dgrad = mode-1 operand) with a 2 x 2 x 4 output
+ * tile: 6 matrix multiply-adds per output voxel and (cin, cout) pair instead of 8, about one bit of fp32 accuracy less.
+ * ONE entry point covers every fused epilogue of the F(2,3)^3 family; the sign words it writes / reads have the SAME layout
+ * (df_wino_signbits_bytes, df_lrelu_bits_bwd_pool2x), so the two families can be mixed layer by layer:
+ *   flags        DF_CONV_BIAS | LRELU | RESIDUAL (fine tensor `residual`) | MASK | ADDUP (`residual` = the COARSE tensor, y2 = y + up2x)
+ *   mask_src     fp32 activation whose sign is the lrelu mask of DF_CONV_MASK, or
+ *   mask_bits    the same mask as sign words (exactly one of the two with DF_CONV_MASK)
+ *   sign_bits    non-null: also emit the sign words of y;  y == NULL (only with ADDUP + sign_bits): y itself is not written. */
+int64_t df_wino43_packed_elems(int64_t cin, int64_t cout, int mode);
+int df_wino43_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, int mode, df_stream_t stream);
+int df_wino43_conv(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src, const void* mask_bits,
+                   float* y, float* y2, void* sign_bits, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags,
+                   float leak, df_stream_t stream);
 
 /* Sign-bit masks.  A masked dgrad (DF_CONV_MASK) multiplies its output by the lrelu slope of the layer below, i.e. it needs ONE BIT
  * per element of that layer's activation; read from the fp32 activation that is 3.2 GB per top-level launch at cfg3.  The forward

@@ -23,6 +23,24 @@ def test_library_present_and_exports_every_declared_symbol():
     assert not extra, extra
 
 
+def test_release_library_holds_only_the_production_kernel_instantiations():
+    """`wino3d_kernel<DBG, FL, MODE, PREC, XS>` carries diagnosis / experiment switches for the -DDF_TUNING library (tools/); the shipped
+    library must hold exactly the production instantiations -- DBG = PREC = XS = 0, MODE in {0 plain, 2 pooled adjoint, 3 up-sampling-aware
+    forward on the coarse halo block} -- with these epilogues (FL): -1 run-time flags, 0 none, 2 residual, 4 mask, 9 bias + lrelu,
+    25 ... + add-up, 73 ... + sign words, 132 mask from sign words, 345 add-up + sign words without the primary output."""
+    out = subprocess.check_output(["nm", "-C", _lib.LIB_PATH]).decode()
+    import re
+    inst = sorted(set(re.findall(r"wino3d_kernel<([-0-9, ]+)>", out)))
+    got = sorted(tuple(int(v) for v in i.split(",")) for i in inst)
+    assert got, "no wino3d_kernel symbols in the library (stripped?)"
+    assert all(g[0] == 0 and g[3] == 0 and g[4] == 0 and g[2] in (0, 2, 3) for g in got), got
+    want = sorted([(0, f, 0, 0, 0) for f in (-1, 0, 2, 4, 9, 25, 73, 132, 345)] + [(0, 0, 2, 0, 0), (0, 9, 3, 0, 0), (0, 73, 3, 0, 0)])
+    assert got == want, got
+    # the 2-D twin and the weight-gradient kernels have no experiment template switches; the tuning knobs are entry points the release
+    # library must not export (checked above by name: no df_debug_*)
+    assert "df_debug_" not in out
+
+
 def test_version_and_error_convention():
     h = _lib.lib()
     assert h.df_version() == 205
