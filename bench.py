@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 peak
 PEAK_HBM_GBS = 8000.0
 # fraction of the convolution's algorithmic (direct-form) multiply-adds the Winograd kernels execute on the matrix pipe
-EXEC_RATIO = {"wino3d_kernel": 8.0 / 27.0, "wino2d_kernel": 4.0 / 9.0, "conv_mfma_kernel": 1.0, "wgrad_kernel": None,
+EXEC_RATIO = {"wino43_kernel": 6.0 / 27.0, "wino3d_kernel": 8.0 / 27.0, "wino2d_kernel": 4.0 / 9.0, "conv_mfma_kernel": 1.0, "wgrad_kernel": None,
               "wino3d_27pt_kernel up": 1.0 / 8.0, "wino3d_27pt_kernel pooled": 1.0 / 8.0}      # 27 of the 64 points: 27/8 MACs per output voxel and channel pair
 
 
@@ -127,6 +127,9 @@ def select_kernel(name, args):
     if name in ("df_wino_conv_fwd", "df_wino_conv_fwd_addup", "df_wino_conv_fwd_addup_bits", "df_wino_conv_fwd_bits"):
         B, D, H, W, cin, cout = args[6:12]
         return ("wino3d_kernel fwd/dgrad %dx%dx%d C%d->%d" % (D, H, W, cin, cout), 2.0 * 27 * cin * cout * B * D * H * W)
+    if name == "df_wino43_conv":      # F(2,3) x F(2,3) x F(4,3): 6 of the 27 direct-form multiply-adds
+        B, D, H, W, cin, cout = args[9:15]
+        return ("wino43_kernel fwd/dgrad %dx%dx%d C%d->%d" % (D, H, W, cin, cout), 2.0 * 27 * cin * cout * B * D * H * W)
     if name in ("df_wino_upconv_fwd", "df_wino_upconv_fwd_bits", "df_wino_upconv_dgrad"):      # the 27-point forms (fine grid = 2 x coarse)
         o = {"df_wino_upconv_fwd": 4, "df_wino_upconv_fwd_bits": 5, "df_wino_upconv_dgrad": 3}[name]
         B, Dc, Hc, Wc, cin, cout = args[o:o + 6]
@@ -424,7 +427,7 @@ def roofline_of(ks, prefix, pmc, with_traffic, pmc_source=None):
         out.update(achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS,
                    frac_definition="EXECUTED multiply-add flops on the fp32 matrix pipe / time / peak (this kernel executes %.3f of the "
                                    "direct-form flops the roofline numerator of SURVEY 8(d) counts: %s)" % (
-                                       ratio, "Winograd F(2,3) per axis" if ratio < 1 else "direct form"),
+                                       ratio, "Winograd F(2,3) x F(2,3) x F(4,3)" if abs(ratio - 6.0 / 27.0) < 1e-9 else "Winograd F(2,3) per axis" if ratio < 1 else "direct form"),
                    executed_over_algorithmic=ratio, algorithmic_bytes=abytes,
                    algorithmic_tflops=alg, algorithmic_speedup=1.0 / ratio,
                    note="achieved = multiply-add flops EXECUTED on the fp32 matrix pipe / time; algorithmic_tflops = direct-convolution "
@@ -517,7 +520,7 @@ def stencil_rooflines(B, Z, Y, X):
     return out
 
 
-def timed_steps(tr, x, y, warm, n, rooflines=None, families=("wino3d_kernel", "wgrad_kernel", "conv_mfma_kernel")):
+def timed_steps(tr, x, y, warm, n, rooflines=None, families=("wino43_kernel", "wino3d_kernel", "wgrad_kernel", "conv_mfma_kernel")):
     """Mean wall time per step; ``rooflines`` (a dict) additionally receives the live HIP-event rooflines of the dominant conv /
     weight-gradient kernel families of these steps."""
     import torch
@@ -542,6 +545,8 @@ def timed_steps(tr, x, y, warm, n, rooflines=None, families=("wino3d_kernel", "w
             r = roofline_of(ks, fam, {}, False)
             if r is not None:
                 rooflines["roofline_" + fam.split("_")[0]] = r
+        if "roofline_wino43" in rooflines:      # the plain 3-D Winograd convs run on the F(2,2,4) family: it is "the" wino3d roofline of the extras
+            rooflines["roofline_wino3d"] = rooflines["roofline_wino43"]
     return el, m
 
 
@@ -1065,7 +1070,8 @@ def main():
         "loss": loss,
         "roofline_wgrad": roofline_of(ks, "wgrad_kernel", pmc, default_shape, pmc_source),
         "roofline_conv": roofline_of(ks, "conv_mfma_kernel", pmc, default_shape, pmc_source),
-        "roofline_wino": roofline_of(ks, "wino3d_kernel" if is_3d else "wino2d_kernel", pmc, default_shape, pmc_source),
+        "roofline_wino": (roofline_of(ks, "wino43_kernel", pmc, default_shape, pmc_source) or roofline_of(ks, "wino3d_kernel", pmc, default_shape, pmc_source))
+                         if is_3d else roofline_of(ks, "wino2d_kernel", pmc, default_shape, pmc_source),
         "roofline_up27": roofline_of(ks, "wino3d_27pt_kernel up", {}, False),          # the 27-point forms (verdict r4 item 3a)
         "roofline_pool27": roofline_of(ks, "wino3d_27pt_kernel pooled", {}, False),
         "roofline_tail_fwd": roofline_of(ks, "velocity_loss3d_fwd_kernel", {}, False),
@@ -1080,7 +1086,7 @@ def main():
         fam[k.split(" ")[0]] = fam.get(k.split(" ")[0], 0.0) + v["seconds"]
     dom = max((f for f in fam if not (f.startswith("jacobian") or f.startswith("velocity_loss"))), key=lambda f: fam[f], default=None)
     out["roofline"] = {"wgrad_kernel": out["roofline_wgrad"], "conv_mfma_kernel": out["roofline_conv"],
-                       "wino3d_kernel": out["roofline_wino"], "wino2d_kernel": out["roofline_wino"]}.get(dom)
+                       "wino43_kernel": out["roofline_wino"], "wino3d_kernel": out["roofline_wino"], "wino2d_kernel": out["roofline_wino"]}.get(dom)
     for key in ("alt_bf16x3_mode", "extra_ref_grids", "extra_2d_128x96", "extra_cfg4_slice", "extra_ae_cfg5"):
         out[key] = None
     if world == 1 and is_3d:

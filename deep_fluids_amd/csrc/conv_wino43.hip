@@ -6,20 +6,25 @@
 //   1/4, 1/6, 1/12, 1/24 in the fp64-transformed weights) cost about one bit: relative L1 error of one layer 9e-7 against 4e-7 of
 //   F(2,3)^3 and 9e-7 of the direct fp32 sum (profiles/r06_probes.md, section 3).
 //
-// Everything AROUND the 96 GEMMs is conv_wino.hip's design, kept on purpose so that the two families are interchangeable:
+// Around the 96 GEMMs the decomposition is conv_wino.hip's, kept on purpose so that the two families are interchangeable:
 //   * persistent 8-wave workgroup per CU, XCD-pinned (cout slice, tile block) items; tile block = 4 x 8 x 8 output voxels x 32 couts;
-//   * the 6 x 10 x 10 halo block of a 16-channel chunk staged channel-major in LDS ([c][z*144 + y*12 + x]), double buffered, one LDS-only
-//     barrier per chunk, SAME padding by the buffer range check, the next block's first chunk staged during the last chunk;
+//   * double-buffered LDS staging of a 16-channel chunk of the 6 x 10 x 10 halo block, one LDS-only barrier per chunk, SAME padding by the
+//     buffer range check, the next block's first chunk staged during the last chunk;
 //   * after the combine a lane holds the SAME 2 x 2 x 2 output cube of one cout as in conv_wino.hip (wave = (z pair, x pair), lane =
 //     (y pair, cout)), so the fused epilogues -- bias, lrelu, residual, lrelu mask, skip add-up, sign words out / mask from sign words --
 //     and the sign-word layout (ops.sign_bits_to_mask, df_lrelu_bits_bwd_pool2x) are shared bit for bit.
 // What differs:
 //   * a tile block is 16 tiles (tz 2 x ty 4 x tx 2) = ONE MFMA row block; wave = (xi_z, xi_y pair) owns 2 x 6 points for all 16 tiles and
 //     both 16-cout blocks: 24 MFMA 16x16x4 per k-step (32 before), 96 accumulators (128);
-//   * A operand: lane = (tile, cin % 4) reads 3 rows x 6 columns of the two z planes its xi_z combines (18 ds_read_b64, conflict-free with
-//     the same pitches), z and y stages as before, x stage = B^T of F(4,3);
+//   * the z part of B^T moves to the STAGING threads: thread = (halo row, column, channel quad) loads its z column (6 float4; a plane outside
+//     the tensor through a zero-length descriptor) and writes the 8 planes (tile z-row, xi_z) -- the A path then reads ONE plane: 3 rows x
+//     6 columns = 9 ds_read_b64 per k-step (conv_wino.hip: 16), no z stage, 18 fewer registers, one staging offset per thread instead of
+//     ten; y stage 6 packed ops, x stage = B^T of F(4,3) in 6 packed ops per row (op_sel picks the halves);
 //   * B operand: U packed [cs][xi_z][xi_y pair][cin/4][cout block][cin%4][cout%16][12 points]: three 16-byte loads per lane and block;
 //   * inverse: x (A^T of F(4,3), 6 -> 4) in registers, the two xi_y halves through LDS (one extra exchange), then the xi_z combine.
+// Measured (profiles/r06_probes.md section 3): 128 -> 128 at 64x96x64, B = 16: 13.3 ms per launch against 16.4 ms (F(2,3)^3), bit-compatible
+// epilogues; 0 spills at 204-217 VGPRs, 156,032 B of LDS.
+#include <type_traits>
 #include "df_common.hpp"
 #include "conv_args.hpp"
 
@@ -144,7 +149,8 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
 
 // FL >= 0: the epilogue flags are the compile-time constant FL; FL < 0: run-time a.flags (public DF_CONV_* bits only)
 // DBG (probe build -DDF_W43_PROBE only, results wrong by construction): 1 no input transform, 2 no LDS operand reads, 4 no staging,
-// 8 no weight reloads -- tools/r06_wino43_probe.py's time breakdown
+// 8 no weight reloads, 64 staging loads kept but nothing written to LDS, 128 staged zeros (z transform + LDS writes, no loads)
+// -- tools/r06_wino43_probe.py's time breakdown
 template <int FL, int DBG = 0>
 __global__ __launch_bounds__(kT, 1) void wino43_kernel(const W43Args a) {
 #ifndef DF_W43_PROBE
@@ -285,7 +291,11 @@ __global__ __launch_bounds__(kT, 1) void wino43_kernel(const W43Args a) {
 
   // ---- B operand: three float4 per lane and cout block = its 12 points --------------------------------------------------------------------
   const int nk4 = a.Cin >> 2;
-  f32x4 bq[2][3];
+#ifndef W43_NBQ
+#define W43_NBQ 1      // 2: two weight register sets (even / odd k-steps), every reload two k-steps ahead
+#endif
+  constexpr int NBQ = W43_NBQ;
+  f32x4 bq[NBQ][2][3];
   const unsigned laneb = static_cast<unsigned>(lane) * 48u;
   const __amdgpu_buffer_rsrc_t wsrd = make_srd(a.wp, static_cast<unsigned>(a.Cin) * a.Cout * (kPts * 4u));
   const unsigned wbase_b = static_cast<unsigned>(((cs * 4 + mz) * 2 + yh) * nk4) * 6144u;
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(kT, 1) void wino43_kernel(const W43Args a) {
     const int kl = k4 < nk4 ? k4 : 0;
     const unsigned sb = wbase_b + static_cast<unsigned>(kl) * 6144u + nb * 3072u;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) bq[nb][q] = buf_load16(wsrd, laneb + q * 16u, sb);
+    for (int q = 0; q < 3; ++q) bq[k4 & (NBQ - 1)][nb][q] = buf_load16(wsrd, laneb + q * 16u, sb);
   };
 
   f32x4 acc[2][12];
@@ -320,7 +330,10 @@ __global__ __launch_bounds__(kT, 1) void wino43_kernel(const W43Args a) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) Av[i] = ra[i % 9][0] + static_cast<float>(i);
     }
-    if (itb == 0) { issue_b(0, 0); issue_b(1, 0); }      // (later blocks: the last k-step of the previous block reloaded k-step 0's weights)
+    if (itb == 0) {
+      issue_b(0, 0); issue_b(1, 0);
+      if (NBQ == 2) { issue_b(0, 1); issue_b(1, 1); }
+    }      // (later blocks: the last k-step of the previous block reloaded k-step 0's weights)
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
       const int bo = ((chunk + pb) & 1) * BUFF * 4, bn = BUFF * 4 - bo;
@@ -332,25 +345,39 @@ __global__ __launch_bounds__(kT, 1) void wino43_kernel(const W43Args a) {
       for (int ks = 0; ks < 4; ++ks) {
         if (!(DBG & 1)) transform();
         __builtin_amdgcn_sched_barrier(0);
-        if (ks == 2 && !(DBG & 4) && stager) stage_store(bn, stg);
+        if (ks == 2 && !(DBG & 4) && stager) {
+          if (DBG & 64) {      // (probe: the loads stay alive, nothing is written)
+#pragma unroll
+            for (int z = 0; z < 6; ++z) asm volatile("" :: "v"(stg[z]));
+          } else {
+            stage_store(bn, stg);
+          }
+        }
         if (ks == 3) lds_barrier();
         if (!(DBG & 2)) raw_read(ks < 3 ? bo + (ks + 1) * 16 * CP : bn);
         __builtin_amdgcn_sched_barrier(0);
-        const int k4n = chunk * 4 + ks + 1;
-        const unsigned sbn = wbase_b + static_cast<unsigned>(k4n < nk4 ? k4n : 0) * 6144u;      // wraps to the next block's first k-step
+        const int k4n = chunk * 4 + ks + NBQ;
+        const unsigned sbn = wbase_b + static_cast<unsigned>(k4n < nk4 ? k4n : k4n - nk4) * 6144u;      // wraps to the next block's first k-step(s)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
           for (int i = 0; i < 12; ++i) {
-            acc[nb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(Av[i], bq[nb][i >> 2][i & 3], acc[nb][i], 0, 0, 0);
+            acc[nb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(Av[i], bq[ks & (NBQ - 1)][nb][i >> 2][i & 3], acc[nb][i], 0, 0, 0);
             if ((i & 3) == 3) {      // this quad's four products are issued: reload it with the next k-step's weights
               __builtin_amdgcn_sched_barrier(0);
-              if (!(DBG & 8)) bq[nb][i >> 2] = buf_load16(wsrd, laneb + (i >> 2) * 16u, sbn + nb * 3072u);
+              if (!(DBG & 8)) bq[ks & (NBQ - 1)][nb][i >> 2] = buf_load16(wsrd, laneb + (i >> 2) * 16u, sbn + nb * 3072u);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
         }
-        if (ks == 0 && !(DBG & 4) && stager) stage_load(lastc ? nxt : cur, schunk, stg);      // the next chunk's z columns, behind a weight batch
+        if (ks == 0 && !(DBG & 4) && stager) {      // the next chunk's z columns, behind a weight batch
+          if (DBG & 128) {      // (probe: staged zeros -- the z transform and the LDS writes without the loads)
+#pragma unroll
+            for (int z = 0; z < 6; ++z) stg[z] = f32x4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            stage_load(lastc ? nxt : cur, schunk, stg);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -553,7 +580,7 @@ int df_wino43_probe(const float* x, const float* wp, const float* bias, float* y
   const int64_t grid = w43_grid(a, ntb);
   hipStream_t s = df::as_stream(stream);
 #define DF_P(V) case V: hipLaunchKernelGGL((wino43_kernel<9, V>), dim3((unsigned)grid), dim3(kT), 0, s, a); break
-  switch (dbg) { DF_P(0); DF_P(1); DF_P(2); DF_P(3); DF_P(4); DF_P(8); DF_P(7); DF_P(15); DF_P(12); default: return DF_EINVAL; }
+  switch (dbg) { DF_P(0); DF_P(1); DF_P(2); DF_P(3); DF_P(4); DF_P(8); DF_P(7); DF_P(15); DF_P(12); DF_P(64); DF_P(128); default: return DF_EINVAL; }
 #undef DF_P
   return df::launched("df_wino43_probe");
 }

@@ -18,6 +18,8 @@ FAMILIES = [  # (key, regex on the kernel name, algorithmic read bytes, algorith
     ("velocity_jl1_3d (tail forward, after curl3)", r"velocity_jl1_3d_vec_kernel", 150994944, 0),
     ("velocity_loss3d_tile_kernel (one-kernel tail forward [r3])", r"velocity_loss3d_tile_kernel", 150994944, 75497472),
     ("velocity_du3d (tail backward, before the curl3 adjoint)", r"velocity_du3d_vec_kernel", 150994944, 75497472),
+    ("wino43_kernel", r"wino43_kernel<9[,>]", 3221225472, 3221225472),
+    ("wino43_kernel_dgrad_mask", r"wino43_kernel<4[,>]", 6442450944, 3221225472),
     ("wino3d_kernel", r"wino3d_kernel<0, 9, 0[,>]", 3221225472, 3221225472),
     ("wino3d_kernel_dgrad_mask", r"wino3d_kernel<0, 4, 0[,>]", 6442450944, 3221225472),
     ("wino3d_kernel_up27 (MODE 3: coarse input 32x48x32, coarse-block staging)", r"wino3d_kernel<0, 9, 3[,>]", 402653184, 3221225472),

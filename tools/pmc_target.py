@@ -31,6 +31,13 @@ for _ in range(2):
     call("df_wino_conv_fwd", _ptr(xin), _ptr(ww), _ptr(bias), None, None, _ptr(y), B, Z, Y, X, F, F, 9, 0.2, s)
 for _ in range(2):
     call("df_wino_conv_fwd", _ptr(xin), _ptr(ww), None, None, _ptr(xin), _ptr(y), B, Z, Y, X, F, F, 4, 0.2, s)
+# [r6] the F(2,3) x F(2,3) x F(4,3) family (conv_wino43.hip): plain forward and the dgrad with an fp32 lrelu mask, same shapes
+w43 = torch.empty(query("df_wino43_packed_elems", F, F, 0), device="cuda")
+call("df_wino43_pack_weights", _ptr(wt), _ptr(w43), F, F, 0, s)
+for _ in range(2):
+    call("df_wino43_conv", _ptr(xin), _ptr(w43), _ptr(bias), None, None, None, _ptr(y), None, None, B, Z, Y, X, F, F, 9, 0.2, s)
+for _ in range(2):
+    call("df_wino43_conv", _ptr(xin), _ptr(w43), None, None, _ptr(xin), None, _ptr(y), None, None, B, Z, Y, X, F, F, 4, 0.2, s)
 # [r5] the 27-point forms at the same level: up-sampling-aware forward (coarse 32x48x32 -> 64x96x64, wino3d_kernel MODE 3) and its pooled adjoint (MODE 2)
 xc = torch.rand((B, Z // 2, Y // 2, X // 2, F), device="cuda") - 0.5
 wwd = torch.empty(query("df_wino_packed_elems", F, F, 1), device="cuda")

@@ -71,7 +71,7 @@ def main():
 def breakdown():
     """Time with one part of the main loop removed (probe build libw43_probe.so: hipcc -DDF_W43_PROBE -shared conv_wino43.hip core.hip)."""
     import ctypes
-    so = os.path.join(ROOT, "deep_fluids_amd", "csrc", "libw43_probe.so")
+    so = os.path.join(ROOT, "deep_fluids_amd", "csrc", os.environ.get("W43_PROBE_LIB", "libw43_probe.so"))
     if not os.path.exists(so):
         print("no probe library (%s)" % so)
         return
@@ -88,10 +88,10 @@ def breakdown():
     h.df_wino43_pack_weights(_ptr(w), _ptr(wb), C, C, 0, s)
     y = torch.empty_like(x)
     names = {0: "production", 1: "no input transform", 2: "no LDS operand reads", 3: "no transform, no LDS reads", 4: "no staging", 8: "no weight reloads",
-             7: "MFMA + weights + epilogue", 12: "no staging, no weights", 15: "MFMA + epilogue only"}
+             7: "MFMA + weights + epilogue", 64: "staging loads kept, no LDS writes", 128: "staged zeros (LDS writes only)", 12: "no staging, no weights", 15: "MFMA + epilogue only"}
     base = None
     fl = 2.0 * C * C * B * D * H * W * 6.0
-    for v in (0, 1, 2, 3, 4, 8, 12, 7, 15):
+    for v in [int(t) for t in os.environ.get("W43_VARIANTS", "0,1,2,3,4,8,12,7,15").split(",")]:
         def f():
             rc = h.df_wino43_probe(_ptr(x), _ptr(wb), _ptr(bias), _ptr(y), B, D, H, W, C, C, 0.2, v, s)
             assert rc == 0, rc
