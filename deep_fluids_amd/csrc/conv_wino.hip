@@ -416,9 +416,13 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
   auto stage_pass = [&](int) -> bool { return !UPC || wave < UWIN * 4 / 64; };      // MODE 3: waves 0-5 stage (wave-uniform)
   const unsigned vol_bytes = static_cast<unsigned>(XB ? a.D * a.H * a.Wb * 4 : UP ? (a.D >> 1) * (a.H >> 1) * (a.W >> 1) : a.D * a.H * a.W) * a.Cin * 4u;
   auto set_offs = [&](const BlockInfo& bi) {
+    // [r6] opaque thread id: LLVM otherwise hoists the five pieces' (hz, hy, hx, roff) out of the block loop -- 20 registers that it then spills
+    // (37-56 spilled VGPRs in the plain instantiations, 15 in the pooled adjoint), and the reloads sit in the main loop behind `s_waitcnt vmcnt(0)`
+    int tido = tid;
+    asm volatile("" : "+v"(tido));
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
-      int p = it * kT + tid;
+      int p = it * kT + tido;
       if (UPC) {      // coarse voxel (pz, py, px = t + it) of the 4 x 6 x 6 block whose origin is the coarse voxel under fine (z0 - 1, y0 - 1, x0 - 1)
         const int wq = tid < UWIN * 4 ? tid : UWIN * 4 - 1, q4 = wq & 3, w = wq >> 2;
         const int px = (w & 3) + 2 * it, py = (w >> 2) % 6, pz = w / 24;

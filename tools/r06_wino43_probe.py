@@ -63,6 +63,16 @@ def main():
     y = torch.empty_like(x)
     ta = timeit(lambda: call("df_wino_conv_fwd", _ptr(x), _ptr(wa), _ptr(bias), None, None, _ptr(y), B, D, H, W, C, C, 9, 0.2, s), 4, 2)
     tb = timeit(lambda: call("df_wino43_conv", _ptr(x), _ptr(wb), _ptr(bias), None, None, None, _ptr(y), None, None, B, D, H, W, C, C, 9, 0.2, s), 4, 2)
+    # the 27-point forms of the F(2,3)^3 family at the same level (coarse 32x48x32)
+    xc = torch.rand((B, D // 2, H // 2, W // 2, C), device="cuda") * 2 - 1
+    wad = torch.empty(query("df_wino_packed_elems", C, C, 1), device="cuda")
+    call("df_wino_pack_weights", _ptr(w), _ptr(wad), C, C, 1, s)
+    acc = torch.zeros_like(xc)
+    tu = timeit(lambda: call("df_wino_upconv_fwd", _ptr(xc), _ptr(wa), _ptr(bias), _ptr(y), B, D // 2, H // 2, W // 2, C, C, 9, 0.2, s), 4, 2)
+    tp = timeit(lambda: call("df_wino_upconv_dgrad", _ptr(x), _ptr(wad), _ptr(acc), B, D // 2, H // 2, W // 2, C, C, s), 4, 2)
+    f27 = 2.0 * C * C * B * D * H * W * 27.0 / 8.0
+    print("27-point forms B%d: up-sampling-aware forward %.3f ms (executed %.3f)   pooled adjoint %.3f ms (executed %.3f)" % (
+        B, tu * 1e3, f27 / tu / 157.3e12, tp * 1e3, f27 / tp / 157.3e12), flush=True)
     fl = 2.0 * 27 * C * C * B * D * H * W
     print("top level 64x96x64 C128 B%d: F(2,3)^3 %.3f ms (executed %.3f)   F(2,2,4) %.3f ms (executed %.3f)   ratio %.3f" % (
         B, ta * 1e3, fl * 8 / 27 / ta / 157.3e12, tb * 1e3, fl * 6 / 27 / tb / 157.3e12, tb / ta), flush=True)
