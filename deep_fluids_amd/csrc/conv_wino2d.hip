@@ -174,9 +174,13 @@ __global__ __launch_bounds__(kT, 1) void wino2d_kernel(const Wino2dArgs a) {
   }
   const unsigned img_bytes = static_cast<unsigned>(UP ? (a.H >> 1) * (a.W >> 1) : a.H * a.W) * a.Cin * 4u;
   auto set_offs = [&](const Blk& bi) {
+    // [r6] opaque thread id: LLVM otherwise hoists the five pieces' (hy, hx) decomposition out of the block loop and SPILLS it (39-72 spilled VGPRs
+    // in every instantiation; the reloads sat in the main loop behind `s_waitcnt vmcnt(0)`) -- see conv_wino.hip / profiles/r06_probes.md
+    int tido = tid;
+    asm volatile("" : "+v"(tido));
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
-      int p = it * kT + tid;
+      int p = it * kT + tido;
       if (p > HV * 4 - 1) p = HV * 4 - 1;
       const int hv = p >> 2, q4 = p & 3;
       const int hx = hv % HX, hy = hv / HX;
