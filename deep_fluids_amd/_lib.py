@@ -91,6 +91,9 @@ SIGNATURES = {
     "df_wino43_packed_elems": (I64, [I64, I64, I32]),
     "df_wino43_pack_weights": (I32, [P, P, I64, I64, I32, P]),
     "df_wino43_conv": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, F32, P]),
+    "df_wino2d43_packed_elems": (I64, [I64, I64, I32]),
+    "df_wino2d43_pack_weights": (I32, [P, P, I64, I64, I32, P]),
+    "df_wino2d43_conv": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, F32, P]),
     "df_wino2d_packed_elems": (I64, [I64, I64, I32]),
     "df_wino2d_pack_weights": (I32, [P, P, I64, I64, I32, P]),
     "df_wino2d_conv_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, F32, P]),

@@ -485,7 +485,10 @@ int64_t w43_grid(W43Args& a, int64_t ntb) {
   int64_t grid = df::kCUs;
   a.spx = 1;
   if (8 % a.ncs == 0) {
-    a.spx = a.ncs % 2 == 0 ? 2 : 1;
+#ifndef W43_SPX
+#define W43_SPX 2      // cout slices per XCD (probe builds: 1 | 2 | 4)
+#endif
+    a.spx = a.ncs % W43_SPX == 0 ? W43_SPX : (a.ncs % 2 == 0 ? 2 : 1);
     const int xpg = a.ncs / a.spx, ngroups = 8 / xpg;
     const int64_t need = ceil_div(ntb, ngroups) * a.spx * 8;
     if (need < grid) grid = need;

@@ -301,6 +301,16 @@ class _WgradLane(object):
 # The 27-point forms of an up-sampling block's first conv (forward / pooled adjoint) exist in the F(2,3)^3 family only; both families write /
 # read the same sign-word layout, so they mix freely inside a block.
 WINO3D_FAMILY = _os.environ.get("DF_WINO3D_FAMILY", "f224")
+# ... and the 2-D twin: "f24" = F(2,3) x F(4,3) (conv_wino2d43.hip: 3 multiply-adds per output pixel and channel pair), "f22" = F(2,3)^2
+# (conv_wino2d.hip: 4), "auto" (default) = f24 for the forward convs, f22 for the dgrads: measured at cfg2's top level (profiles/r06_probes.md
+# section 4) the new kernel is 12 % faster forward (0.99 vs 1.13 ms) and 5 % SLOWER as the masked dgrad (1.18 vs 1.12 ms: its fp32 mask
+# reads are not hidden).  The 9-point forms of an up-sampling block's first conv exist in the F(2,3)^2 family only.
+WINO2D_FAMILY = _os.environ.get("DF_WINO2D_FAMILY", "auto")
+
+
+def _w2fam(mode):
+    """The 2-D Winograd family of a conv with pack mode `mode` (0 forward, 1 dgrad)."""
+    return WINO2D_FAMILY if WINO2D_FAMILY != "auto" else ("f24" if mode == 0 else "f22")
 
 
 def _use_wino(cin, cout, dims, kz):
@@ -320,7 +330,8 @@ def _pack(w, taps, cin, cout, mode, dims=None, fp32=False, family=None):
     F(2,3)^3 operand whatever WINO3D_FAMILY says (the 27-point forms)."""
     algo = _use_wino(cin, cout, dims, 3 if taps == 27 else 1) if dims is not None else 0
     if algo:
-        fn = ("df_wino43" if (family or WINO3D_FAMILY) == "f224" else "df_wino") if algo == 3 else "df_wino2d"
+        fn = ("df_wino43" if (family or WINO3D_FAMILY) == "f224" else "df_wino") if algo == 3 else (
+            "df_wino2d43" if (family or _w2fam(mode)) == "f24" else "df_wino2d")
         wp = torch.empty(query(fn + "_packed_elems", cin, cout, mode), dtype=torch.float32, device=w.device)
         call(fn + "_pack_weights", _ptr(w), _ptr(wp), cin, cout, mode, _stream())
         return wp
@@ -364,13 +375,16 @@ SIGN_BITS_FETCH = None
 
 
 def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak, sign_bits=None, mask_bits=None):
-    """`wp` must come from ``_pack(..., dims)`` with the same dims (the two agree on the algorithm)."""
+    """`wp` must come from ``_pack(..., dims)`` with the same dims AND mode (the two agree on the algorithm and the family: every forward
+    call carries DF_CONV_BIAS, no dgrad call does -- that is how the pack mode is recognised here)."""
+    mode = 0 if (flags & DF_CONV_BIAS) else 1
     B, D, H, W = dims
     y = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=x.device)
     algo = _use_wino(cin, cout, dims, kz)
     if DISPATCH_COUNTS is not None:
         thin = min(cin, cout) <= 4
-        _count("conv", ("winograd-f2x2x4" if WINO3D_FAMILY == "f224" else "winograd-f2x2x2") if algo == 3 else "winograd-f2x2" if algo == 2 else
+        _count("conv", ("winograd-f2x2x4" if WINO3D_FAMILY == "f224" else "winograd-f2x2x2") if algo == 3 else
+               ("winograd-f2x4" if _w2fam(mode) == "f24" else "winograd-f2x2") if algo == 2 else
                ("thin" + ("-valu-forced" if THIN_VALU_ONLY else "")) if thin else ("direct-mfma" + _sfx(cin, cout)), dims, cin, cout)
     if algo == 3 and WINO3D_FAMILY == "f224":
         call("df_wino43_conv", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(mask_bits), _ptr(y), None, _ptr(sign_bits),
@@ -386,6 +400,10 @@ def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak,
         return y
     if sign_bits is not None or mask_bits is not None:
         raise _lib.DeepFluidsHipError("sign-bit masks exist for the 3-D Winograd kernels only")
+    if algo == 2 and _w2fam(mode) == "f24":
+        call("df_wino2d43_conv", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, H, W, cin, cout, flags, float(leak),
+             _stream())
+        return y
     if algo == 2:
         call("df_wino2d_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, H, W, cin, cout,
              flags, float(leak), _stream())
@@ -623,7 +641,7 @@ class _UpGenBlock(torch.autograd.Function):
                          DF_CONV_BIAS | DF_CONV_LRELU, float(leak), _stream())
             elif i == 0 and not is3d and _use_wino(cin, cout, fdims, kz) == 2:
                 # 2-D twin: 9 of the 16 Winograd products (conv_wino2d.hip, UP variant)
-                wp = _pack(w, taps, cin, cout, 0, fdims)
+                wp = _pack(w, taps, cin, cout, 0, fdims, family="f22")
                 x = torch.empty(fshape, dtype=torch.float32, device=xc.device)
                 call("df_wino2d_upconv_fwd", _ptr(xc), _ptr(wp), _ptr(b), _ptr(x), cdims[0], cdims[2], cdims[3], cin, cout,
                      DF_CONV_BIAS | DF_CONV_LRELU, float(leak), _stream())
@@ -739,7 +757,7 @@ class _UpGenBlock(torch.autograd.Function):
                         call("df_wino_upconv_dgrad", _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, C,
                              _stream())
                     elif not is3d and _use_wino(C, C, fdims, kz) == 2:
-                        wpd = _pack(w, taps, C, C, 1, fdims)
+                        wpd = _pack(w, taps, C, C, 1, fdims, family="f22")
                         call("df_wino2d_upconv_dgrad", _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[2], cdims[3], C, C, _stream())
                     else:
                         sfx = _sfx(C, C)
@@ -1258,17 +1276,17 @@ ACTIVATION_FETCH = None
 # to change them temporarily: it sets them, restores the previous values on exit -- also when the body raises, so a failing test cannot
 # leak its mode into the next one -- and holds a re-entrant lock for the duration of the block, so two threads cannot interleave
 # different option sets (a second thread entering `options` waits until the first leaves).
-_OPTION_ATTRS = {"conv_precision": "CONV_PRECISION", "conv_algo": "CONV_ALGO", "wino3d_family": "WINO3D_FAMILY", "wgrad_algo": "WGRAD_ALGO",
+_OPTION_ATTRS = {"conv_precision": "CONV_PRECISION", "conv_algo": "CONV_ALGO", "wino3d_family": "WINO3D_FAMILY", "wino2d_family": "WINO2D_FAMILY", "wgrad_algo": "WGRAD_ALGO",
                  "thin_valu_only": "THIN_VALU_ONLY", "sign_bit_masks": "SIGN_BIT_MASKS", "fused_blocks": "FUSED_BLOCKS",
                  "dispatch_counts": "DISPATCH_COUNTS", "concurrent_wgrad_work": "CONCURRENT_WGRAD_WORK", "activation_fetch": "ACTIVATION_FETCH", "sign_bits_fetch": "SIGN_BITS_FETCH"}
-_OPTION_CHOICES = {"conv_precision": ("fp32", "bf16x3"), "conv_algo": ("auto", "direct", "winograd"), "wino3d_family": ("f224", "f222"), "wgrad_algo": (0, 1, 2, 3, 4)}
+_OPTION_CHOICES = {"conv_precision": ("fp32", "bf16x3"), "conv_algo": ("auto", "direct", "winograd"), "wino3d_family": ("f224", "f222"), "wino2d_family": ("auto", "f24", "f22"), "wgrad_algo": (0, 1, 2, 3, 4)}
 _OPTION_LOCK = _threading.RLock()
 
 
 @_contextlib.contextmanager
 def options(**kw):
     """``with ops.options(conv_precision="bf16x3", conv_algo="direct", wgrad_algo=1, activation_fetch=[]): ...``
-    Keys: conv_precision, conv_algo, wino3d_family ("f224" | "f222"), wgrad_algo, thin_valu_only, sign_bit_masks, fused_blocks, dispatch_counts (a dict to count into),
+    Keys: conv_precision, conv_algo, wino3d_family ("f224" | "f222"), wino2d_family ("auto" | "f24" | "f22"), wgrad_algo, thin_valu_only, sign_bit_masks, fused_blocks, dispatch_counts (a dict to count into),
     concurrent_wgrad_work (weight gradients of levels up to that many B x voxels x taps run on a second stream; 0 = serial),
     activation_fetch / sign_bits_fetch (a list to append to).  Unknown keys and out-of-range values raise before anything changes."""
     for k, v in kw.items():

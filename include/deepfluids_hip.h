@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DF_VERSION 205 /* 0.2.5: + df_adam_tf1_step_dev, df_gd_step(_dev), df_store_scalars (hipGraph replay of the train step); 0.2.4: + df_conv_s2_dgrad; 0.2.3: + df_conv_s2_wgrad; 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
+#define DF_VERSION 206 /* 0.2.6: + df_wino43_*, df_wino2d43_*, df_conv_s2_dgrad_form; 0.2.5: + df_adam_tf1_step_dev, df_gd_step(_dev), df_store_scalars (hipGraph replay of the train step); 0.2.4: + df_conv_s2_dgrad; 0.2.3: + df_conv_s2_wgrad; 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
 
 enum {
   DF_OK = 0,
@@ -329,6 +329,14 @@ int df_wino43_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout,
 int df_wino43_conv(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src, const void* mask_bits,
                    float* y, float* y2, void* sign_bits, int64_t B, int64_t D, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags,
                    float leak, df_stream_t stream);
+
+/* The 2-D twin (conv_wino2d43.hip): slim.conv2d k=3 s=1 SAME (ops.py:12-13; model.py:24-28) as Winograd F(2,3) x F(4,3) -- 3 matrix multiply-adds
+ * per output pixel and (cin, cout) pair instead of the 4 of df_wino2d_conv_fwd; same arguments, flags (BIAS | LRELU | RESIDUAL | MASK with an
+ * fp32 mask_src) and error convention as df_wino2d_conv_fwd; mode 1 of the pack = the dgrad operand. */
+int64_t df_wino2d43_packed_elems(int64_t cin, int64_t cout, int mode);
+int df_wino2d43_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, int mode, df_stream_t stream);
+int df_wino2d43_conv(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src, float* y, int64_t B,
+                     int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream);
 
 /* Sign-bit masks.  A masked dgrad (DF_CONV_MASK) multiplies its output by the lrelu slope of the layer below, i.e. it needs ONE BIT
  * per element of that layer's activation; read from the fp32 activation that is 3.2 GB per top-level launch at cfg3.  The forward

@@ -9,7 +9,7 @@ import torch
 
 import df_oracle as orc
 from gpu_util import dev, host, rel_l1, rel_linf
-from test_gpu_layers import WINO_CASES, _conv_case
+from test_gpu_layers import WINO2D_CASES, WINO_CASES, _conv_case
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -30,6 +30,68 @@ def test_conv3d_fwd_bwd_both_families_vs_oracle(ops, family, shape, cin, cout, l
     assert max(errs.values()) < TOL, errs
     want = "conv winograd-" + ("f2x2x4" if family == "f224" else "f2x2x2")
     assert any(k.startswith(want) for k in counts), counts          # the family asked for is the one that ran
+
+
+@pytest.mark.parametrize("family", ["f22", "f24"])
+@pytest.mark.parametrize("shape,cin,cout,leak", WINO2D_CASES)
+def test_conv2d_fwd_bwd_both_families_vs_oracle(ops, family, shape, cin, cout, leak):
+    """The 2-D twins: F(2,3)^2 (conv_wino2d.hip) and F(2,3) x F(4,3) (conv_wino2d43.hip, the default since round 6), forward and dgrad
+    through _ConvSame3, against the fp64 oracle (reference: slim.conv2d, ops.py:12-13, model.py:24-28)."""
+    counts = {}
+    with ops.options(conv_algo="winograd", wino2d_family=family, dispatch_counts=counts):
+        errs = _conv_case(ops, shape, cin, cout, leak, seed=cin * 3 + cout + sum(shape), mask_from_gpu=True)
+    assert max(errs.values()) < TOL, errs
+    assert any(k.startswith("conv winograd-" + ("f2x4" if family == "f24" else "f2x2 ")) for k in counts), counts
+
+
+@pytest.mark.parametrize("dims", [(2, 24, 40, 64, 32), (1, 16, 32, 32, 32), (3, 33, 47, 32, 64), (2, 16, 64, 128, 128), (1, 10, 12, 32, 32)])
+def test_wino2d43_fused_epilogues_match_the_direct_kernel(dims):
+    """bias / lrelu / residual / lrelu-mask epilogues of df_wino2d43_conv vs df_conv_fwd on the same inputs (full, ragged and sub-block images)."""
+    from deep_fluids_amd._lib import call, query
+    from deep_fluids_amd.ops import _ptr, _stream
+    B, H, W, C, N = dims
+    rng = np.random.RandomState(sum(dims))
+    x = dev(rng.uniform(-1, 1, (B, H, W, C)).astype(np.float32))
+    w = dev((rng.uniform(-1, 1, (3, 3, C, N)) / np.sqrt(9 * C)).astype(np.float32))
+    bias = dev(rng.uniform(-0.5, 0.5, N).astype(np.float32))
+    res = dev(rng.uniform(-1, 1, (B, H, W, N)).astype(np.float32))
+    msk = dev(rng.uniform(-1, 1, (B, H, W, N)).astype(np.float32))
+    wd = torch.empty(query("df_conv_packed_elems", 9, C, N, 0), device="cuda")
+    call("df_conv_pack_weights", _ptr(w), _ptr(wd), 9, C, N, 0, _stream())
+    ww = torch.empty(query("df_wino2d43_packed_elems", C, N, 0), device="cuda")
+    call("df_wino2d43_pack_weights", _ptr(w), _ptr(ww), C, N, 0, _stream())
+    for flags in (0, 8, 8 | 1, 2, 4, 8 | 1 | 2, 2 | 4, 8 | 1 | 2 | 4):
+        y0 = torch.empty((B, H, W, N), device="cuda"); y1 = torch.full_like(y0, float("nan"))
+        call("df_conv_fwd", _ptr(x), _ptr(wd), _ptr(bias), _ptr(res), _ptr(msk), _ptr(y0), B, 1, H, W, C, N, 1, flags, 0.2, _stream())
+        call("df_wino2d43_conv", _ptr(x), _ptr(ww), _ptr(bias), _ptr(res) if flags & 2 else None, _ptr(msk) if flags & 4 else None, _ptr(y1),
+             B, H, W, C, N, flags, 0.2, _stream())
+        err = rel_linf(host(y1), host(y0))
+        assert err < 2e-5, (flags, err)
+
+
+def test_train_step_2d_both_families_vs_oracle(ops):
+    """One 2-D velocity-field train step (128 x 96: the Winograd levels of GeneratorBE) under both 2-D families against the fp64 oracle."""
+    from deep_fluids_amd.trainer import Trainer, default_config
+    rng = np.random.RandomState(6)
+    spatial, filters, batch = (128, 96), 32, 2
+    oshape = list(spatial) + [1]
+    p = orc.generator_init(rng, 3, oshape, filters)
+    x, y = orc.synthetic_batch(rng, batch, spatial)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    opt = {"m": {k: np.zeros_like(v) for k, v in p64.items()}, "v": {k: np.zeros_like(v) for k, v in p64.items()}, "t": 0, "lr": 1e-4}
+    _, _, info = orc.train_step(y.astype(np.float64), x.astype(np.float64), p64, opt, oshape, filters, False)
+    for family in ("f22", "f24"):
+        counts = {}
+        with ops.options(wino2d_family=family, dispatch_counts=counts):
+            ops.reset_variables()
+            tr = Trainer(default_config(is_3d=False, res_x=96, res_y=128, filters=filters, batch_size=batch, num_samples=100))
+            tr.load_variables(p)
+            m = tr.train_step(dev(x), dev(y))
+            u = host(m.G_)
+        ops.reset_variables()
+        assert any("winograd-" + ("f2x4" if family == "f24" else "f2x2 ") in k for k in counts), counts
+        assert rel_l1(u, info["u"]) < 1e-5, (family, rel_l1(u, info["u"]))
+        assert abs(float(m.g_loss.detach()) - info["loss"]) < 1e-5 * abs(info["loss"])
 
 
 def _setup(rng, B, D, H, W, C, N):

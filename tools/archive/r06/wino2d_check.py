@@ -19,3 +19,12 @@ for fl, m, name in ((9, None, "fwd bias+lrelu"), (4, x, "dgrad masked")):
     h = hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest()[:12]
     t = timeit(lambda: f(fl, m), 6, 3)
     print("wino2d %-16s %.3f ms  executed %.3f  sha %s" % (name, t * 1e3, 2.0 * 9 * C * C * B * H * W * (4.0 / 9.0) / t / 157.3e12, h), flush=True)
+w4 = torch.empty(query("df_wino2d43_packed_elems", C, C, 0), device="cuda")
+call("df_wino2d43_pack_weights", _ptr(w), _ptr(w4), C, C, 0, s)
+y2 = torch.empty_like(x)
+f4 = lambda fl, m: call("df_wino2d43_conv", _ptr(x), _ptr(w4), _ptr(bias), None, _ptr(m) if m is not None else None, _ptr(y2), B, H, W, C, C, fl, 0.2, s)
+for fl, m, name in ((9, None, "fwd bias+lrelu"), (4, x, "dgrad masked")):
+    f(fl, m); f4(fl, m); torch.cuda.synchronize()
+    err = float((y2 - y).abs().max() / y.abs().max())
+    t = timeit(lambda: f4(fl, m), 6, 3)
+    print("wino2d43 %-14s %.3f ms  executed %.3f  max rel diff vs F(2,3)^2 %.2e" % (name, t * 1e3, 2.0 * 9 * C * C * B * H * W * (3.0 / 9.0) / t / 157.3e12, err), flush=True)
