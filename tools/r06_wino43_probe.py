@@ -73,6 +73,14 @@ def main():
     f27 = 2.0 * C * C * B * D * H * W * 27.0 / 8.0
     print("27-point forms B%d: up-sampling-aware forward %.3f ms (executed %.3f)   pooled adjoint %.3f ms (executed %.3f)" % (
         B, tu * 1e3, f27 / tu / 157.3e12, tp * 1e3, f27 / tp / 157.3e12), flush=True)
+    # the block tail: add-up + sign words without the primary output (FL 345), and the masked dgrad from sign words (FL 132)
+    from deep_fluids_amd.ops import _new_bits
+    from deep_fluids_amd._lib import DF_CONV_ADDUP
+    tbits = _new_bits((B, D, H, W), C, x)
+    y2 = torch.empty_like(x)
+    tt = timeit(lambda: call("df_wino43_conv", _ptr(x), _ptr(wb), _ptr(bias), _ptr(xc), None, None, None, _ptr(y2), _ptr(tbits), B, D, H, W, C, C, 9 | DF_CONV_ADDUP, 0.2, s), 4, 2)
+    tm = timeit(lambda: call("df_wino43_conv", _ptr(x), _ptr(wb), None, None, None, _ptr(tbits), _ptr(y), None, None, B, D, H, W, C, C, 4, 0.2, s), 4, 2)
+    print("F(2,2,4) epilogue variants B%d: add-up + sign words, no primary %.3f ms   mask from sign words %.3f ms" % (B, tt * 1e3, tm * 1e3), flush=True)
     fl = 2.0 * 27 * C * C * B * D * H * W
     print("top level 64x96x64 C128 B%d: F(2,3)^3 %.3f ms (executed %.3f)   F(2,2,4) %.3f ms (executed %.3f)   ratio %.3f" % (
         B, ta * 1e3, fl * 8 / 27 / ta / 157.3e12, tb * 1e3, fl * 6 / 27 / tb / 157.3e12, tb / ta), flush=True)
