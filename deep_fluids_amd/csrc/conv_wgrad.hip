@@ -746,37 +746,85 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_wx_kernel(const WgradArgs a
   }
 }
 
+// gb[32 cb .. 32 cb + 31] = sum of the n partial bias rows, by ONE workgroup: thread = (column, range group), every 8th row per thread, the 8
+// group sums combined in a fixed order through `sh` (8 x 32 floats of LDS) -- deterministic.  [r6] replaces "workgroup 0 walks all rows serially"
+// (up to 256 dependent load rounds that alone set the duration of every reduce kernel).  Call with a block-uniform condition.
+__device__ __forceinline__ void bias_reduce_cols(const float* __restrict__ bpartial, float* __restrict__ gb, int n, int Cout, int Coutp,
+                                                 float* sh, int cb) {
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = cb * 32 + el;
+  float acc = 0.f;
+  if (c < Cout)
+    for (int rg = grp; rg < n; rg += 8) acc += bpartial[static_cast<int64_t>(rg) * Coutp + c];
+  __syncthreads();
+  sh[grp * 32 + el] = acc;
+  __syncthreads();
+  if (grp == 0 && c < Cout) {
+    float t = sh[el];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += sh[g * 32 + el];
+    gb[c] = t;
+  }
+}
+
 // gw[dzdy][dx][ci][co] from the summed (fixed order) transform-domain partials U0..U3 (U3 was accumulated with +g1)
 __global__ __launch_bounds__(kThreads) void wgrad_wx_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
                                                                    float* __restrict__ gw, float* __restrict__ gb, int nranges,
                                                                    int ndzdy, int Cin, int Cout, int Cinp, int Coutp) {
+  // [r6] workgroup = 32 consecutive (dzdy, ci, co) elements x 8 range groups (thread sums every 8th range; the 8 group sums are combined in a
+  // fixed order through LDS: deterministic).  Rounds 1-5 had ONE thread walk all ranges of an element -- a serial chain of up to 256 dependent
+  // load rounds, and workgroup 0 alone another one for the bias: 33-127 us per call at the reference's default batch sizes, 20-30 % of the
+  // 2-D steps' kernel time (profiles/r06_probes.md section 5).  Workgroups past the weight elements reduce the bias the same way.
+  __shared__ float sU[8][4][32];
   const int64_t total = static_cast<int64_t>(ndzdy) * Cin * Cout;
+  const int64_t nwg = (total + 31) / 32;
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  if (static_cast<int64_t>(blockIdx.x) >= nwg) {      // bias workgroups
+    const int co = static_cast<int>(blockIdx.x - nwg) * 32 + el;
+    float acc = 0.f;
+    if (gb && co < Cout)
+      for (int rg = grp; rg < nranges; rg += 8) acc += bpartial[static_cast<int64_t>(rg) * Coutp + co];
+    sU[grp][0][el] = acc;
+    __syncthreads();
+    if (grp == 0 && gb && co < Cout) {
+      float t = sU[0][0][el];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) t += sU[g][0][el];
+      gb[co] = t;
+    }
+    return;
+  }
   const int64_t slot = static_cast<int64_t>(Cinp) * Coutp;
   const int64_t pstride = static_cast<int64_t>(ndzdy) * 4 * slot;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kThreads) {
-    const int co = static_cast<int>(i % Cout);
-    const int64_t t2 = i / Cout;
-    const int ci = static_cast<int>(t2 % Cin);
-    const int dzdy = static_cast<int>(t2 / Cin);
-    const float* p = partial + (static_cast<int64_t>(dzdy) * 4 * Cinp + ci) * Coutp + co;
-    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
-    for (int rg = 0; rg < nranges; ++rg) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 32 + el;
+  const bool ok = i < total;
+  const int co = ok ? static_cast<int>(i % Cout) : 0;
+  const int64_t t2 = ok ? i / Cout : 0;
+  const int ci = static_cast<int>(t2 % Cin);
+  const int dzdy = static_cast<int>(t2 / Cin);
+  const float* p = partial + (static_cast<int64_t>(dzdy) * 4 * Cinp + ci) * Coutp + co;
+  float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+  if (ok)
+    for (int rg = grp; rg < nranges; rg += 8) {
       const float* q = p + rg * pstride;
       u0 += q[0]; u1 += q[slot]; u2 += q[2 * slot]; u3 += q[3 * slot];
     }
-    const float h = 0.5f * (u1 + u2);
-    float* o = gw + (static_cast<int64_t>(dzdy) * 3 * Cin + ci) * Cout + co;
-    o[0] = u0 + h;
-    o[static_cast<int64_t>(Cin) * Cout] = 0.5f * (u1 - u2);
-    o[2 * static_cast<int64_t>(Cin) * Cout] = h - u3;
-  }
-  if (gb && blockIdx.x == 0) {
-    for (int co = threadIdx.x; co < Cout; co += kThreads) {
-      float acc = 0.f;
-      for (int rg = 0; rg < nranges; ++rg) acc += bpartial[static_cast<int64_t>(rg) * Coutp + co];
-      gb[co] = acc;
+  sU[grp][0][el] = u0; sU[grp][1][el] = u1; sU[grp][2][el] = u2; sU[grp][3][el] = u3;
+  __syncthreads();
+  if (grp == 0 && ok) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t = sU[0][k][el];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) t += sU[g][k][el];
+      v[k] = t;
     }
+    const float h = 0.5f * (v[1] + v[2]);
+    float* o = gw + (static_cast<int64_t>(dzdy) * 3 * Cin + ci) * Cout + co;
+    o[0] = v[0] + h;
+    o[static_cast<int64_t>(Cin) * Cout] = 0.5f * (v[1] - v[2]);
+    o[2 * static_cast<int64_t>(Cin) * Cout] = h - v[3];
   }
 }
 
@@ -1022,13 +1070,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_wxy_reduce_kernel(const float*
       o[(dy * 3 + 2) * tapstride] = h - w[dy][3];
     }
   }
-  if (gb && blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < Cout; c += kThreads) {
-      float acc = 0.f;
-      for (int rg = 0; rg < nranges; ++rg) acc += bpartial[static_cast<int64_t>(rg) * Coutp + c];
-      gb[c] = acc;
-    }
-  }
+  if (gb && static_cast<int>(blockIdx.x) * 32 < Cout) bias_reduce_cols(bpartial, gb, nranges, Cout, Coutp, &sU[0][0][0], blockIdx.x);
 }
 
 // ---- Winograd-in-(x,y,z) weight gradient ------------------------------------------------------------------------------------------
@@ -1406,13 +1448,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_wxyz_reduce_kernel(const float
     for (int g = 1; g < 8; ++g) t += sV[g][k][el];
     gw[(static_cast<int64_t>(k) * Cin + ci) * Cout + co] = t;
   }
-  if (gb && blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < Cout; c += kThreads) {
-      float acc = 0.f;
-      for (int rg = 0; rg < nranges; ++rg) acc += bpartial[static_cast<int64_t>(rg) * Coutp + c];
-      gb[c] = acc;
-    }
-  }
+  if (gb && static_cast<int>(blockIdx.x) * 32 < Cout) bias_reduce_cols(bpartial, gb, nranges, Cout, Coutp, &sV[0][0][0], blockIdx.x);
 }
 
 // the Winograd-in-x variant exists for the fully unrolled row lengths below (even channel counts: float2 operand loads)
@@ -1650,25 +1686,42 @@ __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float* __r
                                                                 float* __restrict__ gw, float* __restrict__ gb,
                                                                 int nranges, int taps, int Cin, int Cout, int Cinp,
                                                                 int Coutp) {
+  // [r6] 32 consecutive elements x 8 range groups per workgroup, group sums combined in a fixed order through LDS (see wgrad_wx_reduce_kernel);
+  // the workgroups past the weight elements reduce the bias
+  __shared__ float sP[8][32];
   const int64_t total = static_cast<int64_t>(taps) * Cin * Cout;
-  const int64_t pstride = static_cast<int64_t>(taps) * Cinp * Coutp;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kThreads) {
-    const int co = static_cast<int>(i % Cout);
-    const int64_t t2 = i / Cout;
-    const int ci = static_cast<int>(t2 % Cin);
-    const int tap = static_cast<int>(t2 / Cin);
-    const float* p = partial + (static_cast<int64_t>(tap) * Cinp + ci) * Coutp + co;
-    float acc = 0.f;
-    for (int rg = 0; rg < nranges; ++rg) acc += p[rg * pstride];
-    gw[i] = acc;
-  }
-  if (gb && blockIdx.x == 0) {
-    for (int co = threadIdx.x; co < Cout; co += kThreads) {
-      float acc = 0.f;
-      for (int rg = 0; rg < nranges; ++rg) acc += bpartial[static_cast<int64_t>(rg) * Coutp + co];
-      gb[co] = acc;
+  const int64_t nwg = (total + 31) / 32;
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  float acc = 0.f;
+  bool ok;
+  float* dst;
+  if (static_cast<int64_t>(blockIdx.x) >= nwg) {
+    const int co = static_cast<int>(blockIdx.x - nwg) * 32 + el;
+    ok = gb && co < Cout;
+    dst = ok ? gb + co : nullptr;
+    if (ok)
+      for (int rg = grp; rg < nranges; rg += 8) acc += bpartial[static_cast<int64_t>(rg) * Coutp + co];
+  } else {
+    const int64_t pstride = static_cast<int64_t>(taps) * Cinp * Coutp;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 32 + el;
+    ok = i < total;
+    dst = ok ? gw + i : nullptr;
+    if (ok) {
+      const int co = static_cast<int>(i % Cout);
+      const int64_t t2 = i / Cout;
+      const int ci = static_cast<int>(t2 % Cin);
+      const int tap = static_cast<int>(t2 / Cin);
+      const float* p = partial + (static_cast<int64_t>(tap) * Cinp + ci) * Coutp + co;
+      for (int rg = grp; rg < nranges; rg += 8) acc += p[rg * pstride];
     }
+  }
+  sP[grp][el] = acc;
+  __syncthreads();
+  if (grp == 0 && ok) {
+    float t = sP[0][el];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += sP[g][el];
+    *dst = t;
   }
 }
 
@@ -1818,11 +1871,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_small_reduce_kernel(const floa
                                                                       int nstreams, int64_t per_stream, int CO,
                                                                       int Cout) {
   __shared__ float sP[8][32];
-  if (gb && blockIdx.x == 0 && threadIdx.x < Cout) {
-    float acc = 0.f;
-    for (int sidx = 0; sidx < nstreams; ++sidx) acc += bpartial[sidx * CO + threadIdx.x];
-    gb[threadIdx.x] = acc;
-  }
+  __shared__ float sB[8 * 32];
+  // (bias: Cout <= 4 columns over up to 2048 stream rows -- grouped, not one serial walk by workgroup 0: that alone was 126 us per call)
+  if (gb && blockIdx.x == 0) bias_reduce_cols(bpartial, gb, nstreams, Cout, CO, sB, 0);
   const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 32 + el;
   float acc = 0.f;
@@ -2052,11 +2103,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_thin_reduce_kernel(const float
     else gw[(static_cast<int64_t>(m / CT) * NCH + ch) * CT + (m % CT)] = t;
   }
   const int nbias = swap ? NCH : CT;
-  if (gb && blockIdx.x == 0 && threadIdx.x < nbias) {
-    float t = 0.f;
-    for (int sidx = 0; sidx < nstreams; ++sidx) t += bpartial[sidx * nbias + threadIdx.x];
-    gb[threadIdx.x] = t;
-  }
+  if (gb && static_cast<int>(blockIdx.x) * 32 < nbias) bias_reduce_cols(bpartial, gb, nstreams, nbias, nbias, &sP[0][0], blockIdx.x);
 }
 
 // wide channels 64 | 128, thin <= 4, rows of 16-voxel groups, at most two 64-lane passes per thin row, LDS 4 waves x 19 rows x
@@ -2147,13 +2194,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_up_reduce_kernel(const float* 
     for (int g = 1; g < 8; ++g) t += sP[g][el];
     gw[i] = t;
   }
-  if (gb && blockIdx.x == 0) {
-    for (int co = threadIdx.x; co < Cout; co += kThreads) {
-      float a2 = 0.f;
-      for (int q = 0; q < nranges * ncls; ++q) a2 += bpartial[static_cast<int64_t>(q) * Coutp + co];
-      gb[co] = a2;
-    }
-  }
+  if (gb && static_cast<int>(blockIdx.x) * 32 < Cout) bias_reduce_cols(bpartial, gb, nranges * ncls, Cout, Coutp, &sP[0][0], blockIdx.x);
 }
 
 struct Plan {
@@ -2484,8 +2525,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
     else if (c128) hipLaunchKernelGGL((wgrad_wx_kernel<2, 128>), grid, dim3(kThreads), 0, s, a);
     else hipLaunchKernelGGL((wgrad_wx_kernel<2, 0>), grid, dim3(kThreads), 0, s, a);
     const int64_t tot = static_cast<int64_t>(p.ndzdy) * Cin * Cout;
-    int64_t rgx = ceil_div(tot, kThreads);
-    if (rgx > 2048) rgx = 2048;
+    const int64_t rgx = ceil_div(tot, 32) + (gb ? ceil_div(Cout, 32) : 0);      // 32 elements per workgroup + the bias workgroups
     hipLaunchKernelGGL(wgrad_wx_reduce_kernel, dim3((unsigned)rgx), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
                        p.nranges * p.nsub, p.ndzdy, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
     return df::launched("df_conv_wgrad(winograd-x)");
@@ -2507,8 +2547,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, float* gb
   else hipLaunchKernelGGL((wgrad_kernel<false, false, 0>), grid, dim3(kThreads), 0, s, a);
   }
   const int64_t total = static_cast<int64_t>(p.taps) * Cin * Cout;
-  int64_t rg = ceil_div(total, kThreads);
-  if (rg > 2048) rg = 2048;
+  const int64_t rg = ceil_div(total, 32) + (gb ? ceil_div(Cout, 32) : 0);      // 32 elements per workgroup + the bias workgroups
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
                      p.nranges * p.nsub, p.taps, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
   return df::launched("df_conv_wgrad");
@@ -2570,8 +2609,7 @@ int df_conv_s2_wgrad(const float* x, const float* gy, float* gw, float* gb, int6
   else if (Wo == 16) hipLaunchKernelGGL((wgrad_s2_kernel<2>), grid, dim3(kThreads), 0, s, a);
   else hipLaunchKernelGGL((wgrad_s2_kernel<1>), grid, dim3(kThreads), 0, s, a);
   const int64_t total = static_cast<int64_t>(p.taps) * Cin * Cout;
-  int64_t rg = ceil_div(total, kThreads);
-  if (rg > 2048) rg = 2048;
+  const int64_t rg = ceil_div(total, 32) + (gb ? ceil_div(Cout, 32) : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rg), dim3(kThreads), 0, s, a.partial, a.bpartial, gw, gb,
                      p.nranges * p.nsub, p.taps, (int)Cin, (int)Cout, p.Cinp, p.Coutp);
   return df::launched("df_conv_s2_wgrad");
