@@ -52,34 +52,38 @@ struct Wino2dArgs {
 
 // ---- weight transform + packing: Up[cs][k4][nb][xy][kq][j][xx] = sum_taps G[xy][ty] G[xx][tx] g[tap][4 k4 + kq][32 cs + 16 nb + j]
 // mode 0: g[tap][k][n] = w[tap][k][n];  mode 1: g[tap][k][n] = w[8 - tap][n][k]  (dgrad operand)
-__device__ __forceinline__ double gmat2(int xi, int t) {
-  return xi == 0 ? (t == 0 ? 1.0 : 0.0) : xi == 3 ? (t == 2 ? 1.0 : 0.0) : (xi == 2 && t == 1 ? -0.5 : 0.5);
-}
+// [r6] thread = one (k, n) filter: its 9 taps are read once and all 16 transform points come out of the separable G transform in fp64, written as
+// four float4 (the four xi_x of a xi_y) -- 5 us per 128 x 128 layer.  (Rounds 2-5: one thread per OUTPUT element re-reading the taps, 18 us.)
 __global__ __launch_bounds__(kPackT) void wino2d_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout,
                                                              int mode, int64_t total) {
-  const int K = mode == 0 ? cin : cout;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kPackT + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kPackT) {
-    int64_t r = i;
-    const int xx = static_cast<int>(r & 3); r >>= 2;
-    const int j = static_cast<int>(r & 15); r >>= 4;
-    const int kq = static_cast<int>(r & 3); r >>= 2;
-    const int xy = static_cast<int>(r & 3); r >>= 2;
-    const int nb = static_cast<int>(r & 1); r >>= 1;
-    const int k4 = static_cast<int>(r % (K / 4)); r /= (K / 4);
-    const int cs = static_cast<int>(r);
-    const int k = 4 * k4 + kq, n = cs * 32 + nb * 16 + j;
-    double acc = 0.0;
-    for (int ty = 0; ty < 3; ++ty)
-      for (int tx = 0; tx < 3; ++tx) {
-        const double c = gmat2(xy, ty) * gmat2(xx, tx);
-        if (c == 0.0) continue;
-        const int tap = ty * 3 + tx;
-        const float v = mode == 0 ? w[(static_cast<int64_t>(tap) * cin + k) * cout + n]
-                                  : w[(static_cast<int64_t>(8 - tap) * cin + n) * cout + k];
-        acc += c * static_cast<double>(v);
+  (void)total;
+  const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+  const int64_t nfil = static_cast<int64_t>(K) * N;
+  for (int64_t f = static_cast<int64_t>(blockIdx.x) * kPackT + threadIdx.x; f < nfil; f += static_cast<int64_t>(gridDim.x) * kPackT) {
+    const int n = static_cast<int>(f % N), k = static_cast<int>(f / N);
+    double g[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+      g[tap] = static_cast<double>(mode == 0 ? w[(static_cast<int64_t>(tap) * cin + k) * cout + n]
+                                             : w[(static_cast<int64_t>(8 - tap) * cin + n) * cout + k]);
+    double gx[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double a = g[r * 3], b = g[r * 3 + 1], c = g[r * 3 + 2];
+      gx[r][0] = a; gx[r][1] = 0.5 * (a + b + c); gx[r][2] = 0.5 * (a - b + c); gx[r][3] = c;
+    }
+    const int cs = n >> 5, nb = (n >> 4) & 1, j = n & 15, k4 = k >> 2, kq = k & 3;
+#pragma unroll
+    for (int xy = 0; xy < 4; ++xy) {
+      f32x4 o;
+#pragma unroll
+      for (int xx = 0; xx < 4; ++xx) {
+        const double a = gx[0][xx], b = gx[1][xx], c = gx[2][xx];
+        o[xx] = static_cast<float>(xy == 0 ? a : xy == 3 ? c : xy == 1 ? 0.5 * (a + b + c) : 0.5 * (a - b + c));
       }
-    wp[i] = static_cast<float>(acc);
+      const int64_t idx = (((((static_cast<int64_t>(cs) * (K / 4) + k4) * 2 + nb) * 4 + xy) * 4 + kq) * 16 + j) * 4;
+      *reinterpret_cast<f32x4*>(wp + idx) = o;
+    }
   }
 }
 
@@ -404,7 +408,7 @@ int df_wino2d_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout,
   DF_REQUIRE(cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 && (mode == 0 || mode == 1), DF_ESHAPE,
              "df_wino2d_pack_weights: cin, cout must be multiples of 32; mode 0|1");
   const int64_t total = 16 * cin * cout;
-  int64_t g = ceil_div(total, kPackT);
+  int64_t g = ceil_div(cin * cout, kPackT);      // one thread per (k, n) filter
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(wino2d_pack_kernel, dim3((unsigned)g), dim3(kPackT), 0, df::as_stream(stream), w, wp, (int)cin, (int)cout, mode,
                      total);
