@@ -79,6 +79,24 @@ def set_random_seed(seed):
 
 def reset_variables():
     _VARS.clear()
+    _DIRECT_GRADS.clear()
+
+
+# Direct gradient targets: data_ptr of a variable -> the tensor its gradient kernel writes (the variable's slice of a trainer's flat gradient slab).
+# A backward node then hands the weight / bias gradient kernels that slice as their OUTPUT and returns None for the input, instead of allocating a
+# tensor that autograd's AccumulateGrad adds to the (zeroed) slab in a second launch: 42 launches and passes per 2-D step saved.  Valid only where
+# every registered variable receives exactly ONE gradient per backward pass and nobody listens for post-accumulate hooks -- the single-process
+# `de` / `ae` trainers register theirs (Trainer._build_variables); data parallelism and the GAN trainer (D is applied twice) do not.
+_DIRECT_GRADS = {}
+
+
+def _grad_out(ptr, shape, device):
+    """-> (tensor the gradient kernel writes, what backward returns for that input)."""
+    g = _DIRECT_GRADS.get(ptr)
+    if g is not None:
+        return g, None
+    t = torch.empty(shape, dtype=torch.float32, device=device)
+    return t, t
 
 
 def all_variables():
@@ -437,6 +455,7 @@ class _ConvSame3(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if leak is not None else None)
         ctx.leak = leak
         ctx.geom = (dims, cin, cout, kz, taps)
+        ctx.bptr = b.data_ptr()
         return y
 
     @staticmethod
@@ -450,14 +469,14 @@ class _ConvSame3(torch.autograd.Function):
             call("df_lrelu_bwd", _ptr(gy), _ptr(y), _ptr(dp), float(ctx.leak), gy.numel(), _stream())
         else:
             dp = gy
-        gw = torch.empty_like(w)
-        gb = torch.empty(cout, dtype=torch.float32, device=x.device)
+        gw, rw = _grad_out(w.data_ptr(), w.shape, x.device)
+        gb, rb = _grad_out(ctx.bptr, (cout,), x.device)
         _wgrad(x, dp, gw, gb, B, D, H, W, cin, cout, kz, _sfx(cin, cout))
         gx = None
         if ctx.needs_input_grad[0]:
             wpd = _pack(w, taps, cin, cout, 1, dims)
             gx = _conv_raw(dp, wpd, None, None, None, dims, cout, cin, kz, 0, 0.0).view(x.shape)
-        return gx, gw, gb, None
+        return gx, rw, rb, None
 
 
 class _GenBlock(torch.autograd.Function):
@@ -499,6 +518,7 @@ class _GenBlock(torch.autograd.Function):
         ctx.save_for_backward(*(xs + [wb[2 * i] for i in range(n)]))
         ctx.geom = (n, dims, kz, taps, float(leak))
         ctx.bits = bits
+        ctx.bptrs = [wb[2 * i + 1].data_ptr() for i in range(n)]
         return y
 
     @staticmethod
@@ -516,10 +536,10 @@ class _GenBlock(torch.autograd.Function):
         for i in range(n, 0, -1):
             w = ws[i - 1]
             cin, cout = w.shape[-2], w.shape[-1]
-            gw = torch.empty_like(w)
-            gb = torch.empty(cout, dtype=torch.float32, device=dy.device)
+            gw, rw = _grad_out(w.data_ptr(), w.shape, dy.device)
+            gb, rb = _grad_out(ctx.bptrs[i - 1], (cout,), dy.device)
             lane.run(lambda: _wgrad(xs[i - 1], dp, gw, gb, B, D, H, W, cin, cout, kz, _sfx(cin, cout)), dp, gw, gb)
-            grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
+            grads[2 * (i - 1)] = rw; grads[2 * (i - 1) + 1] = rb
             wpd = _pack(w, taps, cin, cout, 1, dims)
             if i > 1:      # dgrad, times the lrelu slope of the layer below: directly the next dp
                 mb = ctx.bits[i - 2]      # sign bits of conv i-1's output, if its forward emitted them
@@ -564,6 +584,7 @@ class _ConvChain(torch.autograd.Function):
         ctx.save_for_backward(*(xs + [wb[2 * i] for i in range(n)]))
         ctx.geom = (n, dims, kz, taps, float(leak))
         ctx.bits = bits
+        ctx.bptrs = [wb[2 * i + 1].data_ptr() for i in range(n)]
         return x
 
     @staticmethod
@@ -581,10 +602,10 @@ class _ConvChain(torch.autograd.Function):
         for i in range(n, 0, -1):
             w = ws[i - 1]
             cin, cout = w.shape[-2], w.shape[-1]
-            gw = torch.empty_like(w)
-            gb = torch.empty(cout, dtype=torch.float32, device=dy.device)
+            gw, rw = _grad_out(w.data_ptr(), w.shape, dy.device)
+            gb, rb = _grad_out(ctx.bptrs[i - 1], (cout,), dy.device)
             lane.run(lambda: _wgrad(xs[i - 1], dp, gw, gb, B, D, H, W, cin, cout, kz, _sfx(cin, cout)), dp, gw, gb)
-            grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
+            grads[2 * (i - 1)] = rw; grads[2 * (i - 1) + 1] = rb
             if i > 1 or ctx.needs_input_grad[0]:
                 wpd = _pack(w, taps, cin, cout, 1, dims)
                 if i > 1:      # dgrad, times the lrelu slope of the layer below: directly the next dp
@@ -695,6 +716,7 @@ class _UpGenBlock(torch.autograd.Function):
         ctx.geom = (n, cdims, fdims, kz, taps, float(leak), C, is3d)
         ctx.bits = bits
         ctx.tail_bits = tail_bits
+        ctx.bptrs = [wb[2 * i + 1].data_ptr() for i in range(n)]
         return y
 
     @staticmethod
@@ -723,8 +745,8 @@ class _UpGenBlock(torch.autograd.Function):
         lane = _WgradLane(fdims, dy, taps)
         for i in range(n, 0, -1):
             w = ws[i - 1]
-            gw = torch.empty_like(w)
-            gb = torch.empty(C, dtype=torch.float32, device=dy.device)
+            gw, rw = _grad_out(w.data_ptr(), w.shape, dy.device)
+            gb, rb = _grad_out(ctx.bptrs[i - 1], (C,), dy.device)
             if i > 1:
                 lane.run(lambda: _wgrad(xs[i - 2], dp, gw, gb, B, D, H, W, C, C, kz, _sfx(C, C)), dp, gw, gb)
                 wpd = _pack(w, taps, C, C, 1, fdims)
@@ -766,7 +788,7 @@ class _UpGenBlock(torch.autograd.Function):
                         call("df_upconv_pack_weights" + sfx, _ptr(w), _ptr(wpd), C, C, kz, 1, _stream())
                         call("df_upconv_dgrad" + sfx, _ptr(dp), _ptr(wpd), _ptr(dxc), cdims[0], cdims[1], cdims[2], cdims[3], C, C,
                              kz, _stream())
-            grads[2 * (i - 1)] = gw; grads[2 * (i - 1) + 1] = gb
+            grads[2 * (i - 1)] = rw; grads[2 * (i - 1) + 1] = rb
         lane.join()
         return (dxc if ctx.needs_input_grad[0] else None, None) + tuple(grads)
 
@@ -801,6 +823,7 @@ class _ConvSame3S2(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if leak is not None else None)
         ctx.leak = leak
         ctx.geom = (idims, odims, cin, cout, kz, taps)
+        ctx.bptr = b.data_ptr()
         return y
 
     @staticmethod
@@ -814,8 +837,8 @@ class _ConvSame3S2(torch.autograd.Function):
             call("df_lrelu_bwd", _ptr(gy), _ptr(y), _ptr(dp), float(ctx.leak), gy.numel(), _stream())
         else:
             dp = gy
-        gw = torch.empty_like(w)
-        gb = torch.empty(cout, dtype=torch.float32, device=x.device)
+        gw, rw = _grad_out(w.data_ptr(), w.shape, x.device)
+        gb, rb = _grad_out(ctx.bptr, (cout,), x.device)
         up = None
         nbytes = query("df_conv_s2_wgrad_workspace_bytes", odims[0], odims[1], odims[2], odims[3], cin, cout, kz)
         if nbytes > 0 and WGRAD_ALGO == 0:
@@ -851,7 +874,7 @@ class _ConvSame3S2(torch.autograd.Function):
                     call("df_dilate2_odd", _ptr(dp), _ptr(up), odims[0], odims[1], odims[2], odims[3], cout, int(kz == 3), _stream())
                 wpd = _pack(w, taps, cin, cout, 1, idims)
                 gx = _conv_raw(up, wpd, None, None, None, idims, cout, cin, kz, 0, 0.0).view(x.shape)
-        return gx, gw, gb, None
+        return gx, rw, rb, None
 
 
 class _Concat2(torch.autograd.Function):
@@ -957,6 +980,7 @@ class _Linear(torch.autograd.Function):
         ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
         call("df_linear_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, K, N, _ptr(ws), nbytes, _stream())
         ctx.save_for_backward(x, w)
+        ctx.bptr = b.data_ptr()
         return y
 
     @staticmethod
@@ -965,11 +989,11 @@ class _Linear(torch.autograd.Function):
         gy = _prep(gy, "grad")
         B, K = x.shape
         N = w.shape[1]
-        gw = torch.empty_like(w)
-        gb = _empty((N,), x)
+        gw, rw = _grad_out(w.data_ptr(), w.shape, x.device)
+        gb, rb = _grad_out(ctx.bptr, (N,), x.device)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         call("df_linear_bwd", _ptr(x), _ptr(w), _ptr(gy), _ptr(gx), _ptr(gw), _ptr(gb), B, K, N, _stream())
-        return gx, gw, gb
+        return gx, rw, rb
 
 
 class _Upsample2x(torch.autograd.Function):

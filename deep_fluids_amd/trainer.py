@@ -39,7 +39,7 @@ def default_config(**over):
              start_step=0, random_seed=123, num_samples=21000, c_num=3, use_curl3_alias=True,
              z_num=16, use_sparse=False, sparsity=0.01, w4=1.0, w5=1.0, p_num=2, x_channels=None, w3=0.005,
              log_step=500, test_step=1000, test_batch_size=100, model_dir=None, load_path="", code_path="", save_sec=3600,   # config.py:62-68
-             fused_tail=True, graph=False)
+             fused_tail=True, graph=False, direct_grads=True)
     c.update(over)
     return SimpleNamespace(**c)
 
@@ -133,6 +133,21 @@ class Trainer(object):
             self.G_var.append(v)
             off += n
         self.n_params = total
+        self._register_direct_grads()
+
+    _direct_grads_ok = True          # False in trainers whose variables receive more than one gradient per step (GANTrainer)
+
+    def _register_direct_grads(self):
+        """The gradient kernels write straight into the flat gradient slab (ops._DIRECT_GRADS) where every variable receives exactly one
+        gradient per backward pass: the `de` / `ae` trainers of a single process.  Not under data parallelism (its post-accumulate hooks would
+        never fire: enable_data_parallel un-registers) and not in the GAN trainer."""
+        if self._direct_grads_ok and bool(getattr(self.config, "direct_grads", True)):
+            for v in self.G_var:
+                ops._DIRECT_GRADS[v.data_ptr()] = v.grad
+
+    def _unregister_direct_grads(self):
+        for v in self.G_var:
+            ops._DIRECT_GRADS.pop(v.data_ptr(), None)
 
     def load_variables(self, params):
         """Inject weights by slim name (dict name -> ndarray), e.g. from the oracle's generator_init."""
@@ -229,6 +244,8 @@ class Trainer(object):
             n = sum(self.var_slices[k][1] for k in ks)
             buckets.append((off, n, [ops._VARS[k] for k in ks]))
         self.grad_sync = GradSync(self.flat_g, buckets, group, profile=profile, force=force)
+        if self.grad_sync.enabled:
+            self._unregister_direct_grads()      # the exchange is driven by post-accumulate hooks: gradients must go through AccumulateGrad
         self.sync_state_from_rank0(group)
         return self.grad_sync
 
@@ -716,6 +733,7 @@ class GANTrainer(Trainer):
     forward pass like ``sess.run([g_optim, d_optim])`` (trainer.py:149-156, 174-184, 265-267; trainer3.py:26-33,53-63)."""
 
     _restore_in_base = False
+    _direct_grads_ok = False      # G's backward runs inside a graph that also reaches D's variables (applied twice): classic accumulation
 
     def __init__(self, config, device="cuda", name="G"):
         self.w3 = config.w3

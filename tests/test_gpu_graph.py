@@ -46,11 +46,11 @@ def _batches(name, kw, B, n):
     return out
 
 
-def _run(name, graph, steps=5):
+def _run(name, graph, steps=5, **extra):
     from deep_fluids_amd import ops, trainer as T
     cls, kw, B = CASES[name]
     ops.reset_variables()
-    cfg = T.default_config(batch_size=B, num_samples=B * 8, max_epoch=1, graph=graph, **kw)      # max_step = 8: a visible cosine
+    cfg = T.default_config(batch_size=B, num_samples=B * 8, max_epoch=1, graph=graph, **dict(kw, **extra))      # max_step = 8: a visible cosine
     tr = getattr(T, cls)(cfg)
     losses = []
     for x, y in _batches(name, kw, B, steps):
@@ -177,3 +177,32 @@ def test_concurrent_weight_gradient_lane_is_bitwise_the_serial_order(name):
     np.testing.assert_array_equal(a["loss"], b["loss"])
     for k in ("p", "m", "v", "g"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["de2", "de3_f128", "de3_unfused_tail", "ae2", "ae3_sparse"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_direct_gradient_targets_are_bitwise_the_accumulated_gradients(name, graph):
+    """config.direct_grads: the weight / bias gradient kernels write their variable's slice of the flat gradient slab themselves instead of
+    returning a tensor that AccumulateGrad adds to the zeroed slab (the reference's optimizer consumes tf.gradients' outputs directly,
+    trainer.py:149-152).  0 + g == g: parameters, Adam slots, gradients and losses are bitwise equal, eager and captured."""
+    from deep_fluids_amd import ops
+    a = _run(name, graph, 3, direct_grads=False)
+    assert not ops._DIRECT_GRADS
+    b = _run(name, graph, 3, direct_grads=True)
+    np.testing.assert_array_equal(a["loss"], b["loss"])
+    for k in ("p", "m", "v", "g", "u"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_direct_gradient_targets_are_off_where_a_variable_gets_two_gradients_or_hooks():
+    from deep_fluids_amd import ops, trainer as T
+    ops.reset_variables()
+    tr = T.GANTrainer(T.default_config(is_3d=False, res_x=32, res_y=64, filters=32, arch="dg", batch_size=2))
+    assert not ops._DIRECT_GRADS
+    del tr
+    ops.reset_variables()
+    tr = T.Trainer(T.default_config(is_3d=False, res_x=32, res_y=64, filters=32, batch_size=2))
+    assert len(ops._DIRECT_GRADS) == len(tr.G_var)
+    tr._unregister_direct_grads()
+    assert not ops._DIRECT_GRADS
+    ops.reset_variables()
