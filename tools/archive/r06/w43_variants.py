@@ -9,7 +9,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 from deep_fluids_amd.ops import _ptr, _stream  # noqa: E402
 from tools.gpu_probe import timeit  # noqa: E402
