@@ -141,6 +141,7 @@ class Trainer(object):
         """The gradient kernels write straight into the flat gradient slab (ops._DIRECT_GRADS) where every variable receives exactly one
         gradient per backward pass: the `de` / `ae` trainers of a single process.  Not under data parallelism (its post-accumulate hooks would
         never fire: enable_data_parallel un-registers) and not in the GAN trainer."""
+        ops._DIRECT_GRADS.clear()      # the variable store (ops._VARS) has ONE owner at a time: targets of an earlier trainer are stale pointers
         if self._direct_grads_ok and bool(getattr(self.config, "direct_grads", True)):
             for v in self.G_var:
                 ops._DIRECT_GRADS[v.data_ptr()] = v.grad
