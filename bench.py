@@ -137,7 +137,7 @@ def select_kernel(name, args):
         return ("wino3d_27pt_kernel %s -> %dx%dx%d C%d->%d" % (kind, 2 * Dc, 2 * Hc, 2 * Wc, cin, cout), 2.0 * 27 * cin * cout * B * 8 * Dc * Hc * Wc)
     if name == "df_wino2d43_conv":      # F(2,3) x F(4,3): 3 of the 9 direct-form multiply-adds
         B, H, W, cin, cout = args[6:11]
-        return ("wino2d43_kernel fwd %dx%d C%d->%d" % (H, W, cin, cout), 2.0 * 9 * cin * cout * B * H * W)
+        return ("wino2d43_kernel fwd/dgrad %dx%d C%d->%d" % (H, W, cin, cout), 2.0 * 9 * cin * cout * B * H * W)
     if name == "df_wino2d_conv_fwd":
         B, H, W, cin, cout = args[6:11]
         return ("wino2d_kernel fwd/dgrad %dx%d C%d->%d" % (H, W, cin, cout), 2.0 * 9 * cin * cout * B * H * W)
@@ -592,7 +592,8 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
             r = {"ms_per_step": el * 1e3, "value": 64 * 128 * 96 / el, "unit": "pixels/s", "batch": 64, "l1_vs_ref": rel,
                  "conv_tflops_reference_equivalent": 3.71e12 / el / 1e12}
             if rf:
-                r["roofline"] = rf.get("roofline_wino2d")              # the F(2,3)^2 kernel (dgrads); the forward convs' F(2,3) x F(4,3) kernel beside it
+                # the F(2,3) x F(4,3) kernel (forward convs and dgrads since the 16-byte epilogue); ops.WINO2D_FAMILY "auto" / "f22": the F(2,3)^2 kernel
+                r["roofline"] = rf.get("roofline_wino2d43") or rf.get("roofline_wino2d")
                 r["roofline_fwd_f24"] = rf.get("roofline_wino2d43")
                 r["roofline_wgrad"] = rf.get("roofline_wgrad")
                 r["roofline_stencil"] = rf.get("roofline_jacobian2d")

@@ -113,7 +113,7 @@ template <int FL>
 __global__ __launch_bounds__(kT, 1) void wino2d43_kernel(const W2Args a) {
   __shared__ __attribute__((aligned(16))) float sIn[2 * BUFF];
   __shared__ __attribute__((aligned(16))) float sXb[8192];      // exchange area of cout block 1 (block 0 goes through the idle input buffer)
-  __shared__ float sBias[32];
+  __shared__ __attribute__((aligned(16))) float sBias[32];
 
   const int eflags = FL >= 0 ? FL : a.flags;
   const int tid = threadIdx.x;
@@ -339,43 +339,66 @@ __global__ __launch_bounds__(kT, 1) void wino2d43_kernel(const W2Args a) {
       }
     }
     const int etx0 = (kq & 1) * 4;
-    const int64_t obase = ((static_cast<int64_t>(cur.b) * a.H + oy) * a.W + cur.x0 + 2 * yh) * a.Cout + n0 + tl;
-    const int64_t sW_ = a.Cout, sH_ = static_cast<int64_t>(a.W) * a.Cout;
+    // The combined 2 x 2 output patch of a tile's x pair sits in ONE lane per cout (lane = (cout tl, tile quad kq), element e): a 4 x 4 transpose
+    // inside every lane quad (couts 4 m .. 4 m + 3) x (the patch's 4 pixels) hands lane i of the quad pixel i for the four couts -- every store,
+    // residual load and lrelu-mask load of the epilogue is then ONE 16-byte access per lane (four lanes = the 64 contiguous bytes of a pixel's 16
+    // couts) instead of four 4-byte ones: 8 stores per lane and tile block instead of 32, and the masked dgrad's 32 mask loads become 8.
+    // Same values through the same operations in the same order: bit-identical to the per-cout epilogue.
+    const int qi = tl & 3, qm = tl >> 2;
+    const bool odd1 = (qi & 1) != 0, odd2 = (qi & 2) != 0;
+    auto quad_t = [&](const f32x4& v) -> f32x4 {
+      // stage 1: swap bit 0 of (lane, register): registers (0, 1) and (2, 3) with lane ^ 1;  stage 2: bit 1: registers (0, 2) and (1, 3) with lane ^ 2
+      auto dpp1 = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)); };
+      auto dpp2 = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)); };
+      const float p0 = dpp1(v[0]), p1 = dpp1(v[1]), p2 = dpp1(v[2]), p3 = dpp1(v[3]);
+      const f32x4 a1 = {odd1 ? p1 : v[0], odd1 ? v[1] : p0, odd1 ? p3 : v[2], odd1 ? v[3] : p2};
+      const float r0 = dpp2(a1[0]), r1 = dpp2(a1[1]), r2 = dpp2(a1[2]), r3 = dpp2(a1[3]);
+      return f32x4{odd2 ? r2 : a1[0], odd2 ? r3 : a1[1], odd2 ? a1[2] : r0, odd2 ? a1[3] : r1};
+    };
+    const int py = oy + (qi >> 1);
+    const int64_t sW_ = a.Cout;
+    // element offset of (pixel qi of the patch of tile column etx0, couts 4 qm ..): + 4 e sW_ per tile column, + 16 per cout block
+    const int64_t obase = ((static_cast<int64_t>(cur.b) * a.H + py) * a.W + cur.x0 + 4 * etx0 + 2 * yh + (qi & 1)) * a.Cout + n0 + 4 * qm;
     lds_barrier();
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      const float bv = sBias[nb * 16 + tl];
-      float rres[4][4], rmsk[4][4];      // residual / mask operands of this cout block's 16 outputs: the loads are issued together (full blocks)
+      const f32x4 bv4 = *reinterpret_cast<const f32x4*>(&sBias[nb * 16 + 4 * qm]);
+      f32x4 rres[4], rmsk[4];      // residual / mask operands of this cout block: the loads are issued together (full blocks)
       if (full && (eflags & (DF_CONV_RESIDUAL | DF_CONV_MASK))) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int s_ = 0; s_ < 4; ++s_) {
-            const int64_t o = obase + nb * 16 + (4 * (etx0 + e) + (s_ & 1)) * sW_ + (s_ >> 1) * sH_;
-            rres[e][s_] = (eflags & DF_CONV_RESIDUAL) ? a.residual[o] : 0.f;
-            rmsk[e][s_] = (eflags & DF_CONV_MASK) ? a.mask_src[o] : 1.f;
-          }
+        for (int e = 0; e < 4; ++e) {
+          const int64_t o = obase + nb * 16 + 4 * e * sW_;
+          if (eflags & DF_CONV_RESIDUAL) rres[e] = *reinterpret_cast<const f32x4*>(a.residual + o);
+          if (eflags & DF_CONV_MASK) rmsk[e] = *reinterpret_cast<const f32x4*>(a.mask_src + o);
+        }
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const f32x4 q = sYn[nb][(((1 - yh) * 4 + rp) * 4 + e) * 64 + lane];
         // (fixed order: the xi_y 0, 1 half first, then the xi_y 2, 3 half -- whichever wave finishes)
-        const f32x4 v4 = yh == 0 ? mine[nb][e] + q : q + mine[nb][e];
-        const int ox = cur.x0 + 4 * (etx0 + e) + 2 * yh;
+        const f32x4 v4 = quad_t(yh == 0 ? mine[nb][e] + q : q + mine[nb][e]);      // couts 4 qm .. 4 qm + 3 of pixel qi
+        const int px = cur.x0 + 4 * (etx0 + e) + 2 * yh + (qi & 1);
+        const int64_t o = obase + nb * 16 + 4 * e * sW_;
+        f32x4 v = v4 + bv4;
+        if (eflags & DF_CONV_LRELU) {
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-          const int64_t o = obase + nb * 16 + (4 * (etx0 + e) + (s_ & 1)) * sW_ + (s_ >> 1) * sH_;
-          float v = v4[s_] + bv;
-          if (eflags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
-          if (full) {
-            if (eflags & DF_CONV_RESIDUAL) v += rres[e][s_];
-            if (eflags & DF_CONV_MASK) v = rmsk[e][s_] > 0.f ? v : a.leak * v;
-            a.y[o] = v;
-          } else if (oy + (s_ >> 1) < a.H && ox + (s_ & 1) < a.W) {
-            if (eflags & DF_CONV_RESIDUAL) v += a.residual[o];
-            if (eflags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
-            a.y[o] = v;
+          for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], a.leak * v[c]);
+        }
+        if (full) {
+          if (eflags & DF_CONV_RESIDUAL) v += rres[e];
+          if (eflags & DF_CONV_MASK) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = rmsk[e][c] > 0.f ? v[c] : a.leak * v[c];
           }
+          *reinterpret_cast<f32x4*>(a.y + o) = v;
+        } else if (py < a.H && px < a.W) {
+          if (eflags & DF_CONV_RESIDUAL) v += *reinterpret_cast<const f32x4*>(a.residual + o);
+          if (eflags & DF_CONV_MASK) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask_src + o);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = mk[c] > 0.f ? v[c] : a.leak * v[c];
+          }
+          *reinterpret_cast<f32x4*>(a.y + o) = v;
         }
       }
     }
@@ -432,7 +455,9 @@ int df_wino2d43_conv(const float* x, const float* wp, const float* bias, const f
   DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "df_wino2d43_conv: DF_CONV_BIAS without bias");
   DF_REQUIRE(!(flags & DF_CONV_RESIDUAL) || residual, DF_EINVAL, "df_wino2d43_conv: DF_CONV_RESIDUAL without residual");
   DF_REQUIRE(!(flags & DF_CONV_MASK) || mask_src, DF_EINVAL, "df_wino2d43_conv: DF_CONV_MASK without mask_src");
-  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x), DF_EALIGN, "df_wino2d43_conv: x and packed weights must be 16-byte aligned");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x) && df::aligned16(y) && (!(flags & DF_CONV_RESIDUAL) || df::aligned16(residual)) &&
+                 (!(flags & DF_CONV_MASK) || df::aligned16(mask_src)),
+             DF_EALIGN, "df_wino2d43_conv: x, y, residual, mask_src and the packed weights must be 16-byte aligned");
   W2Args a;
   a.x = x; a.wp = wp; a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y;
   a.B = (int)B; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;

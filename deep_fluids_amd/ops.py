@@ -319,11 +319,12 @@ class _WgradLane(object):
 # The 27-point forms of an up-sampling block's first conv (forward / pooled adjoint) exist in the F(2,3)^3 family only; both families write /
 # read the same sign-word layout, so they mix freely inside a block.
 WINO3D_FAMILY = _os.environ.get("DF_WINO3D_FAMILY", "f224")
-# ... and the 2-D twin: "f24" = F(2,3) x F(4,3) (conv_wino2d43.hip: 3 multiply-adds per output pixel and channel pair), "f22" = F(2,3)^2
-# (conv_wino2d.hip: 4), "auto" (default) = f24 for the forward convs, f22 for the dgrads: measured at cfg2's top level (profiles/r06_probes.md
-# section 4) the new kernel is 12 % faster forward (0.99 vs 1.13 ms) and 5 % SLOWER as the masked dgrad (1.18 vs 1.12 ms: its fp32 mask
-# reads are not hidden).  The 9-point forms of an up-sampling block's first conv exist in the F(2,3)^2 family only.
-WINO2D_FAMILY = _os.environ.get("DF_WINO2D_FAMILY", "auto")
+# ... and the 2-D twin: "f24" (default) = F(2,3) x F(4,3) (conv_wino2d43.hip: 3 multiply-adds per output pixel and channel pair) for forward convs
+# and dgrads, "f22" = F(2,3)^2 (conv_wino2d.hip: 4), "auto" = f24 for the forward convs, f22 for the dgrads (the default before the f24
+# epilogue moved to 16-byte accesses along the channels -- its 32 scalar fp32 mask reads per lane were not hidden; now 8 float4 reads: cfg2
+# step 16.93 ms with "auto", 16.46 with "f24", profiles/r06_probes.md section 7).  The 9-point forms of an up-sampling block's first conv
+# exist in the F(2,3)^2 family only.
+WINO2D_FAMILY = _os.environ.get("DF_WINO2D_FAMILY", "f24")
 
 
 def _w2fam(mode):
