@@ -393,7 +393,6 @@ __global__ __launch_bounds__(kT, 1) void wino43_kernel(const W43Args a) {
     const int64_t sW = a.Cout, sH = static_cast<int64_t>(a.W) * a.Cout, sD = sH * a.H;
     const int64_t obase = (((static_cast<int64_t>(cur.b) * a.D + oz0) * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl;
     const bool full = cur.z0 + 4 <= a.D && cur.y0 + 8 <= a.H && cur.x0 + 8 <= a.W;
-    const unsigned lane_off = static_cast<unsigned>(((oz0 * a.H + oy0) * a.W + ox0) * a.Cout + n0 + tl) * 4u;
     constexpr bool SB = FL >= 0 && (FL & kSignBits) != 0, MB = FL >= 0 && (FL & kMaskBits) != 0, NOY = FL >= 0 && (FL & kNoPrimary) != 0;
     const int64_t wbase = (static_cast<int64_t>(cur.id) * a.ncs + cs) * kBitBytesPerBlock + wave * 128 + lane;
     // DF_CONV_ADDUP: the 2x2x2 outputs of this lane share ONE coarse voxel of the skip tensor per cout block; both are requested here, in front
@@ -453,6 +452,55 @@ __global__ __launch_bounds__(kT, 1) void wino43_kernel(const W43Args a) {
       const f32x4 m2 = sO[((2 * 2 + th) * 4 + xz) * 64 + lane], m3 = sO[((3 * 2 + th) * 4 + xz) * 64 + lane];
       const f32x4 lo = m0 + m1 + m2, hi = m1 - m2 - m3;
       const float rup = rupv[nb];
+      if (full) {
+        // Full blocks: everything per-cout (bias, lrelu, sign bits, mask from sign words) happens in the accumulator layout -- one lane = one cout, its
+        // 2 x 2 x 2 outputs -- then a 4 x 4 transpose inside every lane quad (conv_wino2d43.hip::quad_t) hands lane i of the quad the outputs (dy, dx) = i
+        // of both z for the quad's four couts: the stores (and the fp32 residual / mask operands where a variant has them) are 16-byte accesses, 2 per
+        // lane and cout block instead of 8.  Same values, same operations, same order per element: bit-identical.
+        f32x4 vz[2];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          float v = (s < 4 ? lo[s & 3] : hi[s & 3]) + bv;
+          if (eflags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
+          if (SB) sbyte |= v > 0.f ? (1u << s) : 0u;
+          vz[s >> 2][s & 3] = v;
+        }
+        const int qi = tl & 3;
+        const bool odd1 = (qi & 1) != 0, odd2 = (qi & 2) != 0;
+        auto quad_t = [&](const f32x4& v) -> f32x4 {
+          auto dpp1 = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)); };
+          auto dpp2 = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)); };
+          const float p0 = dpp1(v[0]), p1 = dpp1(v[1]), p2 = dpp1(v[2]), p3 = dpp1(v[3]);
+          const f32x4 a1 = {odd1 ? p1 : v[0], odd1 ? v[1] : p0, odd1 ? p3 : v[2], odd1 ? v[3] : p2};
+          const float r0 = dpp2(a1[0]), r1 = dpp2(a1[1]), r2 = dpp2(a1[2]), r3 = dpp2(a1[3]);
+          return f32x4{odd2 ? r2 : a1[0], odd2 ? r3 : a1[1], odd2 ? a1[2] : r0, odd2 ? a1[3] : r1};
+        };
+        // this lane after the transpose: voxel (oz0 + z, oy0 + (qi >> 1), ox0 + (qi & 1)), couts n0 + nb * 16 + 4 (tl >> 2) .. + 3
+        const int64_t o4 = obase - tl + 4 * (tl >> 2) + nb * 16 + (qi >> 1) * sH + (qi & 1) * sW;
+        const float rup4s = rup;
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+          if (eflags & DF_CONV_RESIDUAL) {      // (per-cout layout: the operand of the lane's own 4 outputs of this z)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vz[z][c] += rres[z * 4 + c];
+          }
+          if (eflags & DF_CONV_MASK) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int sidx = z * 4 + c;
+              const bool pos = MB ? ((mbyte >> sidx) & 1u) != 0u
+                                  : a.mask_src[obase + nb * 16 + (sidx >> 2) * sD + ((sidx >> 1) & 1) * sH + (sidx & 1) * sW] > 0.f;
+              vz[z][c] = pos ? vz[z][c] : a.leak * vz[z][c];
+            }
+          }
+          const int64_t o = o4 + z * sD;
+          if (!NOY) *reinterpret_cast<f32x4*>(a.y + o) = quad_t(vz[z]);
+          if (eflags & DF_CONV_ADDUP) {
+            const f32x4 w = {vz[z][0] + rup4s, vz[z][1] + rup4s, vz[z][2] + rup4s, vz[z][3] + rup4s};
+            *reinterpret_cast<f32x4*>(a.y2 + o) = quad_t(w);
+          }
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         float v = (s < 4 ? lo[s & 3] : hi[s & 3]) + bv;
@@ -460,23 +508,13 @@ __global__ __launch_bounds__(kT, 1) void wino43_kernel(const W43Args a) {
         const int64_t o = obase + nb * 16 + (s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW;
         if (SB) sbyte |= v > 0.f ? (1u << s) : 0u;
         const bool mpos = !MB || ((mbyte >> s) & 1u) != 0u;
-        if (full) {
-          if (eflags & DF_CONV_RESIDUAL) v += rres[s];
-          if (eflags & DF_CONV_MASK) v = (MB ? mpos : a.mask_src[o] > 0.f) ? v : a.leak * v;
-          char* yb = reinterpret_cast<char*>(a.y + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
-                                             ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
-          if (!NOY) *reinterpret_cast<float*>(yb + lane_off) = v;
-          if (eflags & DF_CONV_ADDUP) {
-            char* yb2 = reinterpret_cast<char*>(a.y2 + static_cast<int64_t>(cur.b) * a.D * a.H * a.W * a.Cout +
-                                                ((s >> 2) * sD + ((s >> 1) & 1) * sH + (s & 1) * sW) + nb * 16);
-            *reinterpret_cast<float*>(yb2 + lane_off) = v + rup;
-          }
-        } else if (oz0 + (s >> 2) < a.D && oy0 + ((s >> 1) & 1) < a.H && ox0 + (s & 1) < a.W) {
+        if (oz0 + (s >> 2) < a.D && oy0 + ((s >> 1) & 1) < a.H && ox0 + (s & 1) < a.W) {
           if (eflags & DF_CONV_RESIDUAL) v += a.residual[o];
           if (eflags & DF_CONV_MASK) v = (MB ? mpos : a.mask_src[o] > 0.f) ? v : a.leak * v;
           if (!NOY) a.y[o] = v;
           if (eflags & DF_CONV_ADDUP) a.y2[o] = v + rup;
         }
+      }
       }
       if (SB) a.bits_out[wbase + nb * 64] = static_cast<unsigned char>(sbyte);
     }
@@ -541,8 +579,8 @@ int df_wino43_conv(const float* x, const float* wp, const float* bias, const flo
   DF_REQUIRE(!(flags & DF_CONV_MASK) || ((mask_src != nullptr) != (mask_bits != nullptr)), DF_EINVAL,
              "df_wino43_conv: DF_CONV_MASK needs exactly one of mask_src / mask_bits");
   DF_REQUIRE(y || ((flags & DF_CONV_ADDUP) && sign_bits), DF_EINVAL, "df_wino43_conv: y may be null only with ADDUP + sign_bits");
-  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x) && df::aligned16(mask_bits) && df::aligned16(sign_bits), DF_EALIGN,
-             "df_wino43_conv: x, packed weights and bit words must be 16-byte aligned");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x) && df::aligned16(mask_bits) && df::aligned16(sign_bits) && df::aligned16(y) && df::aligned16(y2),
+             DF_EALIGN, "df_wino43_conv: x, y, y2, packed weights and bit words must be 16-byte aligned");
   W43Args a;
   a.x = x; a.wp = wp; a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y; a.y2 = y2;
   a.bits_out = static_cast<unsigned char*>(sign_bits); a.bits_in = static_cast<const unsigned char*>(mask_bits);
