@@ -33,6 +33,7 @@ constexpr int CP = HY * PY + 2;                    // dwords per channel plane (
 constexpr int NLOAD = 5;                           // ceil(612 * 4 float4 pieces / 512 threads)
 constexpr int BUFF = CKW * CP;
 constexpr int kPts = 24;
+constexpr int kSignBits = 64, kMaskBits = 128;      // internal epilogue flags (compile-time variants only), as conv_wino43.hip
 
 struct W2Args {
   const float* x;
@@ -41,6 +42,8 @@ struct W2Args {
   const float* residual;
   const float* mask_src;
   float* y;
+  unsigned* bits_out;          // sign words of the output (kSignBits): one 32-bit word per (tile block, cout slice, thread)
+  const unsigned* bits_in;     // ... of the activation whose lrelu slope masks this dgrad (kMaskBits)
   int B, H, W, Cin, Cout;
   int nby, nbx, ntb, ncs, spx;
   int flags;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(64) void wino2d43_pack_kernel(const float* __restri
   }
 }
 
-struct Blk { const float* xb; int hoff, b, y0, x0; };
+struct Blk { const float* xb; int hoff, b, y0, x0, id; };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(kT, 1) void wino2d43_kernel(const W2Args a) {
   const int niter = (a.ntb - tb0 + tstride - 1) / tstride;
   auto decode = [&](int t) -> Blk {
     Blk bi;
+    bi.id = t;
     const int bx = t % a.nbx;
     const int t2 = t / a.nbx;
     const int by = t2 % a.nby;
@@ -356,6 +360,14 @@ __global__ __launch_bounds__(kT, 1) void wino2d43_kernel(const W2Args a) {
       return f32x4{odd2 ? r2 : a1[0], odd2 ? r3 : a1[1], odd2 ? a1[2] : r0, odd2 ? a1[3] : r1};
     };
     const int py = oy + (qi >> 1);
+    // Sign words (the 2-D twin of conv_wino43.hip's): after the transpose a lane holds, per cout block nb and tile column e, pixel qi of the patch
+    // for couts 4 qm .. 4 qm + 3 -- 2 x 4 x 4 = 32 outputs per tile block = ONE 32-bit word, bit (nb * 4 + e) * 4 + c.  The forward conv whose
+    // output only serves as the lrelu mask of the next layer's dgrad writes (activation > 0) there; that dgrad -- the same kernel on a tensor of the
+    // same shape, hence the same (tile block, cout slice, thread) <-> output mapping -- reads the word instead of 32 fp32 activations.
+    constexpr bool SB = FL >= 0 && (FL & kSignBits) != 0, MB = FL >= 0 && (FL & kMaskBits) != 0;
+    const int64_t widx = (static_cast<int64_t>(cur.id) * a.ncs + cs) * kT + tid;
+    unsigned sword = 0u, mword = 0u;
+    if (MB) mword = a.bits_in[widx];
     const int64_t sW_ = a.Cout;
     // element offset of (pixel qi of the patch of tile column etx0, couts 4 qm ..): + 4 e sW_ per tile column, + 16 per cout block
     const int64_t obase = ((static_cast<int64_t>(cur.b) * a.H + py) * a.W + cur.x0 + 4 * etx0 + 2 * yh + (qi & 1)) * a.Cout + n0 + 4 * qm;
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(kT, 1) void wino2d43_kernel(const W2Args a) {
         for (int e = 0; e < 4; ++e) {
           const int64_t o = obase + nb * 16 + 4 * e * sW_;
           if (eflags & DF_CONV_RESIDUAL) rres[e] = *reinterpret_cast<const f32x4*>(a.residual + o);
-          if (eflags & DF_CONV_MASK) rmsk[e] = *reinterpret_cast<const f32x4*>(a.mask_src + o);
+          if ((eflags & DF_CONV_MASK) && !MB) rmsk[e] = *reinterpret_cast<const f32x4*>(a.mask_src + o);
         }
       }
 #pragma unroll
@@ -384,24 +396,30 @@ __global__ __launch_bounds__(kT, 1) void wino2d43_kernel(const W2Args a) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], a.leak * v[c]);
         }
+        if (SB) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sword |= v[c] > 0.f ? (1u << ((nb * 4 + e) * 4 + c)) : 0u;
+        }
         if (full) {
           if (eflags & DF_CONV_RESIDUAL) v += rres[e];
           if (eflags & DF_CONV_MASK) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = rmsk[e][c] > 0.f ? v[c] : a.leak * v[c];
+            for (int c = 0; c < 4; ++c) v[c] = (MB ? ((mword >> ((nb * 4 + e) * 4 + c)) & 1u) != 0u : rmsk[e][c] > 0.f) ? v[c] : a.leak * v[c];
           }
           *reinterpret_cast<f32x4*>(a.y + o) = v;
         } else if (py < a.H && px < a.W) {
           if (eflags & DF_CONV_RESIDUAL) v += *reinterpret_cast<const f32x4*>(a.residual + o);
           if (eflags & DF_CONV_MASK) {
-            const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask_src + o);
+            f32x4 mk = {0.f, 0.f, 0.f, 0.f};
+            if (!MB) mk = *reinterpret_cast<const f32x4*>(a.mask_src + o);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = mk[c] > 0.f ? v[c] : a.leak * v[c];
+            for (int c = 0; c < 4; ++c) v[c] = (MB ? ((mword >> ((nb * 4 + e) * 4 + c)) & 1u) != 0u : mk[c] > 0.f) ? v[c] : a.leak * v[c];
           }
           *reinterpret_cast<f32x4*>(a.y + o) = v;
         }
       }
     }
+    if (SB) a.bits_out[widx] = sword;
     lds_barrier();      // the exchange area is the next block's staging buffer
     pb = (pb + nchunk) & 1;
     cur = nxt;
@@ -444,37 +462,58 @@ int df_wino2d43_pack_weights(const float* w, float* wp, int64_t cin, int64_t cou
   return df::launched("df_wino2d43_pack_weights");
 }
 
-int df_wino2d43_conv(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src, float* y, int64_t B,
-                     int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream) {
-  DF_REQUIRE(x && wp && y, DF_EINVAL, "df_wino2d43_conv: null pointer");
-  DF_REQUIRE(B > 0 && H > 0 && W > 0, DF_EINVAL, "df_wino2d43_conv: non-positive extent");
-  DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE, "df_wino2d43_conv: Cin, Cout must be multiples of 32");
-  DF_REQUIRE(H * W * (Cin > Cout ? Cin : Cout) <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
-             "df_wino2d43_conv: one image must stay below 2 GiB");
-  DF_REQUIRE(!(flags & ~(DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_RESIDUAL | DF_CONV_MASK)), DF_EINVAL, "df_wino2d43_conv: unknown flag");
-  DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "df_wino2d43_conv: DF_CONV_BIAS without bias");
-  DF_REQUIRE(!(flags & DF_CONV_RESIDUAL) || residual, DF_EINVAL, "df_wino2d43_conv: DF_CONV_RESIDUAL without residual");
-  DF_REQUIRE(!(flags & DF_CONV_MASK) || mask_src, DF_EINVAL, "df_wino2d43_conv: DF_CONV_MASK without mask_src");
+static int w2_conv(const char* fn, const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src, const void* mask_bits,
+                   float* y, void* sign_bits, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream) {
+  DF_REQUIRE(x && wp && y, DF_EINVAL, "%s: null pointer", fn);
+  DF_REQUIRE(B > 0 && H > 0 && W > 0, DF_EINVAL, "%s: non-positive extent", fn);
+  DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE, "%s: Cin, Cout must be multiples of 32", fn);
+  DF_REQUIRE(H * W * (Cin > Cout ? Cin : Cout) <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE, "%s: one image must stay below 2 GiB", fn);
+  DF_REQUIRE(!(flags & ~(DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_RESIDUAL | DF_CONV_MASK)), DF_EINVAL, "%s: unknown flag", fn);
+  DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "%s: DF_CONV_BIAS without bias", fn);
+  DF_REQUIRE(!(flags & DF_CONV_RESIDUAL) || residual, DF_EINVAL, "%s: DF_CONV_RESIDUAL without residual", fn);
+  DF_REQUIRE(!(flags & DF_CONV_MASK) || ((mask_src != nullptr) != (mask_bits != nullptr)), DF_EINVAL, "%s: DF_CONV_MASK needs exactly one of mask_src / mask_bits", fn);
   DF_REQUIRE(df::aligned16(wp) && df::aligned16(x) && df::aligned16(y) && (!(flags & DF_CONV_RESIDUAL) || df::aligned16(residual)) &&
-                 (!(flags & DF_CONV_MASK) || df::aligned16(mask_src)),
-             DF_EALIGN, "df_wino2d43_conv: x, y, residual, mask_src and the packed weights must be 16-byte aligned");
+                 (!(flags & DF_CONV_MASK) || df::aligned16(mask_src)) && df::aligned16(mask_bits) && df::aligned16(sign_bits),
+             DF_EALIGN, "%s: x, y, residual, mask_src, the bit words and the packed weights must be 16-byte aligned", fn);
   W2Args a;
   a.x = x; a.wp = wp; a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y;
+  a.bits_out = static_cast<unsigned*>(sign_bits); a.bits_in = static_cast<const unsigned*>(mask_bits);
   a.B = (int)B; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
   a.nby = (int)ceil_div(H, 16); a.nbx = (int)ceil_div(W, 32);
   const int64_t ntb = B * a.nby * a.nbx;
   a.ncs = (int)(Cout / 32);
-  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "df_wino2d43_conv: too many workgroups");
+  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "%s: too many workgroups", fn);
   a.ntb = (int)ntb;
   a.flags = flags; a.leak = leak;
   const int64_t grid = w2_grid(a, ntb);
   const dim3 g((unsigned)grid), b(kT);
   hipStream_t s = df::as_stream(stream);
-  if (flags == (DF_CONV_BIAS | DF_CONV_LRELU)) hipLaunchKernelGGL((wino2d43_kernel<DF_CONV_BIAS | DF_CONV_LRELU>), g, b, 0, s, a);
+  if (sign_bits || mask_bits) {
+    if (flags == (DF_CONV_BIAS | DF_CONV_LRELU) && sign_bits && !mask_bits) hipLaunchKernelGGL((wino2d43_kernel<DF_CONV_BIAS | DF_CONV_LRELU | kSignBits>), g, b, 0, s, a);
+    else if (flags == DF_CONV_MASK && mask_bits && !sign_bits) hipLaunchKernelGGL((wino2d43_kernel<DF_CONV_MASK | kMaskBits>), g, b, 0, s, a);
+    else return df::fail(DF_EINVAL, "%s: sign words exist for BIAS | LRELU (+ sign_bits) and MASK (+ mask_bits) only", fn);
+  }
+  else if (flags == (DF_CONV_BIAS | DF_CONV_LRELU)) hipLaunchKernelGGL((wino2d43_kernel<DF_CONV_BIAS | DF_CONV_LRELU>), g, b, 0, s, a);
   else if (flags == DF_CONV_MASK) hipLaunchKernelGGL((wino2d43_kernel<DF_CONV_MASK>), g, b, 0, s, a);
   else if (flags == DF_CONV_RESIDUAL) hipLaunchKernelGGL((wino2d43_kernel<DF_CONV_RESIDUAL>), g, b, 0, s, a);
   else hipLaunchKernelGGL((wino2d43_kernel<-1>), g, b, 0, s, a);
-  return df::launched("df_wino2d43_conv");
+  return df::launched(fn);
+}
+
+int df_wino2d43_conv(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src, float* y, int64_t B,
+                     int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream) {
+  return w2_conv("df_wino2d43_conv", x, wp, bias, residual, mask_src, nullptr, y, nullptr, B, H, W, Cin, Cout, flags, leak, stream);
+}
+
+int64_t df_wino2d43_signbits_bytes(int64_t B, int64_t H, int64_t W, int64_t C) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32) return 0;
+  return B * ceil_div(H, 16) * ceil_div(W, 32) * (C / 32) * kT * 4;
+}
+
+int df_wino2d43_conv_bits(const float* x, const float* wp, const float* bias, const void* mask_bits, float* y, void* sign_bits, int64_t B, int64_t H,
+                          int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream) {
+  DF_REQUIRE((sign_bits != nullptr) != (mask_bits != nullptr), DF_EINVAL, "df_wino2d43_conv_bits: exactly one of sign_bits (forward) / mask_bits (dgrad)");
+  return w2_conv("df_wino2d43_conv_bits", x, wp, bias, nullptr, nullptr, mask_bits, y, sign_bits, B, H, W, Cin, Cout, flags, leak, stream);
 }
 
 }  // extern "C"

@@ -367,10 +367,37 @@ def _pack(w, taps, cin, cout, mode, dims=None, fp32=False, family=None):
 SIGN_BIT_MASKS = _os.environ.get("DF_SIGN_BIT_MASKS", "1") != "0"
 
 
-def _new_bits(dims, c, like):
+def _bits_kind(cin, cout, dims, kz):
+    """Which sign-word layout a forward conv (cin -> cout on `dims`) can emit for the masked dgrad of the layer above: 0 none, 3 the 3-D Winograd
+    kernels' bytes (both 3-D families read and write them), 2 the words of the 2-D F(2,3) x F(4,3) kernel -- only where the dgrads run on that
+    kernel too (WINO2D_FAMILY "f24": forward and dgrad share the thread <-> output mapping the words are indexed by)."""
+    if not SIGN_BIT_MASKS:
+        return 0
+    algo = _use_wino(cin, cout, dims, kz)
+    if algo == 3:
+        return 3
+    return 2 if (algo == 2 and _w2fam(0) == "f24" and _w2fam(1) == "f24") else 0
+
+
+def _new_bits(dims, c, like, kind=3):
     B, D, H, W = dims
-    nbytes = query("df_wino_signbits_bytes", B, D, H, W, c)
+    nbytes = query("df_wino_signbits_bytes", B, D, H, W, c) if kind == 3 else query("df_wino2d43_signbits_bytes", B, H, W, c)
     return torch.empty(nbytes // 8, dtype=torch.int64, device=like.device)
+
+
+def sign_words2d_to_mask(bits, dims, c):
+    """Decode the sign words of ``df_wino2d43_conv_bits`` (conv_wino2d43.hip) into a bool tensor ``[B, H, W, c]`` = (activation > 0).  One 32-bit word
+    per (tile block of 16 x 32 pixels, 32-cout slice cs, thread); thread = (wave = 4 yh + rp, lane = 16 kq + 4 qm + qi); bit (4 nb + e) * 4 + cc =
+    pixel (16 by + 4 rp + 2 (kq >> 1) + (qi >> 1), 32 bx + 16 (kq & 1) + 4 e + 2 yh + (qi & 1)), channel 32 cs + 16 nb + 4 qm + cc."""
+    B, _, H, W = (int(v) for v in dims)
+    nby, nbx, ncs = -(-H // 16), -(-W // 32), c // 32
+    wd = bits.view(torch.int32)[:B * nby * nbx * ncs * 512].view(B, nby, nbx, ncs, 2, 4, 2, 2, 4, 2, 2)      # [B, by, bx, cs, yh, rp, etr, kql, qm, qih, qil]
+    sh = torch.arange(32, device=bits.device, dtype=torch.int32).view(2, 4, 4)                                # [nb, e, cc]
+    m = ((wd[..., None, None, None] >> sh) & 1).bool()
+    #   0  1   2   3   4   5   6    7    8   9    10   11  12  13
+    #  [B, by, bx, cs, yh, rp, etr, kql, qm, qih, qil, nb, e, cc]  ->  (B | by rp etr qih | bx kql e yh qil | cs nb qm cc)
+    m = m.permute(0, 1, 5, 6, 9, 2, 7, 12, 4, 10, 3, 11, 8, 13).reshape(B, nby * 16, nbx * 32, c)
+    return m[:, :H, :W].contiguous()
 
 
 def sign_bits_to_mask(bits, dims, c):
@@ -417,8 +444,12 @@ def _conv_raw(x, wp, bias, residual, mask_src, dims, cin, cout, kz, flags, leak,
         call("df_wino_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, D, H, W, cin, cout,
              flags, float(leak), _stream())
         return y
-    if sign_bits is not None or mask_bits is not None:
-        raise _lib.DeepFluidsHipError("sign-bit masks exist for the 3-D Winograd kernels only")
+    if (sign_bits is not None or mask_bits is not None) and not (algo == 2 and _w2fam(mode) == "f24"):
+        raise _lib.DeepFluidsHipError("sign-bit masks exist for the 3-D Winograd kernels and the 2-D F(2,3) x F(4,3) kernel only")
+    if algo == 2 and _w2fam(mode) == "f24" and (sign_bits is not None or mask_bits is not None):
+        call("df_wino2d43_conv_bits", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_bits), _ptr(y), _ptr(sign_bits), B, H, W, cin, cout, flags, float(leak),
+             _stream())
+        return y
     if algo == 2 and _w2fam(mode) == "f24":
         call("df_wino2d43_conv", _ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(mask_src), _ptr(y), B, H, W, cin, cout, flags, float(leak),
              _stream())
@@ -505,7 +536,8 @@ class _GenBlock(torch.autograd.Function):
                 raise ValueError("gen_block: weights %s do not match input %s" % (tuple(w.shape), tuple(x.shape)))
             wp = _pack(w, taps, cin, cout, 0, dims)
             # outputs of convs 1 .. n-1 are the masks of the dgrads of convs 2 .. n
-            sb = _new_bits(dims, cout, x0) if (SIGN_BIT_MASKS and i < n - 1 and _use_wino(cin, cout, dims, kz) == 3) else None
+            bk = _bits_kind(cin, cout, dims, kz) if i < n - 1 else 0
+            sb = _new_bits(dims, cout, x0, bk) if bk else None
             bits.append(sb)
             x = _conv_raw(x, wp, b, None, None, dims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak, sign_bits=sb).view(
                 x0.shape[:-1] + (cout,))
@@ -575,7 +607,8 @@ class _ConvChain(torch.autograd.Function):
             if tuple(w.shape[:-2]) != (3,) * nd or x.shape[-1] != cin:
                 raise ValueError("conv_chain: weights %s do not match input %s" % (tuple(w.shape), tuple(x.shape)))
             wp = _pack(w, taps, cin, cout, 0, dims)
-            sb = _new_bits(dims, cout, x0) if (SIGN_BIT_MASKS and i < n - 1 and _use_wino(cin, cout, dims, kz) == 3) else None
+            bk = _bits_kind(cin, cout, dims, kz) if i < n - 1 else 0
+            sb = _new_bits(dims, cout, x0, bk) if bk else None
             bits.append(sb)
             x = _conv_raw(x, wp, b, None, None, dims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak, sign_bits=sb).view(
                 x0.shape[:-1] + (cout,))
@@ -646,7 +679,9 @@ class _UpGenBlock(torch.autograd.Function):
             cin, cout = w.shape[-2], w.shape[-1]
             if tuple(w.shape[:-2]) != (3,) * nd or cin != C or cout != C:
                 raise ValueError("up_gen_block: weights %s do not match %d channels" % (tuple(w.shape), C))
-            sb = _new_bits(fdims, cout, xc) if (SIGN_BIT_MASKS and i < n - 1 and is3d and _use_wino(cin, cout, fdims, kz) == 3) else None
+            # (2-D: the block's first conv runs the 9-point F(2,3)^2 form, which has no sign words -- the dgrad above it reads its fp32 activation)
+            bk = _bits_kind(cin, cout, fdims, kz) if (i < n - 1 and (is3d or i > 0)) else 0
+            sb = _new_bits(fdims, cout, xc, bk) if bk else None
             bits.append(sb)
             if DISPATCH_COUNTS is not None and i == 0:
                 _count("upconv", "winograd-27pt" if (is3d and _use_wino(cin, cout, fdims, kz) == 3) else

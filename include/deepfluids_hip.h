@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DF_VERSION 206 /* 0.2.6: + df_wino43_*, df_wino2d43_*, df_conv_s2_dgrad_form; 0.2.5: + df_adam_tf1_step_dev, df_gd_step(_dev), df_store_scalars (hipGraph replay of the train step); 0.2.4: + df_conv_s2_dgrad; 0.2.3: + df_conv_s2_wgrad; 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
+#define DF_VERSION 207 /* 0.2.7: + df_wino2d43_conv_bits, df_wino2d43_signbits_bytes; 0.2.6: + df_wino43_*, df_wino2d43_*, df_conv_s2_dgrad_form; 0.2.5: + df_adam_tf1_step_dev, df_gd_step(_dev), df_store_scalars (hipGraph replay of the train step); 0.2.4: + df_conv_s2_dgrad; 0.2.3: + df_conv_s2_wgrad; 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
 
 enum {
   DF_OK = 0,
@@ -337,6 +337,14 @@ int64_t df_wino2d43_packed_elems(int64_t cin, int64_t cout, int mode);
 int df_wino2d43_pack_weights(const float* w, float* wp, int64_t cin, int64_t cout, int mode, df_stream_t stream);
 int df_wino2d43_conv(const float* x, const float* wp, const float* bias, const float* residual, const float* mask_src, float* y, int64_t B,
                      int64_t H, int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream);
+/* ... with sign words (the 2-D twin of df_wino_conv_fwd_bits below; reference: the lrelu of slim.conv2d's activation_fn, ops.py:12-13, whose slope TF's
+ * autodiff multiplies into the gradient -- model.py:24-28): flags == BIAS | LRELU + sign_bits: the forward conv also writes (activation > 0) as ONE
+ * 32-bit word per (tile block of 16 x 32 pixels, 32-cout slice, thread) = its 32 outputs; flags == MASK + mask_bits: the dgrad of the SAME geometry
+ * (B, H, W, channel count of the masked tensor) reads those words instead of the fp32 activation (1/32 of the bytes).  df_wino2d43_signbits_bytes
+ * = the buffer size (16-byte aligned buffers).  Results bit-identical to the fp32-mask path. */
+int64_t df_wino2d43_signbits_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
+int df_wino2d43_conv_bits(const float* x, const float* wp, const float* bias, const void* mask_bits, float* y, void* sign_bits, int64_t B, int64_t H,
+                          int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream);
 
 /* Sign-bit masks.  A masked dgrad (DF_CONV_MASK) multiplies its output by the lrelu slope of the layer below, i.e. it needs ONE BIT
  * per element of that layer's activation; read from the fp32 activation that is 3.2 GB per top-level launch at cfg3.  The forward

@@ -43,7 +43,7 @@ def test_release_library_holds_only_the_production_kernel_instantiations():
 
 def test_version_and_error_convention():
     h = _lib.lib()
-    assert h.df_version() == 206
+    assert h.df_version() == 207
     # null pointers / bad extents are argument errors (< 0) caught on the host, with a message
     assert h.df_jacobian3d_fwd(None, None, None, 1, 4, 4, 4, None) == -1
     assert b"null input" in h.df_last_error()

@@ -242,3 +242,84 @@ def test_train_step_both_families_vs_oracle(ops, family):
     _, _, info = orc.train_step(y.astype(np.float64), x.astype(np.float64), p64, opt, oshape, filters, True)
     assert rel_l1(u, info["u"]) < 1e-5, rel_l1(u, info["u"])
     assert abs(float(m.g_loss) - info["loss"]) < 1e-5 * abs(info["loss"])
+
+
+@pytest.mark.parametrize("dims", [(2, 24, 40, 64, 64), (1, 16, 32, 32, 32), (3, 33, 47, 32, 64), (1, 10, 12, 32, 32), (2, 50, 70, 96, 32), (8, 128, 96, 128, 128)])
+def test_wino2d43_sign_words_and_mask_bits(ops, dims):
+    """The 2-D twin of the sign-word epilogues (df_wino2d43_conv_bits):
+    * BIAS | LRELU + sign_bits: same output as the launch without them, and the words decode (ops.sign_words2d_to_mask) to exactly (y > 0);
+    * MASK from mask_bits == MASK from the fp32 activation the words were taken from, bit for bit -- also when the dgrad's own input has another
+      channel count than the masked tensor (full, ragged and sub-block images)."""
+    from deep_fluids_amd import _lib
+    from deep_fluids_amd._lib import call, query, DF_CONV_BIAS, DF_CONV_LRELU, DF_CONV_MASK
+    from deep_fluids_amd.ops import _ptr, _stream, _new_bits, sign_words2d_to_mask
+    B, H, W, C, C2 = dims
+    rng = np.random.RandomState(sum(dims))
+    s = _stream()
+    x = dev(rng.uniform(-1, 1, (B, H, W, C)).astype(np.float32))
+    w = dev((rng.uniform(-1, 1, (3, 3, C, C)) / np.sqrt(9 * C)).astype(np.float32))
+    bias = dev(rng.uniform(-0.5, 0.5, C).astype(np.float32))
+    ww = torch.empty(query("df_wino2d43_packed_elems", C, C, 0), device="cuda")
+    call("df_wino2d43_pack_weights", _ptr(w), _ptr(ww), C, C, 0, s)
+    y = torch.empty((B, H, W, C), device="cuda"); yb = torch.full_like(y, float("nan"))
+    bits = _new_bits((B, 1, H, W), C, x, 2)
+    assert bits.numel() * 8 == query("df_wino2d43_signbits_bytes", B, H, W, C) > 0
+    FW = DF_CONV_BIAS | DF_CONV_LRELU
+    call("df_wino2d43_conv", _ptr(x), _ptr(ww), _ptr(bias), None, None, _ptr(y), B, H, W, C, C, FW, 0.2, s)
+    call("df_wino2d43_conv_bits", _ptr(x), _ptr(ww), _ptr(bias), None, _ptr(yb), _ptr(bits), B, H, W, C, C, FW, 0.2, s)
+    assert torch.equal(y, yb)
+    assert torch.equal(sign_words2d_to_mask(bits, (B, 1, H, W), C), y > 0)
+    # the dgrad of the layer above: its input gradient has C2 channels, its output (and the mask) C
+    g = dev(rng.uniform(-1, 1, (B, H, W, C2)).astype(np.float32))
+    w2 = dev((rng.uniform(-1, 1, (3, 3, C, C2)) / np.sqrt(9 * C)).astype(np.float32))
+    wd = torch.empty(query("df_wino2d43_packed_elems", C, C2, 1), device="cuda")
+    call("df_wino2d43_pack_weights", _ptr(w2), _ptr(wd), C, C2, 1, s)
+    d_bits = torch.full_like(y, float("nan")); d_f32 = torch.empty_like(y)
+    call("df_wino2d43_conv_bits", _ptr(g), _ptr(wd), None, _ptr(bits), _ptr(d_bits), None, B, H, W, C2, C, DF_CONV_MASK, 0.2, s)
+    call("df_wino2d43_conv", _ptr(g), _ptr(wd), None, None, _ptr(y), _ptr(d_f32), B, H, W, C2, C, DF_CONV_MASK, 0.2, s)
+    assert torch.equal(d_bits, d_f32)
+    # argument checks: neither / both bit buffers, a flag combination without a sign-word variant
+    for args in ((None, None, FW), (bits, bits, FW), (None, bits, DF_CONV_BIAS)):
+        with pytest.raises(_lib.DeepFluidsHipError):
+            call("df_wino2d43_conv_bits", _ptr(x), _ptr(ww), _ptr(bias), _ptr(args[0]), _ptr(yb), _ptr(args[1]), B, H, W, C, C, args[2], 0.2, s)
+
+
+@pytest.mark.parametrize("shape,C,up", [((2, 32, 48), 32, False), ((1, 20, 30), 64, False), ((8, 32, 24), 128, False), ((2, 16, 24), 32, True), ((1, 9, 13), 64, True),
+                                        ((4, 32, 24), 128, True)])
+def test_sign_word_masks_2d_are_bit_identical_to_activation_masks(ops, shape, C, up):
+    """2-D generator blocks (plain and up-sampling) forward + backward with the dgrads' lrelu masks read from the F(2,3) x F(4,3) kernel's sign words vs from
+    the fp32 activations: outputs and every gradient bit for bit; the words are really used (dispatch through df_wino2d43_conv_bits)."""
+    from deep_fluids_amd import _lib as L
+    from deep_fluids_amd.ops import _GenBlock, _UpGenBlock
+    rng = np.random.RandomState(sum(shape) + C)
+    n = 4
+    x = rng.uniform(-1, 1, shape + (C,)).astype(np.float32)
+    ws = [(rng.uniform(-1, 1, (3, 3, C, C)) / np.sqrt(C * 9)).astype(np.float32) for _ in range(n)]
+    bs = [rng.uniform(-0.3, 0.3, C).astype(np.float32) for _ in range(n)]
+    fshape = tuple(shape[:1]) + tuple(2 * d for d in shape[1:]) if up else shape
+    go = rng.uniform(-1, 1, fshape + (C,)).astype(np.float32)
+    res, ncalls = [], []
+    orig = L.call
+    for use_bits in (True, False):
+        seen = []
+
+        def spy(name, *a):
+            seen.append(name)
+            return orig(name, *a)
+        with ops.options(conv_algo="winograd", sign_bit_masks=use_bits):
+            ops.call = spy
+            try:
+                xt = dev(x).requires_grad_(True)
+                args = []
+                for w, b in zip(ws, bs):
+                    args += [dev(w).requires_grad_(True), dev(b).requires_grad_(True)]
+                y = (_UpGenBlock if up else _GenBlock).apply(xt, 0.2, *args)
+                (y * dev(go)).sum().backward()
+            finally:
+                ops.call = orig
+            res.append([host(y), host(xt.grad)] + [host(a.grad) for a in args])
+        ncalls.append(seen.count("df_wino2d43_conv_bits"))
+    # plain block: convs 1..3 emit words, dgrads of convs 2..4 read them (6 launches); up block: conv 1 is the 9-point form (no words): 2 + 2
+    assert ncalls == [4 if up else 6, 0], ncalls
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
