@@ -1,5 +1,5 @@
 import os, sys, hashlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, ROOT)
 import torch
 from deep_fluids_amd._lib import call, query
 from deep_fluids_amd.ops import _ptr, _stream
