@@ -676,7 +676,7 @@ def extras(out, a, cfg, x, y, vox_per_step, pmc):
                 tr = GANTrainer(default_config(arch="dg", **kw))
             else:
                 tr = Trainer(default_config(**kw))
-            el, m = timed_steps(tr, xr, yr, 2, 5)
+            el, m = timed_steps(tr, xr, yr, 2, 5) if is3 else timed_steps(tr, xr, yr, 3, 20)      # (ms-scale 2-D steps: 5 would mostly time the host's lead-in)
             n = B
             for g in grid:
                 n *= g
