@@ -96,6 +96,8 @@ SIGNATURES = {
     "df_wino2d43_conv": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, F32, P]),
     "df_wino2d43_signbits_bytes": (I64, [I64, I64, I64, I64]),
     "df_wino2d43_conv_bits": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, F32, P]),
+    "df_wino2d43_conv_addup_bits": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P]),
+    "df_lrelu_words2d_bwd_pool2x": (I32, [P, P, P, P, F32, I64, I64, I64, I64, P]),
     "df_wino2d_packed_elems": (I64, [I64, I64, I32]),
     "df_wino2d_pack_weights": (I32, [P, P, I64, I64, I32, P]),
     "df_wino2d_conv_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, F32, P]),

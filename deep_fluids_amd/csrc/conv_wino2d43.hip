@@ -33,7 +33,7 @@ constexpr int CP = HY * PY + 2;                    // dwords per channel plane (
 constexpr int NLOAD = 5;                           // ceil(612 * 4 float4 pieces / 512 threads)
 constexpr int BUFF = CKW * CP;
 constexpr int kPts = 24;
-constexpr int kSignBits = 64, kMaskBits = 128;      // internal epilogue flags (compile-time variants only), as conv_wino43.hip
+constexpr int kSignBits = 64, kMaskBits = 128, kNoPrimary = 256;      // internal epilogue flags (compile-time variants only), as conv_wino43.hip
 
 struct W2Args {
   const float* x;
@@ -42,6 +42,7 @@ struct W2Args {
   const float* residual;
   const float* mask_src;
   float* y;
+  float* y2;                   // DF_CONV_ADDUP: y2 = y + nearest_up2x(residual), residual = the COARSE tensor [B, H/2, W/2, Cout]
   unsigned* bits_out;          // sign words of the output (kSignBits): one 32-bit word per (tile block, cout slice, thread)
   const unsigned* bits_in;     // ... of the activation whose lrelu slope masks this dgrad (kMaskBits)
   int B, H, W, Cin, Cout;
@@ -364,24 +365,28 @@ __global__ __launch_bounds__(kT, 1) void wino2d43_kernel(const W2Args a) {
     // for couts 4 qm .. 4 qm + 3 -- 2 x 4 x 4 = 32 outputs per tile block = ONE 32-bit word, bit (nb * 4 + e) * 4 + c.  The forward conv whose
     // output only serves as the lrelu mask of the next layer's dgrad writes (activation > 0) there; that dgrad -- the same kernel on a tensor of the
     // same shape, hence the same (tile block, cout slice, thread) <-> output mapping -- reads the word instead of 32 fp32 activations.
-    constexpr bool SB = FL >= 0 && (FL & kSignBits) != 0, MB = FL >= 0 && (FL & kMaskBits) != 0;
+    constexpr bool SB = FL >= 0 && (FL & kSignBits) != 0, MB = FL >= 0 && (FL & kMaskBits) != 0, NOY = FL >= 0 && (FL & kNoPrimary) != 0;
     const int64_t widx = (static_cast<int64_t>(cur.id) * a.ncs + cs) * kT + tid;
     unsigned sword = 0u, mword = 0u;
     if (MB) mword = a.bits_in[widx];
     const int64_t sW_ = a.Cout;
     // element offset of (pixel qi of the patch of tile column etx0, couts 4 qm ..): + 4 e sW_ per tile column, + 16 per cout block
     const int64_t obase = ((static_cast<int64_t>(cur.b) * a.H + py) * a.W + cur.x0 + 4 * etx0 + 2 * yh + (qi & 1)) * a.Cout + n0 + 4 * qm;
+    // ... and of the coarse pixel (py >> 1, px >> 1) of the add-up operand [B, H/2, W/2, Cout]: + 2 e sW_ per tile column (4 fine = 2 coarse pixels)
+    const int64_t cbase = ((static_cast<int64_t>(cur.b) * (a.H >> 1) + (py >> 1)) * (a.W >> 1) + ((cur.x0 + 4 * etx0 + 2 * yh) >> 1)) * a.Cout + n0 + 4 * qm;
     lds_barrier();
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const f32x4 bv4 = *reinterpret_cast<const f32x4*>(&sBias[nb * 16 + 4 * qm]);
-      f32x4 rres[4], rmsk[4];      // residual / mask operands of this cout block: the loads are issued together (full blocks)
-      if (full && (eflags & (DF_CONV_RESIDUAL | DF_CONV_MASK))) {
+      f32x4 rres[4], rmsk[4];      // residual / mask / add-up operands of this cout block: the loads are issued together (full blocks)
+      if (full && (eflags & (DF_CONV_RESIDUAL | DF_CONV_MASK | DF_CONV_ADDUP))) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int64_t o = obase + nb * 16 + 4 * e * sW_;
           if (eflags & DF_CONV_RESIDUAL) rres[e] = *reinterpret_cast<const f32x4*>(a.residual + o);
           if ((eflags & DF_CONV_MASK) && !MB) rmsk[e] = *reinterpret_cast<const f32x4*>(a.mask_src + o);
+          // ADDUP: the four lanes of a quad (the 2 x 2 patch) share ONE coarse pixel of the skip tensor
+          if (eflags & DF_CONV_ADDUP) rres[e] = *reinterpret_cast<const f32x4*>(a.residual + cbase + nb * 16 + 2 * e * sW_);
         }
       }
 #pragma unroll
@@ -406,7 +411,8 @@ __global__ __launch_bounds__(kT, 1) void wino2d43_kernel(const W2Args a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = (MB ? ((mword >> ((nb * 4 + e) * 4 + c)) & 1u) != 0u : rmsk[e][c] > 0.f) ? v[c] : a.leak * v[c];
           }
-          *reinterpret_cast<f32x4*>(a.y + o) = v;
+          if (!NOY) *reinterpret_cast<f32x4*>(a.y + o) = v;
+          if (eflags & DF_CONV_ADDUP) *reinterpret_cast<f32x4*>(a.y2 + o) = v + rres[e];
         } else if (py < a.H && px < a.W) {
           if (eflags & DF_CONV_RESIDUAL) v += *reinterpret_cast<const f32x4*>(a.residual + o);
           if (eflags & DF_CONV_MASK) {
@@ -415,7 +421,8 @@ __global__ __launch_bounds__(kT, 1) void wino2d43_kernel(const W2Args a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = (MB ? ((mword >> ((nb * 4 + e) * 4 + c)) & 1u) != 0u : mk[c] > 0.f) ? v[c] : a.leak * v[c];
           }
-          *reinterpret_cast<f32x4*>(a.y + o) = v;
+          if (!NOY) *reinterpret_cast<f32x4*>(a.y + o) = v;
+          if (eflags & DF_CONV_ADDUP) *reinterpret_cast<f32x4*>(a.y2 + o) = v + *reinterpret_cast<const f32x4*>(a.residual + cbase + nb * 16 + 2 * e * sW_);
         }
       }
     }
@@ -424,6 +431,54 @@ __global__ __launch_bounds__(kT, 1) void wino2d43_kernel(const W2Args a) {
     pb = (pb + nchunk) & 1;
     cur = nxt;
   }
+}
+
+// The backward tail of a 2-D up-sampling block on the sign words of its last conv (the 2-D twin of conv_wino.hip's lrelu_bits_bwd_pool_kernel): one
+// workgroup = the 512 words of a (tile block, cout slice), thread = word = the same (pixel qi of a 2 x 2 patch, couts 4 qm ..) x (cout block nb, tile
+// column e) outputs as in wino2d43_kernel's epilogue.  gx = gy * lrelu'(activation) from the bits; gpool = the 2 x 2 sum-pool of gy (the skip path's
+// gradient): the patch is the lane quad, summed (dy, dx) ascending like lrelu_bwd_pool_kernel / upsample_bwd_kernel (bit-identical).
+__global__ __launch_bounds__(kT) void lrelu_words2d_bwd_pool_kernel(const float* __restrict__ gy, const unsigned* __restrict__ bits, float* __restrict__ gx,
+                                                                   float* __restrict__ gpool, float leak, int H, int W, int C, int nby, int nbx, int ncs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tl = lane & 15, kq = lane >> 4, rp = wave & 3, yh = wave >> 2;
+  const int qi = tl & 3, qm = tl >> 2;
+  const int cs = blockIdx.x % ncs;
+  int t = blockIdx.x / ncs;
+  const int bx = t % nbx; t /= nbx;
+  const int by = t % nby;
+  const int b = t / nby;
+  const unsigned word = bits[static_cast<int64_t>(blockIdx.x) * kT + tid];
+  const int py = by * 16 + 2 * (2 * rp + (kq >> 1)) + (qi >> 1);
+  const int px0 = bx * 32 + 4 * ((kq & 1) * 4) + 2 * yh + (qi & 1);
+  const int c0 = cs * 32 + 4 * qm;
+  auto bc = [](float x, int k) -> float {      // broadcast lane k of the quad
+    const int v = __builtin_bit_cast(int, x);
+    const int r = k == 0 ? __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true) : k == 1 ? __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true)
+                : k == 2 ? __builtin_amdgcn_mov_dpp(v, 0xAA, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(v, 0xFF, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, r);
+  };
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int px = px0 + 4 * e;
+      const bool ok = py < H && px < W;      // (H, W even: a 2 x 2 patch is inside or outside as a whole)
+      const int64_t o = ((static_cast<int64_t>(b) * H + py) * W + px) * C + c0 + nb * 16;
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (ok) g = *reinterpret_cast<const f32x4*>(gy + o);
+      f32x4 d, p;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        d[c] = ((word >> ((nb * 4 + e) * 4 + c)) & 1u) != 0u ? g[c] : leak * g[c];
+        float acc = 0.f;
+        acc += bc(g[c], 0); acc += bc(g[c], 1); acc += bc(g[c], 2); acc += bc(g[c], 3);
+        p[c] = acc;
+      }
+      if (ok) {
+        *reinterpret_cast<f32x4*>(gx + o) = d;
+        if (qi == 0) *reinterpret_cast<f32x4*>(gpool + ((static_cast<int64_t>(b) * (H >> 1) + (py >> 1)) * (W >> 1) + (px >> 1)) * C + c0 + nb * 16) = p;
+      }
+    }
 }
 
 int64_t w2_grid(W2Args& a, int64_t ntb) {
@@ -476,7 +531,7 @@ static int w2_conv(const char* fn, const float* x, const float* wp, const float*
                  (!(flags & DF_CONV_MASK) || df::aligned16(mask_src)) && df::aligned16(mask_bits) && df::aligned16(sign_bits),
              DF_EALIGN, "%s: x, y, residual, mask_src, the bit words and the packed weights must be 16-byte aligned", fn);
   W2Args a;
-  a.x = x; a.wp = wp; a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y;
+  a.x = x; a.wp = wp; a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y; a.y2 = nullptr;
   a.bits_out = static_cast<unsigned*>(sign_bits); a.bits_in = static_cast<const unsigned*>(mask_bits);
   a.B = (int)B; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
   a.nby = (int)ceil_div(H, 16); a.nbx = (int)ceil_div(W, 32);
@@ -514,6 +569,45 @@ int df_wino2d43_conv_bits(const float* x, const float* wp, const float* bias, co
                           int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream) {
   DF_REQUIRE((sign_bits != nullptr) != (mask_bits != nullptr), DF_EINVAL, "df_wino2d43_conv_bits: exactly one of sign_bits (forward) / mask_bits (dgrad)");
   return w2_conv("df_wino2d43_conv_bits", x, wp, bias, nullptr, nullptr, mask_bits, y, sign_bits, B, H, W, Cin, Cout, flags, leak, stream);
+}
+
+int df_wino2d43_conv_addup_bits(const float* x, const float* wp, const float* bias, const float* xc, float* y2, void* sign_bits, int64_t B, int64_t H,
+                                int64_t W, int64_t Cin, int64_t Cout, float leak, df_stream_t stream) {
+  const char* fn = "df_wino2d43_conv_addup_bits";
+  DF_REQUIRE(x && wp && bias && xc && y2 && sign_bits, DF_EINVAL, "%s: null pointer", fn);
+  DF_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, DF_EINVAL, "%s: extents must be positive and even (the output of a 2x up-sampling block)", fn);
+  DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE, "%s: Cin, Cout must be multiples of 32", fn);
+  DF_REQUIRE(H * W * (Cin > Cout ? Cin : Cout) <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE, "%s: one image must stay below 2 GiB", fn);
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x) && df::aligned16(xc) && df::aligned16(y2) && df::aligned16(sign_bits), DF_EALIGN,
+             "%s: x, xc, y2, the bit words and the packed weights must be 16-byte aligned", fn);
+  W2Args a;
+  a.x = x; a.wp = wp; a.bias = bias; a.residual = xc; a.mask_src = nullptr; a.y = nullptr; a.y2 = y2;
+  a.bits_out = static_cast<unsigned*>(sign_bits); a.bits_in = nullptr;
+  a.B = (int)B; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.Cout = (int)Cout;
+  a.nby = (int)ceil_div(H, 16); a.nbx = (int)ceil_div(W, 32);
+  const int64_t ntb = B * a.nby * a.nbx;
+  a.ncs = (int)(Cout / 32);
+  DF_REQUIRE(ntb * a.ncs < (1LL << 31), DF_ESHAPE, "%s: too many workgroups", fn);
+  a.ntb = (int)ntb;
+  a.flags = DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_ADDUP; a.leak = leak;
+  const int64_t grid = w2_grid(a, ntb);
+  hipLaunchKernelGGL((wino2d43_kernel<DF_CONV_BIAS | DF_CONV_LRELU | DF_CONV_ADDUP | kSignBits | kNoPrimary>), dim3((unsigned)grid), dim3(kT), 0,
+                     df::as_stream(stream), a);
+  return df::launched(fn);
+}
+
+int df_lrelu_words2d_bwd_pool2x(const float* gy, const void* mask_bits, float* gx, float* gpool, float leak, int64_t B, int64_t Hc, int64_t Wc, int64_t C,
+                                df_stream_t stream) {
+  const char* fn = "df_lrelu_words2d_bwd_pool2x";
+  DF_REQUIRE(gy && mask_bits && gx && gpool, DF_EINVAL, "%s: null pointer", fn);
+  DF_REQUIRE(B > 0 && Hc > 0 && Wc > 0, DF_EINVAL, "%s: non-positive extent", fn);
+  DF_REQUIRE(C > 0 && C % 32 == 0, DF_ESHAPE, "%s: C must be a multiple of 32 (the sign words' cout slices)", fn);
+  DF_REQUIRE(df::aligned16(gy) && df::aligned16(gx) && df::aligned16(gpool) && df::aligned16(mask_bits), DF_EALIGN, "%s: 16-byte alignment", fn);
+  const int64_t H = 2 * Hc, W = 2 * Wc, nby = ceil_div(H, 16), nbx = ceil_div(W, 32), ncs = C / 32;
+  DF_REQUIRE(B * nby * nbx * ncs < (1LL << 31) && H * W * C <= (1LL << 29), DF_ESHAPE, "%s: tensor too large", fn);
+  hipLaunchKernelGGL(lrelu_words2d_bwd_pool_kernel, dim3((unsigned)(B * nby * nbx * ncs)), dim3(kT), 0, df::as_stream(stream), gy,
+                     static_cast<const unsigned*>(mask_bits), gx, gpool, leak, (int)H, (int)W, (int)C, (int)nby, (int)nbx, (int)ncs);
+  return df::launched(fn);
 }
 
 }  // extern "C"

@@ -740,6 +740,14 @@ class _UpGenBlock(torch.autograd.Function):
                     else:
                         call("df_wino_conv_fwd_addup", _ptr(x_in), _ptr(wp), _ptr(b), _ptr(xc), _ptr(x), _ptr(y), fdims[0], fdims[1],
                              fdims[2], fdims[3], cin, cout, float(leak), _stream())
+                elif i == n - 1 and not is3d and _bits_kind(cin, cout, fdims, kz) == 2 and ACTIVATION_FETCH is None:
+                    # the 2-D twin of the fused block tail: y = lrelu(conv(x)) + upscale(xc) from the conv's epilogue, only the sign words of its activation kept
+                    _count("conv", "winograd-f2x4+addup+signwords", fdims, cin, cout)
+                    tail_bits = _new_bits(fdims, cout, xc, 2)
+                    y = torch.empty(fshape, dtype=torch.float32, device=xc.device)
+                    call("df_wino2d43_conv_addup_bits", _ptr(x), _ptr(wp), _ptr(b), _ptr(xc), _ptr(y), _ptr(tail_bits), fdims[0], fdims[2], fdims[3], cin, cout,
+                         float(leak), _stream())
+                    x = None
                 else:
                     x = _conv_raw(x, wp, b, None, None, fdims, cin, cout, kz, DF_CONV_BIAS | DF_CONV_LRELU, leak, sign_bits=sb).view(fshape)
             xs.append(x)
@@ -768,8 +776,11 @@ class _UpGenBlock(torch.autograd.Function):
             # the lrelu mask of the last conv from its sign bits (its fp32 activation was never written): 6.9 GB moved at the cfg3 top
             # level instead of 12.9; the pooled skip gradient comes with it (dropped below if xc needs no gradient)
             dxc = torch.empty_like(xc)
-            call("df_lrelu_bits_bwd_pool2x", _ptr(dy), _ptr(ctx.tail_bits), _ptr(dp), _ptr(dxc), leak, cdims[0], cdims[1], cdims[2], cdims[3],
-                 C, _stream())
+            if is3d:
+                call("df_lrelu_bits_bwd_pool2x", _ptr(dy), _ptr(ctx.tail_bits), _ptr(dp), _ptr(dxc), leak, cdims[0], cdims[1], cdims[2], cdims[3],
+                     C, _stream())
+            else:
+                call("df_lrelu_words2d_bwd_pool2x", _ptr(dy), _ptr(ctx.tail_bits), _ptr(dp), _ptr(dxc), leak, cdims[0], cdims[2], cdims[3], C, _stream())
         elif ctx.needs_input_grad[0]:
             # both consumers of dy in one pass: the masked gradient entering the last conv and the skip path's 2x2(x2) sum-pool
             dxc = torch.empty_like(xc)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DF_VERSION 207 /* 0.2.7: + df_wino2d43_conv_bits, df_wino2d43_signbits_bytes; 0.2.6: + df_wino43_*, df_wino2d43_*, df_conv_s2_dgrad_form; 0.2.5: + df_adam_tf1_step_dev, df_gd_step(_dev), df_store_scalars (hipGraph replay of the train step); 0.2.4: + df_conv_s2_dgrad; 0.2.3: + df_conv_s2_wgrad; 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
+#define DF_VERSION 207 /* 0.2.7: + df_wino2d43_conv_bits, df_wino2d43_signbits_bytes, df_wino2d43_conv_addup_bits, df_lrelu_words2d_bwd_pool2x; 0.2.6: + df_wino43_*, df_wino2d43_*, df_conv_s2_dgrad_form; 0.2.5: + df_adam_tf1_step_dev, df_gd_step(_dev), df_store_scalars (hipGraph replay of the train step); 0.2.4: + df_conv_s2_dgrad; 0.2.3: + df_conv_s2_wgrad; 0.2.2: + df_conv_wgrad_form, df_upconv_wgrad_form; 0.2.1: + df_lrelu_bwd_pool2x, df_wino_conv_fwd_addup_bits, df_lrelu_bits_bwd_pool2x (0.2.0: df_conv_wgrad_algo, df_upconv_wgrad_algo, DF_CONV_VALU_ONLY, df_velocity_loss2d/3d) */
 
 enum {
   DF_OK = 0,
@@ -345,6 +345,15 @@ int df_wino2d43_conv(const float* x, const float* wp, const float* bias, const f
 int64_t df_wino2d43_signbits_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
 int df_wino2d43_conv_bits(const float* x, const float* wp, const float* bias, const void* mask_bits, float* y, void* sign_bits, int64_t B, int64_t H,
                           int64_t W, int64_t Cin, int64_t Cout, int flags, float leak, df_stream_t stream);
+/* The block tail of a 2-D up-sampling generator block on sign words (the twins of df_wino_conv_fwd_addup_bits / df_lrelu_bits_bwd_pool2x; reference:
+ * model.py:36-40 -- x = conv(...); x += x0 with x0 = upscale(previous block)).  df_wino2d43_conv_addup_bits: y2 = lrelu(conv(x) + bias) + nearest_up2x(xc),
+ * xc = the COARSE tensor [B, H/2, W/2, Cout]; the conv's own activation is NOT written, only its sign words (all the backward pass needs of it).
+ * df_lrelu_words2d_bwd_pool2x: gx = gy * lrelu'(activation) from those words and gpool[B, Hc, Wc, C] = the 2 x 2 sum-pool of gy (the skip path's
+ * gradient), one pass over gy [B, 2 Hc, 2 Wc, C].  Bit-identical to df_wino2d43_conv + df_add_up2x / df_lrelu_bwd_pool2x. */
+int df_wino2d43_conv_addup_bits(const float* x, const float* wp, const float* bias, const float* xc, float* y2, void* sign_bits, int64_t B, int64_t H,
+                                int64_t W, int64_t Cin, int64_t Cout, float leak, df_stream_t stream);
+int df_lrelu_words2d_bwd_pool2x(const float* gy, const void* mask_bits, float* gx, float* gpool, float leak, int64_t B, int64_t Hc, int64_t Wc, int64_t C,
+                                df_stream_t stream);
 
 /* Sign-bit masks.  A masked dgrad (DF_CONV_MASK) multiplies its output by the lrelu slope of the layer below, i.e. it needs ONE BIT
  * per element of that layer's activation; read from the fp32 activation that is 3.2 GB per top-level launch at cfg3.  The forward

@@ -323,3 +323,32 @@ def test_sign_word_masks_2d_are_bit_identical_to_activation_masks(ops, shape, C,
     assert ncalls == [4 if up else 6, 0], ncalls
     for a, b in zip(*res):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("dims", [(2, 32, 64, 64), (1, 16, 32, 32), (3, 34, 46, 32), (1, 10, 12, 64), (8, 128, 96, 128)])
+def test_wino2d43_block_tail_on_sign_words_equals_the_fp32_path(ops, dims):
+    """df_wino2d43_conv_addup_bits (no fp32 activation written, sign words instead) + df_lrelu_words2d_bwd_pool2x ==
+    df_wino2d43_conv + df_add_up2x / df_lrelu_bwd_pool2x bit for bit; full, ragged and sub-block images (tile block 16 x 32 pixels)."""
+    from deep_fluids_amd._lib import call, query, DF_CONV_BIAS, DF_CONV_LRELU
+    from deep_fluids_amd.ops import _ptr, _stream, _new_bits, sign_words2d_to_mask
+    B, H, W, C = dims
+    rng = np.random.RandomState(sum(dims))
+    s = _stream()
+    x = dev(rng.uniform(-1, 1, (B, H, W, C)).astype(np.float32))
+    w = dev((rng.uniform(-1, 1, (3, 3, C, C)) / np.sqrt(9 * C)).astype(np.float32))
+    bias = dev(rng.uniform(-0.5, 0.5, C).astype(np.float32))
+    xc = dev(rng.uniform(-1, 1, (B, H // 2, W // 2, C)).astype(np.float32))
+    ww = torch.empty(query("df_wino2d43_packed_elems", C, C, 0), device="cuda")
+    call("df_wino2d43_pack_weights", _ptr(w), _ptr(ww), C, C, 0, s)
+    act = torch.empty((B, H, W, C), device="cuda"); y_ref = torch.empty_like(act); y2 = torch.full_like(act, float("nan"))
+    call("df_wino2d43_conv", _ptr(x), _ptr(ww), _ptr(bias), None, None, _ptr(act), B, H, W, C, C, DF_CONV_BIAS | DF_CONV_LRELU, 0.2, s)
+    call("df_add_up2x", _ptr(act), _ptr(xc), _ptr(y_ref), B, 1, H // 2, W // 2, C, 0, s)
+    bits = _new_bits((B, 1, H, W), C, x, 2)
+    call("df_wino2d43_conv_addup_bits", _ptr(x), _ptr(ww), _ptr(bias), _ptr(xc), _ptr(y2), _ptr(bits), B, H, W, C, C, 0.2, s)
+    assert torch.equal(y2, y_ref)
+    assert torch.equal(sign_words2d_to_mask(bits, (B, 1, H, W), C), act > 0)
+    gy = dev(rng.uniform(-1, 1, (B, H, W, C)).astype(np.float32))
+    gx1 = torch.empty_like(gy); p1 = torch.empty_like(xc); gx2 = torch.full_like(gy, float("nan")); p2 = torch.full_like(xc, float("nan"))
+    call("df_lrelu_bwd_pool2x", _ptr(gy), _ptr(act), _ptr(gx1), _ptr(p1), 0.2, B, 1, H // 2, W // 2, C, 0, s)
+    call("df_lrelu_words2d_bwd_pool2x", _ptr(gy), _ptr(bits), _ptr(gx2), _ptr(p2), 0.2, B, H // 2, W // 2, C, s)
+    assert torch.equal(gx1, gx2) and torch.equal(p1, p2)
