@@ -457,15 +457,24 @@ __global__ __launch_bounds__(kT) void lrelu_words2d_bwd_pool_kernel(const float*
                 : k == 2 ? __builtin_amdgcn_mov_dpp(v, 0xAA, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(v, 0xFF, 0xf, 0xf, true);
     return __builtin_bit_cast(float, r);
   };
+  // (e outer, nb inner: the two 64-byte halves of a pixel's 128-byte cout-slice line are requested back to back; all eight loads first)
+  f32x4 gq[4][2];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
+  for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int nb = 0; nb < 2; ++nb) {
+      const int px = px0 + 4 * e;
+      gq[e][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (py < H && px < W) gq[e][nb] = *reinterpret_cast<const f32x4*>(gy + ((static_cast<int64_t>(b) * H + py) * W + px) * C + c0 + nb * 16);
+    }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
       const int px = px0 + 4 * e;
       const bool ok = py < H && px < W;      // (H, W even: a 2 x 2 patch is inside or outside as a whole)
       const int64_t o = ((static_cast<int64_t>(b) * H + py) * W + px) * C + c0 + nb * 16;
-      f32x4 g = {0.f, 0.f, 0.f, 0.f};
-      if (ok) g = *reinterpret_cast<const f32x4*>(gy + o);
+      const f32x4 g = gq[e][nb];
       f32x4 d, p;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
