@@ -14,8 +14,12 @@
 //   * B operand: U packed [cs][xi_y pair][cin/4][cout block][cin%4][cout%16][12 points]: three 16-byte loads per lane and block straight from
 //     L2 / L1 (the four waves of an xi_y half read the same words);
 //   * inverse: x (A^T of F(4,3)) in registers; the xi_y halves meet through the idle LDS buffer in ONE exchange -- the yh = 0 wave finishes the
-//     x pairs 0 of its tiles, the yh = 1 wave the pairs 1, so all eight waves store.  Epilogues: bias, lrelu, residual, fp32 lrelu mask (as
-//     df_wino2d_conv_fwd).
+//     x pairs 0 of its tiles, the yh = 1 wave the pairs 1, so all eight waves store;
+//   * epilogue: a 4 x 4 transpose inside every lane quad (DPP quad_perm) turns the accumulator layout (one cout per lane, its 2 x 2 pixel patch) into
+//     (one pixel per lane, four couts): every store / residual / mask access is 16 bytes per lane.  Bias, lrelu, residual, lrelu mask from an fp32
+//     activation or from SIGN WORDS (one 32-bit word per thread and tile block = its 32 outputs; written by the forward conv, read by the dgrad of the
+//     same geometry), and the block tail of an up-sampling block (add-up of the coarse skip tensor, only the sign words of the activation kept) with its
+//     backward twin lrelu_words2d_bwd_pool_kernel.  Forward convs AND dgrads of the 2-D generator run here (ops.WINO2D_FAMILY "f24").
 #include "df_common.hpp"
 #include "conv_args.hpp"
 

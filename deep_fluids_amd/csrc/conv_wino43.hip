@@ -21,7 +21,8 @@
 //     6 columns = 9 ds_read_b64 per k-step (conv_wino.hip: 16), no z stage, 18 fewer registers, one staging offset per thread instead of
 //     ten; y stage 6 packed ops, x stage = B^T of F(4,3) in 6 packed ops per row (op_sel picks the halves);
 //   * B operand: U packed [cs][xi_z][xi_y pair][cin/4][cout block][cin%4][cout%16][12 points]: three 16-byte loads per lane and block;
-//   * inverse: x (A^T of F(4,3), 6 -> 4) in registers, the two xi_y halves through LDS (one extra exchange), then the xi_z combine.
+//   * inverse: x (A^T of F(4,3), 6 -> 4) in registers, the two xi_y halves through LDS (one extra exchange), then the xi_z combine; full blocks store
+//     through a 4 x 4 lane-quad transpose (DPP): 2 float4 stores per lane and cout block instead of 8 scalar ones, the sign-word layout untouched.
 // Measured (profiles/r06_probes.md section 3): 128 -> 128 at 64x96x64, B = 16: 13.3 ms per launch against 16.4 ms (F(2,3)^3), bit-compatible
 // epilogues; 0 spills at 204-217 VGPRs, 156,032 B of LDS.
 #include <type_traits>
