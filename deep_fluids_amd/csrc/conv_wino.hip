@@ -1142,6 +1142,33 @@ __global__ __launch_bounds__(kT, 1) void wino3d_kernel(const WinoArgs a) {
         if ((eflags & DF_CONV_ADDUP) && oz0 < a.D && oy0 < a.H && ox0 < a.W)
           rup = a.residual[(((static_cast<int64_t>(cur.b) * (a.D >> 1) + (oz0 >> 1)) * (a.H >> 1) + (oy0 >> 1)) * (a.W >> 1) + (ox0 >> 1)) * a.Cout +
                            n0 + nb * 16 + tl];
+        // Full blocks of the variants without a per-output operand (bias / lrelu / sign bits only: the 27-point up-sampling-aware forward and the plain
+        // forward): the stores go through the 4 x 4 lane-quad transpose of conv_wino43.hip -- 2 float4 stores per lane and cout block instead of 8 scalar
+        // ones; bias, lrelu and the sign bits stay in the accumulator layout (the sign-byte layout is unchanged).  Bit-identical.
+        const bool wide = full && !(eflags & (DF_CONV_RESIDUAL | DF_CONV_MASK | DF_CONV_ADDUP)) && !NOY && !(DBG & 512);
+        if (wide) {
+          f32x4 vz[2];
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            float v = (s < 4 ? lo[s & 3] : hi[s & 3]) + bv;
+            if (eflags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
+            if (SB) sbyte |= v > 0.f ? (1u << s) : 0u;
+            vz[s >> 2][s & 3] = v;
+          }
+          const int qi = tl & 3;
+          const bool odd1 = (qi & 1) != 0, odd2 = (qi & 2) != 0;
+          auto quad_t = [&](const f32x4& v) -> f32x4 {
+            auto dpp1 = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)); };
+            auto dpp2 = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)); };
+            const float p0 = dpp1(v[0]), p1 = dpp1(v[1]), p2 = dpp1(v[2]), p3 = dpp1(v[3]);
+            const f32x4 a1 = {odd1 ? p1 : v[0], odd1 ? v[1] : p0, odd1 ? p3 : v[2], odd1 ? v[3] : p2};
+            const float r0 = dpp2(a1[0]), r1 = dpp2(a1[1]), r2 = dpp2(a1[2]), r3 = dpp2(a1[3]);
+            return f32x4{odd2 ? r2 : a1[0], odd2 ? r3 : a1[1], odd2 ? a1[2] : r0, odd2 ? a1[3] : r1};
+          };
+          const int64_t o4 = obase - tl + 4 * (tl >> 2) + nb * 16 + (qi >> 1) * sH + (qi & 1) * sW;
+          *reinterpret_cast<f32x4*>(a.y + o4) = quad_t(vz[0]);
+          *reinterpret_cast<f32x4*>(a.y + o4 + sD) = quad_t(vz[1]);
+        } else
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           float v = (s < 4 ? lo[s & 3] : hi[s & 3]) + bv;
@@ -1429,7 +1456,7 @@ int df_wino_conv_fwd(const float* x, const float* wp, const float* bias, const f
   DF_REQUIRE(!(flags & DF_CONV_BIAS) || bias, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_BIAS without bias");
   DF_REQUIRE(!(flags & DF_CONV_RESIDUAL) || residual, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_RESIDUAL without residual");
   DF_REQUIRE(!(flags & DF_CONV_MASK) || mask_src, DF_EINVAL, "df_wino_conv_fwd: DF_CONV_MASK without mask_src");
-  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x), DF_EALIGN, "df_wino_conv_fwd: x and packed weights must be 16-byte aligned");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x) && df::aligned16(y), DF_EALIGN, "df_wino_conv_fwd: x, y and packed weights must be 16-byte aligned");
   WinoArgs a;
   a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
   a.bias = bias; a.residual = residual; a.mask_src = mask_src; a.y = y; a.y2 = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
@@ -1498,7 +1525,7 @@ int df_wino_upconv_fwd(const float* xc, const float* wp, const float* bias, floa
   DF_REQUIRE(flags == (DF_CONV_BIAS | DF_CONV_LRELU) && bias, DF_EINVAL, "df_wino_upconv_fwd: flags must be DF_CONV_BIAS | DF_CONV_LRELU");
   DF_REQUIRE(8 * Dc * Hc * Wc * Cout <= (1LL << 29) && Dc * Hc * Wc * Cin <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
              "df_wino_upconv_fwd: one batch volume must stay below 2 GiB (use df_upconv_fwd)");
-  DF_REQUIRE(df::aligned16(wp) && df::aligned16(xc), DF_EALIGN, "df_wino_upconv_fwd: xc and packed weights must be 16-byte aligned");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(xc) && df::aligned16(y), DF_EALIGN, "df_wino_upconv_fwd: xc, y and packed weights must be 16-byte aligned");
   WinoArgs a;
   a.x = xc; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
   a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y; a.y2 = nullptr; a.bits_out = nullptr; a.bits_in = nullptr;
@@ -1540,8 +1567,8 @@ int df_wino_conv_fwd_bits(const float* x, const float* wp, const float* bias, co
   const bool fwd = flags == (DF_CONV_BIAS | DF_CONV_LRELU) && bias && sign_bits && !mask_bits;
   const bool dgr = flags == DF_CONV_MASK && mask_bits && !sign_bits;
   DF_REQUIRE(fwd || dgr, DF_EINVAL, "df_wino_conv_fwd_bits: either (BIAS|LRELU, bias, sign_bits out) or (MASK, mask_bits in)");
-  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x) && df::aligned16(mask_bits) && df::aligned16(sign_bits), DF_EALIGN,
-             "df_wino_conv_fwd_bits: x, packed weights and bit words must be 16-byte aligned");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(x) && df::aligned16(y) && df::aligned16(mask_bits) && df::aligned16(sign_bits), DF_EALIGN,
+             "df_wino_conv_fwd_bits: x, y, packed weights and bit words must be 16-byte aligned");
   WinoArgs a;
   a.x = x; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
   a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y; a.y2 = nullptr;
@@ -1566,8 +1593,8 @@ int df_wino_upconv_fwd_bits(const float* xc, const float* wp, const float* bias,
   DF_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DF_ESHAPE, "df_wino_upconv_fwd_bits: Cin, Cout must be multiples of 32");
   DF_REQUIRE(8 * Dc * Hc * Wc * Cout <= (1LL << 29) && Dc * Hc * Wc * Cin <= (1LL << 29) && Cin * Cout <= (1LL << 24), DF_ESHAPE,
              "df_wino_upconv_fwd_bits: one batch volume must stay below 2 GiB");
-  DF_REQUIRE(df::aligned16(wp) && df::aligned16(xc) && df::aligned16(sign_bits), DF_EALIGN,
-             "df_wino_upconv_fwd_bits: xc, packed weights and bit words must be 16-byte aligned");
+  DF_REQUIRE(df::aligned16(wp) && df::aligned16(xc) && df::aligned16(y) && df::aligned16(sign_bits), DF_EALIGN,
+             "df_wino_upconv_fwd_bits: xc, y, packed weights and bit words must be 16-byte aligned");
   WinoArgs a;
   a.x = xc; a.wp = reinterpret_cast<const f32x4*>(wp); a.zeros = wp + 64 * Cin * Cout;
   a.bias = bias; a.residual = nullptr; a.mask_src = nullptr; a.y = y; a.y2 = nullptr;
