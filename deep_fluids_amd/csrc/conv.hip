@@ -339,6 +339,76 @@ int launch_n(const ConvArgs& a, hipStream_t s) {
   return launch<KZ, TZ, TY, TX, 4, 1, 1, 1, S, KT>(a, s);
 }
 
+// ---- the lowest-resolution 2-D levels (8x6 ... 16x16 pixels per image): small blocks, short chains ---------------------------------------------
+// conv_mfma_kernel gives a wave a 32 x 32 block and the WHOLE K = 9 Cin as one dependent MFMA chain: 576 x 64 cycles = 15 us at Cin = 128 before
+// any staging, on 8 - 32 workgroups -- 28-30 us per launch, 16 such launches on the critical path of a 2-D step at the reference's default batch
+// (config.py:40; profiles/r06_probes.md section 1).  Here a wave owns 16 pixels x 16 couts on v_mfma_f32_16x16x4_f32: a quarter of the chain
+// (288 x 32 cycles), four times the waves, no LDS and no barrier -- both operands are 16-byte loads straight from L1 / L2 (a level's activations and
+// the filter bank are a few hundred KB): lane (row | col r, k-quad kq) loads x[pixel r + tap][16 g + 4 kq .. + 3] and the SAME packed operand as
+// conv_mfma_kernel, Wp[tap][2 g + (kq >> 1)][kq & 1][n0 + r][0..3], and feeds element j of both to MFMA j of the group (the K order inside a
+// 16-channel group is a fixed permutation).  SAME padding through the buffer range check.  Chosen by the image size alone (not the batch): results do
+// not depend on the batch size.  Epilogues as conv_mfma_kernel (bias, lrelu, residual, lrelu mask).
+__device__ __forceinline__ f32x4 tiny_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__global__ __launch_bounds__(kThreads) void conv_tiny2d_kernel(const ConvArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int n0 = (blockIdx.y * 4 + wave) * 16;
+  if (n0 >= a.Cout) return;                                   // wave-uniform
+  const int npix = a.B * a.H * a.W;
+  const int p = blockIdx.x * 16 + r;                          // this lane's A row
+  const bool pok = p < npix;
+  const int px = p % a.W, py = (p / a.W) % a.H, pb = p / (a.W * a.H);
+  const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, static_cast<unsigned>(npix) * a.Cin * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.wp), 0, 9u * a.Kpad * a.Npad * 4u, 0x00020000);
+  const int ng = a.Cin >> 4;                                  // 16-channel groups
+  const unsigned wlane = static_cast<unsigned>(((kq >> 1) * 2 + (kq & 1)) * a.Npad + n0 + r) * 16u;      // (k8 = 2 g + (kq >> 1), half = kq & 1, n): 16 bytes each
+  const unsigned wgroup = static_cast<unsigned>(a.Npad) * 64u;                                           // two k8 = four (k8, half) rows per group
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int tap = 0; tap < 9; ++tap) {
+    const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+    const bool ok = pok && static_cast<unsigned>(yy) < static_cast<unsigned>(a.H) && static_cast<unsigned>(xx) < static_cast<unsigned>(a.W);
+    const unsigned xo = ok ? static_cast<unsigned>(((pb * a.H + yy) * a.W + xx) * a.Cin + 4 * kq) * 4u : 0x80000000u;
+    const unsigned wt = static_cast<unsigned>(tap) * static_cast<unsigned>(a.Kpad / 8) * 2u * a.Npad * 16u;
+    for (int g = 0; g < ng; g += 2) {      // (Cin % 32 == 0) two groups per trip: four loads in flight in front of eight MFMAs
+      const f32x4 av0 = tiny_load16(xs, xo, static_cast<unsigned>(g) * 64u), av1 = tiny_load16(xs, xo, static_cast<unsigned>(g + 1) * 64u);
+      const f32x4 bv0 = tiny_load16(ws, wlane, wt + static_cast<unsigned>(g) * wgroup), bv1 = tiny_load16(ws, wlane, wt + static_cast<unsigned>(g + 1) * wgroup);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bv0[j], acc, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv1[j], acc, 0, 0, 0);
+    }
+  }
+  // D layout: acc[e] = (pixel 4 kq + e of the tile, cout n0 + r)
+  const int col = n0 + r;
+  const float bias = (a.flags & DF_CONV_BIAS) ? a.bias[col] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int q = blockIdx.x * 16 + 4 * kq + e;
+    if (q < npix) {
+      const int64_t o = static_cast<int64_t>(q) * a.Cout + col;
+      float v = acc[e] + bias;
+      if (a.flags & DF_CONV_LRELU) v = fmaxf(v, a.leak * v);
+      if (a.flags & DF_CONV_RESIDUAL) v += a.residual[o];
+      if (a.flags & DF_CONV_MASK) v = a.mask_src[o] > 0.f ? v : a.leak * v;
+      a.y[o] = v;
+    }
+  }
+}
+// the images this kernel takes: stride-1 2-D convs of at most 256 pixels per image (the levels below the Winograd kernels' 16 x 24), channel counts the
+// 16-wide blocks tile exactly
+inline bool tiny2d_ok(const ConvArgs& a, int kz, int stride) {
+  return kz == 1 && stride == 1 && a.nclass <= 1 && static_cast<int64_t>(a.H) * a.W <= 256 && a.Cin % 32 == 0 && a.Cout % 16 == 0 && a.Cout >= 32 &&
+         df::aligned16(a.x) && static_cast<int64_t>(a.B) * a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) < (1LL << 29);
+}
+int launch_tiny2d(const ConvArgs& a, hipStream_t s) {
+  const int64_t npix = static_cast<int64_t>(a.B) * a.H * a.W;
+  dim3 grid((unsigned)ceil_div(npix, 16), (unsigned)ceil_div(a.Cout, 64), 1u);
+  hipLaunchKernelGGL(conv_tiny2d_kernel, grid, dim3(kThreads), 0, s, a);
+  return df::launched("df_conv_fwd");
+}
+
 // One parity class of the stride-2 dgrad with its LIVE taps only (nz x ny x nx in {1, 2}^3; 128-wide N tile, 64 | 32-channel chunks).
 template <int KZ, int KTY, int KTX, int TZ, int TY, int TX>
 int launch_s2d_class(const ConvArgs& a_in, hipStream_t s) {
@@ -448,6 +518,7 @@ static int conv_common(const char* fn, const float* x, const float* wp, const fl
   }
   if (Cout <= 4) return launch_small_n(a, kz, s);                 // thin output: vector-ALU kernel
   if (Cin <= 4 && Cout >= 32) return launch_small_k(a, kz, s);    // thin input (dgrad of the last layer; 3 -> F)
+  if (tiny2d_ok(a, kz, stride)) return launch_tiny2d(a, s);      // the lowest 2-D levels: 16 x 16 blocks, short chains
   if (kz == 3) {
     if (W >= 12) return launch_n<3, 2, 4, 16, 1>(a, s);
     return launch_n<3, 4, 4, 8, 1>(a, s);

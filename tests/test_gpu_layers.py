@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import df_oracle as orc
-from gpu_util import dev, host, rel_linf
+from gpu_util import dev, host, rel_linf, rel_l1
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -653,3 +653,47 @@ def test_block_tail_on_sign_bits_equals_the_fp32_mask_path(ops, dims):
     call("df_lrelu_bwd_pool2x", _ptr(dy), _ptr(y1), _ptr(gx1), _ptr(p1), 0.2, B, D // 2, H // 2, W // 2, C, 1, _stream())
     call("df_lrelu_bits_bwd_pool2x", _ptr(dy), _ptr(bits), _ptr(gx2), _ptr(p2), 0.2, B, D // 2, H // 2, W // 2, C, _stream())
     assert torch.equal(gx1, gx2) and torch.equal(p1, p2)
+
+
+@pytest.mark.parametrize("dims", [(8, 8, 6, 128, 128), (8, 16, 12, 128, 128), (3, 7, 5, 32, 96), (5, 16, 16, 64, 32), (1, 3, 3, 32, 32), (2, 9, 11, 96, 160)])
+def test_tiny_2d_conv_kernel_vs_fp64_and_batch_invariance(ops, dims):
+    """conv_tiny2d_kernel (conv.hip: the 2-D levels of at most 256 pixels per image -- 16 x 16 blocks on v_mfma_f32_16x16x4_f32, operands straight from L1 / L2)
+    behind df_conv_fwd: forward and dgrad operands against an fp64 reference, every fused epilogue, pixel counts that do not fill the last 16-pixel tile, couts
+    that do not fill a workgroup's 64 -- and the result of an image does not depend on the batch it sits in (the kernel is chosen by the image size alone)."""
+    import torch.nn.functional as F
+    from deep_fluids_amd._lib import call, query, DF_CONV_BIAS, DF_CONV_LRELU, DF_CONV_MASK, DF_CONV_RESIDUAL
+    from deep_fluids_amd.ops import _ptr, _stream
+    B, H, W, Ci, Co = dims
+    rng = np.random.RandomState(sum(dims))
+    s = _stream()
+    x = dev(rng.uniform(-1, 1, (B, H, W, Ci)).astype(np.float32))
+    w = dev((rng.uniform(-1, 1, (3, 3, Ci, Co)) / np.sqrt(9 * Ci)).astype(np.float32))
+    bias = dev(rng.uniform(-0.5, 0.5, Co).astype(np.float32))
+    aux = dev(rng.uniform(-1, 1, (B, H, W, Co)).astype(np.float32))
+    wp = torch.empty(query("df_conv_packed_elems", 9, Ci, Co, 0), device="cuda")
+    call("df_conv_pack_weights", _ptr(w), _ptr(wp), 9, Ci, Co, 0, s)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().permute(3, 2, 0, 1).cpu(), bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    y = torch.full((B, H, W, Co), float("nan"), device="cuda")
+    call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), None, None, _ptr(y), B, 1, H, W, Ci, Co, 1, DF_CONV_BIAS, 0.2, s)
+    assert rel_l1(host(y), ref.numpy()) < 2e-6
+    # epilogues: lrelu;  residual + mask on the bias-free launch
+    y1 = torch.empty_like(y); y2 = torch.empty_like(y); y3 = torch.empty_like(y)
+    call("df_conv_fwd", _ptr(x), _ptr(wp), _ptr(bias), None, None, _ptr(y1), B, 1, H, W, Ci, Co, 1, DF_CONV_BIAS | DF_CONV_LRELU, 0.2, s)
+    assert torch.equal(y1, torch.maximum(y, 0.2 * y))
+    call("df_conv_fwd", _ptr(x), _ptr(wp), None, None, None, _ptr(y2), B, 1, H, W, Ci, Co, 1, 0, 0.2, s)
+    call("df_conv_fwd", _ptr(x), _ptr(wp), None, _ptr(aux), _ptr(aux), _ptr(y3), B, 1, H, W, Ci, Co, 1, DF_CONV_MASK | DF_CONV_RESIDUAL, 0.2, s)
+    e = y2 + aux
+    assert torch.equal(y3, torch.where(aux > 0, e, 0.2 * e))
+    # dgrad operand (mode 1): dx = conv_transpose(g, w)
+    g = dev(rng.uniform(-1, 1, (B, H, W, Co)).astype(np.float32))
+    wd = torch.empty(query("df_conv_packed_elems", 9, Ci, Co, 1), device="cuda")
+    call("df_conv_pack_weights", _ptr(w), _ptr(wd), 9, Ci, Co, 1, s)
+    dx = torch.full((B, H, W, Ci), float("nan"), device="cuda")
+    call("df_conv_fwd", _ptr(g), _ptr(wd), None, None, None, _ptr(dx), B, 1, H, W, Co, Ci, 1, 0, 0.2, s)
+    dref = F.conv_transpose2d(g.double().permute(0, 3, 1, 2).cpu(), w.double().permute(3, 2, 0, 1).cpu(), padding=1).permute(0, 2, 3, 1)
+    assert rel_l1(host(dx), dref.numpy()) < 2e-6
+    # batch invariance: image B - 1 alone
+    ys = torch.empty((1, H, W, Co), device="cuda")
+    xs = x[B - 1:].contiguous()
+    call("df_conv_fwd", _ptr(xs), _ptr(wp), _ptr(bias), None, None, _ptr(ys), 1, 1, H, W, Ci, Co, 1, DF_CONV_BIAS, 0.2, s)
+    assert torch.equal(ys[0], y[B - 1])
