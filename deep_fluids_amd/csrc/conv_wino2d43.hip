@@ -79,14 +79,20 @@ __global__ __launch_bounds__(64) void wino2d43_pack_kernel(const float* __restri
     }
     const int cs = n >> 5, nb = (n >> 4) & 1, j = n & 15, k4 = k >> 2, kq = k & 3;
 #pragma unroll
-    for (int xy = 0; xy < 4; ++xy) {
-      const int yh = xy >> 1, xyl = xy & 1;
-      const int64_t idx = ((((((static_cast<int64_t>(cs) * 2 + yh) * (K / 4) + k4) * 2 + nb) * 4 + kq) * 16 + j) * 12) + xyl * 6;
+    for (int yh = 0; yh < 2; ++yh) {      // a lane record = the 12 points of an xi_y pair: written as three 16-byte stores (24 scattered 4-byte ones before)
+      float o[12];
 #pragma unroll
-      for (int xx = 0; xx < 6; ++xx) {
-        const double a = gx[0][xx], b = gx[1][xx], c = gx[2][xx];
-        wp[idx + xx] = static_cast<float>(xy == 0 ? a : xy == 3 ? c : xy == 1 ? 0.5 * (a + b + c) : 0.5 * (a - b + c));
+      for (int xyl = 0; xyl < 2; ++xyl) {
+        const int xy = 2 * yh + xyl;
+#pragma unroll
+        for (int xx = 0; xx < 6; ++xx) {
+          const double a = gx[0][xx], b = gx[1][xx], c = gx[2][xx];
+          o[xyl * 6 + xx] = static_cast<float>(xy == 0 ? a : xy == 3 ? c : xy == 1 ? 0.5 * (a + b + c) : 0.5 * (a - b + c));
+        }
       }
+      const int64_t idx = ((((((static_cast<int64_t>(cs) * 2 + yh) * (K / 4) + k4) * 2 + nb) * 4 + kq) * 16 + j) * 12);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<f32x4*>(wp + idx + 4 * q) = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
     }
   }
 }

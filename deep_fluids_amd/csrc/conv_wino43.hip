@@ -102,17 +102,20 @@ __global__ __launch_bounds__(64) void wino43_pack_kernel(const float* __restrict
           gz[ty][xx] = xz == 0 ? a : xz == 3 ? c : xz == 1 ? 0.5 * (a + b + c) : 0.5 * (a - b + c);
         }
 #pragma unroll
-      for (int xy = 0; xy < 4; ++xy) {
-        float o[6];
+      for (int yh = 0; yh < 2; ++yh) {      // a lane record = the 12 points of an xi_y pair: three 16-byte stores (24 scattered 4-byte ones before)
+        float o[12];
 #pragma unroll
-        for (int xx = 0; xx < 6; ++xx) {
-          const double a = gz[0][xx], b = gz[1][xx], c = gz[2][xx];
-          o[xx] = static_cast<float>(xy == 0 ? a : xy == 3 ? c : xy == 1 ? 0.5 * (a + b + c) : 0.5 * (a - b + c));
+        for (int xyl = 0; xyl < 2; ++xyl) {
+          const int xy = 2 * yh + xyl;
+#pragma unroll
+          for (int xx = 0; xx < 6; ++xx) {
+            const double a = gz[0][xx], b = gz[1][xx], c = gz[2][xx];
+            o[xyl * 6 + xx] = static_cast<float>(xy == 0 ? a : xy == 3 ? c : xy == 1 ? 0.5 * (a + b + c) : 0.5 * (a - b + c));
+          }
         }
-        const int yh = xy >> 1, xyl = xy & 1;
-        const int64_t idx = (((((((static_cast<int64_t>(cs) * 4 + xz) * 2 + yh) * (K / 4) + k4) * 2 + nb) * 4 + kq) * 16 + j) * 12) + xyl * 6;
+        const int64_t idx = (((((((static_cast<int64_t>(cs) * 4 + xz) * 2 + yh) * (K / 4) + k4) * 2 + nb) * 4 + kq) * 16 + j) * 12);
 #pragma unroll
-        for (int xx = 0; xx < 6; ++xx) wp[idx + xx] = o[xx];
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<f32x4*>(wp + idx + 4 * q) = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
       }
     }
   }
